@@ -1,0 +1,360 @@
+"""CPU ORACLE — test infrastructure, NOT product code.
+
+A plain torch-CPU (fp32) restatement of the reference's hot path.  Only tests/,
+__graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this file; the
+product package (dex_gan_grasp_amd/) never does.
+
+Parity pin: every function here is checked against outputs of the reference's own
+Python (imported from /root/reference in the build container with the four shims of
+SURVEY.md 8(c)) through the committed fixtures under tests/golden/ — see
+tests/golden/make_goldens.py (generator) and tests/test_oracle_vs_golden.py (check).
+
+Each function cites the reference file:line it follows (paths relative to the
+reference root).  State is carried in plain dicts keyed by the reference's
+state_dict names, so the same tensors can be loaded into the reference modules.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+LRELU = 0.2  # networks.py:41
+BN_EPS = 1e-5  # torch.nn.BatchNorm1d default used at networks.py:33,36,71,117,289
+BN_MOM = 0.1
+DROP_P = 0.3  # networks.py:294
+
+
+# ----------------------------------------------------------------------------------------------
+# utils/utils.py (math subset)
+# ----------------------------------------------------------------------------------------------
+def normalize_vector(v):
+    """utils/utils.py:323-332 (the hard .cuda() of :326 dropped; eps 1e-8)."""
+    mag = torch.sqrt(v.pow(2).sum(1))
+    mag = torch.max(mag, torch.tensor([1e-8], dtype=v.dtype))
+    return v / mag.view(-1, 1)
+
+
+def cross_product(u, v):
+    """utils/utils.py:68-78."""
+    i = u[:, 1] * v[:, 2] - u[:, 2] * v[:, 1]
+    j = u[:, 2] * v[:, 0] - u[:, 0] * v[:, 2]
+    k = u[:, 0] * v[:, 1] - u[:, 1] * v[:, 0]
+    return torch.stack((i, j, k), 1)
+
+
+def rot_matrix_from_ortho6d(o6):
+    """utils/utils.py:380-394: Gram-Schmidt, x,y,z are the COLUMNS of R."""
+    x = normalize_vector(o6[:, 0:3])
+    z = normalize_vector(cross_product(x, o6[:, 3:6]))
+    y = cross_product(z, x)
+    return torch.stack((x, y, z), 2)  # (B,3,3), [:, :, 0] = x
+
+
+def translate_along_axis(transl, rot_matrix, axis, translation):
+    """utils/utils.py:19-48: t <- t - R @ e_axis * translation, evaluated in float64 numpy and
+    stored back into the (float32) array, exactly as the per-sample python loop does."""
+    t = np.array(transl, copy=True)
+    off = np.zeros(3)
+    off[axis] = translation
+    for i in range(t.shape[0]):
+        tm = np.eye(4)
+        tm[:3, :3] = rot_matrix[i]
+        tm[:3, 3] = t[i]
+        t[i] = tm[:3, 3] - tm[:3, :3] @ off
+    return t
+
+
+def class_labels_from_logits(p, thresh):
+    """utils/utils.py:60-64."""
+    return (p >= thresh).to(p.dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# networks.py
+# ----------------------------------------------------------------------------------------------
+def _bn(sd, prefix, x, train):
+    """nn.BatchNorm1d: train -> batch mean / biased var for normalisation, running stats updated
+    with momentum 0.1 and the UNBIASED var; eval -> running stats."""
+    out = F.batch_norm(
+        x, sd[prefix + "running_mean"], sd[prefix + "running_var"], sd[prefix + "weight"], sd[prefix + "bias"],
+        training=train, momentum=BN_MOM, eps=BN_EPS)
+    if train:
+        sd[prefix + "num_batches_tracked"] += 1
+    return out
+
+
+def resblock(sd, prefix, x, train):
+    """networks.py:43-56 (final_nl is True at every call site; Fin != Fout always)."""
+    xin = F.leaky_relu(F.linear(x, sd[prefix + "fc3.weight"], sd[prefix + "fc3.bias"]), LRELU)
+    h = F.linear(x, sd[prefix + "fc1.weight"], sd[prefix + "fc1.bias"])
+    h = F.leaky_relu(_bn(sd, prefix + "bn1.", h, train), LRELU)
+    o = F.linear(h, sd[prefix + "fc2.weight"], sd[prefix + "fc2.bias"])
+    o = _bn(sd, prefix + "bn2.", o, train)
+    return F.leaky_relu(xin + o, LRELU)
+
+
+def generator_forward(sd, z, bps, train, prefix=""):
+    """networks.py:88-103."""
+    p = prefix
+    o = _bn(sd, p + "gen_bn1.", bps.contiguous(), train)
+    x0 = torch.cat([z, o], 1)
+    x = resblock(sd, p + "gen_rb1.", x0, train)
+    x = resblock(sd, p + "gen_rb2.", torch.cat([x0, x], 1), train)
+    return {
+        "rot_6D": F.linear(x, sd[p + "gen_rot.weight"], sd[p + "gen_rot.bias"]),
+        "transl": F.linear(x, sd[p + "gen_transl.weight"], sd[p + "gen_transl.bias"]),
+        "joint_conf": F.linear(x, sd[p + "gen_joint_conf.weight"], sd[p + "gen_joint_conf.bias"]),
+        "z": z,
+    }
+
+
+def discriminator_forward(sd, bps, rot, transl, joint, train, prefix=""):
+    """networks.py:132-159.  rot may be (B,3,3) or (B,9): view(B,-1) is the row-major flatten."""
+    p = prefix
+    b = bps.shape[0]
+    x = torch.cat([bps.float(), rot.float().reshape(b, -1), transl.float(), joint.float()], 1)
+    x0 = _bn(sd, p + "disc_bn1.", x, train)
+    x = resblock(sd, p + "disc_rb1.", x0, train)
+    x = resblock(sd, p + "disc_rb2.", torch.cat([x0, x], 1), train)
+    return torch.sigmoid(F.linear(x, sd[p + "out_success.weight"], sd[p + "out_success.bias"]))
+
+
+def _dropout(x, train, mask):
+    """nn.Dropout(0.3) (networks.py:294): keep-mask scaled by 1/(1-p).  The mask is an explicit
+    input (1 = keep); mask=None in train mode draws from torch's global RNG like the reference."""
+    if not train:
+        return x
+    if mask is None:
+        return F.dropout(x, DROP_P, True)
+    return x * mask * (1.0 / (1.0 - DROP_P))
+
+
+def evaluator_forward(sd, bps, rot, transl, train, drop_masks=None, prefix=""):
+    """networks.py:315-338.  NOTE the concat order cat[X, X0] (hidden first), networks.py:330,332."""
+    p = prefix
+    b = bps.shape[0]
+    x = torch.cat([bps.float(), rot.float().reshape(b, -1), transl.float()], 1)
+    x0 = _bn(sd, p + "bn1.", x, train)
+    dm = drop_masks if drop_masks is not None else [None, None, None]
+    x = _dropout(resblock(sd, p + "rb1.", x0, train), train, dm[0])
+    x = _dropout(resblock(sd, p + "rb2.", torch.cat([x, x0], 1), train), train, dm[1])
+    x = _dropout(resblock(sd, p + "rb3.", torch.cat([x, x0], 1), train), train, dm[2])
+    return torch.sigmoid(F.linear(x, sd[p + "out_success.weight"], sd[p + "out_success.bias"]))
+
+
+# ----------------------------------------------------------------------------------------------
+# losses (dexgangrasp.py:142-147, 213-232, 272-307; losses.py:5-16, 61-76)
+# ----------------------------------------------------------------------------------------------
+def bce(p, target):
+    """torch.nn.BCELoss(reduction='mean') (dexgangrasp.py:122): log clamped at -100."""
+    return F.binary_cross_entropy(p, target, reduction="mean")
+
+
+def loss_discriminator(real_score, fake_score, bce_weight=1.0):
+    """dexgangrasp.py:213-232."""
+    lr = bce_weight * bce(real_score, torch.ones_like(real_score))
+    lf = bce_weight * bce(fake_score, torch.zeros_like(fake_score))
+    tot = (lr + lf) / 2
+    return tot, {"total_loss_disc": tot, "bce_loss_real": lr, "bce_loss_fake": lf}
+
+
+def loss_generator(fake, gt_rot9, gt_transl, gt_joint, fake_score, bce_weight=1.0):
+    """dexgangrasp.py:272-307 + losses.py:61-76; coefficients dexgangrasp.py:92-94."""
+    pred_r = rot_matrix_from_ortho6d(fake["rot_6D"]).reshape(-1, 9)
+    l_rot = F.mse_loss(pred_r, gt_rot9.float())
+    l_tr = F.mse_loss(fake["transl"], gt_transl.float())
+    l_cf = F.mse_loss(fake["joint_conf"].float(), gt_joint.float())
+    l_f = bce_weight * bce(fake_score, torch.ones_like(fake_score))
+    d = {"gen_loss_fake": l_f, "transl_loss": 100.0 * l_tr, "rot_loss": 1.0 * l_rot, "conf_loss": 10.0 * l_cf}
+    tot = l_f + (d["transl_loss"] + d["rot_loss"] + d["conf_loss"])
+    d["total_loss_gen"] = tot
+    return tot, d
+
+
+def loss_evaluator(p, label, bce_weight=1.0):
+    """dexgangrasp.py:142-147."""
+    v = bce_weight * bce(p, label)
+    return v, {"total_loss_eva": v, "bce_loss": v}
+
+
+def accuracy_evaluator(pred_label, gt_label):
+    """losses.py:5-16."""
+    correct = torch.eq(pred_label, gt_label)
+    tp = torch.sum(correct * gt_label) / torch.sum(gt_label)
+    tn = torch.sum(correct * (1.0 - gt_label)) / torch.sum(1.0 - gt_label)
+    acc = correct.sum() / float(len(gt_label))
+    return tp, tn, acc
+
+
+# ----------------------------------------------------------------------------------------------
+# Adam as configured at dexgangrasp.py:97-112 (torch.optim.Adam, L2-coupled weight decay)
+# ----------------------------------------------------------------------------------------------
+class AdamState:
+    def __init__(self, names):
+        self.t = 0
+        self.m = {n: None for n in names}
+        self.v = {n: None for n in names}
+
+
+def adam_step(sd, grads, st, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8, wd=5e-4):
+    """g <- g + wd*theta; m <- b1 m + (1-b1) g; v <- b2 v + (1-b2) g^2;
+    theta <- theta - lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  Params with grad None are
+    skipped (their step counter does not advance either; here one shared t, all params get grads)."""
+    st.t += 1
+    t = st.t
+    bc1 = 1.0 - b1 ** t
+    bc2 = 1.0 - b2 ** t
+    with torch.no_grad():
+        for n, g in grads.items():
+            if g is None:
+                continue
+            p = sd[n]
+            g = g + wd * p
+            if st.m[n] is None:
+                st.m[n] = torch.zeros_like(p)
+                st.v[n] = torch.zeros_like(p)
+            st.m[n].mul_(b1).add_(g, alpha=1 - b1)
+            st.v[n].mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (st.v[n].sqrt() / math.sqrt(bc2)).add_(eps)
+            p.addcdiv_(st.m[n], denom, value=-(lr / bc1))
+
+
+def param_names(sd):
+    return [n for n, t in sd.items() if t.dtype.is_floating_point and "running_" not in n]
+
+
+def _grads(loss, sd, names):
+    ps = [sd[n] for n in names]
+    gs = torch.autograd.grad(loss, ps, allow_unused=True)
+    return dict(zip(names, gs))
+
+
+def _set_requires_grad(sd, names, flag):
+    for n in names:
+        sd[n].requires_grad_(flag)
+
+
+# ----------------------------------------------------------------------------------------------
+# Train steps (dexgangrasp.py:739-823)
+# ----------------------------------------------------------------------------------------------
+def cgan_step(sd, batch, z, adam_g, adam_d, cfg, is_train_gen=True, return_grads=False):
+    """dexgangrasp.py:757-823 (BCE branch).  `sd` holds the DexGANGrasp state_dict
+    ('generator.*', 'discriminator.*'), modified in place.  z is the injected latent (:770)."""
+    bw = float(cfg.get("bce_weight", 1))
+    gn = [n for n in param_names(sd) if n.startswith("generator.")]
+    dn = [n for n in param_names(sd) if n.startswith("discriminator.")]
+    _set_requires_grad(sd, gn + dn, True)
+    b = batch["bps_object"].shape[0]
+    bps = batch["bps_object"].float()
+    rot = batch["rot_matrix"].float().reshape(b, 9)
+    transl = batch["transl"].float()
+    joint = batch["joint_conf"].float()
+
+    # :772-776  G forward #1 (train mode, graph kept), R from ortho6d
+    y = generator_forward(sd, z, bps, True, "generator.")
+    r_fake = rot_matrix_from_ortho6d(y["rot_6D"])
+    # :788-789  D on real then on detached fake (BN buffers updated in that order)
+    real_score = discriminator_forward(sd, bps, rot, transl, joint, True, "discriminator.")
+    fake_score = discriminator_forward(
+        sd, bps, r_fake.detach(), y["transl"].detach(), y["joint_conf"].detach(), True, "discriminator.")
+    l_d, dict_d = loss_discriminator(real_score, fake_score, bw)
+    # :792-794
+    g_d = _grads(l_d, sd, dn)
+    adam_step(sd, g_d, adam_d, lr=cfg["lr_dis"], b1=cfg["beta1"], wd=cfg["weight_decay"])
+    out = {k: v.detach() for k, v in dict_d.items()}
+    g_g = None
+    if is_train_gen:
+        # :808 D forward #3 with the UPDATED discriminator, graph through G
+        fake_score_gen = discriminator_forward(sd, bps, r_fake, y["transl"], y["joint_conf"], True, "discriminator.")
+        l_g, dict_g = loss_generator(y, rot, transl, joint, fake_score_gen, bw)
+        g_g = _grads(l_g, sd, gn)
+        adam_step(sd, g_g, adam_g, lr=cfg["lr_gen"], b1=cfg["beta1"], wd=cfg["weight_decay"])
+        out.update({k: v.detach() for k, v in dict_g.items()})
+    _set_requires_grad(sd, gn + dn, False)
+    if return_grads:
+        return out, g_d, g_g, {"real_score": real_score.detach(), "fake_score": fake_score.detach(),
+                               "rot_6D": y["rot_6D"].detach(), "transl": y["transl"].detach(),
+                               "joint_conf": y["joint_conf"].detach()}
+    return out
+
+
+def eva_step(sd, batch, adam_e, cfg, drop_masks=None, return_grads=False):
+    """dexgangrasp.py:739-755."""
+    bw = float(cfg.get("bce_weight", 1))
+    en = param_names(sd)
+    _set_requires_grad(sd, en, True)
+    label = batch["label"].float().unsqueeze(-1)  # networks.py:312
+    p = evaluator_forward(sd, batch["bps_object"], batch["rot_matrix"], batch["transl"], True, drop_masks)
+    l_e, dict_e = loss_evaluator(p, label, bw)
+    g_e = _grads(l_e, sd, en)
+    adam_step(sd, g_e, adam_e, lr=cfg["lr"], b1=cfg["beta1"], wd=cfg["weight_decay"])
+    _set_requires_grad(sd, en, False)
+    out = {k: v.detach() for k, v in dict_e.items()}
+    if return_grads:
+        return out, g_e, p.detach()
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Inference (networks.py:223-276, dexgangrasp.py:367-442, 495-514)
+# ----------------------------------------------------------------------------------------------
+def generate_grasps(sd_gen, bps_row, z, z_offset=0.025, prefix="generator."):
+    """dexgangrasp.py:495-514 -> networks.py:223-255: eval-mode G on the tiled BPS row, R from
+    ortho6d, then translate_along_axis(axis=0).  z is the injected latent (networks.py:240)."""
+    n = z.shape[0]
+    bps = torch.as_tensor(np.tile(np.asarray(bps_row).squeeze(), (n, 1)), dtype=torch.float32)
+    with torch.no_grad():
+        y = generator_forward(sd_gen, z, bps, False, prefix)
+        r = rot_matrix_from_ortho6d(y["rot_6D"])
+    res = {"transl": y["transl"].numpy().copy(), "joint_conf": y["joint_conf"].numpy().copy(),
+           "z": z.numpy().copy(), "rot_matrix": r.numpy().copy()}
+    res["transl"] = translate_along_axis(res["transl"], res["rot_matrix"], 0, z_offset)
+    return res
+
+
+def evaluate_grasps(sd_eva, bps_row, grasps):
+    """dexgangrasp.py:367-391 (evaluator in eval mode, as after load_dexevaluator)."""
+    n = grasps["rot_matrix"].shape[0]
+    bps = torch.as_tensor(np.tile(np.asarray(bps_row).squeeze(), (n, 1)), dtype=torch.float32)
+    with torch.no_grad():
+        p = evaluator_forward(sd_eva, bps, torch.as_tensor(grasps["rot_matrix"], dtype=torch.float32),
+                              torch.as_tensor(grasps["transl"], dtype=torch.float32), False)
+    return p.squeeze(-1).numpy()
+
+
+def filter_grasps(sd_eva, bps_row, grasps, thresh=0.5):
+    """dexgangrasp.py:393-442: sort descending, ValueError if best < thresh, keep score > thresh,
+    gather every entry (adds 'bps_object')."""
+    n = grasps["rot_matrix"].shape[0]
+    p = torch.as_tensor(evaluate_grasps(sd_eva, bps_row, grasps))
+    score, idx = p.sort(descending=True)
+    if score[0] < thresh:
+        raise ValueError("In total predicted ", n, " grasps, but best score ", score[0],
+                         " is still lower than thresh", thresh)
+    idx = idx[score > thresh]
+    out = {k: np.asarray(v)[idx.numpy()] for k, v in grasps.items()}
+    out["bps_object"] = np.tile(np.asarray(bps_row).squeeze(), (n, 1)).astype(np.float32)[idx.numpy()]
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# eval.py MAGD (pure numpy; eval.py:48-137)
+# ----------------------------------------------------------------------------------------------
+def magd(gt, pred):
+    """eval.py:98-137 with the distances of eval.py:48-96: for every predicted grasp find the
+    ground-truth grasp nearest in squared translation distance; accumulate translation L2^2,
+    rotation geodesic and joint L2^2 to it; coverage = fraction of GT grasps that were hit."""
+    gt_t, pr_t = np.asarray(gt["transl"], np.float64), np.asarray(pred["transl"], np.float64)
+    d2 = ((pr_t[:, None, :] - gt_t[None, :, :]) ** 2).sum(-1)
+    nn = d2.argmin(1)
+    tr = d2[np.arange(len(nn)), nn].sum()
+    r_gt = np.asarray(gt["rot_matrix"], np.float64)[nn]
+    r_pr = np.asarray(pred["rot_matrix"], np.float64)
+    cos = (np.einsum("nij,nij->n", r_pr, r_gt) - 1.0) / 2.0
+    rot = np.arccos(np.clip(cos, -1.0, 1.0)).sum()
+    jt = ((np.asarray(pred["joint_conf"], np.float64) - np.asarray(gt["joint_conf"], np.float64)[nn]) ** 2).sum()
+    cov = len(np.unique(nn)) / float(len(gt_t))
+    return {"transl": tr, "rot": rot, "joint": jt, "coverage": cov}

@@ -1,0 +1,317 @@
+#!/usr/bin/env python3
+"""Generates the fixtures under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference, read-only).  Nothing of the
+reference's source is copied: the outputs are data (tensors, scalars) and the reference's own
+data files (basis_point_set.npy, real_objects/*.pcd -> xyz, real_objects/bps/*.npy,
+eval_batch.pth rows).  The reference is imported on CPU with the four in-process shims of
+SURVEY.md 8(c): stub modules for h5py/open3d/transforms3d/cv2, a falsy torch.cuda.is_available
+object, Tensor.cuda = identity, np.Inf.
+
+    python tests/golden/make_goldens.py            # rewrites tests/golden/*.npz
+
+Weights/batches come from dex_gan_grasp_amd.synth (seed only), so the tests can regenerate the
+exact inputs on any box with the same torch build.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from dex_gan_grasp_amd import synth  # noqa: E402
+from summ import summarize, pack_mask  # noqa: E402
+
+
+def install_shims():
+    for name in ["h5py", "open3d", "transforms3d", "transforms3d.quaternions", "transforms3d.euler", "cv2"]:
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["transforms3d"].quaternions = sys.modules["transforms3d.quaternions"]
+    sys.modules["transforms3d"].euler = sys.modules["transforms3d.euler"]
+
+    class _Falsy:
+        def __call__(self):
+            return False
+
+        def __bool__(self):
+            return False
+
+    torch.cuda.is_available = _Falsy()
+    torch.cuda.empty_cache = lambda: None
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    np.Inf = np.inf
+    sys.path.insert(0, REF)
+
+
+def read_pcd_xyz(path):
+    """Binary PCD v0.7, all-float32 fields; returns (N,3) float32 of x,y,z."""
+    with open(path, "rb") as f:
+        fields, npts = None, None
+        while True:
+            line = f.readline().decode("ascii", "replace").strip()
+            if line.startswith("FIELDS"):
+                fields = line.split()[1:]
+            elif line.startswith("POINTS"):
+                npts = int(line.split()[1])
+            elif line.startswith("DATA"):
+                assert line.split()[1] == "binary"
+                break
+        raw = np.frombuffer(f.read(npts * 4 * len(fields)), dtype=np.float32).reshape(npts, len(fields))
+    return np.ascontiguousarray(raw[:, [fields.index("x"), fields.index("y"), fields.index("z")]])
+
+
+def gen_bps_fixture():
+    objs = sorted(f[:-4] for f in os.listdir(os.path.join(REF, "data/real_objects/object")) if f.endswith(".pcd"))
+    out = {"basis": np.load(os.path.join(REF, "models/basis_point_set.npy"))}
+    for o in objs:
+        out["cloud_" + o] = read_pcd_xyz(os.path.join(REF, "data/real_objects/object", o + ".pcd"))
+        out["dists_" + o] = np.load(os.path.join(REF, "data/real_objects/bps", o + ".npy"))
+    out["names"] = np.array(objs)
+    np.savez_compressed(os.path.join(HERE, "bps_real_objects.npz"), **out)
+    print("bps fixture:", {k: v.shape for k, v in out.items()})
+
+
+def gen_eval_rows():
+    d = torch.load(os.path.join(REF, "data/eval_batch.pth"), map_location="cpu", weights_only=False)
+    out = {k: d[k][:16].numpy() for k in ["rot_matrix", "transl", "joint_conf", "bps_object"]}
+    np.savez_compressed(os.path.join(HERE, "eval_batch_rows16.npz"), **out)
+    return {k: torch.from_numpy(v.copy()) for k, v in out.items()}
+
+
+def clone_batch(b):
+    return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}
+
+
+WEIGHT_VARIANTS = {
+    # name: (seed_gan, seed_eva, gain, trained_like)
+    "init": (0, 5, 0.02, False),
+    "wide": (10, 15, 1.0, True),
+}
+
+
+def build_reference(cfg, variant, is_train=True):
+    from DexGanGrasp.models.dexgangrasp import DexGanGrasp
+    sg, se, gain, tl = WEIGHT_VARIANTS[variant]
+    c = dict(cfg)
+    c["is_train"] = is_train
+    m = DexGanGrasp(c)
+    m.DexGANGrasp.load_state_dict(synth.make_state_dict("dexgangrasp", sg, gain, tl))
+    m.DexEvaluator.load_state_dict(synth.make_state_dict("evaluator", se, gain, tl))
+    return m
+
+
+def batches(eval_rows):
+    return {
+        "real16": eval_rows,
+        "syn8": synth.make_batch(8, 1),
+        "syn64": synth.make_batch(64, 1),
+    }
+
+
+def gen_forward_goldens(cfg, eval_rows):
+    from DexGanGrasp.utils import utils as rutils
+    out = {}
+    for variant in WEIGHT_VARIANTS:
+        for bname, batch in batches(eval_rows).items():
+            b = batch["bps_object"].shape[0]
+            z = synth.make_z(b, 3)
+            for mode in ["train", "eval"]:
+                m = build_reference(cfg, variant)
+                gan, eva = m.DexGANGrasp, m.DexEvaluator
+                (gan.train if mode == "train" else gan.eval)()
+                (eva.train if mode == "train" else eva.eval)()
+                key = "%s/%s/%s/" % (variant, bname, mode)
+                with torch.no_grad():
+                    y = gan.generator(z, batch["bps_object"])
+                    r = rutils.rot_matrix_from_ortho6d(y["rot_6D"])
+                    out[key + "gen_rot_6D"] = y["rot_6D"].numpy()
+                    out[key + "gen_transl"] = y["transl"].numpy()
+                    out[key + "gen_joint_conf"] = y["joint_conf"].numpy()
+                    out[key + "gen_rot_matrix"] = r.numpy()
+                    gan.discriminator.cfg = dict(gan.discriminator.cfg, is_train=False)  # no requires_grad_ under no_grad
+                    out[key + "disc_real"] = gan.discriminator(clone_batch(batch)).numpy()
+                    fake = {"bps_object": batch["bps_object"], "rot_matrix": r, "transl": y["transl"],
+                            "joint_conf": y["joint_conf"]}
+                    out[key + "disc_fake"] = gan.discriminator(fake).numpy()
+                    if mode == "eval":
+                        out[key + "eva"] = eva(clone_batch(batch)).numpy()
+                    else:
+                        masks = []
+                        h = eva.dout.register_forward_hook(lambda mod, i, o: masks.append((o != 0).float()))
+                        torch.manual_seed(77)
+                        out[key + "eva"] = eva(clone_batch(batch)).numpy()
+                        h.remove()
+                        out[key + "eva_masks"] = pack_mask(torch.stack(masks))
+                    # BN running statistics after the train-mode passes (momentum / unbiased var pin)
+                    if mode == "train":
+                        sd = gan.state_dict()
+                        for n in ["generator.gen_bn1.running_mean", "generator.gen_bn1.running_var",
+                                  "discriminator.disc_bn1.running_var", "discriminator.disc_rb2.bn2.running_mean"]:
+                            out[key + "bn/" + n] = summarize(sd[n])
+    np.savez_compressed(os.path.join(HERE, "forward_goldens.npz"), **out)
+    print("forward goldens:", len(out), "arrays")
+
+
+def gen_step_goldens(cfg, eval_rows):
+    out = {}
+    for variant in WEIGHT_VARIANTS:
+        for bname in ["real16", "syn64"]:
+            batch = batches(eval_rows)[bname]
+            b = batch["bps_object"].shape[0]
+            m = build_reference(cfg, variant)
+            key = "%s/%s/" % (variant, bname)
+            # capture grads right before each optimiser step
+            cap = {}
+
+            def wrap(opt, tag, module, prefix):
+                orig = opt.step
+
+                def step(*a, **k):
+                    cap[tag] = {prefix + n: p.grad.detach().clone() for n, p in module.named_parameters()}
+                    return orig(*a, **k)
+                opt.step = step
+            wrap(m.optim_dexgangrasp_discriminator, "d", m.DexGANGrasp.discriminator, "discriminator.")
+            wrap(m.optim_dexgangrasp_generator, "g", m.DexGANGrasp.generator, "generator.")
+            wrap(m.optim_dexevaluator, "e", m.DexEvaluator, "")
+            for step in range(2):
+                torch.manual_seed(100 + step)  # the reference draws Z with torch.randn right after (:770)
+                z_expected = torch.randn((b, 5))
+                torch.manual_seed(100 + step)
+                losses = m.update_dexgangrasp(clone_batch(batch), is_train_gen=True)
+                sk = key + "cgan%d/" % step
+                out[sk + "z"] = z_expected.numpy()
+                for k, v in losses.items():
+                    out[sk + "loss/" + k] = np.float64(v.item())
+                for tag in ["d", "g"]:
+                    for n, g in cap[tag].items():
+                        out[sk + "grad_%s/" % tag + n] = summarize(g)
+                for n, t in m.DexGANGrasp.state_dict().items():
+                    out[sk + "state/" + n] = summarize(t)
+            # evaluator steps: label + captured dropout masks
+            ebatch = synth.make_batch(b, 2, with_label=True)
+            if bname == "real16":
+                ebatch = clone_batch(batch)
+                ebatch["label"] = synth.make_batch(b, 2, with_label=True)["label"]
+            for step in range(2):
+                masks = []
+                h = m.DexEvaluator.dout.register_forward_hook(lambda mod, i, o: masks.append((o != 0).float()))
+                torch.manual_seed(200 + step)
+                losses = m.update_dexevaluator(clone_batch(ebatch))
+                h.remove()
+                sk = key + "eva%d/" % step
+                out[sk + "masks"] = pack_mask(torch.stack(masks))
+                for k, v in losses.items():
+                    out[sk + "loss/" + k] = np.float64(v.item())
+                for n, g in cap["e"].items():
+                    out[sk + "grad_e/" + n] = summarize(g)
+                for n, t in m.DexEvaluator.state_dict().items():
+                    out[sk + "state/" + n] = summarize(t)
+            # eval-mode losses after the two steps (train.py:65,110-111)
+            torch.manual_seed(300)
+            el = m.eval_dexgangrasp_generator_loss(clone_batch(batch))
+            for k, v in el.items():
+                out[key + "evalloss_gen/" + k] = np.float64(v.item())
+            el = m.eval_dexevaluator_loss(clone_batch(ebatch))
+            for k, v in el.items():
+                out[key + "evalloss_eva/" + k] = np.float64(v.item())
+    np.savez_compressed(os.path.join(HERE, "step_goldens.npz"), **out)
+    print("step goldens:", len(out), "arrays")
+
+
+def gen_inference_goldens(cfg):
+    out = {}
+    bps = np.load(os.path.join(REF, "data/real_objects/bps/red_mug.npy"))
+    for variant in WEIGHT_VARIANTS:
+        m = build_reference(cfg, variant, is_train=False)
+        m.DexGANGrasp.eval()
+        m.DexEvaluator.eval()
+        n = 32
+        torch.manual_seed(400)
+        z = torch.randn((n, 5))
+        torch.manual_seed(400)
+        grasps = m.generate_grasps(bps, n_samples=n, return_arr=True)
+        key = variant + "/"
+        out[key + "z"] = z.numpy()
+        for k, v in grasps.items():
+            out[key + "gen/" + k] = np.asarray(v)
+        p = m.evaluate_grasps(bps, {k: v.copy() for k, v in grasps.items()}, return_arr=True)
+        out[key + "scores"] = p
+        thresh = float(np.median(p))
+        out[key + "thresh"] = np.float64(thresh)
+        filt = m.filter_grasps(bps, {k: v.copy() for k, v in grasps.items()}, thresh=thresh)
+        for k, v in filt.items():
+            if k != "bps_object":
+                out[key + "filt/" + k] = np.asarray(v)
+        out[key + "filt/bps_object_shape"] = np.array(filt["bps_object"].shape)
+        pd = m.DexGANGrasp.discriminator
+        fd = m.filter_grasps_discriminator(bps, {k: v.copy() for k, v in grasps.items()}, thresh=0.0)
+        out[key + "filt_disc/transl"] = np.asarray(fd["transl"])
+    np.savez_compressed(os.path.join(HERE, "inference_goldens.npz"), **out)
+    print("inference goldens:", len(out), "arrays")
+
+
+def gen_magd_golden(eval_rows_full):
+    sys.path.insert(0, REF)
+    # eval.py imports heavy modules at top; restate only the import of its pure-numpy function
+    import importlib.util
+    for name in ["open3d", "transforms3d", "h5py", "cv2", "pandas_dummy"]:
+        sys.modules.setdefault(name, types.ModuleType(name))
+    mod = None
+    for _ in range(40):  # stub whatever unrelated GUI/robot modules eval.py's imports pull in
+        try:
+            spec = importlib.util.spec_from_file_location("ref_eval", os.path.join(REF, "eval.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            break
+        except ModuleNotFoundError as e:
+            stub = types.ModuleType(e.name)
+            stub.__path__ = []
+            stub.__getattr__ = lambda name, _n=e.name: type(name, (), {})
+            sys.modules[e.name] = stub
+            mod = None
+        except Exception as e:  # ordinary python error of unrelated code -> skip this golden
+            print("MAGD golden skipped:", repr(e))
+            return
+    if mod is None:
+        print("MAGD golden skipped: too many missing modules")
+        return
+    g = torch.Generator().manual_seed(7)
+    n, mgt = 24, 17
+    pred = {"rot_matrix": synth.random_rotations(n, g, torch.float32).numpy(),
+            "transl": (torch.rand((n, 3), generator=g) * 0.3 - 0.15).numpy(),
+            "joint_conf": torch.rand((n, 12), generator=g).numpy()}
+    gt = {"rot_matrix": synth.random_rotations(mgt, g, torch.float32).numpy(),
+          "transl": (torch.rand((mgt, 3), generator=g) * 0.3 - 0.15).numpy(),
+          "joint_conf": torch.rand((mgt, 12), generator=g).numpy()}
+    t, r, j, c = mod.magd_for_grasp_distribution({k: v.copy() for k, v in pred.items()}, gt)
+    out = {"pred_" + k: v for k, v in pred.items()}
+    out.update({"gt_" + k: v for k, v in gt.items()})
+    out["result"] = np.array([t, r, j, c], np.float64)
+    np.savez_compressed(os.path.join(HERE, "magd_golden.npz"), **out)
+    print("magd golden:", out["result"])
+
+
+def main():
+    import yaml
+    install_shims()
+    cfg = yaml.safe_load(open(os.path.join(REF, "DexGanGrasp/config/config_dexgangrasp.yaml")))
+    cfg["save_dir"] = "/tmp/dgg_ref_ckpt"
+    cfg["eval_dir"] = "/tmp/dgg_ref_ckpt"
+    cfg["train_ffhevaluator"] = True
+    gen_bps_fixture()
+    rows = gen_eval_rows()
+    gen_forward_goldens(cfg, rows)
+    gen_step_goldens(cfg, rows)
+    gen_inference_goldens(cfg)
+    gen_magd_golden(rows)
+
+
+if __name__ == "__main__":
+    main()
