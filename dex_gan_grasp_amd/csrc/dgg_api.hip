@@ -1,0 +1,961 @@
+// C-ABI of libdgg.so (include/dgg.h): flat-buffer layouts, workspace carving and the launch
+// sequences of Generator / Discriminator / DexEvaluator forward+backward
+// (DexGanGrasp/models/networks.py:43-56,88-103,132-159,315-338) and of the training phases
+// (DexGanGrasp/models/dexgangrasp.py:739-823).  Host code only enqueues kernels on the caller's
+// stream: no allocation, no synchronisation, no host<->device copies.
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <math.h>
+#include "dgg_internal.h"
+
+namespace dgg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* what, hipError_t e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(what, e);
+        return DGG_ERR_LAUNCH;
+    }
+    return DGG_OK;
+}
+
+#define DGG_TRY(expr)            \
+    do {                         \
+        int rc__ = (expr);       \
+        if (rc__ != DGG_OK) return rc__; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Layout of the flat parameter / BN-statistics buffers.
+//   fc1.weight and fc3.weight of a ResBlock are stored back to back so that they form ONE
+//   (hidden+n_neurons) x Fin matrix W13 (they share the A operand: fc1 || fc3 fused along N);
+//   likewise their biases, and the generator's three head matrices form one (nj+9) x 512 matrix.
+// ------------------------------------------------------------------------------------------------
+struct RbL {
+    int fin;
+    int64_t w13, b13, bn1w, bn1b, w2, b2, bn2w, bn2b;  // parameter offsets
+    int64_t rm1, rv1, rm2, rv2;                         // running-stat offsets
+};
+struct NetL {
+    int net;
+    int hid, nn, n13;  // 256, 512, 768
+    int k_in;          // width of the BatchNorm'd input concat
+    int nprefix;       // columns copied in front of it (generator: Z)
+    int k0, ldx0;      // k0 = nprefix + k_in; row pitch of X0
+    int in_bps;
+    int nrb;
+    bool x1_first;     // evaluator: cat[X, X0]; generator/discriminator: cat[X0, X]
+    RbL rb[3];
+    int nh;
+    int64_t ibnw, ibnb, wh, bh;
+    int64_t irm, irv;
+    int64_t nparam, nbn;
+};
+
+static inline int64_t align4(int64_t x) { return (x + 3) & ~(int64_t)3; }
+
+static bool cfg_ok(const dgg_cfg* c) {
+    return c && c->latent_d >= 0 && c->latent_d <= 64 && c->n_hand_joints >= 1 && c->n_hand_joints + 9 <= 32 &&
+           c->in_bps >= 1 && c->n_neurons == 512 && c->hidden == 256;
+}
+
+static int build_layout(int net, const dgg_cfg* c, NetL& L) {
+    if (!cfg_ok(c)) return DGG_ERR_INVALID;
+    memset(&L, 0, sizeof(L));
+    L.net = net;
+    L.hid = c->hidden;
+    L.nn = c->n_neurons;
+    L.n13 = L.hid + L.nn;
+    L.in_bps = c->in_bps;
+    if (net == DGG_NET_GEN) {
+        L.k_in = c->in_bps;
+        L.nprefix = c->latent_d;
+        L.nrb = 2;
+        L.nh = c->n_hand_joints + 9;
+        L.x1_first = false;
+    } else if (net == DGG_NET_DISC) {
+        L.k_in = c->in_bps + 12 + c->n_hand_joints;
+        L.nprefix = 0;
+        L.nrb = 2;
+        L.nh = 1;
+        L.x1_first = false;
+    } else if (net == DGG_NET_EVA) {
+        L.k_in = c->in_bps + 12;
+        L.nprefix = 0;
+        L.nrb = 3;
+        L.nh = 1;
+        L.x1_first = true;
+    } else {
+        return DGG_ERR_INVALID;
+    }
+    L.k0 = L.nprefix + L.k_in;
+    L.ldx0 = (int)align4(L.k0);
+    int64_t po = 0, bo = 0;
+    auto P = [&](int64_t n) { int64_t o = po; po = align4(po + n); return o; };
+    auto S = [&](int64_t n) { int64_t o = bo; bo = align4(bo + n); return o; };
+    L.ibnw = P(L.k_in);
+    L.ibnb = P(L.k_in);
+    L.irm = S(L.k_in);
+    L.irv = S(L.k_in);
+    for (int r = 0; r < L.nrb; ++r) {
+        RbL& R = L.rb[r];
+        R.fin = (r == 0) ? L.k0 : L.k0 + L.nn;
+        R.w13 = P((int64_t)L.n13 * R.fin);
+        R.b13 = P(L.n13);
+        R.bn1w = P(L.hid);
+        R.bn1b = P(L.hid);
+        R.w2 = P((int64_t)L.nn * L.hid);
+        R.b2 = P(L.nn);
+        R.bn2w = P(L.nn);
+        R.bn2b = P(L.nn);
+        R.rm1 = S(L.hid);
+        R.rv1 = S(L.hid);
+        R.rm2 = S(L.nn);
+        R.rv2 = S(L.nn);
+    }
+    // heads: weight matrix immediately followed by its bias vector (nh*512 is a multiple of 4)
+    L.wh = P((int64_t)L.nh * L.nn);
+    L.bh = L.wh + (int64_t)L.nh * L.nn;
+    po = align4(L.bh + L.nh);
+    L.nparam = po;
+    L.nbn = bo;
+    return DGG_OK;
+}
+
+static int add_entry(dgg_entry* out, int cap, int& n, const char* name, int64_t off, int rows, int cols, int kind) {
+    if (out && n < cap) {
+        memset(&out[n], 0, sizeof(dgg_entry));
+        snprintf(out[n].name, sizeof(out[n].name), "%s", name);
+        out[n].offset = off;
+        out[n].rows = rows;
+        out[n].cols = cols;
+        out[n].kind = kind;
+    }
+    ++n;
+    return n;
+}
+
+static int fill_table(const NetL& L, const dgg_cfg* c, dgg_entry* out, int cap) {
+    int n = 0;
+    char nm[64];
+    const char* ibn = L.net == DGG_NET_GEN ? "gen_bn1" : L.net == DGG_NET_DISC ? "disc_bn1" : "bn1";
+    const char* rbp = L.net == DGG_NET_GEN ? "gen_rb" : L.net == DGG_NET_DISC ? "disc_rb" : "rb";
+    auto E = [&](const char* a, const char* b, int64_t off, int rows, int cols, int kind) {
+        snprintf(nm, sizeof(nm), "%s.%s", a, b);
+        add_entry(out, cap, n, nm, off, rows, cols, kind);
+    };
+    E(ibn, "weight", L.ibnw, L.k_in, 1, 0);
+    E(ibn, "bias", L.ibnb, L.k_in, 1, 0);
+    E(ibn, "running_mean", L.irm, L.k_in, 1, 1);
+    E(ibn, "running_var", L.irv, L.k_in, 1, 1);
+    for (int r = 0; r < L.nrb; ++r) {
+        const RbL& R = L.rb[r];
+        char pre[32];
+        snprintf(pre, sizeof(pre), "%s%d", rbp, r + 1);
+        E(pre, "fc1.weight", R.w13, L.hid, R.fin, 0);
+        E(pre, "fc3.weight", R.w13 + (int64_t)L.hid * R.fin, L.nn, R.fin, 0);
+        E(pre, "fc1.bias", R.b13, L.hid, 1, 0);
+        E(pre, "fc3.bias", R.b13 + L.hid, L.nn, 1, 0);
+        E(pre, "bn1.weight", R.bn1w, L.hid, 1, 0);
+        E(pre, "bn1.bias", R.bn1b, L.hid, 1, 0);
+        E(pre, "fc2.weight", R.w2, L.nn, L.hid, 0);
+        E(pre, "fc2.bias", R.b2, L.nn, 1, 0);
+        E(pre, "bn2.weight", R.bn2w, L.nn, 1, 0);
+        E(pre, "bn2.bias", R.bn2b, L.nn, 1, 0);
+        E(pre, "bn1.running_mean", R.rm1, L.hid, 1, 1);
+        E(pre, "bn1.running_var", R.rv1, L.hid, 1, 1);
+        E(pre, "bn2.running_mean", R.rm2, L.nn, 1, 1);
+        E(pre, "bn2.running_var", R.rv2, L.nn, 1, 1);
+    }
+    if (L.net == DGG_NET_GEN) {
+        const int nj = c->n_hand_joints;
+        add_entry(out, cap, n, "gen_joint_conf.weight", L.wh, nj, L.nn, 0);
+        add_entry(out, cap, n, "gen_rot.weight", L.wh + (int64_t)nj * L.nn, 6, L.nn, 0);
+        add_entry(out, cap, n, "gen_transl.weight", L.wh + (int64_t)(nj + 6) * L.nn, 3, L.nn, 0);
+        add_entry(out, cap, n, "gen_joint_conf.bias", L.bh, nj, 1, 0);
+        add_entry(out, cap, n, "gen_rot.bias", L.bh + nj, 6, 1, 0);
+        add_entry(out, cap, n, "gen_transl.bias", L.bh + nj + 6, 3, 1, 0);
+    } else {
+        add_entry(out, cap, n, "out_success.weight", L.wh, 1, L.nn, 0);
+        add_entry(out, cap, n, "out_success.bias", L.bh, 1, 1, 0);
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Workspace carving (identical in forward and backward so saved activations are found again)
+// ------------------------------------------------------------------------------------------------
+struct RbW {
+    float *a13, *h, *a2, *y;
+    uint8_t* keep;
+    float *mean1, *rstd1, *mean2, *rstd2;
+};
+struct NetW {
+    float *X0, *imean, *irstd;
+    RbW rb[3];
+    // scratch (not preserved between calls)
+    float *slabs, *part, *sums, *dY13, *dpre, *da2, *dh, *dX0, *dXa, *dXb;
+    int64_t slab_floats;
+    size_t bytes;
+};
+
+struct Bump {
+    char* base;
+    size_t off;
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+struct Seg {
+    const float* p;  // forward operand (B x width, row pitch ld)
+    int ld, width, wcol;
+    float* dp;       // backward: gradient destination for columns [d_lo, d_hi) of this segment
+    int dld, d_lo, d_hi, d_accum;
+};
+
+static const int kSlabCap = 24;  // upper bound on split-K slabs of one GEMM
+
+// Split-K plan for the fused fc1||fc3 GEMM over `nseg` column segments.
+static void plan13(int B, int n13, const int* widths, int nseg, int* splits) {
+    int bm, bn;
+    gemm_tile_shape(GEMM_NT, B, n13, bm, bn);
+    const int tiles = ((B + bm - 1) / bm) * ((n13 + bn - 1) / bn);
+    int total_kt = 0;
+    for (int i = 0; i < nseg; ++i) total_kt += (widths[i] + 31) / 32;
+    static int target = -1;
+    if (target < 0) {
+        const char* e = getenv("DGG_SPLITK_TARGET");
+        target = e ? atoi(e) : 512;
+        if (target < 1) target = 1;
+    }
+    int s_total = target / (tiles > 0 ? tiles : 1);
+    if (s_total < 1) s_total = 1;
+    if (s_total > 16) s_total = 16;
+    int kt_per = (total_kt + s_total - 1) / s_total;
+    if (kt_per < 4) kt_per = 4;
+    for (int i = 0; i < nseg; ++i) {
+        const int kt = (widths[i] + 31) / 32;
+        int s = (kt + kt_per - 1) / kt_per;
+        if (s < 1) s = 1;
+        splits[i] = s;
+    }
+}
+
+static void carve(const NetL& L, int B, void* base, NetW& W) {
+    Bump b{reinterpret_cast<char*>(base), 0};
+    const size_t Bz = (size_t)B;
+    W.X0 = b.take<float>(Bz * L.ldx0);
+    W.imean = b.take<float>(2 * (size_t)L.k_in);
+    W.irstd = b.take<float>(2 * (size_t)L.k_in);
+    for (int r = 0; r < L.nrb; ++r) {
+        RbW& R = W.rb[r];
+        R.a13 = b.take<float>(Bz * L.n13);
+        R.h = b.take<float>(Bz * L.hid);
+        R.a2 = b.take<float>(Bz * L.nn);
+        R.y = b.take<float>(Bz * L.nn);
+        R.keep = b.take<uint8_t>(Bz * L.nn);
+        R.mean1 = b.take<float>(2 * (size_t)L.hid);
+        R.rstd1 = b.take<float>(2 * (size_t)L.hid);
+        R.mean2 = b.take<float>(2 * (size_t)L.nn);
+        R.rstd2 = b.take<float>(2 * (size_t)L.nn);
+    }
+    W.slab_floats = (int64_t)kSlabCap * B * L.n13;
+    // the split plan never needs more than (target/tiles + nseg) slabs; cap the allocation by it
+    {
+        int widths[2] = {L.k0, L.nn};
+        int sp[2];
+        plan13(B, L.n13, widths, 2, sp);
+        int64_t need = (int64_t)(sp[0] + sp[1] + 2) * B * L.n13;
+        if (need < W.slab_floats) W.slab_floats = need;
+    }
+    W.slabs = b.take<float>((size_t)W.slab_floats);
+    const size_t nrb = (Bz + kRowBlock - 1) / kRowBlock + 2;
+    size_t part = 3 * (size_t)L.n13;
+    if (2 * (size_t)L.k_in > part) part = 2 * (size_t)L.k_in;
+    if ((size_t)L.nh * (L.nn + 1) > part) part = (size_t)L.nh * (L.nn + 1);
+    W.part = b.take<float>(nrb * part);
+    size_t sums = 2 * 3 * (size_t)L.n13;
+    if (2 * 2 * (size_t)L.k_in > sums) sums = 2 * 2 * (size_t)L.k_in;
+    W.sums = b.take<float>(sums);
+    W.dY13 = b.take<float>(Bz * L.n13);
+    W.dpre = b.take<float>(Bz * L.nn);
+    W.da2 = b.take<float>(Bz * L.nn);
+    W.dh = b.take<float>(Bz * L.hid);
+    W.dX0 = b.take<float>(Bz * L.ldx0);
+    W.dXa = b.take<float>(Bz * L.nn);
+    W.dXb = b.take<float>(Bz * L.nn);
+    W.bytes = (b.off + 255) & ~(size_t)255;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM helpers
+// ------------------------------------------------------------------------------------------------
+static void prob_init(GemmProb& p, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N,
+                      int K) {
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.B = Bm; p.C = C;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K;
+    p.splits = 0;
+    p.kchunk = K;
+}
+
+static void prob_split(GemmProb& p, int splits, long long slab_stride) {
+    const int ksteps = (p.K + 31) / 32;
+    if (splits < 1) splits = 1;
+    const int per = (ksteps + splits - 1) / splits;
+    p.kchunk = per * 32;
+    p.splits = (p.K + p.kchunk - 1) / p.kchunk;
+    if (p.splits < 1) p.splits = 1;
+    p.slab_stride = slab_stride;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ResBlock forward (networks.py:43-56) on column segments of the (virtual) concatenated input.
+// ------------------------------------------------------------------------------------------------
+struct Ctx {
+    const NetL* L;
+    const float* P;   // params
+    float* G;         // grads (backward)
+    float* bn;        // running stats (forward)
+    NetW W;
+    int B;
+    bool train;
+    hipStream_t st;
+};
+
+static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, const float* keep_in, uint64_t seed,
+                      uint64_t seed_off) {
+    const NetL& L = *c.L;
+    const RbL& R = L.rb[r];
+    RbW& A = c.W.rb[r];
+    const int B = c.B;
+    // 1. [a1 | a3] partial products: X_seg (B x width) * W13[:, wcol:wcol+width]^T -> split-K slabs
+    int widths[4], sp[4];
+    for (int i = 0; i < nseg; ++i) widths[i] = segs[i].width;
+    plan13(B, L.n13, widths, nseg, sp);
+    GemmBatch gb;
+    memset(&gb, 0, sizeof(gb));
+    gb.nprob = nseg;
+    const long long slab = (long long)B * L.n13;
+    int nslab = 0;
+    for (int i = 0; i < nseg; ++i) {
+        prob_init(gb.p[i], segs[i].p, segs[i].ld, c.P + R.w13 + segs[i].wcol, R.fin, c.W.slabs + (size_t)nslab * slab,
+                  L.n13, B, L.n13, segs[i].width);
+        prob_split(gb.p[i], sp[i], slab);
+        nslab += gb.p[i].splits;
+    }
+    if ((int64_t)nslab * slab > c.W.slab_floats) return DGG_ERR_WORKSPACE;
+    DGG_TRY(gemm_launch(GEMM_NT, gb, c.st));
+    // 2. sum slabs + bias; a1 -> statistics, a3 -> s = lrelu(a3)
+    DGG_TRY(reduce_bias_launch(c.W.slabs, nslab, slab, L.n13, c.P + R.b13, A.a13, L.n13, B, B, 1, L.n13, 0, L.hid,
+                               L.hid, L.n13, c.W.part, c.st));
+    DGG_TRY(bn_finalize_launch(c.W.part, B, 1, L.hid, c.train, c.bn ? c.bn + R.rm1 : nullptr,
+                               c.bn ? c.bn + R.rv1 : nullptr, A.mean1, A.rstd1, c.st));
+    // 3. h = lrelu(bn1(a1))
+    DGG_TRY(bn_act_launch(A.a13, L.n13, B, B, L.hid, A.mean1, A.rstd1, c.P + R.bn1w, c.P + R.bn1b, A.h, L.hid, c.st));
+    // 4. a2 = h W2^T + b2 (K = 256)
+    {
+        GemmBatch g2;
+        memset(&g2, 0, sizeof(g2));
+        g2.nprob = 1;
+        prob_init(g2.p[0], A.h, L.hid, c.P + R.w2, L.hid, c.W.slabs, L.nn, B, L.nn, L.hid);
+        const long long slab2 = (long long)B * L.nn;
+        prob_split(g2.p[0], gemm_pick_splits(GEMM_NT, B, L.nn, L.hid, 0), slab2);
+        DGG_TRY(gemm_launch(GEMM_NT, g2, c.st));
+        DGG_TRY(reduce_bias_launch(c.W.slabs, g2.p[0].splits, slab2, L.nn, c.P + R.b2, A.a2, L.nn, B, B, 1, L.nn, 0,
+                                   L.nn, 0, 0, c.W.part, c.st));
+    }
+    DGG_TRY(bn_finalize_launch(c.W.part, B, 1, L.nn, c.train, c.bn ? c.bn + R.rm2 : nullptr,
+                               c.bn ? c.bn + R.rv2 : nullptr, A.mean2, A.rstd2, c.st));
+    // 5. y = lrelu(s + bn2(a2)) [dropout]
+    DGG_TRY(res_out_launch(A.a13 + L.hid, L.n13, A.a2, L.nn, B, B, L.nn, A.mean2, A.rstd2, c.P + R.bn2w, c.P + R.bn2b,
+                           drop_mode, keep_in, seed, seed_off, A.keep, A.y, L.nn, c.st));
+    return DGG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ResBlock backward.  dy: gradient w.r.t. the block output y (B x 512).
+// ------------------------------------------------------------------------------------------------
+static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy, bool had_dropout, bool accum,
+                       bool skip_param) {
+    const NetL& L = *c.L;
+    const RbL& R = L.rb[r];
+    RbW& A = c.W.rb[r];
+    const int B = c.B;
+    const int nrb = (B + kRowBlock - 1) / kRowBlock;
+    float* G = c.G;
+    auto gp = [&](int64_t off) -> float* { return skip_param ? nullptr : G + off; };
+    const int acc = accum ? 1 : 0;
+    // 1. through the output LeakyReLU / dropout; split into the bn2 branch (dpre) and the fc3 branch (da3)
+    DGG_TRY(res_out_bwd_launch(dy, L.nn, A.y, L.nn, had_dropout ? A.keep : nullptr, A.a13 + L.hid, L.n13, A.a2, L.nn,
+                               A.mean2, A.rstd2, B, B, L.nn, c.W.dpre, c.W.dY13 + L.hid, L.n13, c.W.part, c.st));
+    DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 3, L.nn, c.W.sums, gp(R.bn2b), gp(R.bn2w), gp(R.b13 + L.hid),
+                                   acc, c.st));
+    // 2. bn2 backward -> da2; its column sums are fc2.bias' gradient
+    DGG_TRY(bn_bwd_apply_launch(c.W.dpre, L.nn, A.a2, L.nn, A.mean2, A.rstd2, c.P + R.bn2w, c.W.sums, c.train, B, B,
+                                L.nn, c.W.da2, L.nn, c.W.part, c.st));
+    if (!skip_param)
+        DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 1, L.nn, nullptr, G + R.b2, nullptr, nullptr, acc, c.st));
+    // 3. fc2: dW2 = da2^T h ; dh = da2 W2
+    if (!skip_param) {
+        GemmBatch g;
+        memset(&g, 0, sizeof(g));
+        g.nprob = 1;
+        prob_init(g.p[0], c.W.da2, L.nn, A.h, L.hid, G + R.w2, L.hid, L.nn, L.hid, B);
+        g.p[0].accumulate = acc;
+        DGG_TRY(gemm_launch(GEMM_TN, g, c.st));
+    }
+    {
+        GemmBatch g;
+        memset(&g, 0, sizeof(g));
+        g.nprob = 1;
+        prob_init(g.p[0], c.W.da2, L.nn, c.P + R.w2, L.hid, c.W.dh, L.hid, B, L.hid, L.nn);
+        DGG_TRY(gemm_launch(GEMM_NN, g, c.st));
+    }
+    // 4. through lrelu and bn1 -> da1 into dY13[:, 0:256]
+    DGG_TRY(act_bwd_launch(c.W.dh, L.hid, A.h, L.hid, A.a13, L.n13, A.mean1, A.rstd1, B, B, L.hid, c.W.dh, L.hid,
+                           c.W.part, c.st));
+    DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 2, L.hid, c.W.sums, gp(R.bn1b), gp(R.bn1w), nullptr, acc, c.st));
+    DGG_TRY(bn_bwd_apply_launch(c.W.dh, L.hid, A.a13, L.n13, A.mean1, A.rstd1, c.P + R.bn1w, c.W.sums, c.train, B, B,
+                                L.hid, c.W.dY13, L.n13, c.W.part, c.st));
+    if (!skip_param)
+        DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 1, L.hid, nullptr, G + R.b13, nullptr, nullptr, acc, c.st));
+    // 5. wgrad of [fc1;fc3]: dW13[:, wcol:] = dY13^T X_seg
+    if (!skip_param) {
+        GemmBatch g;
+        memset(&g, 0, sizeof(g));
+        g.nprob = nseg;
+        for (int i = 0; i < nseg; ++i) {
+            prob_init(g.p[i], c.W.dY13, L.n13, segs[i].p, segs[i].ld, G + R.w13 + segs[i].wcol, R.fin, L.n13,
+                      segs[i].width, B);
+            g.p[i].accumulate = acc;
+        }
+        // the widest segment decides the tile shape
+        if (nseg == 2 && g.p[1].N > g.p[0].N) { GemmProb t = g.p[0]; g.p[0] = g.p[1]; g.p[1] = t; }
+        DGG_TRY(gemm_launch(GEMM_TN, g, c.st));
+    }
+    // 6. dgrad: dX_seg[:, lo:hi] (+)= dY13 W13[:, wcol+lo : wcol+hi]
+    {
+        GemmBatch g;
+        memset(&g, 0, sizeof(g));
+        int np = 0;
+        for (int i = 0; i < nseg; ++i) {
+            if (!segs[i].dp || segs[i].d_hi <= segs[i].d_lo) continue;
+            prob_init(g.p[np], c.W.dY13, L.n13, c.P + R.w13 + segs[i].wcol + segs[i].d_lo, R.fin,
+                      segs[i].dp + segs[i].d_lo, segs[i].dld, B, segs[i].d_hi - segs[i].d_lo, L.n13);
+            g.p[np].accumulate = segs[i].d_accum;
+            ++np;
+        }
+        if (np == 2 && g.p[1].N > g.p[0].N) { GemmProb t = g.p[0]; g.p[0] = g.p[1]; g.p[1] = t; }
+        g.nprob = np;
+        if (np > 0) DGG_TRY(gemm_launch(GEMM_NN, g, c.st));
+    }
+    return DGG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Whole-network forward / backward
+// ------------------------------------------------------------------------------------------------
+static void make_segs(const NetL& L, NetW& W, int r, Seg* segs, int& nseg) {
+    memset(segs, 0, 2 * sizeof(Seg));
+    if (r == 0) {
+        nseg = 1;
+        segs[0].p = W.X0; segs[0].ld = L.ldx0; segs[0].width = L.k0; segs[0].wcol = 0;
+        return;
+    }
+    nseg = 2;
+    const int ix0 = L.x1_first ? 1 : 0, ix1 = L.x1_first ? 0 : 1;
+    segs[ix0].p = W.X0; segs[ix0].ld = L.ldx0; segs[ix0].width = L.k0; segs[ix0].wcol = L.x1_first ? L.nn : 0;
+    segs[ix1].p = W.rb[r - 1].y; segs[ix1].ld = L.nn; segs[ix1].width = L.nn; segs[ix1].wcol = L.x1_first ? 0 : L.k0;
+}
+
+static int net_forward(const NetL& L, const float* params, float* bn, void* ws, size_t ws_bytes, int B, unsigned flags,
+                       const ColSrcs& srcs, const float* prefix, const float* drop_keep, uint64_t seed, float* out,
+                       hipStream_t st) {
+    if (!params || !ws || !out || B < 1) return DGG_ERR_INVALID;
+    Ctx c;
+    c.L = &L; c.P = params; c.G = nullptr; c.bn = bn; c.B = B; c.train = (flags & DGG_TRAIN) != 0; c.st = st;
+    carve(L, B, ws, c.W);
+    if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
+    if (!bn) return DGG_ERR_INVALID;
+    if (c.train) DGG_TRY(ibn_stats_launch(srcs, B, 1, c.W.part, st));
+    DGG_TRY(bn_finalize_launch(c.W.part, B, 1, L.k_in, c.train, bn + L.irm, bn + L.irv, c.W.imean, c.W.irstd, st));
+    DGG_TRY(ibn_apply_launch(srcs, B, B, c.W.imean, c.W.irstd, params + L.ibnw, params + L.ibnb, prefix, L.nprefix,
+                             c.W.X0, L.ldx0, st));
+    const bool drop = (L.net == DGG_NET_EVA) && c.train;
+    for (int r = 0; r < L.nrb; ++r) {
+        Seg segs[2];
+        int nseg;
+        make_segs(L, c.W, r, segs, nseg);
+        const int mode = drop ? (drop_keep ? 1 : 2) : 0;
+        const float* keep = (drop && drop_keep) ? drop_keep + (size_t)r * B * L.nn : nullptr;
+        DGG_TRY(rb_forward(c, r, segs, nseg, mode, keep, seed, (uint64_t)r * (uint64_t)B * L.nn));
+    }
+    const int sig = L.net != DGG_NET_GEN;
+    DGG_TRY(heads_fwd_launch(c.W.rb[L.nrb - 1].y, L.nn, B, L.nn, params + L.wh, params + L.bh, L.nh, sig, out, L.nh,
+                             st));
+    return DGG_OK;
+}
+
+// restrict a column-source list to the columns [lo, hi) of the concat
+static ColSrcs sub_srcs(const ColSrcs& S, int lo, int hi) {
+    ColSrcs o;
+    memset(&o, 0, sizeof(o));
+    int base = 0;
+    for (int i = 0; i < S.nsrc; ++i) {
+        const int a = base, b = base + S.s[i].n;
+        const int l = lo > a ? lo : a, h = hi < b ? hi : b;
+        if (h > l) {
+            o.s[o.nsrc].p = S.s[i].p + (l - a);
+            o.s[o.nsrc].ld = S.s[i].ld;
+            o.s[o.nsrc].n = h - l;
+            o.total += h - l;
+            ++o.nsrc;
+        }
+        base = b;
+    }
+    return o;
+}
+
+// d_out: gradient w.r.t. the heads' pre-activation outputs (B x nh).
+// d_prefix (B x nprefix), d_in_lo/hi + d_in (B x (hi-lo)): input-gradient requests on the BN'd concat.
+static int net_backward(const NetL& L, const float* params, float* grads, void* ws, size_t ws_bytes, int B,
+                        unsigned flags, const ColSrcs& srcs, const float* d_out, float* d_prefix, int d_in_lo,
+                        int d_in_hi, float* d_in, hipStream_t st) {
+    if (!params || !ws || !d_out || B < 1) return DGG_ERR_INVALID;
+    const bool skip = (flags & DGG_SKIP_PARAM_GRADS) != 0;
+    const bool accum = (flags & DGG_ACCUM_GRADS) != 0;
+    if (!skip && !grads) return DGG_ERR_INVALID;
+    Ctx c;
+    c.L = &L; c.P = params; c.G = grads; c.bn = nullptr; c.B = B; c.train = (flags & DGG_TRAIN) != 0; c.st = st;
+    carve(L, B, ws, c.W);
+    if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
+    const bool want_in = d_in && d_in_hi > d_in_lo;
+    // columns of X0 whose gradient is needed
+    int x_lo, x_hi;
+    if (!skip) { x_lo = 0; x_hi = L.k0; }
+    else {
+        x_lo = L.k0; x_hi = 0;
+        if (d_prefix && L.nprefix > 0) { x_lo = 0; x_hi = L.nprefix; }
+        if (want_in) {
+            if (L.nprefix + d_in_lo < x_lo) x_lo = L.nprefix + d_in_lo;
+            if (L.nprefix + d_in_hi > x_hi) x_hi = L.nprefix + d_in_hi;
+        }
+    }
+    const bool drop = (L.net == DGG_NET_EVA) && c.train;
+    // heads
+    float* dy = c.W.dXa;
+    float* other = c.W.dXb;
+    DGG_TRY(heads_bwd_launch(c.W.rb[L.nrb - 1].y, L.nn, d_out, L.nh, B, L.nn, params + L.wh, L.nh, dy, L.nn,
+                             skip ? nullptr : grads + L.wh, skip ? nullptr : grads + L.bh, accum ? 1 : 0, skip ? 1 : 0,
+                             c.W.part, st));
+    for (int r = L.nrb - 1; r >= 0; --r) {
+        Seg segs[2];
+        int nseg;
+        make_segs(L, c.W, r, segs, nseg);
+        for (int i = 0; i < nseg; ++i) {
+            if (segs[i].p == c.W.X0) {
+                if (x_hi > x_lo) {
+                    segs[i].dp = c.W.dX0; segs[i].dld = L.ldx0; segs[i].d_lo = x_lo; segs[i].d_hi = x_hi;
+                    segs[i].d_accum = (r != L.nrb - 1) ? 1 : 0;
+                }
+            } else {
+                segs[i].dp = other; segs[i].dld = L.nn; segs[i].d_lo = 0; segs[i].d_hi = L.nn; segs[i].d_accum = 0;
+            }
+        }
+        DGG_TRY(rb_backward(c, r, segs, nseg, dy, drop, accum, skip));
+        float* t = dy; dy = other; other = t;
+    }
+    // input BatchNorm backward
+    const int nrb = (B + kRowBlock - 1) / kRowBlock;
+    if (!skip) {
+        DGG_TRY(ibn_bwd_stats_launch(srcs, c.W.dX0, L.ldx0, L.nprefix, c.W.imean, c.W.irstd, B, 1, c.W.part, st));
+        DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 2, L.k_in, c.W.sums, grads + L.ibnb, grads + L.ibnw, nullptr,
+                                       accum ? 1 : 0, st));
+        if (want_in) {
+            // sums laid out [2][k_in]; the apply kernel indexes them with the sub-list's width, so give it
+            // per-quantity pointers through a compacted copy when a sub-range is requested
+            if (d_in_lo == 0 && d_in_hi == L.k_in) {
+                DGG_TRY(ibn_bwd_apply_launch(srcs, c.W.dX0, L.ldx0, L.nprefix, c.W.imean, c.W.irstd, params + L.ibnw,
+                                             c.W.sums, c.train, B, B, 0, L.k_in, d_in, L.k_in, st));
+            } else {
+                ColSrcs sub = sub_srcs(srcs, d_in_lo, d_in_hi);
+                DGG_TRY(ibn_bwd_stats_launch(sub, c.W.dX0, L.ldx0, L.nprefix + d_in_lo, c.W.imean + d_in_lo,
+                                             c.W.irstd + d_in_lo, B, 1, c.W.part, st));
+                DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 2, sub.total, c.W.sums, nullptr, nullptr, nullptr, 0,
+                                               st));
+                DGG_TRY(ibn_bwd_apply_launch(sub, c.W.dX0, L.ldx0, L.nprefix + d_in_lo, c.W.imean + d_in_lo,
+                                             c.W.irstd + d_in_lo, params + L.ibnw + d_in_lo, c.W.sums, c.train, B, B,
+                                             0, sub.total, d_in, sub.total, st));
+            }
+        }
+    } else if (want_in) {
+        ColSrcs sub = sub_srcs(srcs, d_in_lo, d_in_hi);
+        if (c.train) {
+            DGG_TRY(ibn_bwd_stats_launch(sub, c.W.dX0, L.ldx0, L.nprefix + d_in_lo, c.W.imean + d_in_lo,
+                                         c.W.irstd + d_in_lo, B, 1, c.W.part, st));
+            DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 2, sub.total, c.W.sums, nullptr, nullptr, nullptr, 0, st));
+        }
+        DGG_TRY(ibn_bwd_apply_launch(sub, c.W.dX0, L.ldx0, L.nprefix + d_in_lo, c.W.imean + d_in_lo,
+                                     c.W.irstd + d_in_lo, params + L.ibnw + d_in_lo, c.W.sums, c.train, B, B, 0,
+                                     sub.total, d_in, sub.total, st));
+    }
+    if (d_prefix && L.nprefix > 0) DGG_TRY(copy_cols_launch(c.W.dX0, L.ldx0, d_prefix, L.nprefix, B, L.nprefix, st));
+    return DGG_OK;
+}
+
+static ColSrcs srcs_gen(const dgg_cfg* cfg, const float* bps) {
+    ColSrcs s;
+    memset(&s, 0, sizeof(s));
+    s.nsrc = 1;
+    s.s[0].p = bps; s.s[0].ld = cfg->in_bps; s.s[0].n = cfg->in_bps;
+    s.total = cfg->in_bps;
+    return s;
+}
+
+static ColSrcs srcs_pose(const dgg_cfg* cfg, const float* bps, const float* rot9, const float* transl,
+                         const float* joint) {
+    ColSrcs s;
+    memset(&s, 0, sizeof(s));
+    s.s[0].p = bps; s.s[0].ld = cfg->in_bps; s.s[0].n = cfg->in_bps;
+    s.s[1].p = rot9; s.s[1].ld = 9; s.s[1].n = 9;
+    s.s[2].p = transl; s.s[2].ld = 3; s.s[2].n = 3;
+    s.nsrc = 3;
+    s.total = cfg->in_bps + 12;
+    if (joint) {
+        s.s[3].p = joint; s.s[3].ld = cfg->n_hand_joints; s.s[3].n = cfg->n_hand_joints;
+        s.nsrc = 4;
+        s.total += cfg->n_hand_joints;
+    }
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Training phases (dexgangrasp.py:739-823)
+// ------------------------------------------------------------------------------------------------
+struct StepW {
+    void *ws_g, *ws_dr, *ws_df;
+    size_t g_bytes, d_bytes;
+    float *heads, *rfake, *f_transl, *f_joint, *p_real, *p_fake, *p_gen, *dl_real, *dl_fake, *dl_gen, *d_pose,
+        *d_heads;
+    size_t bytes;
+};
+
+static int carve_step(const dgg_cfg* cfg, int B, void* base, StepW& S) {
+    NetL Lg, Ld;
+    DGG_TRY(build_layout(DGG_NET_GEN, cfg, Lg));
+    DGG_TRY(build_layout(DGG_NET_DISC, cfg, Ld));
+    NetW t;
+    carve(Lg, B, nullptr, t);
+    S.g_bytes = t.bytes;
+    carve(Ld, B, nullptr, t);
+    S.d_bytes = t.bytes;
+    Bump b{reinterpret_cast<char*>(base), 0};
+    S.ws_g = b.take<char>(S.g_bytes);
+    S.ws_dr = b.take<char>(S.d_bytes);
+    S.ws_df = b.take<char>(S.d_bytes);
+    const size_t Bz = (size_t)B;
+    const int nj = cfg->n_hand_joints;
+    S.heads = b.take<float>(Bz * (nj + 9));
+    S.rfake = b.take<float>(Bz * 9);
+    S.f_transl = b.take<float>(Bz * 3);
+    S.f_joint = b.take<float>(Bz * nj);
+    S.p_real = b.take<float>(Bz);
+    S.p_fake = b.take<float>(Bz);
+    S.p_gen = b.take<float>(Bz);
+    S.dl_real = b.take<float>(Bz);
+    S.dl_fake = b.take<float>(Bz);
+    S.dl_gen = b.take<float>(Bz);
+    S.d_pose = b.take<float>(Bz * (12 + nj));
+    S.d_heads = b.take<float>(Bz * (nj + 9));
+    S.bytes = (b.off + 255) & ~(size_t)255;
+    return DGG_OK;
+}
+
+}  // namespace dgg
+
+using namespace dgg;
+
+// =================================================================================================
+extern "C" {
+
+const char* dgg_version(void) { return "dgg 0.1 (gfx950, fp32 MFMA)"; }
+const char* dgg_last_error(void) { return g_err; }
+
+int dgg_table(int net, const dgg_cfg* cfg, dgg_entry* out, int cap) {
+    NetL L;
+    int rc = build_layout(net, cfg, L);
+    if (rc) return rc;
+    return fill_table(L, cfg, out, cap);
+}
+
+int64_t dgg_param_floats(int net, const dgg_cfg* cfg) {
+    NetL L;
+    if (build_layout(net, cfg, L)) return DGG_ERR_INVALID;
+    return L.nparam;
+}
+
+int64_t dgg_bnstat_floats(int net, const dgg_cfg* cfg) {
+    NetL L;
+    if (build_layout(net, cfg, L)) return DGG_ERR_INVALID;
+    return L.nbn;
+}
+
+int64_t dgg_workspace_bytes(int net, const dgg_cfg* cfg, int batch) {
+    NetL L;
+    if (batch < 1 || build_layout(net, cfg, L)) return DGG_ERR_INVALID;
+    NetW W;
+    carve(L, batch, nullptr, W);
+    return (int64_t)W.bytes;
+}
+
+int dgg_bps_encode(const float* clouds, int B, int N, const float* basis, int P, float* dists, int32_t* ids,
+                   void* stream) {
+    return bps_encode_launch(clouds, B, N, basis, P, dists, ids, (hipStream_t)stream);
+}
+
+int dgg_gen_forward(const dgg_cfg* cfg, const float* params, float* bnstats, void* ws, size_t ws_bytes, int B,
+                    unsigned flags, const float* z, const float* bps, float* out_heads, void* stream) {
+    NetL L;
+    DGG_TRY(build_layout(DGG_NET_GEN, cfg, L));
+    if (!z || !bps) return DGG_ERR_INVALID;
+    return net_forward(L, params, bnstats, ws, ws_bytes, B, flags, srcs_gen(cfg, bps), z, nullptr, 0, out_heads,
+                       (hipStream_t)stream);
+}
+
+int dgg_gen_backward(const dgg_cfg* cfg, const float* params, float* grads, void* ws, size_t ws_bytes, int B,
+                     unsigned flags, const float* z, const float* bps, const float* d_heads, float* d_z, float* d_bps,
+                     void* stream) {
+    NetL L;
+    DGG_TRY(build_layout(DGG_NET_GEN, cfg, L));
+    if (!bps) return DGG_ERR_INVALID;
+    (void)z;
+    return net_backward(L, params, grads, ws, ws_bytes, B, flags, srcs_gen(cfg, bps), d_heads, d_z, 0,
+                        d_bps ? L.k_in : 0, d_bps, (hipStream_t)stream);
+}
+
+int dgg_disc_forward(const dgg_cfg* cfg, const float* params, float* bnstats, void* ws, size_t ws_bytes, int B,
+                     unsigned flags, const float* bps, const float* rot9, const float* transl, const float* joint,
+                     float* out_p, void* stream) {
+    NetL L;
+    DGG_TRY(build_layout(DGG_NET_DISC, cfg, L));
+    if (!bps || !rot9 || !transl || !joint) return DGG_ERR_INVALID;
+    return net_forward(L, params, bnstats, ws, ws_bytes, B, flags, srcs_pose(cfg, bps, rot9, transl, joint), nullptr,
+                       nullptr, 0, out_p, (hipStream_t)stream);
+}
+
+int dgg_disc_backward(const dgg_cfg* cfg, const float* params, float* grads, void* ws, size_t ws_bytes, int B,
+                      unsigned flags, const float* bps, const float* rot9, const float* transl, const float* joint,
+                      const float* d_logit, float* d_pose, void* stream) {
+    NetL L;
+    DGG_TRY(build_layout(DGG_NET_DISC, cfg, L));
+    if (!bps || !rot9 || !transl || !joint) return DGG_ERR_INVALID;
+    const bool want = (flags & DGG_NEED_INPUT_GRADS) != 0;
+    if (want && !d_pose) return DGG_ERR_INVALID;
+    return net_backward(L, params, grads, ws, ws_bytes, B, flags, srcs_pose(cfg, bps, rot9, transl, joint), d_logit,
+                        nullptr, want ? cfg->in_bps : 0, want ? L.k_in : 0, want ? d_pose : nullptr,
+                        (hipStream_t)stream);
+}
+
+int dgg_eva_forward(const dgg_cfg* cfg, const float* params, float* bnstats, void* ws, size_t ws_bytes, int B,
+                    unsigned flags, const float* bps, const float* rot9, const float* transl, const float* drop_keep,
+                    uint64_t seed, float* out_p, void* stream) {
+    NetL L;
+    DGG_TRY(build_layout(DGG_NET_EVA, cfg, L));
+    if (!bps || !rot9 || !transl) return DGG_ERR_INVALID;
+    return net_forward(L, params, bnstats, ws, ws_bytes, B, flags, srcs_pose(cfg, bps, rot9, transl, nullptr), nullptr,
+                       drop_keep, seed, out_p, (hipStream_t)stream);
+}
+
+int dgg_eva_backward(const dgg_cfg* cfg, const float* params, float* grads, void* ws, size_t ws_bytes, int B,
+                     unsigned flags, const float* bps, const float* rot9, const float* transl, const float* d_logit,
+                     float* d_pose, void* stream) {
+    NetL L;
+    DGG_TRY(build_layout(DGG_NET_EVA, cfg, L));
+    if (!bps || !rot9 || !transl) return DGG_ERR_INVALID;
+    const bool want = (flags & DGG_NEED_INPUT_GRADS) != 0;
+    if (want && !d_pose) return DGG_ERR_INVALID;
+    return net_backward(L, params, grads, ws, ws_bytes, B, flags, srcs_pose(cfg, bps, rot9, transl, nullptr), d_logit,
+                        nullptr, want ? cfg->in_bps : 0, want ? L.k_in : 0, want ? d_pose : nullptr,
+                        (hipStream_t)stream);
+}
+
+int dgg_ortho6d_forward(const float* o6, int ld_o6, int B, float* rot9, void* stream) {
+    if (!o6 || !rot9 || B < 1 || ld_o6 < 6) return DGG_ERR_INVALID;
+    return ortho6d_fwd_launch(o6, ld_o6, B, rot9, (hipStream_t)stream);
+}
+
+int dgg_ortho6d_backward(const float* o6, int ld_o6, int B, const float* d_rot9, float* d_o6, int ld_do6,
+                         void* stream) {
+    if (!o6 || !d_rot9 || !d_o6 || B < 1 || ld_o6 < 6 || ld_do6 < 6) return DGG_ERR_INVALID;
+    return ortho6d_bwd_launch(o6, ld_o6, B, d_rot9, d_o6, ld_do6, (hipStream_t)stream);
+}
+
+int dgg_bce(const float* p, const float* labels, float target_const, int B, float weight, float loss_scale,
+            float* loss_out, float* d_logit, void* stream) {
+    if (!p || !loss_out || B < 1) return DGG_ERR_INVALID;
+    return bce_launch(p, labels, target_const, B, weight, loss_scale, loss_out, d_logit, (hipStream_t)stream);
+}
+
+int dgg_adam_l2(float* params, const float* grads, float* m, float* v, int64_t n, int step, float lr, float beta1,
+                float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+    if (!params || !grads || !m || !v) return DGG_ERR_INVALID;
+    return adam_launch(params, grads, m, v, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                       (hipStream_t)stream);
+}
+
+int dgg_gen_loss(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const float* heads, const float* gt_rot9,
+                 const float* gt_transl, const float* gt_joint, const float* fake_score, const float* d_pose,
+                 float* losses, float* d_heads, void* stream) {
+    if (!cfg_ok(cfg) || !hp || !heads || !gt_rot9 || !gt_transl || !gt_joint || !losses || B < 1)
+        return DGG_ERR_INVALID;
+    return gen_loss_launch(cfg, hp, B, heads, gt_rot9, gt_transl, gt_joint, fake_score, d_pose, losses, d_heads,
+                           (hipStream_t)stream);
+}
+
+int dgg_translate_along_axis(float* transl, const float* rot9, int B, int axis, float offset, void* stream) {
+    if (!transl || !rot9 || B < 1 || axis < 0 || axis > 2) return DGG_ERR_INVALID;
+    return translate_axis_launch(transl, rot9, B, axis, offset, (hipStream_t)stream);
+}
+
+int64_t dgg_cgan_workspace_bytes(const dgg_cfg* cfg, int batch) {
+    if (batch < 1) return DGG_ERR_INVALID;
+    StepW S;
+    if (carve_step(cfg, batch, nullptr, S)) return DGG_ERR_INVALID;
+    return (int64_t)S.bytes;
+}
+
+int dgg_cgan_d_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, void* ws, size_t ws_bytes,
+                     int B, const float* bps, const float* rot9, const float* transl, const float* joint,
+                     const float* z, float* losses, void* stream) {
+    if (!s || !hp || !ws || !bps || !rot9 || !transl || !joint || !z || !losses) return DGG_ERR_INVALID;
+    StepW S;
+    DGG_TRY(carve_step(cfg, B, ws, S));
+    if (S.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
+    const int nj = cfg->n_hand_joints;
+    const int nh = nj + 9;
+    hipStream_t st = (hipStream_t)stream;
+    // :772-776 generator forward (train mode, activations kept for the G phase), R = ortho6d(rot_6D)
+    DGG_TRY(dgg_gen_forward(cfg, s->g_params, s->g_bn, S.ws_g, S.g_bytes, B, DGG_TRAIN, z, bps, S.heads, stream));
+    DGG_TRY(ortho6d_fwd_launch(S.heads + nj, nh, B, S.rfake, st));
+    // fake transl / joint live inside the heads buffer with pitch nh: pack contiguous copies for D
+    float* f_transl = S.f_transl;
+    float* f_joint = S.f_joint;
+    DGG_TRY(copy_cols_launch(S.heads + nj + 6, nh, f_transl, 3, B, 3, st));
+    DGG_TRY(copy_cols_launch(S.heads, nh, f_joint, nj, B, nj, st));
+    // :788-789 D(real) then D(fake.detach()): BN running statistics advance in this order
+    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint,
+                             S.p_real, stream));
+    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN, bps, S.rfake, f_transl,
+                             f_joint, S.p_fake, stream));
+    // :213-232 loss = (BCE(real,1) + BCE(fake,0)) / 2
+    DGG_TRY(bce_launch(S.p_real, nullptr, 1.f, B, hp->bce_weight, 0.5f, losses + DGG_L_BCE_REAL, S.dl_real, st));
+    DGG_TRY(bce_launch(S.p_fake, nullptr, 0.f, B, hp->bce_weight, 0.5f, losses + DGG_L_BCE_FAKE, S.dl_fake, st));
+    DGG_TRY(disc_loss_combine_launch(losses, st));
+    // :792-793 zero_grad + backward: real pass overwrites, fake pass accumulates
+    DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint,
+                              S.dl_real, nullptr, stream));
+    DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_df, S.d_bytes, B, DGG_TRAIN | DGG_ACCUM_GRADS, bps,
+                              S.rfake, f_transl, f_joint, S.dl_fake, nullptr, stream));
+    return DGG_OK;
+}
+
+int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, void* ws, size_t ws_bytes,
+                     int B, const float* bps, const float* rot9, const float* transl, const float* joint,
+                     const float* z, float* losses, void* stream) {
+    if (!s || !hp || !ws || !bps || !rot9 || !transl || !joint || !z || !losses) return DGG_ERR_INVALID;
+    StepW S;
+    DGG_TRY(carve_step(cfg, B, ws, S));
+    if (S.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
+    const int nj = cfg->n_hand_joints;
+    const int nh = nj + 9;
+    hipStream_t st = (hipStream_t)stream;
+    // :808 D forward #3 with the updated discriminator on the (non-detached) fake grasp; the packed
+    // fake transl / joint copies written by the D phase are still valid (same generator output)
+    float* g_transl = S.f_transl;
+    float* g_joint = S.f_joint;
+    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN, bps, S.rfake, g_transl,
+                             g_joint, S.p_gen, stream));
+    // :293-296 BCE(fake_score, 1) and its gradient; backward through D for the pose inputs only
+    DGG_TRY(bce_launch(S.p_gen, nullptr, 1.f, B, hp->bce_weight, 1.0f, losses + DGG_L_GEN_FAKE, S.dl_gen, st));
+    DGG_TRY(dgg_disc_backward(cfg, s->d_params, nullptr, S.ws_df, S.d_bytes, B,
+                              DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_NEED_INPUT_GRADS, bps, S.rfake, g_transl, g_joint,
+                              S.dl_gen, S.d_pose, stream));
+    // :272-307 reconstruction losses + total; d_heads combines the MSE gradients with D's input gradient
+    DGG_TRY(gen_loss_launch(cfg, hp, B, S.heads, rot9, transl, joint, S.p_gen, S.d_pose, losses, S.d_heads, st));
+    // :814-815 zero_grad + backward through G
+    DGG_TRY(dgg_gen_backward(cfg, s->g_params, s->g_grads, S.ws_g, S.g_bytes, B, DGG_TRAIN, z, bps, S.d_heads, nullptr,
+                             nullptr, stream));
+    return DGG_OK;
+}
+
+int dgg_cgan_step(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, void* ws, size_t ws_bytes, int B,
+                  const float* bps, const float* rot9, const float* transl, const float* joint, const float* z,
+                  int step_d, int step_g, int is_train_gen, float* losses, void* stream) {
+    DGG_TRY(dgg_cgan_d_phase(cfg, s, hp, ws, ws_bytes, B, bps, rot9, transl, joint, z, losses, stream));
+    const int64_t nd = dgg_param_floats(DGG_NET_DISC, cfg), ng = dgg_param_floats(DGG_NET_GEN, cfg);
+    DGG_TRY(dgg_adam_l2(s->d_params, s->d_grads, s->d_m, s->d_v, nd, step_d, hp->lr_dis, hp->beta1, hp->beta2, hp->eps,
+                        hp->weight_decay, hp->grad_scale, stream));
+    if (is_train_gen) {
+        DGG_TRY(dgg_cgan_g_phase(cfg, s, hp, ws, ws_bytes, B, bps, rot9, transl, joint, z, losses, stream));
+        DGG_TRY(dgg_adam_l2(s->g_params, s->g_grads, s->g_m, s->g_v, ng, step_g, hp->lr_gen, hp->beta1, hp->beta2,
+                            hp->eps, hp->weight_decay, hp->grad_scale, stream));
+    }
+    return DGG_OK;
+}
+
+int dgg_eva_phase(const dgg_cfg* cfg, const float* e_params, float* e_grads, float* e_bn, const dgg_hparams* hp,
+                  void* ws, size_t ws_bytes, int B, const float* bps, const float* rot9, const float* transl,
+                  const float* label, const float* drop_keep, uint64_t seed, float* losses, void* stream) {
+    if (!hp || !ws || !label || !losses) return DGG_ERR_INVALID;
+    NetL L;
+    DGG_TRY(build_layout(DGG_NET_EVA, cfg, L));
+    NetW W;
+    carve(L, B, nullptr, W);
+    const size_t extra = ((size_t)B * 2 * sizeof(float) + 255) & ~(size_t)255;
+    if (W.bytes + extra > ws_bytes) return DGG_ERR_WORKSPACE;
+    float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + W.bytes);
+    float* dl = p + B;
+    hipStream_t st = (hipStream_t)stream;
+    DGG_TRY(dgg_eva_forward(cfg, e_params, e_bn, ws, W.bytes, B, DGG_TRAIN, bps, rot9, transl, drop_keep, seed, p,
+                            stream));
+    DGG_TRY(bce_launch(p, label, 0.f, B, hp->bce_weight, 1.0f, losses + DGG_L_TOTAL_EVA, dl, st));
+    DGG_TRY(copy_cols_launch(losses + DGG_L_TOTAL_EVA, 1, losses + DGG_L_BCE_EVA, 1, 1, 1, st));
+    DGG_TRY(dgg_eva_backward(cfg, e_params, e_grads, ws, W.bytes, B, DGG_TRAIN, bps, rot9, transl, dl, nullptr, stream));
+    return DGG_OK;
+}
+
+int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc,
+                 int splits, float* slabs, int accumulate, void* stream) {
+    if (!A || !Bm || !C || M < 1 || N < 1 || K < 1 || mode < 0 || mode > 2) return DGG_ERR_INVALID;
+    GemmBatch g;
+    memset(&g, 0, sizeof(g));
+    g.nprob = 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (splits >= 1) {
+        if (!slabs || accumulate) return DGG_ERR_INVALID;
+        prob_init(g.p[0], A, lda, Bm, ldb, slabs, N, M, N, K);
+        prob_split(g.p[0], splits, (long long)M * N);
+        DGG_TRY(gemm_launch(mode, g, st));
+        return reduce_bias_launch(slabs, g.p[0].splits, (long long)M * N, N, nullptr, C, ldc, M, M, 1, N, 0, 0, 0, 0,
+                                  nullptr, st);
+    }
+    prob_init(g.p[0], A, lda, Bm, ldb, C, ldc, M, N, K);
+    g.p[0].accumulate = accumulate;
+    return gemm_launch(mode, g, st);
+}
+
+}  // extern "C"

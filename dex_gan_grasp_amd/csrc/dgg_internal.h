@@ -1,0 +1,140 @@
+// Internal declarations shared by the HIP translation units of libdgg.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/dgg.h"
+
+namespace dgg {
+
+constexpr float kLrelu = 0.2f;   // networks.py:41
+constexpr float kBnEps = 1e-5f;  // nn.BatchNorm1d default
+constexpr float kBnMom = 0.1f;
+constexpr float kDropP = 0.3f;   // networks.py:294
+constexpr int kRowBlock = 32;    // rows per partial-statistics block
+
+void set_error(const char* what, hipError_t e);
+int check_launch(const char* what);
+
+// ---------------------------------------------------------------- GEMM (gemm_f32.hip)
+// C[M,N] (+)= sum_k A(m,k) * B(k,n) on v_mfma_f32_32x32x2_f32 (exact fp32).
+//   a_kc: A is stored [M][K] (k contiguous) else [K][M];  b_kc: B stored [N][K] else [K][N].
+struct GemmProb {
+    const float* A;
+    const float* B;
+    float* C;          // direct output, or slab base when splits > 0 (slab s at C + s*slab_stride)
+    int M, N, K;
+    int lda, ldb, ldc;
+    int splits;        // 0: write C directly (accumulate honoured); >=1: write `splits` slabs
+    int kchunk;        // K range per split (multiple of BK)
+    long long slab_stride;
+    int accumulate;
+    int tiles_m, tiles_n;
+    int blk_begin;     // first block id of this problem in the grouped launch
+};
+struct GemmBatch {
+    GemmProb p[4];
+    int nprob;
+    int total_blocks;
+};
+enum GemmMode { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
+// Fills tiling fields of one problem for the tile shape the launcher will use; returns #blocks.
+int gemm_plan(GemmProb& p, int mode, int splits);
+int gemm_launch(int mode, GemmBatch& batch, hipStream_t st);
+int gemm_pick_splits(int mode, int M, int N, int K, int other_blocks);
+void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn);
+
+// ---------------------------------------------------------------- BPS encode (bps_encode.hip)
+int bps_encode_launch(const float* clouds, int B, int N, const float* basis, int P, float* dists, int32_t* ids,
+                      hipStream_t st);
+
+// ---------------------------------------------------------------- element-wise / BN / losses (elementwise.hip)
+struct ColSrc {           // one column block of a concatenated input
+    const float* p;
+    int ld;
+    int n;
+};
+struct ColSrcs {
+    ColSrc s[4];
+    int nsrc;
+    int total;            // sum of n
+};
+
+// Partial batch statistics (mean, M2) of the virtual concat of `srcs` per (group,row block,column).
+int ibn_stats_launch(const ColSrcs& srcs, int rows_per_group, int groups, float* part, hipStream_t st);
+// Merge partials -> mean/rstd (train) or take running stats (eval); update running stats.
+//   part: [groups][nrb][2][ncols];  mean/rstd out: [groups][ncols]
+int bn_finalize_launch(const float* part, int rows_per_group, int groups, int ncols, int train, float* run_mean,
+                       float* run_var, float* mean, float* rstd, hipStream_t st);
+// X0[m][col_off + c] = (x - mean)*rstd*gamma + beta over the concat; optionally copies `prefix`
+// (B, nprefix) into columns [0, nprefix).
+int ibn_apply_launch(const ColSrcs& srcs, int B, int rows_per_group, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, const float* prefix, int nprefix, float* X0, int ldx,
+                     hipStream_t st);
+
+// out[m][c] = sum_s slabs[s][m][c] + bias[c];  columns [stat_lo, stat_hi) get partial statistics,
+// columns [act_lo, act_hi) get LeakyReLU applied before the store.
+int reduce_bias_launch(const float* slabs, int nslab, long long slab_stride, int ld_slab, const float* bias,
+                       float* out, int ld_out, int B, int rows_per_group, int groups, int N, int stat_lo,
+                       int stat_hi, int act_lo, int act_hi, float* part, hipStream_t st);
+// h[m][c] = lrelu((a[m][c]-mean)*rstd*gamma+beta)
+int bn_act_launch(const float* a, int lda, int B, int rows_per_group, int N, const float* mean, const float* rstd,
+                  const float* gamma, const float* beta, float* h, int ldh, hipStream_t st);
+// y = lrelu(s + bn2(a2)) then dropout (keep mask given as floats, or drawn from Philox when
+// drop_mode == 2); writes the keep mask (bytes) when dropping.  drop_mode: 0 none, 1 given, 2 rng.
+int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, int rows_per_group, int N,
+                   const float* mean, const float* rstd, const float* gamma, const float* beta, int drop_mode,
+                   const float* keep_in, uint64_t seed, uint64_t seed_off, uint8_t* keep_out, float* y, int ldy,
+                   hipStream_t st);
+// heads: out[m][j] = sum_k y[m][k] Wh[j][k] + bh[j]; sigmoid optionally.
+int heads_fwd_launch(const float* y, int ldy, int B, int K, const float* wh, const float* bh, int nh, int sigmoid,
+                     float* out, int ldo, hipStream_t st);
+// heads backward: dy = dout * Wh (written), partial dWh/dbh -> finalize into grads.
+int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B, int K, const float* wh, int nh,
+                     float* dy, int lddy, float* gwh, float* gbh, int accumulate, int skip_param, float* scratch,
+                     hipStream_t st);
+
+// ResBlock backward element-wise stages ----------------------------------------------------
+// Stage 1: dpre = dy * [keep/(1-p)] * lrelu'(y);  da3 = dpre * lrelu'(s) -> dY13[:, c3off + c];
+//          partial sums: sum dpre, sum dpre*xhat2, sum da3.
+int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const uint8_t* keep, const float* s,
+                       int lds, const float* a2, int lda2, const float* mean, const float* rstd, int B,
+                       int rows_per_group, int N, float* dpre, float* da3, int ldda3, float* part,
+                       hipStream_t st);
+// Stage 2/4 (BN backward apply): dx = gamma*rstd*(dz - sum_dz/B - xhat*sum_dzx/B) (train) or
+//          gamma*rstd*dz (eval);  partial sums of dx (-> bias gradient of the preceding Linear).
+int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, const float* mean, const float* rstd,
+                        const float* gamma, const float* sums /*[groups][2][N]*/, int train, int B,
+                        int rows_per_group, int N, float* dx, int lddx, float* part, hipStream_t st);
+// Stage 3: dq = dh * lrelu'(h) (in place on dh allowed); partial sums: sum dq, sum dq*xhat1.
+int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const float* a1, int lda1, const float* mean,
+                   const float* rstd, int B, int rows_per_group, int N, float* dq, int lddq, float* part,
+                   hipStream_t st);
+// Sum partial column sums over row blocks: part [groups][nrb][nq][ncols] ->
+//   sums_out [groups][nq][ncols] (may be NULL) and, summed over groups, into up to 3 gradient
+//   destinations (NULL to skip): dst[q][c] (+)= sum.
+int colsum_finalize_launch(const float* part, int groups, int nrb, int nq, int ncols, float* sums_out, float* dst0,
+                           float* dst1, float* dst2, int accumulate, hipStream_t st);
+// Input BN backward: partial sums of dX0 and dX0*xhat over the concat sources.
+int ibn_bwd_stats_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col_off, const float* mean,
+                         const float* rstd, int rows_per_group, int groups, float* part, hipStream_t st);
+// Input gradient for a column range [c_lo, c_hi) of the concat: dx written to dst (B, c_hi-c_lo).
+int ibn_bwd_apply_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col_off, const float* mean,
+                         const float* rstd, const float* gamma, const float* sums, int train, int B,
+                         int rows_per_group, int c_lo, int c_hi, float* dst, int ldd, hipStream_t st);
+
+// losses -------------------------------------------------------------------------------------
+int bce_launch(const float* p, const float* labels, float target_const, int B, float weight, float loss_scale,
+               float* loss_out, float* d_logit, hipStream_t st);
+int ortho6d_fwd_launch(const float* o6, int ld, int B, float* rot9, hipStream_t st);
+int ortho6d_bwd_launch(const float* o6, int ld, int B, const float* d_rot9, float* d_o6, int ldd, hipStream_t st);
+int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const float* heads, const float* gt_rot9,
+                    const float* gt_transl, const float* gt_joint, const float* fake_score, const float* d_pose,
+                    float* losses, float* d_heads, hipStream_t st);
+int disc_loss_combine_launch(float* losses, hipStream_t st);
+int adam_launch(float* params, const float* grads, float* m, float* v, int64_t n, int step, float lr, float b1,
+                float b2, float eps, float wd, float grad_scale, hipStream_t st);
+int translate_axis_launch(float* transl, const float* rot9, int B, int axis, float offset, hipStream_t st);
+int copy_cols_launch(const float* src, int lds, float* dst, int ldd, int B, int n, hipStream_t st);
+
+}  // namespace dgg

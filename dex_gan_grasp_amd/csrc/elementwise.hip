@@ -1,0 +1,956 @@
+// Everything around the GEMMs of the ResBlock stacks: BatchNorm1d statistics / apply / backward
+// (networks.py:33,36,71,117,289), LeakyReLU(0.2) (networks.py:41), residual add, dropout
+// (networks.py:294), the small heads (networks.py:75-77,121,293), losses
+// (dexgangrasp.py:142-147,213-232,272-307; losses.py:61-76), rot_matrix_from_ortho6d
+// (utils/utils.py:380-394) and Adam (dexgangrasp.py:97-112).
+//
+// These are HBM/L2-bound column kernels: one thread owns one feature column for a block of
+// kRowBlock rows, so a wave reads 64 consecutive floats of a row (coalesced 256 B), keeps its
+// 32 samples in registers and produces exact two-pass partial statistics (mean, M2) that a tiny
+// finalize kernel merges with Chan's formula — deterministic, no atomics.
+// A batch may consist of `groups` independent BatchNorm batches of rows_per_group rows
+// (the discriminator's real/fake pair, dexgangrasp.py:788-789).
+#include "dgg_internal.h"
+
+namespace dgg {
+
+constexpr int RB = kRowBlock;
+
+__device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : kLrelu * x; }
+__device__ __forceinline__ float lrelu_grad(float y) { return y > 0.f ? 1.f : kLrelu; }
+
+__device__ __forceinline__ const float* src_col(const ColSrcs& S, int c, int& ld) {
+    // column c of the virtual concat -> pointer to element (row 0, c)
+    int base = 0;
+    const float* p = nullptr;
+    ld = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < S.nsrc) {
+            if (c >= base && c < base + S.s[i].n) {
+                p = S.s[i].p + (c - base);
+                ld = S.s[i].ld;
+            }
+            base += S.s[i].n;
+        }
+    }
+    return p;
+}
+
+__device__ __forceinline__ void partial_stats(const float (&v)[RB], int n, float& mean, float& m2) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) s += (r < n) ? v[r] : 0.f;
+    mean = s / (float)n;
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const float d = v[r] - mean;
+        q += (r < n) ? d * d : 0.f;
+    }
+    m2 = q;
+}
+
+// grid: (ceil(ncols/256), groups*nrb)
+__global__ __launch_bounds__(256) void ibn_stats_kernel(ColSrcs S, int rpg, int nrb, float* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= S.total) return;
+    const int g = blockIdx.y / nrb, rb = blockIdx.y % nrb;
+    const int r0 = rb * RB;
+    const int n = min(RB, rpg - r0);
+    int ld;
+    const float* p = src_col(S, c, ld);
+    p += (size_t)(g * rpg + r0) * ld;
+    float v[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) v[r] = (r < n) ? p[(size_t)r * ld] : 0.f;
+    float mean, m2;
+    partial_stats(v, n, mean, m2);
+    float* o = part + (size_t)blockIdx.y * 2 * S.total;
+    o[c] = mean;
+    o[S.total + c] = m2;
+}
+
+// one thread per column; groups processed in order so running statistics see the reference's
+// call order (real batch first, then fake).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rpg, int groups,
+                                                          int nrb, int ncols, int train,
+                                                          float* __restrict__ run_mean,
+                                                          float* __restrict__ run_var, float* __restrict__ mean_out,
+                                                          float* __restrict__ rstd_out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncols) return;
+    if (!train) {
+        const float m = run_mean[c];
+        const float rs = 1.0f / sqrtf(run_var[c] + kBnEps);
+        for (int g = 0; g < groups; ++g) {
+            mean_out[g * ncols + c] = m;
+            rstd_out[g * ncols + c] = rs;
+        }
+        return;
+    }
+    float rm = run_mean ? run_mean[c] : 0.f, rv = run_var ? run_var[c] : 0.f;
+    for (int g = 0; g < groups; ++g) {
+        float cnt = 0.f, mean = 0.f, m2 = 0.f;
+        for (int rb = 0; rb < nrb; ++rb) {
+            const float* p = part + (size_t)(g * nrb + rb) * 2 * ncols;
+            const float nb = (float)min(RB, rpg - rb * RB);
+            const float mb = p[c], qb = p[ncols + c];
+            const float tot = cnt + nb;
+            const float d = mb - mean;
+            mean += d * (nb / tot);
+            m2 += qb + d * d * (cnt * nb / tot);
+            cnt = tot;
+        }
+        const float var_b = m2 / cnt;
+        mean_out[g * ncols + c] = mean;
+        rstd_out[g * ncols + c] = 1.0f / sqrtf(var_b + kBnEps);
+        const float var_u = m2 / (cnt - 1.f);
+        rm = (1.f - kBnMom) * rm + kBnMom * mean;
+        rv = (1.f - kBnMom) * rv + kBnMom * var_u;
+    }
+    if (run_mean) run_mean[c] = rm;
+    if (run_var) run_var[c] = rv;
+}
+
+// grid: (ceil((nprefix+ncols)/256), ceil(B/RB))
+__global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rpg, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        const float* __restrict__ prefix, int nprefix,
+                                                        float* __restrict__ X0, int ldx) {
+    const int oc = blockIdx.x * 256 + threadIdx.x;
+    if (oc >= nprefix + S.total) return;
+    const int r0 = blockIdx.y * RB;
+    const int n = min(RB, B - r0);
+    if (oc < nprefix) {
+        for (int r = 0; r < n; ++r) X0[(size_t)(r0 + r) * ldx + oc] = prefix[(size_t)(r0 + r) * nprefix + oc];
+        return;
+    }
+    const int c = oc - nprefix;
+    int ld;
+    const float* p = src_col(S, c, ld);
+    const float ga = gamma[c], be = beta[c];
+    for (int r = 0; r < n; ++r) {
+        const int row = r0 + r;
+        const int g = row / rpg;
+        const float sc = rstd[g * S.total + c] * ga;
+        const float sh = be - mean[g * S.total + c] * sc;
+        X0[(size_t)row * ldx + oc] = fmaf(p[(size_t)row * ld], sc, sh);
+    }
+}
+
+// grid: (ceil(N/256), groups*nrb)
+__global__ __launch_bounds__(256) void reduce_bias_kernel(const float* __restrict__ slabs, int nslab,
+                                                          long long slab_stride, int ld_slab,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          int ld_out, int rpg, int nrb, int N, int stat_lo,
+                                                          int stat_hi, int act_lo, int act_hi,
+                                                          float* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const int g = blockIdx.y / nrb, rb = blockIdx.y % nrb;
+    const int r0 = rb * RB;
+    const int n = min(RB, rpg - r0);
+    const size_t row0 = (size_t)(g * rpg + r0);
+    const float b = bias ? bias[c] : 0.f;
+    const bool act = c >= act_lo && c < act_hi;
+    float v[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        float a = 0.f;
+        if (r < n) {
+            const float* p = slabs + (row0 + r) * ld_slab + c;
+            for (int s = 0; s < nslab; ++s) a += p[(size_t)s * slab_stride];
+            a += b;
+            out[(row0 + r) * ld_out + c] = act ? lrelu(a) : a;
+        }
+        v[r] = a;
+    }
+    if (c >= stat_lo && c < stat_hi) {
+        float mean, m2;
+        partial_stats(v, n, mean, m2);
+        const int ns = stat_hi - stat_lo;
+        float* o = part + (size_t)blockIdx.y * 2 * ns;
+        o[c - stat_lo] = mean;
+        o[ns + c - stat_lo] = m2;
+    }
+}
+
+// grid: (ceil(N/256), ceil(B/RB))
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ a, int lda, int B, int rpg, int N,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ h, int ldh) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const int r0 = blockIdx.y * RB;
+    const int n = min(RB, B - r0);
+    const float ga = gamma[c], be = beta[c];
+    for (int r = 0; r < n; ++r) {
+        const int row = r0 + r;
+        const int g = row / rpg;
+        const float sc = rstd[g * N + c] * ga;
+        const float sh = be - mean[g * N + c] * sc;
+        h[(size_t)row * ldh + c] = lrelu(fmaf(a[(size_t)row * lda + c], sc, sh));
+    }
+}
+
+// Philox4x32-10 (Salmon et al. 2011), one call -> 4 x 32 random bits for counter (idx, seed).
+__device__ __forceinline__ uint4 philox4x32_10(uint64_t ctr, uint64_t key) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+__device__ __forceinline__ float philox_keep(uint64_t seed, uint64_t elem) {
+    const uint4 r = philox4x32_10(elem >> 2, seed);
+    const uint32_t w = (elem & 3) == 0 ? r.x : (elem & 3) == 1 ? r.y : (elem & 3) == 2 ? r.z : r.w;
+    // keep with probability 1-p: uniform in [0,1) >= p
+    return ((float)(w >> 8) * (1.0f / 16777216.0f)) >= kDropP ? 1.f : 0.f;
+}
+
+// grid: (ceil(N/256), ceil(B/RB))
+__global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ s, int lds,
+                                                      const float* __restrict__ a2, int lda2, int B, int rpg, int N,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int drop_mode, const float* __restrict__ keep_in, uint64_t seed,
+                                                      uint64_t seed_off, uint8_t* __restrict__ keep_out,
+                                                      float* __restrict__ y, int ldy) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const int r0 = blockIdx.y * RB;
+    const int n = min(RB, B - r0);
+    const float ga = gamma[c], be = beta[c];
+    const float inv_keep = 1.0f / (1.0f - kDropP);
+    for (int r = 0; r < n; ++r) {
+        const int row = r0 + r;
+        const int g = row / rpg;
+        const float sc = rstd[g * N + c] * ga;
+        const float sh = be - mean[g * N + c] * sc;
+        float v = lrelu(s[(size_t)row * lds + c] + fmaf(a2[(size_t)row * lda2 + c], sc, sh));
+        if (drop_mode) {
+            const size_t e = (size_t)row * N + c;
+            const float k = drop_mode == 1 ? keep_in[e] : philox_keep(seed, seed_off + e);
+            keep_out[e] = (uint8_t)(k != 0.f);
+            v = v * k * inv_keep;
+        }
+        y[(size_t)row * ldy + c] = v;
+    }
+}
+
+// one wave per row; K <= 512*? handled in chunks of 64 lanes
+template <int NHMAX>
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict__ y, int ldy, int B, int K,
+                                                        const float* __restrict__ wh, const float* __restrict__ bh,
+                                                        int nh, int sigmoid, float* __restrict__ out, int ldo) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float acc[NHMAX];
+#pragma unroll
+    for (int j = 0; j < NHMAX; ++j) acc[j] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float v = y[(size_t)row * ldy + k];
+#pragma unroll
+        for (int j = 0; j < NHMAX; ++j)
+            if (j < nh) acc[j] = fmaf(v, wh[(size_t)j * K + k], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NHMAX; ++j) {
+        if (j < nh) {
+            float v = acc[j];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0) {
+                v += bh[j];
+                if (sigmoid) v = 1.0f / (1.0f + expf(-v));
+                out[(size_t)row * ldo + j] = v;
+            }
+        }
+    }
+}
+
+// grid: (ceil(K/256), nrb): dy[m][k] = sum_j dout[m][j] wh[j][k]; partial dWh[j][k], dbh[j]
+template <int NHMAX>
+__global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ y, int ldy,
+                                                        const float* __restrict__ dout, int ldd, int B, int K,
+                                                        const float* __restrict__ wh, int nh,
+                                                        float* __restrict__ dy, int lddy, int skip_param,
+                                                        float* __restrict__ part) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * RB;
+    const int n = min(RB, B - r0);
+    const bool kok = k < K;
+    float w[NHMAX], gw[NHMAX], gb[NHMAX];
+#pragma unroll
+    for (int j = 0; j < NHMAX; ++j) {
+        w[j] = (kok && j < nh) ? wh[(size_t)j * K + k] : 0.f;
+        gw[j] = 0.f;
+        gb[j] = 0.f;
+    }
+    for (int r = 0; r < n; ++r) {
+        const int row = r0 + r;
+        const float yv = kok ? y[(size_t)row * ldy + k] : 0.f;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NHMAX; ++j) {
+            if (j < nh) {
+                const float d = dout[(size_t)row * ldd + j];
+                acc = fmaf(d, w[j], acc);
+                gw[j] = fmaf(d, yv, gw[j]);
+                gb[j] += d;
+            }
+        }
+        if (kok) dy[(size_t)row * lddy + k] = acc;
+    }
+    if (skip_param) return;
+    // part layout per row block: [nh*K weights | nh biases]
+    float* o = part + (size_t)blockIdx.y * ((size_t)nh * K + nh);
+#pragma unroll
+    for (int j = 0; j < NHMAX; ++j) {
+        if (j < nh) {
+            if (kok) o[(size_t)j * K + k] = gw[j];
+            if (k == 0) o[(size_t)nh * K + j] = gb[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- ResBlock backward stages
+// grid: (ceil(N/256), groups*nrb)
+__global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restrict__ dy, int lddy,
+                                                          const float* __restrict__ y, int ldy,
+                                                          const uint8_t* __restrict__ keep,
+                                                          const float* __restrict__ s, int lds,
+                                                          const float* __restrict__ a2, int lda2,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, int rpg, int nrb, int N,
+                                                          float* __restrict__ dpre, float* __restrict__ da3,
+                                                          int ldda3, float* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const int g = blockIdx.y / nrb, rb = blockIdx.y % nrb;
+    const int r0 = rb * RB;
+    const int n = min(RB, rpg - r0);
+    const float mu = mean[g * N + c], rs = rstd[g * N + c];
+    const float inv_keep = 1.0f / (1.0f - kDropP);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < n; ++r) {
+        const size_t row = (size_t)(g * rpg + r0 + r);
+        float d = dy[row * lddy + c];
+        if (keep) d = keep[row * N + c] ? d * inv_keep : 0.f;
+        d *= lrelu_grad(y[row * ldy + c]);
+        dpre[row * N + c] = d;
+        const float xh = (a2[row * lda2 + c] - mu) * rs;
+        const float d3 = d * lrelu_grad(s[row * lds + c]);
+        da3[row * ldda3 + c] = d3;
+        s0 += d;
+        s1 = fmaf(d, xh, s1);
+        s2 += d3;
+    }
+    float* o = part + (size_t)blockIdx.y * 3 * N;
+    o[c] = s0;
+    o[N + c] = s1;
+    o[2 * N + c] = s2;
+}
+
+// grid: (ceil(N/256), groups*nrb)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, int lddz,
+                                                           const float* __restrict__ a, int lda,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums, int train, int rpg,
+                                                           int nrb, int N, float* __restrict__ dx, int lddx,
+                                                           float* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const int g = blockIdx.y / nrb, rb = blockIdx.y % nrb;
+    const int r0 = rb * RB;
+    const int n = min(RB, rpg - r0);
+    const float mu = mean[g * N + c], rs = rstd[g * N + c];
+    const float k = gamma[c] * rs;
+    const float inv_n = 1.0f / (float)rpg;
+    const float m0 = train ? sums[(size_t)(g * 2 + 0) * N + c] * inv_n : 0.f;
+    const float m1 = train ? sums[(size_t)(g * 2 + 1) * N + c] * inv_n : 0.f;
+    float sb = 0.f;
+    for (int r = 0; r < n; ++r) {
+        const size_t row = (size_t)(g * rpg + r0 + r);
+        const float d = dz[row * lddz + c];
+        const float xh = (a[row * lda + c] - mu) * rs;
+        const float v = k * (d - m0 - xh * m1);
+        dx[row * lddx + c] = v;
+        sb += v;
+    }
+    part[(size_t)blockIdx.y * N + c] = sb;
+}
+
+// grid: (ceil(N/256), groups*nrb)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dh, int lddh,
+                                                      const float* __restrict__ h, int ldh,
+                                                      const float* __restrict__ a1, int lda1,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      int rpg, int nrb, int N, float* __restrict__ dq, int lddq,
+                                                      float* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const int g = blockIdx.y / nrb, rb = blockIdx.y % nrb;
+    const int r0 = rb * RB;
+    const int n = min(RB, rpg - r0);
+    const float mu = mean[g * N + c], rs = rstd[g * N + c];
+    float s0 = 0.f, s1 = 0.f;
+    for (int r = 0; r < n; ++r) {
+        const size_t row = (size_t)(g * rpg + r0 + r);
+        const float d = dh[row * lddh + c] * lrelu_grad(h[row * ldh + c]);
+        dq[row * lddq + c] = d;
+        const float xh = (a1[row * lda1 + c] - mu) * rs;
+        s0 += d;
+        s1 = fmaf(d, xh, s1);
+    }
+    float* o = part + (size_t)blockIdx.y * 2 * N;
+    o[c] = s0;
+    o[N + c] = s1;
+}
+
+// grid: ceil(nq*ncols/256)
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int groups, int nrb,
+                                                              int nq, int ncols, float* __restrict__ sums_out,
+                                                              float* __restrict__ d0, float* __restrict__ d1,
+                                                              float* __restrict__ d2, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq * ncols) return;
+    const int q = i / ncols, c = i - q * ncols;
+    float tot = 0.f;
+    for (int g = 0; g < groups; ++g) {
+        float sg = 0.f;
+        for (int rb = 0; rb < nrb; ++rb) sg += part[((size_t)(g * nrb + rb) * nq + q) * ncols + c];
+        if (sums_out) sums_out[((size_t)g * nq + q) * ncols + c] = sg;
+        tot += sg;
+    }
+    float* d = q == 0 ? d0 : q == 1 ? d1 : d2;
+    if (d) d[c] = accumulate ? d[c] + tot : tot;
+}
+
+// grid: (ceil(ncols/256), groups*nrb)
+__global__ __launch_bounds__(256) void ibn_bwd_stats_kernel(ColSrcs S, const float* __restrict__ dX0, int ldx,
+                                                            int col_off, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, int rpg, int nrb,
+                                                            float* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= S.total) return;
+    const int g = blockIdx.y / nrb, rb = blockIdx.y % nrb;
+    const int r0 = rb * RB;
+    const int n = min(RB, rpg - r0);
+    int ld;
+    const float* p = src_col(S, c, ld);
+    const float mu = mean[g * S.total + c], rs = rstd[g * S.total + c];
+    float s0 = 0.f, s1 = 0.f;
+    for (int r = 0; r < n; ++r) {
+        const size_t row = (size_t)(g * rpg + r0 + r);
+        const float d = dX0[row * ldx + col_off + c];
+        const float xh = (p[row * ld] - mu) * rs;
+        s0 += d;
+        s1 = fmaf(d, xh, s1);
+    }
+    float* o = part + (size_t)blockIdx.y * 2 * S.total;
+    o[c] = s0;
+    o[S.total + c] = s1;
+}
+
+// grid: (ceil((c_hi-c_lo)/256), ceil(B/RB))
+__global__ __launch_bounds__(256) void ibn_bwd_apply_kernel(ColSrcs S, const float* __restrict__ dX0, int ldx,
+                                                            int col_off, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ sums, int train, int B, int rpg,
+                                                            int c_lo, int c_hi, float* __restrict__ dst, int ldd) {
+    const int c = c_lo + blockIdx.x * 256 + threadIdx.x;
+    if (c >= c_hi) return;
+    const int r0 = blockIdx.y * RB;
+    const int n = min(RB, B - r0);
+    int ld;
+    const float* p = src_col(S, c, ld);
+    const float ga = gamma[c];
+    const float inv_n = 1.0f / (float)rpg;
+    for (int r = 0; r < n; ++r) {
+        const int row = r0 + r;
+        const int g = row / rpg;
+        const float mu = mean[g * S.total + c], rs = rstd[g * S.total + c];
+        const float d = dX0[(size_t)row * ldx + col_off + c];
+        float v;
+        if (train) {
+            const float m0 = sums[(size_t)(g * 2 + 0) * S.total + c] * inv_n;
+            const float m1 = sums[(size_t)(g * 2 + 1) * S.total + c] * inv_n;
+            const float xh = (p[(size_t)row * ld] - mu) * rs;
+            v = ga * rs * (d - m0 - xh * m1);
+        } else {
+            v = ga * rs * d;
+        }
+        dst[(size_t)row * ldd + (c - c_lo)] = v;
+    }
+}
+
+// ---------------------------------------------------------------- losses
+__device__ __forceinline__ float block_sum_1024(float v, float* sh) {
+    // deterministic: wave shuffle tree, then thread 0 adds the wave sums in order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) t += sh[i];
+    return t;
+}
+
+// single block; torch.nn.BCELoss(mean) with log clamped at -100, backward as torch
+// (binary_cross_entropy_backward: (p - t) / max((1-p) p, 1e-12)) chained through the sigmoid.
+__global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ p, const float* __restrict__ labels,
+                                                   float target_const, int B, float weight, float loss_scale,
+                                                   float* __restrict__ loss_out, float* __restrict__ d_logit) {
+    __shared__ float sh[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const float x = p[i];
+        const float t = labels ? labels[i] : target_const;
+        const float l1 = fmaxf(logf(x), -100.f), l0 = fmaxf(logf(1.f - x), -100.f);
+        acc += -(t * l1 + (1.f - t) * l0);
+        if (d_logit) {
+            const float gp = (x - t) / fmaxf((1.f - x) * x, 1e-12f) * (weight * loss_scale / (float)B);
+            d_logit[i] = gp * (1.f - x) * x;
+        }
+    }
+    const float tot = block_sum_1024(acc, sh);
+    if (threadIdx.x == 0) loss_out[0] = weight * (tot / (float)B);
+}
+
+struct Rot {
+    float x[3], y[3], z[3];
+    float na, nc;      // |a| and |x cross b| before clamping
+    float b[3];
+};
+
+__device__ __forceinline__ void ortho6d(const float* o, Rot& R) {
+    const float a0 = o[0], a1 = o[1], a2 = o[2];
+    R.b[0] = o[3]; R.b[1] = o[4]; R.b[2] = o[5];
+    R.na = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+    const float da = fmaxf(R.na, 1e-8f);
+    R.x[0] = a0 / da; R.x[1] = a1 / da; R.x[2] = a2 / da;
+    const float c0 = R.x[1] * R.b[2] - R.x[2] * R.b[1];
+    const float c1 = R.x[2] * R.b[0] - R.x[0] * R.b[2];
+    const float c2 = R.x[0] * R.b[1] - R.x[1] * R.b[0];
+    R.nc = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+    const float dc = fmaxf(R.nc, 1e-8f);
+    R.z[0] = c0 / dc; R.z[1] = c1 / dc; R.z[2] = c2 / dc;
+    R.y[0] = R.z[1] * R.x[2] - R.z[2] * R.x[1];
+    R.y[1] = R.z[2] * R.x[0] - R.z[0] * R.x[2];
+    R.y[2] = R.z[0] * R.x[1] - R.z[1] * R.x[0];
+}
+
+__device__ __forceinline__ void cross3(const float* u, const float* v, float* o) {
+    o[0] = u[1] * v[2] - u[2] * v[1];
+    o[1] = u[2] * v[0] - u[0] * v[2];
+    o[2] = u[0] * v[1] - u[1] * v[0];
+}
+
+// gR row-major (3x3, R[i][0]=x_i, R[i][1]=y_i, R[i][2]=z_i) -> gradient w.r.t. the 6-vector
+__device__ __forceinline__ void ortho6d_bwd(const Rot& R, const float* gR, float* go) {
+    float gx[3], gy[3], gz[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gx[i] = gR[3 * i]; gy[i] = gR[3 * i + 1]; gz[i] = gR[3 * i + 2]; }
+    float t[3];
+    // y = z x x
+    cross3(R.x, gy, t);
+    gz[0] += t[0]; gz[1] += t[1]; gz[2] += t[2];
+    cross3(gy, R.z, t);
+    gx[0] += t[0]; gx[1] += t[1]; gx[2] += t[2];
+    // z = c / max(|c|, 1e-8)
+    float gc[3];
+    if (R.nc > 1e-8f) {
+        const float dot = R.z[0] * gz[0] + R.z[1] * gz[1] + R.z[2] * gz[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gc[i] = (gz[i] - R.z[i] * dot) / R.nc;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gc[i] = gz[i] / 1e-8f;
+    }
+    // c = x x b
+    cross3(R.b, gc, t);
+    gx[0] += t[0]; gx[1] += t[1]; gx[2] += t[2];
+    float gb[3];
+    cross3(gc, R.x, gb);
+    // x = a / max(|a|, 1e-8)
+    if (R.na > 1e-8f) {
+        const float dot = R.x[0] * gx[0] + R.x[1] * gx[1] + R.x[2] * gx[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) go[i] = (gx[i] - R.x[i] * dot) / R.na;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) go[i] = gx[i] / 1e-8f;
+    }
+    go[3] = gb[0]; go[4] = gb[1]; go[5] = gb[2];
+}
+
+__global__ __launch_bounds__(256) void ortho6d_fwd_kernel(const float* __restrict__ o6, int ld, int B,
+                                                          float* __restrict__ rot9) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    Rot R;
+    ortho6d(o6 + (size_t)i * ld, R);
+    float* o = rot9 + (size_t)i * 9;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { o[3 * r] = R.x[r]; o[3 * r + 1] = R.y[r]; o[3 * r + 2] = R.z[r]; }
+}
+
+__global__ __launch_bounds__(256) void ortho6d_bwd_kernel(const float* __restrict__ o6, int ld, int B,
+                                                          const float* __restrict__ d_rot9, float* __restrict__ d_o6,
+                                                          int ldd) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    Rot R;
+    ortho6d(o6 + (size_t)i * ld, R);
+    float go[6];
+    ortho6d_bwd(R, d_rot9 + (size_t)i * 9, go);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d_o6[(size_t)i * ldd + k] = go[k];
+}
+
+// single block.  heads (B, nj+9) = [joint | rot6 | transl];  d_pose (B, 12+nj) = [d rot9 | d transl | d joint]
+__global__ __launch_bounds__(1024) void gen_loss_kernel(int nj, float bce_w, float c_tr, float c_rot, float c_cf,
+                                                        int B, const float* __restrict__ heads,
+                                                        const float* __restrict__ gt_rot9,
+                                                        const float* __restrict__ gt_transl,
+                                                        const float* __restrict__ gt_joint,
+                                                        const float* __restrict__ fake_score,
+                                                        const float* __restrict__ d_pose, float* __restrict__ losses,
+                                                        float* __restrict__ d_heads) {
+    __shared__ float sh[16];
+    const int nh = nj + 9;
+    float l_tr = 0.f, l_rot = 0.f, l_cf = 0.f, l_f = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const float* hrow = heads + (size_t)i * nh;
+        Rot R;
+        ortho6d(hrow + nj, R);
+        float Rm[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { Rm[3 * r] = R.x[r]; Rm[3 * r + 1] = R.y[r]; Rm[3 * r + 2] = R.z[r]; }
+        float gR[9];
+        const float k_rot = c_rot * 2.f / (9.f * (float)B);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            const float d = Rm[e] - gt_rot9[(size_t)i * 9 + e];
+            l_rot = fmaf(d, d, l_rot);
+            gR[e] = k_rot * d + (d_pose ? d_pose[(size_t)i * (12 + nj) + e] : 0.f);
+        }
+        const float k_tr = c_tr * 2.f / (3.f * (float)B);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const float d = hrow[nj + 6 + e] - gt_transl[(size_t)i * 3 + e];
+            l_tr = fmaf(d, d, l_tr);
+            if (d_heads)
+                d_heads[(size_t)i * nh + nj + 6 + e] = k_tr * d + (d_pose ? d_pose[(size_t)i * (12 + nj) + 9 + e] : 0.f);
+        }
+        const float k_cf = c_cf * 2.f / ((float)nj * (float)B);
+        for (int e = 0; e < nj; ++e) {
+            const float d = hrow[e] - gt_joint[(size_t)i * nj + e];
+            l_cf = fmaf(d, d, l_cf);
+            if (d_heads) d_heads[(size_t)i * nh + e] = k_cf * d + (d_pose ? d_pose[(size_t)i * (12 + nj) + 12 + e] : 0.f);
+        }
+        if (d_heads) {
+            float go[6];
+            ortho6d_bwd(R, gR, go);
+#pragma unroll
+            for (int e = 0; e < 6; ++e) d_heads[(size_t)i * nh + nj + e] = go[e];
+        }
+        if (fake_score) l_f += -fmaxf(logf(fake_score[i]), -100.f);
+    }
+    const float t_tr = block_sum_1024(l_tr, sh);
+    const float t_rot = block_sum_1024(l_rot, sh);
+    const float t_cf = block_sum_1024(l_cf, sh);
+    const float t_f = block_sum_1024(l_f, sh);
+    if (threadIdx.x == 0) {
+        const float lf = bce_w * (t_f / (float)B);
+        const float ltr = c_tr * (t_tr / (3.f * (float)B));
+        const float lrot = c_rot * (t_rot / (9.f * (float)B));
+        const float lcf = c_cf * (t_cf / ((float)nj * (float)B));
+        losses[DGG_L_GEN_FAKE] = lf;
+        losses[DGG_L_TRANSL] = ltr;
+        losses[DGG_L_ROT] = lrot;
+        losses[DGG_L_CONF] = lcf;
+        losses[DGG_L_TOTAL_GEN] = lf + (ltr + lrot + lcf);
+    }
+}
+
+__global__ void disc_loss_combine_kernel(float* losses) {
+    losses[DGG_L_TOTAL_DISC] = (losses[DGG_L_BCE_REAL] + losses[DGG_L_BCE_FAKE]) / 2.f;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float step_size, float bc2_sqrt, float b1, float b2, float eps,
+                                                   float wd, float gscale) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* pa = &pp.x; const float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = fmaf(wd, pa[e], ga[e] * gscale);
+            ma[e] = ma[e] + (gr - ma[e]) * (1.f - b1);
+            va[e] = b2 * va[e] + (1.f - b2) * gr * gr;
+            const float den = sqrtf(va[e]) / bc2_sqrt + eps;
+            pa[e] = pa[e] - step_size * (ma[e] / den);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    // tail (n not a multiple of 4)
+    const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        const float gr = fmaf(wd, p[t], g[t] * gscale);
+        const float mn = m[t] + (gr - m[t]) * (1.f - b1);
+        const float vn = b2 * v[t] + (1.f - b2) * gr * gr;
+        m[t] = mn;
+        v[t] = vn;
+        p[t] = p[t] - step_size * (mn / (sqrtf(vn) / bc2_sqrt + eps));
+    }
+}
+
+__global__ __launch_bounds__(256) void translate_axis_kernel(float* __restrict__ transl,
+                                                             const float* __restrict__ rot9, int B, int axis,
+                                                             float offset) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) transl[(size_t)i * 3 + r] -= rot9[(size_t)i * 9 + 3 * r + axis] * offset;
+}
+
+__global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict__ src, int lds,
+                                                        float* __restrict__ dst, int ldd, int B, int n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * n) return;
+    const int r = (int)(i / n), c = (int)(i % n);
+    dst[(size_t)r * ldd + c] = src[(size_t)r * lds + c];
+}
+
+// ================================================================= host launchers
+static inline int nrb_of(int rpg) { return (rpg + RB - 1) / RB; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+int ibn_stats_launch(const ColSrcs& srcs, int rpg, int groups, float* part, hipStream_t st) {
+    dim3 grid(cdiv(srcs.total, 256), groups * nrb_of(rpg));
+    hipLaunchKernelGGL(ibn_stats_kernel, grid, dim3(256), 0, st, srcs, rpg, nrb_of(rpg), part);
+    return check_launch("ibn_stats");
+}
+
+int bn_finalize_launch(const float* part, int rpg, int groups, int ncols, int train, float* run_mean, float* run_var,
+                       float* mean, float* rstd, hipStream_t st) {
+    if (train && rpg < 2) return DGG_ERR_INVALID;  // torch: "Expected more than 1 value per channel when training"
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(ncols, 256)), dim3(256), 0, st, part, rpg, groups, nrb_of(rpg),
+                       ncols, train, run_mean, run_var, mean, rstd);
+    return check_launch("bn_finalize");
+}
+
+int ibn_apply_launch(const ColSrcs& srcs, int B, int rpg, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, const float* prefix, int nprefix, float* X0, int ldx, hipStream_t st) {
+    dim3 grid(cdiv(nprefix + srcs.total, 256), cdiv(B, RB));
+    hipLaunchKernelGGL(ibn_apply_kernel, grid, dim3(256), 0, st, srcs, B, rpg, mean, rstd, gamma, beta, prefix,
+                       nprefix, X0, ldx);
+    return check_launch("ibn_apply");
+}
+
+int reduce_bias_launch(const float* slabs, int nslab, long long slab_stride, int ld_slab, const float* bias,
+                       float* out, int ld_out, int B, int rpg, int groups, int N, int stat_lo, int stat_hi,
+                       int act_lo, int act_hi, float* part, hipStream_t st) {
+    (void)B;
+    dim3 grid(cdiv(N, 256), groups * nrb_of(rpg));
+    hipLaunchKernelGGL(reduce_bias_kernel, grid, dim3(256), 0, st, slabs, nslab, slab_stride, ld_slab, bias, out,
+                       ld_out, rpg, nrb_of(rpg), N, stat_lo, stat_hi, act_lo, act_hi, part);
+    return check_launch("reduce_bias");
+}
+
+int bn_act_launch(const float* a, int lda, int B, int rpg, int N, const float* mean, const float* rstd,
+                  const float* gamma, const float* beta, float* h, int ldh, hipStream_t st) {
+    dim3 grid(cdiv(N, 256), cdiv(B, RB));
+    hipLaunchKernelGGL(bn_act_kernel, grid, dim3(256), 0, st, a, lda, B, rpg, N, mean, rstd, gamma, beta, h, ldh);
+    return check_launch("bn_act");
+}
+
+int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, int rpg, int N, const float* mean,
+                   const float* rstd, const float* gamma, const float* beta, int drop_mode, const float* keep_in,
+                   uint64_t seed, uint64_t seed_off, uint8_t* keep_out, float* y, int ldy, hipStream_t st) {
+    dim3 grid(cdiv(N, 256), cdiv(B, RB));
+    hipLaunchKernelGGL(res_out_kernel, grid, dim3(256), 0, st, s, lds, a2, lda2, B, rpg, N, mean, rstd, gamma, beta,
+                       drop_mode, keep_in, seed, seed_off, keep_out, y, ldy);
+    return check_launch("res_out");
+}
+
+constexpr int kNhMax = 32;
+
+int heads_fwd_launch(const float* y, int ldy, int B, int K, const float* wh, const float* bh, int nh, int sigmoid,
+                     float* out, int ldo, hipStream_t st) {
+    if (nh > kNhMax) return DGG_ERR_UNSUPPORTED;
+    if (nh == 1)
+        hipLaunchKernelGGL((heads_fwd_kernel<1>), dim3(cdiv(B, 4)), dim3(256), 0, st, y, ldy, B, K, wh, bh, nh, sigmoid,
+                           out, ldo);
+    else
+        hipLaunchKernelGGL((heads_fwd_kernel<kNhMax>), dim3(cdiv(B, 4)), dim3(256), 0, st, y, ldy, B, K, wh, bh, nh,
+                           sigmoid, out, ldo);
+    return check_launch("heads_fwd");
+}
+
+int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B, int K, const float* wh, int nh,
+                     float* dy, int lddy, float* gwh, float* gbh, int accumulate, int skip_param, float* scratch,
+                     hipStream_t st) {
+    if (nh > kNhMax) return DGG_ERR_UNSUPPORTED;
+    const int nrb = cdiv(B, RB);
+    dim3 grid(cdiv(K, 256), nrb);
+    if (nh == 1)
+        hipLaunchKernelGGL((heads_bwd_kernel<1>), grid, dim3(256), 0, st, y, ldy, dout, ldd, B, K, wh, nh, dy, lddy,
+                           skip_param, scratch);
+    else
+        hipLaunchKernelGGL((heads_bwd_kernel<kNhMax>), grid, dim3(256), 0, st, y, ldy, dout, ldd, B, K, wh, nh, dy,
+                           lddy, skip_param, scratch);
+    int rc = check_launch("heads_bwd");
+    if (rc || skip_param) return rc;
+    // weights and biases are adjacent in the flat layout iff gbh == gwh + nh*K; finalize separately otherwise
+    const int ncols = nh * K + nh;
+    if (gbh == gwh + (size_t)nh * K) return colsum_finalize_launch(scratch, 1, nrb, 1, ncols, nullptr, gwh, nullptr,
+                                                                   nullptr, accumulate, st);
+    return DGG_ERR_INVALID;
+}
+
+int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const uint8_t* keep, const float* s,
+                       int lds, const float* a2, int lda2, const float* mean, const float* rstd, int B, int rpg, int N,
+                       float* dpre, float* da3, int ldda3, float* part, hipStream_t st) {
+    const int groups = B / rpg;
+    dim3 grid(cdiv(N, 256), groups * nrb_of(rpg));
+    hipLaunchKernelGGL(res_out_bwd_kernel, grid, dim3(256), 0, st, dy, lddy, y, ldy, keep, s, lds, a2, lda2, mean,
+                       rstd, rpg, nrb_of(rpg), N, dpre, da3, ldda3, part);
+    return check_launch("res_out_bwd");
+}
+
+int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, const float* mean, const float* rstd,
+                        const float* gamma, const float* sums, int train, int B, int rpg, int N, float* dx, int lddx,
+                        float* part, hipStream_t st) {
+    const int groups = B / rpg;
+    dim3 grid(cdiv(N, 256), groups * nrb_of(rpg));
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, dz, lddz, a, lda, mean, rstd, gamma, sums, train,
+                       rpg, nrb_of(rpg), N, dx, lddx, part);
+    return check_launch("bn_bwd_apply");
+}
+
+int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const float* a1, int lda1, const float* mean,
+                   const float* rstd, int B, int rpg, int N, float* dq, int lddq, float* part, hipStream_t st) {
+    const int groups = B / rpg;
+    dim3 grid(cdiv(N, 256), groups * nrb_of(rpg));
+    hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, st, dh, lddh, h, ldh, a1, lda1, mean, rstd, rpg,
+                       nrb_of(rpg), N, dq, lddq, part);
+    return check_launch("act_bwd");
+}
+
+int colsum_finalize_launch(const float* part, int groups, int nrb, int nq, int ncols, float* sums_out, float* dst0,
+                           float* dst1, float* dst2, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(nq * ncols, 256)), dim3(256), 0, st, part, groups, nrb, nq,
+                       ncols, sums_out, dst0, dst1, dst2, accumulate);
+    return check_launch("colsum_finalize");
+}
+
+int ibn_bwd_stats_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col_off, const float* mean,
+                         const float* rstd, int rpg, int groups, float* part, hipStream_t st) {
+    dim3 grid(cdiv(srcs.total, 256), groups * nrb_of(rpg));
+    hipLaunchKernelGGL(ibn_bwd_stats_kernel, grid, dim3(256), 0, st, srcs, dX0, ldx, col_off, mean, rstd, rpg,
+                       nrb_of(rpg), part);
+    return check_launch("ibn_bwd_stats");
+}
+
+int ibn_bwd_apply_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col_off, const float* mean,
+                         const float* rstd, const float* gamma, const float* sums, int train, int B, int rpg, int c_lo,
+                         int c_hi, float* dst, int ldd, hipStream_t st) {
+    if (c_hi <= c_lo) return DGG_OK;
+    dim3 grid(cdiv(c_hi - c_lo, 256), cdiv(B, RB));
+    hipLaunchKernelGGL(ibn_bwd_apply_kernel, grid, dim3(256), 0, st, srcs, dX0, ldx, col_off, mean, rstd, gamma, sums,
+                       train, B, rpg, c_lo, c_hi, dst, ldd);
+    return check_launch("ibn_bwd_apply");
+}
+
+int bce_launch(const float* p, const float* labels, float target_const, int B, float weight, float loss_scale,
+               float* loss_out, float* d_logit, hipStream_t st) {
+    hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, st, p, labels, target_const, B, weight, loss_scale,
+                       loss_out, d_logit);
+    return check_launch("bce");
+}
+
+int ortho6d_fwd_launch(const float* o6, int ld, int B, float* rot9, hipStream_t st) {
+    hipLaunchKernelGGL(ortho6d_fwd_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, o6, ld, B, rot9);
+    return check_launch("ortho6d_fwd");
+}
+
+int ortho6d_bwd_launch(const float* o6, int ld, int B, const float* d_rot9, float* d_o6, int ldd, hipStream_t st) {
+    hipLaunchKernelGGL(ortho6d_bwd_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, o6, ld, B, d_rot9, d_o6, ldd);
+    return check_launch("ortho6d_bwd");
+}
+
+int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const float* heads, const float* gt_rot9,
+                    const float* gt_transl, const float* gt_joint, const float* fake_score, const float* d_pose,
+                    float* losses, float* d_heads, hipStream_t st) {
+    hipLaunchKernelGGL(gen_loss_kernel, dim3(1), dim3(1024), 0, st, cfg->n_hand_joints, hp->bce_weight,
+                       hp->transl_coef, hp->rot_coef, hp->conf_coef, B, heads, gt_rot9, gt_transl, gt_joint,
+                       fake_score, d_pose, losses, d_heads);
+    return check_launch("gen_loss");
+}
+
+int disc_loss_combine_launch(float* losses, hipStream_t st) {
+    hipLaunchKernelGGL(disc_loss_combine_kernel, dim3(1), dim3(1), 0, st, losses);
+    return check_launch("disc_loss_combine");
+}
+
+int adam_launch(float* params, const float* grads, float* m, float* v, int64_t n, int step, float lr, float b1,
+                float b2, float eps, float wd, float grad_scale, hipStream_t st) {
+    if (n <= 0 || step < 1) return DGG_ERR_INVALID;
+    const double bc1 = 1.0 - pow((double)b1, (double)step);
+    const double bc2 = 1.0 - pow((double)b2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    int64_t blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, m, v, n, step_size,
+                       bc2_sqrt, b1, b2, eps, wd, grad_scale);
+    return check_launch("adam");
+}
+
+int translate_axis_launch(float* transl, const float* rot9, int B, int axis, float offset, hipStream_t st) {
+    hipLaunchKernelGGL(translate_axis_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, transl, rot9, B, axis, offset);
+    return check_launch("translate_axis");
+}
+
+int copy_cols_launch(const float* src, int lds, float* dst, int ldd, int B, int n, hipStream_t st) {
+    const int64_t tot = (int64_t)B * n;
+    hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, lds, dst, ldd, B,
+                       n);
+    return check_launch("copy_cols");
+}
+
+}  // namespace dgg

@@ -1,0 +1,266 @@
+// fp32 GEMM family for the fc / ResBlock stacks (networks.py:32,35,39,75-77,121,293 and their
+// autograd) on the CDNA4 matrix cores: v_mfma_f32_32x32x2_f32 — f32 in, f32 accumulate, bit-for-bit
+// a k-ordered fmaf chain, so results are exact-fp32 GEMMs (no TF32-like path exists on gfx950).
+//
+// One kernel template serves the three operand orientations of forward / dgrad / wgrad:
+//   NT  C[M,N] = A[M,K]  * B[N,K]^T   forward:  Y  = X  W^T       (both operands k-contiguous)
+//   NN  C[M,N] = A[M,K]  * B[K,N]     dgrad:    dX = dY W
+//   TN  C[M,N] = A[K,M]^T* B[K,N]     wgrad:    dW = dY^T X
+// Tiles: BM x BN x 32 per 256-thread workgroup (4 waves as 2x2, each wave (BM/2)x(BN/2) as
+// 32x32 MFMA tiles).  LDS holds both operands k-major ([k][m], row pitch BM+1 so the transposing
+// store of a k-contiguous operand is bank-conflict-free) and double-buffered; the next k-tile is
+// fetched global->registers while the current one feeds the MFMAs, one barrier per k-tile.
+// Shapes of this model are awkward (K = 4101..4632, N = 21/256/512/768): every global access is
+// predicated, K/M/N tails are zero-filled in LDS, never padded in the checkpoint tensors.
+// A launch carries up to 4 independent problems (grouped GEMM) so the two column segments of a
+// concatenated ResBlock input ([X0 | X1], networks.py:95,154,330) share one grid, and split-K
+// partial products go to slabs that the bias/BN-statistics reduce kernel sums.
+#include "dgg_internal.h"
+
+namespace dgg {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 32;
+
+template <int BR, bool KC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ G, int ld, int row0, int nrows, int k0, int kend,
+                                          float (&r)[BR * BK / 256]) {
+    const int tid = threadIdx.x;
+    constexpr int NE = BR * BK / 256;
+    if constexpr (KC) {
+        // global [row][k]: a half-wave reads 32 consecutive k of one row (128 B)
+        const int k = tid & 31;
+        const int gk = k0 + k;
+        const bool kok = gk < kend;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int gr = row0 + (tid >> 5) + 8 * e;
+            r[e] = (kok && gr < nrows) ? G[(size_t)gr * ld + gk] : 0.f;
+        }
+    } else {
+        // global [k][col]: a wave reads 64 consecutive columns of one k row (256 B)
+        constexpr int KSTEP = 256 / BR;
+        const int col = tid % BR;
+        const int gc = row0 + col;
+        const bool cok = gc < nrows;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int gk = k0 + tid / BR + KSTEP * e;
+            r[e] = (cok && gk < kend) ? G[(size_t)gk * ld + gc] : 0.f;
+        }
+    }
+}
+
+template <int BR, bool KC>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, const float (&r)[BR * BK / 256]) {
+    const int tid = threadIdx.x;
+    constexpr int NE = BR * BK / 256;
+    constexpr int LDS_PITCH = BR + 1;
+    if constexpr (KC) {
+        const int k = tid & 31;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) S[k * LDS_PITCH + (tid >> 5) + 8 * e] = r[e];
+    } else {
+        constexpr int KSTEP = 256 / BR;
+        const int col = tid % BR;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) S[(tid / BR + KSTEP * e) * LDS_PITCH + col] = r[e];
+    }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch) {
+    constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
+    constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave along m / n
+    constexpr int BUF = BK * (LDA_S + LDB_S);
+    __shared__ float smem[2 * BUF];
+
+    // ---- which problem / tile / k-split does this workgroup own (all wave-uniform)
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (q < batch.nprob && (int)blockIdx.x >= batch.p[q].blk_begin) pi = q;
+    const GemmProb& P = batch.p[pi];
+    const int local = (int)blockIdx.x - P.blk_begin;
+    const int ntile = P.tiles_m * P.tiles_n;
+    const int split = local / ntile;
+    const int tile = local - split * ntile;
+    const int tn_i = tile / P.tiles_m;
+    const int tm_i = tile - tn_i * P.tiles_m;
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+    const int M = P.M, N = P.N;
+    int kbeg = 0, kend = P.K;
+    if (P.splits > 0) {
+        kbeg = split * P.kchunk;
+        kend = min(P.K, kbeg + P.kchunk);
+    }
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    const int li = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float ra[BM * BK / 256], rb[BN * BK / 256];
+    if (nkt > 0) {
+        load_tile<BM, A_KC>(P.A, P.lda, m0, M, kbeg, kend, ra);
+        load_tile<BN, B_KC>(P.B, P.ldb, n0, N, kbeg, kend, rb);
+        store_tile<BM, A_KC>(smem, ra);
+        store_tile<BN, B_KC>(smem + BK * LDA_S, rb);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const float* As = smem + (kt & 1) * BUF;
+        const float* Bs = As + BK * LDA_S;
+        const bool more = kt + 1 < nkt;
+        if (more) {  // prefetch the next k-tile into registers; latency hides under the MFMAs below
+            const int k0 = kbeg + (kt + 1) * BK;
+            load_tile<BM, A_KC>(P.A, P.lda, m0, M, k0, kend, ra);
+            load_tile<BN, B_KC>(P.B, P.ldb, n0, N, k0, kend, rb);
+        }
+#pragma unroll 4
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            const int k = 2 * kp + lh;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) a[t] = As[k * LDA_S + wm0 + t * 32 + li];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[t] = Bs[k * LDB_S + wn0 + t * 32 + li];
+#pragma unroll
+            for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < TN; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+        }
+        if (more) {
+            float* Sn = smem + ((kt + 1) & 1) * BUF;
+            store_tile<BM, A_KC>(Sn, ra);
+            store_tile<BN, B_KC>(Sn + BK * LDA_S, rb);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* Cb = P.C + (P.splits > 0 ? (size_t)split * (size_t)P.slab_stride : (size_t)0);
+    const bool accum = (P.splits == 0) && P.accumulate;
+#pragma unroll
+    for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TN; ++tb) {
+            const int col = n0 + wn0 + tb * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < M && col < N) {
+                    float* p = Cb + (size_t)row * P.ldc + col;
+                    float v = acc[ta][tb][r];
+                    if (accum) v += *p;
+                    *p = v;
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn) {
+    // Big tiles when they alone (or with split-K in NT mode) can fill 256 CUs; otherwise 64-wide.
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    bm = 128;
+    bn = 128;
+    if (mode == GEMM_NT) {
+        if (t128 < 24) { bm = 64; bn = 64; }
+        return;
+    }
+    if (t128 < 200) {
+        bm = (M >= 1024) ? 128 : 64;
+        bn = 64;
+        const long t = (long)((M + bm - 1) / bm) * ((N + 63) / 64);
+        if (t < 200) bm = 64;
+    }
+}
+
+int gemm_pick_splits(int mode, int M, int N, int K, int other_blocks) {
+    int bm, bn;
+    gemm_tile_shape(mode, M, N, bm, bn);
+    const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    const int ksteps = (K + BK - 1) / BK;
+    static int target = -1;
+    if (target < 0) {
+        const char* e = getenv("DGG_SPLITK_TARGET");
+        target = e ? atoi(e) : 512;
+    }
+    int s = (target - other_blocks) / (tiles > 0 ? tiles : 1);
+    if (s < 1) s = 1;
+    if (s > 16) s = 16;
+    const int max_by_k = ksteps / 4 > 0 ? ksteps / 4 : 1;  // keep >= 4 k-tiles per split
+    if (s > max_by_k) s = max_by_k;
+    return s;
+}
+
+int gemm_plan(GemmProb& p, int mode, int splits) {
+    int bm, bn;
+    gemm_tile_shape(mode, p.M, p.N, bm, bn);
+    p.tiles_m = (p.M + bm - 1) / bm;
+    p.tiles_n = (p.N + bn - 1) / bn;
+    p.splits = splits;
+    if (splits > 0) {
+        const int ksteps = (p.K + BK - 1) / BK;
+        const int per = (ksteps + splits - 1) / splits;
+        p.kchunk = per * BK;
+        // drop empty trailing splits
+        int used = (p.K + p.kchunk - 1) / p.kchunk;
+        if (used < 1) used = 1;
+        p.splits = used;
+    } else {
+        p.kchunk = p.K;
+    }
+    return p.tiles_m * p.tiles_n * (p.splits > 0 ? p.splits : 1);
+}
+
+template <bool A_KC, bool B_KC>
+static void launch_shape(int bm, int bn, const GemmBatch& b, hipStream_t st) {
+    dim3 grid(b.total_blocks), block(256);
+    if (bm == 128 && bn == 128)
+        hipLaunchKernelGGL((gemm_f32_kernel<128, 128, A_KC, B_KC>), grid, block, 0, st, b);
+    else if (bm == 128 && bn == 64)
+        hipLaunchKernelGGL((gemm_f32_kernel<128, 64, A_KC, B_KC>), grid, block, 0, st, b);
+    else if (bm == 64 && bn == 128)
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 128, A_KC, B_KC>), grid, block, 0, st, b);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 64, A_KC, B_KC>), grid, block, 0, st, b);
+}
+
+// All problems of one grouped launch must use the same tile shape: the launcher derives it from
+// problem 0 and re-plans the others with it.
+int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
+    if (batch.nprob < 1 || batch.nprob > 4) return DGG_ERR_INVALID;
+    int bm, bn;
+    gemm_tile_shape(mode, batch.p[0].M, batch.p[0].N, bm, bn);
+    int blocks = 0;
+    for (int i = 0; i < batch.nprob; ++i) {
+        GemmProb& p = batch.p[i];
+        if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.A || !p.B || !p.C) return DGG_ERR_INVALID;
+        p.tiles_m = (p.M + bm - 1) / bm;
+        p.tiles_n = (p.N + bn - 1) / bn;
+        p.blk_begin = blocks;
+        blocks += p.tiles_m * p.tiles_n * (p.splits > 0 ? p.splits : 1);
+    }
+    batch.total_blocks = blocks;
+    if (mode == GEMM_NT) launch_shape<true, true>(bm, bn, batch, st);
+    else if (mode == GEMM_NN) launch_shape<true, false>(bm, bn, batch, st);
+    else if (mode == GEMM_TN) launch_shape<false, false>(bm, bn, batch, st);
+    else return DGG_ERR_INVALID;
+    return check_launch("gemm_f32");
+}
+
+}  // namespace dgg

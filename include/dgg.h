@@ -1,0 +1,207 @@
+/* dgg.h — C-ABI of libdgg.so: the MI355X (gfx950) implementation of the DexGANGrasp hot path.
+ *
+ * The reference (david-s-martinez/Dex-GAN-Grasp) is pure Python on PyTorch-CUDA and has no FFI
+ * layer of its own: its "operator API" for this path is the Python classes
+ *   DexGanGrasp/models/networks.py:26-338   (ResBlock, Generator, Discriminator, DexGANGrasp, DexEvaluator)
+ *   DexGanGrasp/models/dexgangrasp.py:65-823 (DexGanGrasp wrapper: losses, update_*, generate/filter)
+ *   DexGanGrasp/data/bps_encoder.py:12-55    (BPSEncoder -> bps_torch.encode)
+ * Each entry point below names the reference interface it replaces; the Python mirror in
+ * dex_gan_grasp_amd/ binds them with ctypes (INTEGRATION.md shows the stub a maintainer adds).
+ *
+ * Conventions:
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked `host`;
+ *  - the library never allocates or frees caller memory: parameters, gradients, Adam moments, BN
+ *    running statistics and workspaces are caller-owned buffers whose sizes the *_floats / *_bytes
+ *    queries return; layouts of the flat buffers are described by dgg_table();
+ *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = the
+ *    null stream); nothing synchronises, so calls are graph-capturable;
+ *  - return value: DGG_OK (0) or a negative dgg_status; no exceptions cross the boundary;
+ *  - re-entrant across streams with distinct workspaces; not thread-safe on one workspace.
+ *  - all tensors fp32 row-major contiguous unless a leading dimension is given.
+ */
+#ifndef DGG_H
+#define DGG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    DGG_OK = 0,
+    DGG_ERR_INVALID = -1,   /* bad argument (null pointer, non-positive size, unsupported config) */
+    DGG_ERR_LAUNCH = -2,    /* hipLaunch / runtime error; dgg_last_error() has the text */
+    DGG_ERR_WORKSPACE = -3, /* workspace too small for the requested batch */
+    DGG_ERR_UNSUPPORTED = -4
+} dgg_status;
+
+typedef enum { DGG_NET_GEN = 0, DGG_NET_DISC = 1, DGG_NET_EVA = 2 } dgg_net;
+
+/* Network hyper-parameters (config_dexgangrasp.yaml:36,42; networks.py:27,61-62). */
+typedef struct {
+    int32_t latent_d;      /* cfg["latentD"] = 5 */
+    int32_t n_hand_joints; /* cfg["n_hand_joints"] = 12 */
+    int32_t in_bps;        /* 4096 */
+    int32_t n_neurons;     /* 512 (ResBlock Fout) */
+    int32_t hidden;        /* 256 (ResBlock n_neurons) */
+} dgg_cfg;
+
+/* One entry of a flat-buffer layout table.  kind: 0 = trainable parameter (offset into the params /
+ * grads / adam_m / adam_v buffers), 1 = BatchNorm running statistic (offset into the bnstats
+ * buffer).  `name` is the reference's state_dict key relative to the module
+ * (e.g. "gen_rb1.fc1.weight", networks.py:71-77). */
+typedef struct {
+    char name[64];
+    int64_t offset; /* in floats */
+    int32_t rows;
+    int32_t cols;   /* 1-D tensors: rows = n, cols = 1 */
+    int32_t kind;
+    int32_t pad_;
+} dgg_entry;
+
+const char* dgg_version(void);
+const char* dgg_last_error(void);
+
+/* Layout queries ------------------------------------------------------------------------------ */
+/* Fills up to `cap` entries; returns the number of entries of the table (or <0). */
+int dgg_table(int net, const dgg_cfg* cfg, dgg_entry* out /*host*/, int cap);
+int64_t dgg_param_floats(int net, const dgg_cfg* cfg);   /* size of params/grads/m/v buffers */
+int64_t dgg_bnstat_floats(int net, const dgg_cfg* cfg);  /* size of the running-stat buffer */
+int64_t dgg_workspace_bytes(int net, const dgg_cfg* cfg, int batch); /* activations + scratch */
+
+/* A1 — replaces bps_torch.encode as called at data/bps_encoder.py:33 and
+ * dexgangrasp_real_robot.py:139.  clouds (B,N,3), basis (P,3) -> dists (B,P), ids (B,P) (ids may
+ * be NULL).  id = argmin_j |b - x_j|^2 with strict '<' (lowest j wins ties); dist = sqrt of it. */
+int dgg_bps_encode(const float* clouds, int B, int N, const float* basis, int P, float* dists,
+                   int32_t* ids, void* stream);
+
+/* Flags */
+#define DGG_TRAIN 1u            /* BatchNorm batch statistics + running-stat update, dropout on */
+#define DGG_ACCUM_GRADS 2u      /* backward: add into grads instead of overwriting */
+#define DGG_SKIP_PARAM_GRADS 4u /* backward: input gradients only (G-phase pass through D) */
+#define DGG_NEED_INPUT_GRADS 8u /* backward: also produce gradients w.r.t. the network inputs */
+
+/* A3 — Generator.forward(Zin, bps_object), networks.py:88-103.
+ * out_heads (B,21) = [joint_conf(12) | rot_6D(6) | transl(3)] (column blocks of one buffer). */
+int dgg_gen_forward(const dgg_cfg* cfg, const float* params, float* bnstats, void* ws, size_t ws_bytes,
+                    int B, unsigned flags, const float* z, const float* bps, float* out_heads, void* stream);
+/* Backward of the above (autograd of networks.py:88-103).  d_heads (B,21).  d_z (B,latent) and
+ * d_bps (B,4096) may be NULL. */
+int dgg_gen_backward(const dgg_cfg* cfg, const float* params, float* grads, void* ws, size_t ws_bytes, int B,
+                     unsigned flags, const float* z, const float* bps, const float* d_heads, float* d_z,
+                     float* d_bps, void* stream);
+
+/* A4 — Discriminator.forward(data), networks.py:132-159: inputs bps (B,4096), rot (B,9) row-major
+ * of rot_matrix.view(B,-1), transl (B,3), joint_conf (B,nj) -> p (B,1) after sigmoid. */
+int dgg_disc_forward(const dgg_cfg* cfg, const float* params, float* bnstats, void* ws, size_t ws_bytes, int B,
+                     unsigned flags, const float* bps, const float* rot9, const float* transl,
+                     const float* joint, float* out_p, void* stream);
+/* d_logit (B,1) is the gradient w.r.t. the pre-sigmoid output.  d_pose (B,12+nj) =
+ * [d rot9 | d transl | d joint] is written when DGG_NEED_INPUT_GRADS (else may be NULL). */
+int dgg_disc_backward(const dgg_cfg* cfg, const float* params, float* grads, void* ws, size_t ws_bytes, int B,
+                      unsigned flags, const float* bps, const float* rot9, const float* transl,
+                      const float* joint, const float* d_logit, float* d_pose, void* stream);
+
+/* A5 — DexEvaluator.forward(data), networks.py:315-338.  Dropout (p = 0.3, three sites): in train
+ * mode either `drop_keep` (3,B,512) floats in {0,1} is given (parity tests) or, if NULL, masks are
+ * drawn in-kernel from Philox4x32-10 keyed by (seed, element index). */
+int dgg_eva_forward(const dgg_cfg* cfg, const float* params, float* bnstats, void* ws, size_t ws_bytes, int B,
+                    unsigned flags, const float* bps, const float* rot9, const float* transl,
+                    const float* drop_keep, uint64_t seed, float* out_p, void* stream);
+int dgg_eva_backward(const dgg_cfg* cfg, const float* params, float* grads, void* ws, size_t ws_bytes, int B,
+                     unsigned flags, const float* bps, const float* rot9, const float* transl,
+                     const float* d_logit, float* d_pose /* (B,12) or NULL */, void* stream);
+
+/* A6 — utils.rot_matrix_from_ortho6d, utils/utils.py:380-394 (+ normalize_vector :323-332,
+ * cross_product :68-78).  o6 (B,6) with row stride ld_o6 -> R (B,9) row-major, columns x,y,z. */
+int dgg_ortho6d_forward(const float* o6, int ld_o6, int B, float* rot9, void* stream);
+int dgg_ortho6d_backward(const float* o6, int ld_o6, int B, const float* d_rot9, float* d_o6, int ld_do6,
+                         void* stream);
+
+/* A7/A9 — torch.nn.BCELoss(reduction='mean') as used at dexgangrasp.py:142-147, 213-232, 293-296.
+ * p (B,1); target: `labels` (B) if non-NULL else the constant `target_const`.
+ * loss_out[0] = weight * mean BCE (log clamped at -100).  If d_logit != NULL it receives
+ * d(loss_scale * loss)/d(logit) through the sigmoid (BCELoss backward divides by
+ * max((1-p)p, 1e-12), as torch does). */
+int dgg_bce(const float* p, const float* labels, float target_const, int B, float weight, float loss_scale,
+            float* loss_out, float* d_logit, void* stream);
+
+/* A12 — torch.optim.Adam as configured at dexgangrasp.py:97-112 (L2-coupled weight decay):
+ * g += wd*theta; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * theta -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  `step` is t (1-based). */
+int dgg_adam_l2(float* params, const float* grads, float* m, float* v, int64_t n, int step, float lr,
+                float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
+/* A10 — DexGanGrasp.update_dexgangrasp, dexgangrasp.py:757-823, split at the two points where a
+ * data-parallel run all-reduces gradients (between backward and Adam).
+ *
+ * Hyper-parameters of one step. */
+typedef struct {
+    float lr_gen, lr_dis, lr_eva; /* cfg lr_gen / lr_dis / lr */
+    float beta1, beta2, eps, weight_decay;
+    float bce_weight;
+    float transl_coef, rot_coef, conf_coef; /* 100, 1, 10 (dexgangrasp.py:92-94) */
+    float grad_scale; /* 1/world_size after a sum all-reduce, else 1 */
+} dgg_hparams;
+
+/* State of the GAN pair (device pointers, layouts from dgg_table). */
+typedef struct {
+    float *g_params, *g_grads, *g_m, *g_v, *g_bn;
+    float *d_params, *d_grads, *d_m, *d_v, *d_bn;
+} dgg_gan_state;
+
+int64_t dgg_cgan_workspace_bytes(const dgg_cfg* cfg, int batch);
+
+/* Losses written by the phases: indices into a device float[16]. */
+enum {
+    DGG_L_TOTAL_DISC = 0, DGG_L_BCE_REAL = 1, DGG_L_BCE_FAKE = 2, DGG_L_GEN_FAKE = 3,
+    DGG_L_TRANSL = 4, DGG_L_ROT = 5, DGG_L_CONF = 6, DGG_L_TOTAL_GEN = 7,
+    DGG_L_TOTAL_EVA = 8, DGG_L_BCE_EVA = 9
+};
+
+/* Steps 1-8 of SURVEY.md 3.1 up to (not including) optim_D.step: G forward (train), ortho6d,
+ * D forward on real then on fake.detach(), discriminator loss, D backward (both) -> st->d_grads.
+ * Inputs: bps (B,4096), rot9 (B,9), transl (B,3), joint (B,nj) = the real batch; z (B,latent). */
+int dgg_cgan_d_phase(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hparams* hp, void* ws,
+                     size_t ws_bytes, int B, const float* bps, const float* rot9, const float* transl,
+                     const float* joint, const float* z, float* losses, void* stream);
+/* Steps 9-12 up to (not including) optim_G.step: D forward #3 with the updated discriminator,
+ * generator loss, backward through D (input gradients only) and G -> st->g_grads.
+ * Must follow dgg_cgan_d_phase on the same workspace (reuses the saved generator activations). */
+int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hparams* hp, void* ws,
+                     size_t ws_bytes, int B, const float* bps, const float* rot9, const float* transl,
+                     const float* joint, const float* z, float* losses, void* stream);
+/* Convenience single-GPU step: d_phase, Adam(D), [g_phase, Adam(G)] (is_train_gen). */
+int dgg_cgan_step(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hparams* hp, void* ws, size_t ws_bytes,
+                  int B, const float* bps, const float* rot9, const float* transl, const float* joint,
+                  const float* z, int step_d, int step_g, int is_train_gen, float* losses, void* stream);
+
+/* A11 — DexGanGrasp.update_dexevaluator, dexgangrasp.py:739-755: forward (train), BCE, backward
+ * -> e_grads (no Adam: the caller all-reduces, then dgg_adam_l2).  label (B) floats in {0,1}. */
+int dgg_eva_phase(const dgg_cfg* cfg, const float* e_params, float* e_grads, float* e_bn, const dgg_hparams* hp,
+                  void* ws, size_t ws_bytes, int B, const float* bps, const float* rot9, const float* transl,
+                  const float* label, const float* drop_keep, uint64_t seed, float* losses, void* stream);
+
+/* Generator-loss pieces (A8, dexgangrasp.py:272-307 + losses.py:61-76), exposed for the parity
+ * tests and for the autograd path: heads (B,21) -> losses[DGG_L_GEN_FAKE..DGG_L_TOTAL_GEN] and
+ * d_heads (B,21) given the discriminator's input gradient d_pose (B,12+nj) (may be NULL). */
+int dgg_gen_loss(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const float* heads, const float* gt_rot9,
+                 const float* gt_transl, const float* gt_joint, const float* fake_score, const float* d_pose,
+                 float* losses, float* d_heads, void* stream);
+
+/* A13 helper — utils.translate_along_axis (utils/utils.py:19-48) on device:
+ * transl[i] -= R[i][:, axis] * offset. */
+int dgg_translate_along_axis(float* transl, const float* rot9, int B, int axis, float offset, void* stream);
+
+/* Plain GEMM entry used by the unit tests of the MFMA kernel (not part of the reference surface):
+ * mode 0: C[M,N] = A[M,K] * B[N,K]^T;  1: C[M,N] = A[M,K] * B[K,N];  2: C[M,N] = A[K,M]^T * B[K,N].
+ * splits >= 1 (split-K through `slabs`, S*M*N floats; reduced into C); accumulate: C += . */
+int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C,
+                 int ldc, int splits, float* slabs, int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGG_H */

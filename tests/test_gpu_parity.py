@@ -1,0 +1,294 @@
+"""GPU parity tests: the HIP path (through the C-ABI of libdgg.so) against the CPU oracle on the same
+seeded inputs, and against the fixtures produced by the reference itself (tests/golden).
+
+Tolerances (north_star): BPS nearest-neighbour indices bit-exact; fp32 poses / joint angles /
+scores within 1e-4 (we assert tighter where the arithmetic allows)."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from dex_gan_grasp_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CFG = synth.DEFAULT_CFG
+DEV = "cuda"
+
+
+def _ops():
+    from dex_gan_grasp_amd import ops, _lib
+    return ops, _lib
+
+
+# ------------------------------------------------------------------ GEMM kernel (fp32 MFMA)
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(64, 64, 32), (128, 128, 64), (100, 77, 45), (256, 768, 4101), (1024, 24, 768),
+                                   (768, 517, 300), (33, 1, 512), (1, 130, 7)])
+def test_gemm_modes(mode, shape):
+    ops, _ = _ops()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + mode)
+    # asymmetric integer-ish data catches transposed fragment maps; then real-valued data
+    for kind in ["int", "real"]:
+        if kind == "int":
+            A = torch.randint(-3, 4, (M, K), generator=g).float()
+            Bm = torch.randint(-3, 4, (K, N), generator=g).float()
+        else:
+            A = torch.randn((M, K), generator=g)
+            Bm = torch.randn((K, N), generator=g)
+        ref = (A.double() @ Bm.double())
+        a_dev = (A if mode in (0, 1) else A.t().contiguous()).to(DEV)      # mode 2 stores A as [K][M]
+        b_dev = (Bm.t().contiguous() if mode == 0 else Bm).to(DEV)          # mode 0 stores B as [N][K]
+        out = ops.gemm(mode, a_dev, b_dev, M, N, K).cpu().double()
+        if kind == "int":
+            assert torch.equal(out, ref)
+        else:
+            scale = (A.abs().double() @ Bm.abs().double())
+            assert ((out - ref).abs() <= 4e-7 * scale + 1e-30).all()
+
+
+def test_gemm_splitk_and_accumulate():
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 256, 768, 4613
+    A = torch.randn((M, K), generator=g)
+    W = torch.randn((N, K), generator=g)
+    ref = A.double() @ W.double().t()
+    scale = A.abs().double() @ W.abs().double().t()
+    for splits in [1, 3, 8]:
+        out = ops.gemm(0, A.to(DEV), W.to(DEV), M, N, K, splits=splits).cpu().double()
+        assert ((out - ref).abs() <= 4e-7 * scale).all(), splits
+    base = torch.randn((M, N), generator=g)
+    out = ops.gemm(0, A.to(DEV), W.to(DEV), M, N, K, C_out=base.clone().to(DEV), accumulate=True).cpu().double()
+    assert ((out - (ref + base.double())).abs() <= 4e-7 * scale + 1e-6).all()
+    # strided views (leading dimensions larger than the logical width), as the concat segments use
+    big = torch.randn((M, K + 37), generator=g).to(DEV)
+    out = ops.gemm(0, big[:, 5:5 + K], W.to(DEV), M, N, K).cpu().double()
+    ref2 = big[:, 5:5 + K].cpu().double() @ W.double().t()
+    assert ((out - ref2).abs() <= 4e-7 * scale + 1e-6).all()
+
+
+# ------------------------------------------------------------------ A1: BPS encode
+def _ulp(a, b):
+    return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+
+
+def test_bps_known_answers_and_oracle_bit_exact():
+    ops, _ = _ops()
+    from oracle import bps_oracle
+    d = H.load("bps_real_objects.npz")
+    basis = d["basis"]
+    for name in d["names"]:
+        cloud = d["cloud_" + str(name)]
+        want = d["dists_" + str(name)].reshape(-1)
+        dist, ids = ops.bps_encode(torch.from_numpy(cloud).to(DEV), torch.from_numpy(basis).to(DEV))
+        dist, ids = dist.cpu().numpy()[0], ids.cpu().numpy()[0]
+        od, oi = bps_oracle.encode_f32(cloud, basis)
+        assert (ids == oi).all(), name                       # bit-exact integer work vs the oracle
+        assert _ulp(dist, od).max() == 0, name               # same fp32 contract -> identical bits
+        assert _ulp(dist, want).max() <= 2, name             # the reference's own stored encodings
+        d64, i64, i2, gap = bps_oracle.encode_f64(cloud, basis)
+        bad = (ids != i64) & ~((gap < 1e-6) & (ids == i2))
+        assert not bad.any(), name
+
+
+@pytest.mark.parametrize("B,N", [(1, 1), (1, 5), (3, 1000), (64, 257), (130, 512)])
+def test_bps_batched_and_edges(B, N):
+    ops, _ = _ops()
+    from oracle import bps_oracle
+    basis = H.load("bps_real_objects.npz")["basis"]
+    clouds = synth.make_clouds(B, N, 100 + B + N)
+    if N >= 5:
+        clouds[0, 3] = clouds[0, 1]  # exact duplicate point: tie -> lowest index
+    dist, ids = ops.bps_encode(clouds.to(DEV), torch.from_numpy(basis).to(DEV))
+    dist, ids = dist.cpu().numpy(), ids.cpu().numpy()
+    for b in range(0, B, max(1, B // 5)):
+        od, oi = bps_oracle.encode_f32(clouds[b].numpy(), basis)
+        assert (ids[b] == oi).all()
+        assert _ulp(dist[b], od).max() == 0
+    if N >= 5:
+        assert not (ids[0] == 3).any()  # point 3 duplicates point 1: the lower index always wins
+
+
+# ------------------------------------------------------------------ A6 / A7: small ops
+def test_ortho6d_forward_backward():
+    ops, _ = _ops()
+    from oracle import dexgan_oracle as O
+    g = torch.Generator().manual_seed(9)
+    o6 = torch.randn((257, 6), generator=g)
+    o6[0] = torch.tensor([1.0, 0, 0, 0, 1.0, 0])
+    r = ops.ortho6d_forward(o6.to(DEV)).cpu()
+    ref = O.rot_matrix_from_ortho6d(o6)
+    np.testing.assert_allclose(r.numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    gr = torch.randn((257, 3, 3), generator=g)
+    o6r = o6.clone().requires_grad_(True)
+    (O.rot_matrix_from_ortho6d(o6r) * gr).sum().backward()
+    d = ops.ortho6d_backward(o6.to(DEV), gr.to(DEV)).cpu()
+    np.testing.assert_allclose(d.numpy(), o6r.grad.numpy(), rtol=2e-4, atol=2e-5)
+
+
+def test_bce_matches_torch():
+    ops, _ = _ops()
+    g = torch.Generator().manual_seed(4)
+    logit = (torch.randn((300, 1), generator=g) * 3).requires_grad_(True)
+    logit.data[0] = 40.0   # saturates: p == 1 -> log(1-p) clamps at -100
+    logit.data[1] = -120.0  # p == 0
+    p = torch.sigmoid(logit)
+    lab = (torch.rand((300, 1), generator=g) < 0.3).float()
+    loss = 0.7 * torch.nn.functional.binary_cross_entropy(p, lab)
+    loss.backward()
+    l, dl = ops.bce(p.detach().to(DEV), lab.to(DEV), weight=0.7)
+    np.testing.assert_allclose(float(l), float(loss), rtol=1e-5)
+    np.testing.assert_allclose(dl.cpu().numpy(), logit.grad.numpy(), rtol=1e-4, atol=1e-8)
+    for t in [0.0, 1.0]:
+        l, _ = ops.bce(p.detach().to(DEV), t, want_grad=False)
+        ref = torch.nn.functional.binary_cross_entropy(p.detach(), torch.full_like(p, t))
+        np.testing.assert_allclose(float(l), float(ref), rtol=1e-5)
+
+
+# ------------------------------------------------------------------ A2-A5: network forward / backward
+def _flat(net, sd, prefix=""):
+    _, L = _ops()
+    fn = L.FlatNet(net, CFG, DEV)
+    fn.load_state_dict(sd, prefix)
+    return fn
+
+
+def _heads_split(h):
+    return {"joint_conf": h[:, :12], "rot_6D": h[:, 12:18], "transl": h[:, 18:21]}
+
+
+@pytest.mark.parametrize("variant", ["init", "wide"])
+@pytest.mark.parametrize("bname", ["real16", "syn8", "syn64"])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_forward_vs_reference_goldens(variant, bname, mode):
+    ops, L = _ops()
+    from summ import unpack_mask
+    g = H.load("forward_goldens.npz")
+    key = "%s/%s/%s/" % (variant, bname, mode)
+    batch = H.batches()[bname]
+    b = batch["bps_object"].shape[0]
+    z = synth.make_z(b, 3)
+    train = mode == "train"
+    sd = H.gan_sd(variant)
+    fg = _flat(L.NET_GEN, sd, "generator.")
+    fd = _flat(L.NET_DISC, sd, "discriminator.")
+    fe = _flat(L.NET_EVA, H.eva_sd(variant))
+    tol = dict(rtol=1e-4, atol=1e-4)  # north_star: poses / joint angles / scores within 1e-4
+    h = ops.gen_forward(fg, z, batch["bps_object"], train)
+    y = {k: v.cpu().numpy() for k, v in _heads_split(h).items()}
+    np.testing.assert_allclose(y["rot_6D"], g[key + "gen_rot_6D"], **tol)
+    np.testing.assert_allclose(y["transl"], g[key + "gen_transl"], **tol)
+    np.testing.assert_allclose(y["joint_conf"], g[key + "gen_joint_conf"], **tol)
+    r = ops.ortho6d_forward(h[:, 12:18])
+    np.testing.assert_allclose(r.cpu().numpy(), g[key + "gen_rot_matrix"], **tol)
+    pr = ops.disc_forward(fd, batch["bps_object"], batch["rot_matrix"], batch["transl"], batch["joint_conf"], train)
+    np.testing.assert_allclose(pr.cpu().numpy(), g[key + "disc_real"], **tol)
+    pf = ops.disc_forward(fd, batch["bps_object"], r, h[:, 18:21].contiguous(), h[:, :12].contiguous(), train)
+    np.testing.assert_allclose(pf.cpu().numpy(), g[key + "disc_fake"], **tol)
+    masks = unpack_mask(g[key + "eva_masks"], (3, b, 512)) if train else None
+    pe = ops.eva_forward(fe, batch["bps_object"], batch["rot_matrix"], batch["transl"], train, masks)
+    np.testing.assert_allclose(pe.cpu().numpy(), g[key + "eva"], **tol)
+    if train:
+        sdo = fg.state_dict("generator.")
+        sdo.update(fd.state_dict("discriminator."))
+        for n in ["generator.gen_bn1.running_mean", "generator.gen_bn1.running_var",
+                  "discriminator.disc_bn1.running_var", "discriminator.disc_rb2.bn2.running_mean"]:
+            H.assert_summary_close(sdo[n], g[key + "bn/" + n], 1e-4, 1e-5, n)
+
+
+def _oracle_grads(net, sd, batch, z, train, masks, seed):
+    """Oracle forward + autograd for a random upstream gradient; returns outputs, param grads, input grads."""
+    from oracle import dexgan_oracle as O
+    names = O.param_names(sd)
+    for n in names:
+        sd[n].requires_grad_(True)
+    b = batch["bps_object"].shape[0]
+    g = torch.Generator().manual_seed(seed)
+    bps = batch["bps_object"].float().clone().requires_grad_(True)
+    rot = batch["rot_matrix"].float().reshape(b, 9).clone().requires_grad_(True)
+    tr = batch["transl"].float().clone().requires_grad_(True)
+    jt = batch["joint_conf"].float().clone().requires_grad_(True)
+    if net == "gen":
+        zz = z.clone().requires_grad_(True)
+        y = O.generator_forward(sd, zz, bps, train)
+        out = torch.cat([y["joint_conf"], y["rot_6D"], y["transl"]], 1)
+        up = torch.randn(out.shape, generator=g)
+        ins = [zz, bps]
+    elif net == "disc":
+        p = O.discriminator_forward(sd, bps, rot, tr, jt, train)
+        out = torch.logit(p)  # gradient is injected at the pre-sigmoid output
+        up = torch.randn(out.shape, generator=g)
+        ins = [rot, tr, jt]
+    else:
+        p = O.evaluator_forward(sd, bps, rot, tr, train, masks)
+        out = torch.logit(p)
+        up = torch.randn(out.shape, generator=g)
+        ins = [rot, tr]
+    # d/d(logit) of sum(up*logit(p)) == up: feeds `up` as d_logit
+    loss = (out * up).sum()
+    gs = torch.autograd.grad(loss, [sd[n] for n in names] + ins, allow_unused=True)
+    for n in names:
+        sd[n].requires_grad_(False)
+    pg = dict(zip(names, gs[:len(names)]))
+    ig = gs[len(names):]
+    return out.detach(), up, pg, ig
+
+
+@pytest.mark.parametrize("net", ["gen", "disc", "eva"])
+@pytest.mark.parametrize("variant,bname,train", [("wide", "syn64", True), ("init", "real16", True),
+                                                 ("wide", "syn8", False)])
+def test_backward_vs_oracle(net, variant, bname, train):
+    ops, L = _ops()
+    batch = H.batches()[bname]
+    b = batch["bps_object"].shape[0]
+    z = synth.make_z(b, 3)
+    masks = synth.make_dropout_masks(b, 21) if (net == "eva" and train) else None
+    if net == "gen":
+        sd = {k[len("generator."):]: v for k, v in H.gan_sd(variant).items() if k.startswith("generator.")}
+        fn = _flat(L.NET_GEN, sd)
+    elif net == "disc":
+        sd = {k[len("discriminator."):]: v for k, v in H.gan_sd(variant).items() if k.startswith("discriminator.")}
+        fn = _flat(L.NET_DISC, sd)
+    else:
+        sd = H.eva_sd(variant)
+        fn = _flat(L.NET_EVA, sd)
+    out, up, pg, ig = _oracle_grads(net, sd, batch, z, train, masks, 31)
+    rot9 = batch["rot_matrix"].float().reshape(b, 9)
+    if net == "gen":
+        h = ops.gen_forward(fn, z, batch["bps_object"], train)
+        np.testing.assert_allclose(h.cpu().numpy(), out.numpy(), rtol=1e-4, atol=1e-4)
+        dz, dbps = ops.gen_backward(fn, z, batch["bps_object"], up, train, want_dz=True, want_dbps=True)
+        got_in = [dz.cpu(), dbps.cpu()]
+    elif net == "disc":
+        p = ops.disc_forward(fn, batch["bps_object"], rot9, batch["transl"], batch["joint_conf"], train)
+        np.testing.assert_allclose(torch.logit(p.cpu()).numpy(), out.numpy(), rtol=1e-3, atol=2e-4)
+        dp = ops.disc_backward(fn, batch["bps_object"], rot9, batch["transl"], batch["joint_conf"], up, train,
+                               need_input=True).cpu()
+        got_in = [dp[:, :9], dp[:, 9:12], dp[:, 12:]]
+    else:
+        p = ops.eva_forward(fn, batch["bps_object"], rot9, batch["transl"], train, masks)
+        np.testing.assert_allclose(torch.logit(p.cpu()).numpy(), out.numpy(), rtol=1e-3, atol=2e-4)
+        dp = ops.eva_backward(fn, batch["bps_object"], rot9, batch["transl"], up, train, need_input=True).cpu()
+        got_in = [dp[:, :9], dp[:, 9:12]]
+    gv = {k: v.cpu() for k, v in fn.views("grads").items()}
+    for n, ref in pg.items():
+        got = gv[n]
+        if H.is_pre_bn_bias(n) and train:
+            sib = float(pg[H.sibling_bn_bias(n)].pow(2).mean().sqrt())
+            assert float(got.abs().max()) <= 1e-3 * sib, n
+            continue
+        scale = float(ref.abs().max()) + 1e-30
+        err = float((got - ref).abs().max())
+        assert err <= 2e-3 * scale, "%s: err %.3e scale %.3e" % (n, err, scale)
+    for got, ref in zip(got_in, ig):
+        scale = float(ref.abs().max()) + 1e-30
+        assert float((got - ref).abs().max()) <= 2e-3 * scale
+    # skip-param pass (G phase through D): same input gradients, no parameter gradients touched
+    if net == "disc":
+        before = fn.grads.clone()
+        dp2 = ops.disc_backward(fn, batch["bps_object"], rot9, batch["transl"], batch["joint_conf"], up, train,
+                                need_input=True, skip_param=True).cpu()
+        assert torch.equal(before, fn.grads)
+        np.testing.assert_allclose(dp2.numpy(), dp.numpy(), rtol=1e-5, atol=1e-7 * float(dp.abs().max()))
