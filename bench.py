@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — grasps/sec of the gen+eval train step (BASELINE.json metric), batch 1024 / BPS-4096 per GPU.
+
+A "step" = one DexGanGrasp.update_dexgangrasp (D phase, Adam(D), G phase, Adam(G)) + one
+update_dexevaluator (fwd, BCE, bwd, Adam) on one batch of synthetic inputs already resident in HBM
+(dexgangrasp.py:739-823).  value = global_batch * steps / time, max over ranks, weak scaling (batch
+1024 per GPU; gradients all-reduced over RCCL when N > 1).
+
+    python bench.py [--gpus N --steps K --warmup W]        # N > 1: launched by torch.distributed.run
+
+Prints ONE JSON line with the contract fields + "roofline" (dominant kernel: the fp32-MFMA GEMM,
+timed live with HIP events on the launch stream) + "cpu_baseline" (the CPU oracle = plain-PyTorch
+restatement of the reference step, timed on this host's cores, rank 0, N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from dex_gan_grasp_amd import _lib, engine, ops, parallel, synth  # noqa: E402
+
+MFLOP_PER_GRASP_FULL = 231.38   # cGAN 167.51 + evaluator 63.87 as the reference executes it
+MFLOP_PER_GRASP_EXEC = 217.41   # the never-applied discriminator dW of the G phase is skipped (153.54 + 63.87)
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def gemm_roofline(dev, iters=20):
+    """Dominant kernel: gemm_f32_kernel<128,128,NT> on the fused fc1||fc3 layer of a ResBlock at the
+    bench batch: C[1024,768] = X[1024,4613] W[768,4613]^T, split-K as the forward uses it.
+    achieved = algorithmic FLOPs (2*M*N*K) / mean launch duration (HIP events on the launch stream)."""
+    M, N, K = 1024, 768, 4613
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn((M, K), generator=g).to(dev)
+    W = torch.randn((N, K), generator=g).to(dev)
+    out = torch.empty((M, N), device=dev)
+    splits = 10
+    slabs = torch.empty((splits * M * N,), device=dev)
+    lib = _lib.lib()
+    st = torch.cuda.current_stream()
+
+    def launch():
+        # mode 0, split-K slabs (the reduce kernel that follows is a separate, tiny launch and is
+        # excluded by timing the GEMM launch alone through splits=0 ... see below)
+        _lib.check(lib.dgg_gemm_f32(0, M, N, K, _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(out), N, 0, None, 0,
+                                    C.c_void_p(st.cuda_stream)))
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        launch()
+    e1.record(st)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * M * N * K
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "gemm_f32_kernel<128,128,NT> M=1024 N=768 K=4613 (fc1||fc3 of a ResBlock)",
+            "ms_per_launch": round(ms, 4)}
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """The CPU oracle (port of the reference step) on this host's cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import dexgan_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    b = 256
+    sd = synth.make_state_dict("dexgangrasp", 0)
+    sde = synth.make_state_dict("evaluator", 5)
+    batch = synth.make_batch(b, 1, with_label=True)
+    z = synth.make_z(b, 3)
+    masks = synth.make_dropout_masks(b, 4)
+    ag = O.AdamState([n for n in O.param_names(sd) if n.startswith("generator.")])
+    ad = O.AdamState([n for n in O.param_names(sd) if n.startswith("discriminator.")])
+    ae = O.AdamState(O.param_names(sde))
+    def step():
+        O.cgan_step(sd, batch, z, ag, ad, cfg, True)
+        O.eva_step(sde, batch, ae, cfg, masks)
+    step()
+    t0 = time.time()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if time.time() - t0 > budget_s or n >= 50:
+            break
+    dt = time.time() - t0
+    return {"value": round(b * n / dt, 1), "unit": "grasps/s", "cores": cores, "kind": "port",
+            "sample": "%d gen+eval steps at batch %d (same step, smaller batch so the sample stays within ~%ds)" % (n, b, int(budget_s))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch (BASELINE: 1024)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = parallel.init_from_env()
+    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cfg = dict(synth.DEFAULT_CFG)
+    B = args.batch
+
+    fg, fd, fe = (_lib.FlatNet(k, cfg, dev) for k in (_lib.NET_GEN, _lib.NET_DISC, _lib.NET_EVA))
+    sd = synth.make_state_dict("dexgangrasp", 0)       # reference-style init (xavier 0.02), same on every rank
+    fg.load_state_dict(sd, "generator.")
+    fd.load_state_dict(sd, "discriminator.")
+    fe.load_state_dict(synth.make_state_dict("evaluator", 5))
+    eng = engine.TrainEngine(cfg, fg, fd, fe, dev)
+    # synthetic batches of this rank's shard (seeds offset by rank), resident in HBM before timing
+    gb = synth.make_batch(B, 1 + 100 * rank)
+    eb = synth.make_batch(B, 2 + 100 * rank, with_label=True)
+    f = lambda t: t.float().to(dev).contiguous()
+    g_in = (f(gb["bps_object"]), f(gb["rot_matrix"]).reshape(B, 9), f(gb["transl"]), f(gb["joint_conf"]))
+    e_in = (f(eb["bps_object"]), f(eb["rot_matrix"]).reshape(B, 9), f(eb["transl"]), f(eb["label"]))
+    zs = [synth.make_z(B, 3 + 100 * rank + i).to(dev) for i in range(4)]
+
+    def step(i):
+        eng.cgan_step(*g_in, zs[i % 4], True)
+        eng.eva_step(*e_in, None, 1234 + i)
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = eng.losses.cpu().numpy()
+    assert all(map(lambda x: x == x, losses[:10])), "NaN in losses"
+
+    if rank == 0:
+        value = B * world * args.steps / dt
+        res = {
+            "metric": "grasps/sec (gen+eval train step), batch=1024 BPS-4096", "value": round(value, 1),
+            "unit": "grasps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cGAN step (update_dexgangrasp) + evaluator step (update_dexevaluator), "
+                                   "batch %d per GPU, BPS-4096, fp32, Adam included" % B,
+                       "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "mflop_per_grasp_as_reference": MFLOP_PER_GRASP_FULL,
+                       "mflop_per_grasp_executed": MFLOP_PER_GRASP_EXEC,
+                       "step_tflops_executed": round(value * MFLOP_PER_GRASP_EXEC * 1e6 / 1e12 / world, 2)},
+        }
+        res["roofline"] = gemm_roofline(dev)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

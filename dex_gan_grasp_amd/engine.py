@@ -1,0 +1,95 @@
+"""Training engine: owns the flat buffers of G, D, E and drives the fused phases of libdgg.so
+(dgg_cgan_d_phase -> [all-reduce] -> dgg_adam_l2 -> dgg_cgan_g_phase -> [all-reduce] -> dgg_adam_l2,
+dgg_eva_phase -> [all-reduce] -> dgg_adam_l2).  Mirrors the ordering of
+DexGanGrasp.update_dexgangrasp / update_dexevaluator (dexgangrasp.py:739-823); see SURVEY.md 3.1."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib, ops, parallel
+from ._lib import check, lib, ptr, stream_ptr, f32c
+
+
+class TrainEngine:
+    def __init__(self, cfg, flat_g, flat_d, flat_e, device):
+        self.cfg = cfg
+        self.G, self.D, self.E = flat_g, flat_d, flat_e
+        self.device = torch.device(device)
+        self.ccfg = _lib.make_cfg(cfg)
+        self.losses = torch.zeros(16, dtype=torch.float32, device=self.device)
+        self._ws = {}
+        self._ws_e = {}
+
+    # ---- helpers
+    def _hp(self, lr_gen=None, lr_dis=None, lr_eva=None):
+        hp = ops.make_hparams(self.cfg, parallel.grad_scale())
+        if lr_gen is not None:
+            hp.lr_gen = lr_gen
+        if lr_dis is not None:
+            hp.lr_dis = lr_dis
+        if lr_eva is not None:
+            hp.lr_eva = lr_eva
+        return hp
+
+    def _cgan_ws(self, B):
+        ws = self._ws.get(B)
+        if ws is None:
+            n = int(lib().dgg_cgan_workspace_bytes(C.byref(self.ccfg), B))
+            if n < 0:
+                raise _lib.DggError("dgg_cgan_workspace_bytes: %d" % n)
+            ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws[B] = ws
+        return ws
+
+    def _eva_ws(self, B):
+        ws = self._ws_e.get(B)
+        if ws is None:
+            n = int(lib().dgg_workspace_bytes(_lib.NET_EVA, C.byref(self.ccfg), B)) + 8 * B + 4096
+            ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws_e[B] = ws
+        return ws
+
+    def _state(self):
+        G, D = self.G, self.D
+        vals = [G.params, G.grads, G.m, G.v, G.bn, D.params, D.grads, D.m, D.v, D.bn]
+        return _lib.GanState(*[t.data_ptr() for t in vals])
+
+    # ---- A10
+    def cgan_step(self, bps, rot9, transl, joint, z, is_train_gen=True, lr_gen=None, lr_dis=None):
+        """One update_dexgangrasp step on this rank's shard.  Inputs: fp32 device tensors.
+        Returns a (16,) device tensor of losses (slots: _lib.L_*); values are a fresh copy."""
+        dev = self.device
+        bps, rot9, transl, joint, z = (f32c(t, dev) for t in (bps, rot9.reshape(-1, 9), transl, joint, z))
+        B = bps.shape[0]
+        ws = self._cgan_ws(B)
+        hp = self._hp(lr_gen, lr_dis)
+        st = self._state()
+        cfg_p, args = C.byref(self.ccfg), (ptr(bps), ptr(rot9), ptr(transl), ptr(joint), ptr(z))
+        check(lib().dgg_cgan_d_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(self.losses),
+                                     stream_ptr()), "dgg_cgan_d_phase")
+        parallel.allreduce_sum_(self.D.grads)
+        self.D.adam_step(hp.lr_dis, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
+        if is_train_gen:
+            check(lib().dgg_cgan_g_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args,
+                                         ptr(self.losses), stream_ptr()), "dgg_cgan_g_phase")
+            parallel.allreduce_sum_(self.G.grads)
+            self.G.adam_step(hp.lr_gen, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
+        return self.losses.clone()
+
+    # ---- A11
+    def eva_step(self, bps, rot9, transl, label, drop_keep=None, seed=0, lr=None):
+        dev = self.device
+        bps, rot9, transl, label = (f32c(t, dev) for t in (bps, rot9.reshape(-1, 9), transl, label.reshape(-1)))
+        dk = f32c(drop_keep, dev) if drop_keep is not None else None
+        B = bps.shape[0]
+        ws = self._eva_ws(B)
+        hp = self._hp(lr_eva=lr)
+        E = self.E
+        check(lib().dgg_eva_phase(C.byref(self.ccfg), ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(ws),
+                                  ws.numel(), B, ptr(bps), ptr(rot9), ptr(transl), ptr(label), ptr(dk), int(seed),
+                                  ptr(self.losses), stream_ptr()), "dgg_eva_phase")
+        parallel.allreduce_sum_(E.grads)
+        E.adam_step(hp.lr_eva, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
+        return self.losses.clone()

@@ -1,0 +1,429 @@
+"""Drop-in mirror of DexGanGrasp/models/dexgangrasp.py (class DexGanGrasp, reference lines cited per
+method): same constructor (cfg dict), method names, loss-dict keys, ValueError/NotImplementedError
+behaviour and checkpoint layout, with the training steps and inference running in libdgg.so.
+
+The training steps (update_dexgangrasp / update_dexevaluator) do not go through torch autograd:
+they call the fused phases of the C-ABI (forward, losses, backward, Adam entirely on the GPU, no
+host synchronisation); the returned loss dict holds 0-d device tensors like the reference's.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from .. import _lib, ops, parallel
+from ..engine import TrainEngine
+from ..utils import utils
+from ..utils.train_tools import EarlyStopping
+from . import losses, networks
+from .networks import DexEvaluator, DexGANGrasp
+
+
+def define_losses(loss_type_recon):
+    """dexgangrasp.py:13-25."""
+    kl_loss = losses.kl_divergence
+    if loss_type_recon == 'transl_rot_6D_l2':
+        reconstruction_loss = losses.transl_rot_6D_l2_loss
+    else:
+        raise Exception('Requested loss not available, choose [transl_rot_6D_l2]')
+    return kl_loss, reconstruction_loss
+
+
+def build_network(cfg, device, is_train):
+    """dexgangrasp.py:28-37."""
+    gen = DexGANGrasp(cfg)
+    eva = DexEvaluator(cfg)
+    gen.to(device)
+    eva.to(device)
+    if is_train:
+        init_net(gen)
+        init_net(eva)
+    return gen, eva
+
+
+def init_net(net):
+    """dexgangrasp.py:39-62."""
+    init_type = net.cfg["weight_init_type"]
+    init_gain = net.cfg["init_gain"]
+
+    def init_func(m):
+        classname = m.__class__.__name__
+        if hasattr(m, 'weight') and (classname.find('Conv') != -1 or classname.find('Linear') != -1):
+            if init_type == 'normal':
+                torch.nn.init.normal_(m.weight.data, 0.0, init_gain)
+            elif init_type == 'xavier':
+                torch.nn.init.xavier_normal_(m.weight.data, gain=init_gain)
+            elif init_type == 'kaiming':
+                torch.nn.init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
+            elif init_type == 'orthogonal':
+                torch.nn.init.orthogonal_(m.weight.data, gain=init_gain)
+            else:
+                raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
+        elif classname.find('BatchNorm') != -1:
+            torch.nn.init.normal_(m.weight.data, 1.0, init_gain)
+            torch.nn.init.constant_(m.bias.data, 0.0)
+
+    net.apply(init_func)
+
+
+class DexGanGrasp(object):
+    """Wrapper which houses the network blocks, the losses and training logic (dexgangrasp.py:65-823)."""
+
+    def __init__(self, cfg):
+        self.dtype = torch.float32
+        torch.set_default_dtype(self.dtype)
+        self.cfg = cfg
+        self.is_train = cfg["is_train"]
+        self.is_wgan = cfg["is_wgan"]
+        if torch.cuda.is_available():
+            # one process per GPU under torchrun (LOCAL_RANK); otherwise the first configured id
+            _, world, local = parallel.env_rank_world()
+            self.device = torch.device('cuda:{}'.format(local if world > 1 else cfg["gpu_ids"][0]))
+        else:
+            self.device = torch.device('cpu')
+        if len(cfg["gpu_ids"]) > 1 and parallel.env_rank_world()[1] == 1:
+            raise NotImplementedError(
+                "multi-GPU runs use one process per GPU: launch with torchrun / torch.distributed.run "
+                "(gradients are all-reduced over RCCL); nn.DataParallel is not used")
+        if self.is_wgan:
+            raise NotImplementedError("is_wgan=True (WGAN-GP, dexgangrasp.py:149-211,234-270) is not built yet")
+
+        if cfg["model"] in ("ffhnet", "dexgangrasp"):
+            self.DexGANGrasp, self.DexEvaluator = build_network(cfg, self.device, is_train=self.is_train)
+        else:
+            raise ValueError('Wrong configure model name of', cfg["model"])
+
+        if self.is_train:
+            self.bce_weight = cfg["bce_weight"]
+            self.kl_coef = cfg["kl_coef"]
+            self.transl_coef = 100.
+            self.rot_coef = 1.
+            self.conf_coef = 10.
+            self.train_dexgenerator = cfg["train_ffhgenerator"]
+            self.train_dexevaluator = cfg["train_ffhevaluator"]
+            adam = lambda params, lr: torch.optim.Adam(params, lr=lr, betas=(cfg["beta1"], 0.999),
+                                                       weight_decay=cfg["weight_decay"])
+            # The torch optimiser objects carry hyper-parameters, schedulers and the checkpoint format
+            # (dexgangrasp.py:97-116); the update itself is the fused dgg_adam_l2 kernel.
+            self.optim_dexgenerator = adam(self.DexGANGrasp.parameters(), cfg["lr"])
+            self.optim_dexgangrasp_generator = adam(self.DexGANGrasp.generator.parameters(), cfg["lr_gen"])
+            self.optim_dexgangrasp_discriminator = adam(self.DexGANGrasp.discriminator.parameters(), cfg["lr_dis"])
+            self.optim_dexevaluator = adam(self.DexEvaluator.parameters(), cfg["lr"])
+            self.scheduler_dexgenerator = networks.get_scheduler(self.optim_dexgenerator, cfg)
+            self.scheduler_dexgangrasp_generator = networks.get_scheduler(self.optim_dexgangrasp_generator, cfg)
+            self.scheduler_dexgangrasp_discriminator = networks.get_scheduler(self.optim_dexgangrasp_discriminator, cfg)
+            self.scheduler_dexevaluator = networks.get_scheduler(self.optim_dexevaluator, cfg)
+            self.estop_dexgenerator = EarlyStopping()
+            self.estop_dexevaluator = EarlyStopping()
+
+        self.kl_loss, self.rec_pose_loss = define_losses('transl_rot_6D_l2')
+        self.L2_loss = torch.nn.MSELoss(reduction='mean')
+        self.BCE_loss = torch.nn.BCELoss(reduction='mean')
+        self.compute_eva_accuracy = losses.accuracy_evaluator
+
+        dexgenerator_n_params = sum(p.numel() for p in self.DexGANGrasp.parameters() if p.requires_grad)
+        print("The dexgenerator has {:2.2f} parms".format(dexgenerator_n_params))
+        dexevaluator_n_params = sum(p.numel() for p in self.DexEvaluator.parameters() if p.requires_grad)
+        print("The dexevaluator has {:2.2f} parms".format(dexevaluator_n_params))
+        self.file_path = os.path.dirname(os.path.abspath(__file__))
+        self.logit_thresh = 0.5
+        self._engine = None
+        self._z_override = None      # tests: inject the latent instead of torch.randn (:770)
+        self._drop_keep = None       # tests: explicit evaluator dropout masks
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _eng(self):
+        if self._engine is None:
+            g = self.DexGANGrasp.generator._require_flat()
+            d = self.DexGANGrasp.discriminator._require_flat()
+            e = self.DexEvaluator._require_flat()
+            self._engine = TrainEngine(self.cfg, g, d, e, self.device)
+        else:  # modules may have been moved (cpu() for a checkpoint and back): re-resolve the buffers
+            self._engine.G = self.DexGANGrasp.generator._require_flat()
+            self._engine.D = self.DexGANGrasp.discriminator._require_flat()
+            self._engine.E = self.DexEvaluator._require_flat()
+        return self._engine
+
+    @staticmethod
+    def _bump(mod, times):
+        for m in mod.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.num_batches_tracked += times
+
+    def _export_adam(self, optim, module, flat):
+        """Expose the fused Adam moments as a torch optimizer state (checkpoint format of
+        dexgangrasp.py:662-712): state[p] = {step, exp_avg, exp_avg_sq}."""
+        if flat is None or flat.step == 0:
+            return
+        mv, vv = flat.views("m"), flat.views("v")
+        for name, p in module.named_parameters():
+            optim.state[p] = {"step": torch.tensor(float(flat.step)), "exp_avg": mv[name], "exp_avg_sq": vv[name]}
+
+    def _import_adam(self, optim, module, flat):
+        """After optim.load_state_dict: copy loaded moments into the flat buffers the kernel uses."""
+        mv, vv = flat.views("m"), flat.views("v")
+        step = 0
+        for name, p in module.named_parameters():
+            st = optim.state.get(p)
+            if st:
+                mv[name].copy_(st["exp_avg"].to(mv[name].device))
+                vv[name].copy_(st["exp_avg_sq"].to(vv[name].device))
+                step = max(step, int(float(st["step"])))
+        flat.step = step
+
+    # ------------------------------------------------------------------ losses (torch-level API)
+    def compute_loss_dexevaluator(self, pred_success_p):
+        """dexgangrasp.py:142-147 (BCE in dgg_bce)."""
+        loss, _ = ops.bce(pred_success_p.detach(), self.DexEvaluator.gt_label, weight=self.bce_weight, want_grad=False)
+        return loss, {'total_loss_eva': loss, 'bce_loss': loss}
+
+    def compute_loss_dexgangrasp_discriminator(self, real_score, fake_score, real_data=None, fake_data_disc=None):
+        """dexgangrasp.py:213-232."""
+        lr, _ = ops.bce(real_score.detach(), 1.0, weight=self.bce_weight, want_grad=False)
+        lf, _ = ops.bce(fake_score.detach(), 0.0, weight=self.bce_weight, want_grad=False)
+        tot = (lr + lf) / 2
+        return tot, {'total_loss_disc': tot, 'bce_loss_real': lr, 'bce_loss_fake': lf}
+
+    def compute_loss_dexgangrasp_generator(self, real_data, fake_data, fake_score):
+        """dexgangrasp.py:272-307 (+ losses.py:61-76) evaluated by dgg_gen_loss (values only)."""
+        dev = self.device
+        nj = self.cfg["n_hand_joints"]
+        B = fake_score.shape[0]
+        heads = torch.cat([fake_data['joint_conf'].detach().float(), fake_data['rot_6D'].detach().float(),
+                           fake_data['transl'].detach().float()], 1).contiguous()
+        gt_rot = _lib.f32c(real_data['rot_matrix'], dev).reshape(B, 9)
+        gt_tr = _lib.f32c(real_data['transl'], dev)
+        gt_j = _lib.f32c(real_data['joint_conf'], dev)
+        out = torch.zeros(16, dtype=torch.float32, device=dev)
+        hp = ops.make_hparams(self.cfg)
+        hp.bce_weight = float(self.bce_weight) if self.is_train else float(self.cfg.get("bce_weight", 1))
+        ccfg = _lib.make_cfg(self.cfg)
+        _lib.check(_lib.lib().dgg_gen_loss(_lib.C.byref(ccfg), _lib.C.byref(hp), B, _lib.ptr(heads), _lib.ptr(gt_rot),
+                                           _lib.ptr(gt_tr), _lib.ptr(gt_j), _lib.ptr(_lib.f32c(fake_score.detach(), dev)),
+                                           None, _lib.ptr(out), None, _lib.stream_ptr()), "dgg_gen_loss")
+        loss_dict = {'gen_loss_fake': out[_lib.L_GEN_FAKE], 'transl_loss': out[_lib.L_TRANSL],
+                     'rot_loss': out[_lib.L_ROT], 'conf_loss': out[_lib.L_CONF],
+                     'total_loss_gen': out[_lib.L_TOTAL_GEN]}
+        self.last_loss_dict_gen = loss_dict
+        return out[_lib.L_TOTAL_GEN], loss_dict
+
+    # ------------------------------------------------------------------ eval helpers
+    def eval_dexevaluator_accuracy(self, data):
+        """dexgangrasp.py:309-322."""
+        with torch.no_grad():
+            logits = self.DexEvaluator(data)
+        pred_label = utils.class_labels_from_logits(logits.clone(), self.logit_thresh)
+        pos_acc, neg_acc, acc = self.compute_eva_accuracy(pred_label, self.DexEvaluator.gt_label)
+        return pos_acc, neg_acc, pred_label.detach().cpu().numpy(), self.DexEvaluator.gt_label.detach().cpu().numpy()
+
+    def eval_dexevaluator_loss(self, data):
+        """dexgangrasp.py:325-332."""
+        self.DexEvaluator.eval()
+        with torch.no_grad():
+            out = self.DexEvaluator(data)
+            if not self.is_train:
+                self.bce_weight = self.cfg["bce_weight"]
+            _, loss_dict_dexevaluator = self.compute_loss_dexevaluator(out)
+        return loss_dict_dexevaluator
+
+    def eval_dexgangrasp_generator_loss(self, real_data):
+        """dexgangrasp.py:334-365."""
+        self.DexGANGrasp.eval()
+        with torch.no_grad():
+            n_samples = real_data["bps_object"].shape[0]
+            Zgen = self._draw_z(n_samples)
+            y_fake = self.DexGANGrasp.generator(Zgen, real_data["bps_object"].to(self.DexGANGrasp.device))
+            y_fake["rot_matrix"] = utils.rot_matrix_from_ortho6d(y_fake["rot_6D"])
+            fake_data = {"bps_object": real_data["bps_object"], "rot_matrix": y_fake["rot_matrix"],
+                         "rot_6D": y_fake["rot_6D"], "transl": y_fake["transl"], "joint_conf": y_fake["joint_conf"]}
+            fake_score_gen = self.DexGANGrasp.discriminator(fake_data)
+            real_data["rot_matrix"] = real_data["rot_matrix"].view(real_data["bps_object"].shape[0], -1)
+            if not self.is_train:
+                self.bce_weight = self.cfg["bce_weight"]
+            _, loss_dict_dexgenerator = self.compute_loss_dexgangrasp_generator(real_data, fake_data, fake_score_gen)
+        return loss_dict_dexgenerator
+
+    # ------------------------------------------------------------------ inference
+    def evaluate_grasps(self, bps, grasps, thresh=0.5, return_arr=True):
+        """dexgangrasp.py:367-391."""
+        n_samples = grasps['rot_matrix'].shape[0]
+        if len(bps.shape) > 1:
+            bps = bps.squeeze()
+        bps = np.tile(bps, (n_samples, 1))
+        grasps['bps_object'] = bps
+        grasps_t = utils.dict_to_tensor(grasps, device=self.device, dtype=self.dtype)
+        with torch.no_grad():
+            p_success = self.DexEvaluator(grasps_t).squeeze()
+        if return_arr:
+            p_success = p_success.cpu().detach().numpy()
+        return p_success
+
+    def _filter(self, scorer, bps, grasps, thresh, return_arr):
+        n_samples = grasps['rot_matrix'].shape[0]
+        if len(bps.shape) > 1:
+            bps = bps.squeeze()
+        bps = np.tile(bps, (n_samples, 1))
+        grasps['bps_object'] = bps
+        grasps_t = utils.dict_to_tensor(grasps, device=self.device, dtype=self.dtype)
+        with torch.no_grad():
+            p_success = scorer(grasps_t).squeeze()
+        sorted_score, indices = p_success.sort(descending=True)
+        if sorted_score[0] < thresh:
+            raise ValueError("In total predicted ", n_samples, " grasps, but best score ", sorted_score[0],
+                             " is still lower than thresh", thresh)
+        indices = indices[sorted_score > thresh]
+        filt_grasps = {k: torch.index_select(v, 0, indices) for k, v in grasps_t.items()}
+        if return_arr:
+            filt_grasps = {k: v.cpu().detach().numpy() for k, v in filt_grasps.items()}
+        return filt_grasps
+
+    def filter_grasps(self, bps, grasps, thresh=0.5, return_arr=True):
+        """dexgangrasp.py:393-442."""
+        return self._filter(self.DexEvaluator, bps, grasps, thresh, return_arr)
+
+    def filter_grasps_discriminator(self, bps, grasps, thresh=0.5, return_arr=True):
+        """dexgangrasp.py:444-493."""
+        return self._filter(self.DexGANGrasp.discriminator, bps, grasps, thresh, return_arr)
+
+    def generate_grasps(self, bps, n_samples, return_arr=True, z_offset=0.025):
+        """dexgangrasp.py:495-514."""
+        if len(bps.shape) > 1:
+            bps = bps.squeeze()
+        bps = np.tile(bps, (n_samples, 1))
+        bps_tensor = torch.tensor(bps, dtype=self.dtype, device=self.device)
+        with torch.no_grad():
+            return self.DexGANGrasp.generate_poses(bps_tensor, return_arr=return_arr, z_offset=z_offset)
+
+    # ------------------------------------------------------------------ checkpoints
+    def load_dexevaluator(self, epoch, load_path=None):
+        """dexgangrasp.py:571-592."""
+        if load_path is None:
+            load_path = self.cfg["load_path"]
+        load_path = os.path.join(load_path, str(epoch) + '_eva_net.pt')
+        ckpt = torch.load(load_path, map_location=self.device, weights_only=False)
+        self.DexEvaluator.load_state_dict(ckpt['ffhevaluator_state_dict'])
+        if self.cfg["is_train"]:
+            self.optim_dexevaluator.load_state_dict(ckpt['optim_ffhevaluator_state_dict'])
+            self.scheduler_dexevaluator.load_state_dict(ckpt['scheduler_ffhevaluator_state_dict'])
+            self._import_adam(self.optim_dexevaluator, self.DexEvaluator, self.DexEvaluator._require_flat())
+            self.cfg["load_epoch"] = ckpt['epoch']
+            self.DexEvaluator.train()
+        else:
+            self.DexEvaluator.eval()
+
+    def load_dexgenerator(self, epoch, load_path=None):
+        """dexgangrasp.py:594-617 (+ the GAN optimisers, which the reference saves but leaves as a TODO
+        to reload at :611)."""
+        if load_path is None:
+            load_path = self.cfg["load_path"]
+        load_path = os.path.join(load_path, str(epoch) + '_gen_net.pt')
+        ckpt = torch.load(load_path, map_location=self.device, weights_only=False)
+        self.DexGANGrasp.load_state_dict(ckpt['ffhgenerator_state_dict'])
+        if self.cfg["is_train"]:
+            print("Load TRAIN mode")
+            self.optim_dexgenerator.load_state_dict(ckpt['optim_ffhgenerator_state_dict'])
+            self.scheduler_dexgenerator.load_state_dict(ckpt['scheduler_ffhgenerator_state_dict'])
+            for key, opt, mod in (("optim_ffhgan_generator_state_dict", self.optim_dexgangrasp_generator,
+                                   self.DexGANGrasp.generator),
+                                  ("optim_ffhgan_discriminator_state_dict", self.optim_dexgangrasp_discriminator,
+                                   self.DexGANGrasp.discriminator)):
+                if key in ckpt and ckpt[key].get("state"):
+                    opt.load_state_dict(ckpt[key])
+                    self._import_adam(opt, mod, mod._require_flat())
+            self.DexGANGrasp.train()
+        else:
+            print("Network in EVAL mode")
+            self.DexGANGrasp.eval()
+
+    def save_dexevaluator(self, net_name, epoch):
+        """dexgangrasp.py:662-683: same file name and dict keys."""
+        save_path = os.path.join(self.cfg["save_dir"], net_name + '_eva_net.pt')
+        self._export_adam(self.optim_dexevaluator, self.DexEvaluator, self.DexEvaluator._require_flat())
+        sd = {k: v.detach().cpu().clone() for k, v in self.DexEvaluator.state_dict().items()}
+        torch.save({'epoch': epoch, 'ffhevaluator_state_dict': sd,
+                    'optim_ffhevaluator_state_dict': self.optim_dexevaluator.state_dict(),
+                    'scheduler_ffhevaluator_state_dict': self.scheduler_dexevaluator.state_dict()}, save_path)
+
+    def save_dexgenerator(self, net_name, epoch):
+        """dexgangrasp.py:685-712: same file name and dict keys."""
+        save_path = os.path.join(self.cfg["save_dir"], net_name + '_gen_net.pt')
+        self._export_adam(self.optim_dexgangrasp_generator, self.DexGANGrasp.generator,
+                          self.DexGANGrasp.generator._require_flat())
+        self._export_adam(self.optim_dexgangrasp_discriminator, self.DexGANGrasp.discriminator,
+                          self.DexGANGrasp.discriminator._require_flat())
+        sd = {k: v.detach().cpu().clone() for k, v in self.DexGANGrasp.state_dict().items()}
+        torch.save({'epoch': epoch, 'ffhgenerator_state_dict': sd,
+                    'optim_ffhgenerator_state_dict': self.optim_dexgenerator.state_dict(),
+                    'scheduler_ffhgenerator_state_dict': self.scheduler_dexgenerator.state_dict(),
+                    'optim_ffhgan_generator_state_dict': self.optim_dexgangrasp_generator.state_dict(),
+                    'scheduler_ffhgan_generator_state_dict': self.scheduler_dexgangrasp_generator.state_dict(),
+                    'optim_ffhgan_discriminator_state_dict': self.optim_dexgangrasp_discriminator.state_dict(),
+                    'scheduler_ffhgan_discriminator_state_dict': self.scheduler_dexgangrasp_discriminator.state_dict(),
+                    }, save_path)
+
+    # ------------------------------------------------------------------ schedule hooks
+    def update_estop(self, eval_loss_dict):
+        """dexgangrasp.py:714-725."""
+        if self.train_dexevaluator:
+            if self.estop_dexevaluator(eval_loss_dict['total_loss_eva']):
+                self.train_dexevaluator = False
+        if self.train_dexgenerator:
+            if self.estop_dexgenerator(eval_loss_dict['total_loss_gen']):
+                self.train_dexgenerator = False
+
+    def update_learning_rate(self, eval_loss_dict):
+        """dexgangrasp.py:727-737."""
+        if self.train_dexevaluator:
+            self.scheduler_dexevaluator.step(eval_loss_dict['total_loss_eva'])
+            print('learning rate evaluator = %.7f' % self.optim_dexevaluator.param_groups[0]['lr'])
+        if self.train_dexgenerator:
+            self.scheduler_dexgenerator.step(eval_loss_dict['total_loss_gen'])
+            print('learning rate generator = %.7f' % self.optim_dexgenerator.param_groups[0]['lr'])
+
+    # ------------------------------------------------------------------ training steps
+    def _draw_z(self, n):
+        if self._z_override is not None:
+            return self._z_override.to(self.device, self.dtype)
+        return torch.randn((n, self.DexGANGrasp.latentD), dtype=self.DexGANGrasp.dtype, device=self.DexGANGrasp.device)
+
+    def update_dexevaluator(self, data):
+        """dexgangrasp.py:739-755 as one fused phase (dgg_eva_phase) + dgg_adam_l2."""
+        self.DexEvaluator.train()
+        eva = self.DexEvaluator
+        eva.set_input(data)  # same casts / side-effect attributes as the reference's forward (:307-313)
+        seed = 0
+        if self._drop_keep is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        lr = self.optim_dexevaluator.param_groups[0]['lr']
+        out = self._eng().eva_step(eva.bps_object, eva.rot_matrix, eva.transl, eva.gt_label, self._drop_keep, seed, lr)
+        self._bump(eva, 1)
+        return {'total_loss_eva': out[_lib.L_TOTAL_EVA], 'bce_loss': out[_lib.L_BCE_EVA]}
+
+    def update_dexgangrasp(self, real_data, is_train_gen=True):
+        """dexgangrasp.py:757-823: discriminator phase, Adam(D), generator phase, Adam(G) — the 13
+        steps of SURVEY.md 3.1 — as two fused phases of libdgg.so."""
+        gan = self.DexGANGrasp
+        gan.train()
+        dev = gan.device
+        n_samples = real_data["bps_object"].shape[0]
+        Zgen = self._draw_z(n_samples)
+        bps = _lib.f32c(real_data["bps_object"], dev)
+        rot9 = _lib.f32c(real_data["rot_matrix"], dev).reshape(n_samples, 9)
+        transl = _lib.f32c(real_data["transl"], dev)
+        joint = _lib.f32c(real_data["joint_conf"], dev)
+        out = self._eng().cgan_step(bps, rot9, transl, joint, Zgen, is_train_gen,
+                                    self.optim_dexgangrasp_generator.param_groups[0]['lr'],
+                                    self.optim_dexgangrasp_discriminator.param_groups[0]['lr'])
+        self._bump(gan.generator, 1)
+        self._bump(gan.discriminator, 3 if is_train_gen else 2)
+        loss_dict = {'total_loss_disc': out[_lib.L_TOTAL_DISC], 'bce_loss_real': out[_lib.L_BCE_REAL],
+                     'bce_loss_fake': out[_lib.L_BCE_FAKE]}
+        if is_train_gen:
+            real_data["rot_matrix"] = real_data["rot_matrix"].view(n_samples, -1)  # :810 mutates the caller's dict
+            self.last_loss_dict_gen = {'gen_loss_fake': out[_lib.L_GEN_FAKE], 'transl_loss': out[_lib.L_TRANSL],
+                                       'rot_loss': out[_lib.L_ROT], 'conf_loss': out[_lib.L_CONF],
+                                       'total_loss_gen': out[_lib.L_TOTAL_GEN]}
+        loss_dict.update(self.last_loss_dict_gen)
+        return loss_dict

@@ -44,11 +44,11 @@ def gemm(mode, A, Bm, M, N, K, splits=0, C_out=None, accumulate=False):
 
 
 # ------------------------------------------------------------------------------------------ networks
-def gen_forward(fn, z, bps, train):
+def gen_forward(fn, z, bps, train, ws=None):
     dev = fn.device
     z, bps = f32c(z, dev), f32c(bps, dev)
     B = bps.shape[0]
-    ws = fn.workspace(B)
+    ws = ws if ws is not None else fn.workspace(B)
     out = torch.empty((B, fn.ccfg.n_hand_joints + 9), dtype=torch.float32, device=dev)
     check(lib().dgg_gen_forward(C.byref(fn.ccfg), ptr(fn.params), ptr(fn.bn), ptr(ws), ws.numel(), B,
                                 _lib.TRAIN if train else 0, ptr(z), ptr(bps), ptr(out), stream_ptr()), "dgg_gen_forward")

@@ -1,0 +1,107 @@
+"""CPU tests of the boundary: libdgg.so loads, exports every symbol include/dgg.h declares, its
+layout tables describe exactly the reference's state_dict, argument validation returns error
+codes (no compute is launched without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from dex_gan_grasp_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "dgg.h")).read()
+    declared = set(re.findall(r"\b(dgg_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"dgg_status", "dgg_net", "dgg_cfg", "dgg_entry", "dgg_hparams", "dgg_gan_state"}
+    assert len(declared) >= 20
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), "libdgg.so does not export " + name
+    assert declared == set(_lib.SIGNATURES.keys()), declared ^ set(_lib.SIGNATURES.keys())
+    assert b"gfx950" in _lib.lib().dgg_version()
+
+
+@pytest.mark.parametrize("net,name", [(_lib.NET_GEN, "generator"), (_lib.NET_DISC, "discriminator"),
+                                      (_lib.NET_EVA, "evaluator")])
+def test_layout_table_matches_reference_state_dict(net, name):
+    c = _lib.make_cfg(synth.DEFAULT_CFG)
+    t = _lib.table(net, c)
+    spec = {n: sh for n, sh, k in synth.net_spec(name) if k != "bn_nbt"}
+    assert set(spec) == {e[0] for e in t}
+    used = []
+    for nm, off, rows, cols, kind in t:
+        got = (rows, cols) if cols > 1 else (rows,)
+        assert tuple(spec[nm]) == got, nm
+        assert off % 4 == 0 or "fc3" in nm or "bias" in nm or "gen_" in nm
+        used.append((kind, off, off + rows * cols))
+    # entries of one buffer never overlap
+    for kind in (0, 1):
+        iv = sorted((a, b) for k, a, b in used if k == kind)
+        for (a0, b0), (a1, b1) in zip(iv, iv[1:]):
+            assert b0 <= a1
+    n_par = sum(r * cc for _, _, r, cc, k in t if k == 0)
+    assert n_par == {"generator": 6979093, "discriminator": 6998065, "evaluator": 10661657}[name]
+    assert int(_lib.lib().dgg_param_floats(net, C.byref(c))) >= n_par
+    # fc1.weight and fc3.weight are adjacent: one (768 x Fin) matrix for the fused fc1||fc3 GEMM
+    d = {nm: (off, rows, cols) for nm, off, rows, cols, _ in t}
+    for nm in d:
+        if nm.endswith("fc1.weight"):
+            o1, r1, c1 = d[nm]
+            o3, _, c3 = d[nm.replace("fc1", "fc3")]
+            assert o3 == o1 + r1 * c1 and c1 == c3
+
+
+def test_queries_and_argument_validation():
+    c = _lib.make_cfg(synth.DEFAULT_CFG)
+    lib = _lib.lib()
+    for net in (0, 1, 2):
+        assert lib.dgg_workspace_bytes(net, C.byref(c), 1024) > 0
+        assert lib.dgg_workspace_bytes(net, C.byref(c), 0) < 0
+    assert lib.dgg_cgan_workspace_bytes(C.byref(c), 256) > 0
+    assert lib.dgg_table(7, C.byref(c), None, 0) < 0
+    bad = _lib.make_cfg({"n_neurons": 300})
+    assert lib.dgg_param_floats(0, C.byref(bad)) < 0
+    # null pointers / bad sizes are rejected before anything is launched
+    assert lib.dgg_bps_encode(None, 1, 10, None, 4096, None, None, None) == -1
+    assert lib.dgg_adam_l2(None, None, None, None, 10, 1, 1e-4, 0.9, 0.999, 1e-8, 0.0, 1.0, None) == -1
+    assert lib.dgg_gemm_f32(5, 1, 1, 1, None, 1, None, 1, None, 1, 0, None, 0, None) == -1
+    assert lib.dgg_ortho6d_forward(None, 6, 4, None, None) == -1
+
+
+def test_modules_construct_and_serialise_without_gpu_but_forward_fails_loudly():
+    from dex_gan_grasp_amd.models import networks
+    cfg = dict(synth.DEFAULT_CFG)
+    gen = networks.Generator(cfg)
+    sd = gen.state_dict()
+    spec = synth.net_spec("generator")
+    assert list(sd.keys()) == [n for n, _, _ in spec]
+    gen.load_state_dict({k[len("generator."):]: v for k, v in synth.make_state_dict("dexgangrasp", 0).items()
+                         if k.startswith("generator.")})
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.DggError):
+            gen(torch.zeros(2, 5), torch.zeros(2, 4096))
+        from dex_gan_grasp_amd.utils import utils
+        with pytest.raises(_lib.DggError):
+            utils.rot_matrix_from_ortho6d(torch.zeros(2, 6))
+    with pytest.raises(_lib.DggError):
+        networks.ResBlock(10, 20)(torch.zeros(2, 10))
+
+
+def test_wrapper_error_conventions():
+    from dex_gan_grasp_amd.models.dexgangrasp import DexGanGrasp
+    cfg = dict(synth.DEFAULT_CFG)
+    cfg["model"] = "nope"
+    with pytest.raises(ValueError):
+        DexGanGrasp(cfg)
+    cfg = dict(synth.DEFAULT_CFG)
+    cfg["lr_policy"] = "cosine"
+    with pytest.raises(NotImplementedError):
+        DexGanGrasp(cfg)
+    cfg = dict(synth.DEFAULT_CFG)
+    cfg["weight_init_type"] = "bogus"
+    with pytest.raises(NotImplementedError):
+        DexGanGrasp(cfg)

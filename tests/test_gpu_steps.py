@@ -1,0 +1,361 @@
+"""GPU parity of the training steps (A10-A12) and of the drop-in Python surface (A13-A15, checkpoints):
+HIP path vs the CPU oracle on the same seeded inputs, and vs the fixtures produced by the reference."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from dex_gan_grasp_amd import synth
+
+pytestmark = pytest.mark.gpu
+CFG = dict(synth.DEFAULT_CFG)
+DEV = "cuda"
+
+
+def _mods():
+    from dex_gan_grasp_amd import _lib, ops, engine
+    return _lib, ops, engine
+
+
+def _strip(sd, prefix):
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def _cmp_grads(flat, ref, prefix=""):
+    gv = {k: v.cpu() for k, v in flat.views("grads").items()}
+    for n, r in ref.items():
+        n = n[len(prefix):]
+        got = gv[n]
+        if H.is_pre_bn_bias(n):
+            sib = float(ref[prefix + H.sibling_bn_bias(n)].pow(2).mean().sqrt())
+            assert float(got.abs().max()) <= 1e-3 * sib, n
+            continue
+        scale = float(r.abs().max()) + 1e-30
+        err = float((got - r).abs().max())
+        assert err <= 2e-3 * scale, "%s: err %.3e scale %.3e" % (n, err, scale)
+
+
+def _cmp_state(flat, sd_ref, prefix, step, lr=1e-4):
+    sd = flat.state_dict()
+    for n, t in sd.items():
+        r = sd_ref[prefix + n]
+        d = (t - r).abs()
+        if H.is_pre_bn_bias(n) or ("rb" in n and n.endswith("running_mean")):
+            assert float(d.max()) <= 2.5 * lr * (step + 1), n   # see helpers.assert_state_close
+            continue
+        tol = 1e-4 * r.abs() + 1e-4 * float(r.pow(2).mean().sqrt()) + 5e-3 * lr * (step + 1)
+        assert bool((d <= tol).all()), "%s: max err %.3e" % (n, float(d.max()))
+
+
+@pytest.mark.parametrize("variant,bname", [("wide", "syn64"), ("init", "real16"), ("init", "syn64")])
+def test_cgan_and_eva_steps_vs_oracle_and_goldens(variant, bname):
+    L, ops, engine = _mods()
+    from oracle import dexgan_oracle as O
+    from summ import unpack_mask
+    g = H.load("step_goldens.npz")
+    has_golden = (variant + "/" + bname + "/cgan0/z") in g.files
+    key = "%s/%s/" % (variant, bname)
+    batch = H.batches()[bname]
+    b = batch["bps_object"].shape[0]
+    sd = H.gan_sd(variant)
+    fg, fd = L.FlatNet(L.NET_GEN, CFG, DEV), L.FlatNet(L.NET_DISC, CFG, DEV)
+    fg.load_state_dict(sd, "generator.")
+    fd.load_state_dict(sd, "discriminator.")
+    fe = L.FlatNet(L.NET_EVA, CFG, DEV)
+    sde = H.eva_sd(variant)
+    fe.load_state_dict(sde)
+    eng = engine.TrainEngine(CFG, fg, fd, fe, DEV)
+    ag = O.AdamState([n for n in O.param_names(sd) if n.startswith("generator.")])
+    ad = O.AdamState([n for n in O.param_names(sd) if n.startswith("discriminator.")])
+    bps = batch["bps_object"].to(DEV)
+    rot9 = batch["rot_matrix"].float().reshape(b, 9).to(DEV)
+    tr, jt = batch["transl"].float().to(DEV), batch["joint_conf"].float().to(DEV)
+    hp = ops.make_hparams(CFG)
+    for step in range(2):
+        z = torch.from_numpy(g[key + "cgan%d/z" % step]) if has_golden else synth.make_z(b, 100 + step)
+        ref_losses, g_d, g_g, _ = O.cgan_step(sd, H.clone_batch(batch), z, ag, ad, CFG, True, return_grads=True)
+        # phases by hand so the gradients can be inspected before each Adam
+        ws = eng._cgan_ws(b)
+        st = eng._state()
+        zd = z.to(DEV)
+        args = (L.ptr(bps), L.ptr(rot9), L.ptr(tr), L.ptr(jt), L.ptr(zd))
+        L.check(L.lib().dgg_cgan_d_phase(C.byref(eng.ccfg), C.byref(st), C.byref(hp), L.ptr(ws), ws.numel(), b, *args,
+                                         L.ptr(eng.losses), L.stream_ptr()))
+        _cmp_grads(fd, g_d, "discriminator.")
+        fd.adam_step(hp.lr_dis)
+        L.check(L.lib().dgg_cgan_g_phase(C.byref(eng.ccfg), C.byref(st), C.byref(hp), L.ptr(ws), ws.numel(), b, *args,
+                                         L.ptr(eng.losses), L.stream_ptr()))
+        _cmp_grads(fg, g_g, "generator.")
+        fg.adam_step(hp.lr_gen)
+        got = eng.losses.cpu().numpy()
+        names = ["total_loss_disc", "bce_loss_real", "bce_loss_fake", "gen_loss_fake", "transl_loss", "rot_loss",
+                 "conf_loss", "total_loss_gen"]
+        for i, n in enumerate(names):
+            np.testing.assert_allclose(got[i], float(ref_losses[n]), rtol=1e-4, atol=1e-6, err_msg=n)
+            if has_golden:  # the reference's own numbers
+                np.testing.assert_allclose(got[i], float(g[key + "cgan%d/loss/%s" % (step, n)]), rtol=1e-4, atol=1e-6,
+                                           err_msg="golden " + n)
+        _cmp_state(fg, sd, "generator.", step)
+        _cmp_state(fd, sd, "discriminator.", step)
+        if has_golden:
+            cur = fg.state_dict("generator.")
+            cur.update(fd.state_dict("discriminator."))
+            for n, t in cur.items():
+                H.assert_state_close(n, t, g[key + "cgan%d/state/%s" % (step, n)], step)
+    # evaluator
+    ae = O.AdamState(O.param_names(sde))
+    eb = H.eva_batch(bname)
+    for step in range(2):
+        masks = unpack_mask(g[key + "eva%d/masks" % step], (3, b, 512)) if has_golden else \
+            synth.make_dropout_masks(b, 50 + step)
+        ref_losses, g_e, _ = O.eva_step(sde, H.clone_batch(eb), ae, CFG, masks, return_grads=True)
+        ws = eng._eva_ws(b)
+        ebps, erot = eb["bps_object"].to(DEV), eb["rot_matrix"].float().reshape(b, 9).to(DEV)
+        etr, elab = eb["transl"].float().to(DEV), eb["label"].float().to(DEV)
+        md = masks.to(DEV).contiguous()
+        L.check(L.lib().dgg_eva_phase(C.byref(eng.ccfg), L.ptr(fe.params), L.ptr(fe.grads), L.ptr(fe.bn), C.byref(hp),
+                                      L.ptr(ws), ws.numel(), b, L.ptr(ebps), L.ptr(erot), L.ptr(etr), L.ptr(elab),
+                                      L.ptr(md), 0, L.ptr(eng.losses), L.stream_ptr()))
+        _cmp_grads(fe, g_e)
+        fe.adam_step(hp.lr_eva)
+        got = eng.losses.cpu().numpy()
+        np.testing.assert_allclose(got[L.L_TOTAL_EVA], float(ref_losses["total_loss_eva"]), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(got[L.L_BCE_EVA], float(ref_losses["bce_loss"]), rtol=1e-4, atol=1e-6)
+        if has_golden:
+            np.testing.assert_allclose(got[L.L_TOTAL_EVA], float(g[key + "eva%d/loss/total_loss_eva" % step]),
+                                       rtol=1e-4, atol=1e-6)
+            for n, t in fe.state_dict().items():
+                H.assert_state_close(n, t, g[key + "eva%d/state/%s" % (step, n)], step)
+        _cmp_state(fe, sde, "", step)
+
+
+def test_step_properties_at_full_size():
+    """BASELINE batch 1024: size-independent properties — (i) the fused single-call step equals the
+    hand-sequenced phases bit for bit (determinism, no atomics), (ii) a batch made of two identical
+    halves gives the same BatchNorm statistics and mean gradients as one half (batch-mean
+    linearity of the whole backward), (iii) is_train_gen=False leaves the generator untouched."""
+    L, ops, engine = _mods()
+    b = 1024
+    batch = synth.make_batch(b, 1)
+    z = synth.make_z(b, 3)
+    sd = H.gan_sd("wide")
+
+    def run(bt, zz, train_gen=True):
+        fg, fd = L.FlatNet(L.NET_GEN, CFG, DEV), L.FlatNet(L.NET_DISC, CFG, DEV)
+        fg.load_state_dict(sd, "generator.")
+        fd.load_state_dict(sd, "discriminator.")
+        fe = L.FlatNet(L.NET_EVA, CFG, DEV)
+        eng = engine.TrainEngine(CFG, fg, fd, fe, DEV)
+        n = bt["bps_object"].shape[0]
+        out = eng.cgan_step(bt["bps_object"].to(DEV), bt["rot_matrix"].float().reshape(n, 9).to(DEV),
+                            bt["transl"].float().to(DEV), bt["joint_conf"].float().to(DEV), zz.to(DEV), train_gen)
+        return fg, fd, out
+
+    fg1, fd1, o1 = run(batch, z)
+    fg2, fd2, o2 = run(batch, z)
+    assert torch.equal(fg1.params, fg2.params) and torch.equal(fd1.params, fd2.params) and torch.equal(o1, o2)
+    half = {k: v[:512] for k, v in batch.items()}
+    dup = {k: torch.cat([v[:512], v[:512]]) for k, v in batch.items()}
+    fgh, fdh, oh = run(half, z[:512])
+    fgd, fdd, od = run(dup, torch.cat([z[:512], z[:512]]))
+    np.testing.assert_allclose(od.cpu().numpy()[:8], oh.cpu().numpy()[:8], rtol=2e-5, atol=1e-6)
+    # gradients: duplicated batch -> identical mean gradients -> identical first Adam step (tolerance: summation order)
+    gd, gh = fgd.grads.cpu(), fgh.grads.cpu()
+    assert float((gd - gh).abs().max()) <= 2e-4 * float(gh.abs().max())
+    gd, gh = fdd.grads.cpu(), fdh.grads.cpu()
+    assert float((gd - gh).abs().max()) <= 2e-4 * float(gh.abs().max())
+    fg3, fd3, o3 = run(batch, z, train_gen=False)
+    ref = L.FlatNet(L.NET_GEN, CFG, DEV)
+    ref.load_state_dict(sd, "generator.")
+    assert torch.equal(fg3.params, ref.params)
+    assert torch.equal(fd3.params, fd1.params)  # D is only updated in the D phase
+
+
+# ------------------------------------------------------------------ drop-in Python surface
+def _wrapper(variant, is_train=True):
+    from dex_gan_grasp_amd.models.dexgangrasp import DexGanGrasp
+    cfg = dict(CFG)
+    cfg["is_train"] = is_train
+    cfg["train_ffhevaluator"] = True
+    m = DexGanGrasp(cfg)
+    m.DexGANGrasp.load_state_dict(H.gan_sd(variant))
+    m.DexEvaluator.load_state_dict(H.eva_sd(variant))
+    return m
+
+
+def test_wrapper_state_dict_layout():
+    m = _wrapper("init")
+    sd = m.DexGANGrasp.state_dict()
+    spec = synth.net_spec("dexgangrasp")
+    assert list(sd.keys()) == [n for n, _, _ in spec]          # 82 entries, reference order
+    assert len(sd) == 82 and len(m.DexEvaluator.state_dict()) == 55
+    for n, shape, _ in spec:
+        assert tuple(sd[n].shape) == tuple(shape), n
+    ref = H.gan_sd("init")
+    for n in sd:
+        assert torch.equal(sd[n].cpu(), ref[n]), n
+
+
+@pytest.mark.parametrize("variant,bname", [("wide", "syn64"), ("init", "real16")])
+def test_wrapper_update_steps_vs_reference_goldens(variant, bname, tmp_path):
+    from summ import unpack_mask
+    g = H.load("step_goldens.npz")
+    key = "%s/%s/" % (variant, bname)
+    m = _wrapper(variant)
+    batch = H.batches()[bname]
+    b = batch["bps_object"].shape[0]
+    for step in range(2):
+        m._z_override = torch.from_numpy(g[key + "cgan%d/z" % step])
+        data = H.clone_batch(batch)
+        losses = m.update_dexgangrasp(data, is_train_gen=True)
+        assert tuple(data["rot_matrix"].shape) == (b, 9)        # :810 mutates the caller's dict
+        for k, v in losses.items():
+            assert v.dim() == 0
+            np.testing.assert_allclose(v.item(), float(g[key + "cgan%d/loss/%s" % (step, k)]), rtol=1e-4, atol=1e-6,
+                                       err_msg=k)
+        for n, t in m.DexGANGrasp.state_dict().items():
+            H.assert_state_close(n, t.cpu(), g[key + "cgan%d/state/%s" % (step, n)], step)
+    sd = m.DexGANGrasp.state_dict()
+    assert int(sd["generator.gen_bn1.num_batches_tracked"]) == 2
+    assert int(sd["discriminator.disc_bn1.num_batches_tracked"]) == 6
+    eb = H.eva_batch(bname)
+    for step in range(2):
+        m._drop_keep = unpack_mask(g[key + "eva%d/masks" % step], (3, b, 512))
+        losses = m.update_dexevaluator(H.clone_batch(eb))
+        for k, v in losses.items():
+            np.testing.assert_allclose(v.item(), float(g[key + "eva%d/loss/%s" % (step, k)]), rtol=1e-4, atol=1e-6)
+        for n, t in m.DexEvaluator.state_dict().items():
+            H.assert_state_close(n, t.cpu(), g[key + "eva%d/state/%s" % (step, n)], step)
+    # eval-mode losses after the two steps (train.py:65,110-111)
+    m._z_override = None
+    torch.manual_seed(300)
+    m._z_override = torch.randn((b, 5))  # the reference drew Z on the CPU generator after manual_seed(300)
+    el = m.eval_dexgangrasp_generator_loss(H.clone_batch(batch))
+    for k, v in el.items():
+        np.testing.assert_allclose(float(v), float(g[key + "evalloss_gen/" + k]), rtol=2e-3, atol=1e-5, err_msg=k)
+    el = m.eval_dexevaluator_loss(H.clone_batch(eb))
+    for k, v in el.items():
+        np.testing.assert_allclose(float(v), float(g[key + "evalloss_eva/" + k]), rtol=2e-3, atol=1e-5, err_msg=k)
+    # checkpoint round trip in the reference's file layout (dexgangrasp.py:662-712)
+    m.cfg["save_dir"] = str(tmp_path)
+    m.save_dexgenerator("3", 3)
+    m.save_dexevaluator("3", 3)
+    ck = torch.load(os.path.join(str(tmp_path), "3_gen_net.pt"), map_location="cpu", weights_only=False)
+    assert set(ck.keys()) == {"epoch", "ffhgenerator_state_dict", "optim_ffhgenerator_state_dict",
+                              "scheduler_ffhgenerator_state_dict", "optim_ffhgan_generator_state_dict",
+                              "scheduler_ffhgan_generator_state_dict", "optim_ffhgan_discriminator_state_dict",
+                              "scheduler_ffhgan_discriminator_state_dict"}
+    assert len(ck["ffhgenerator_state_dict"]) == 82
+    st = ck["optim_ffhgan_discriminator_state_dict"]["state"]
+    assert len(st) == 34 and float(st[0]["step"]) == 2.0
+    cke = torch.load(os.path.join(str(tmp_path), "3_eva_net.pt"), map_location="cpu", weights_only=False)
+    assert set(cke.keys()) == {"epoch", "ffhevaluator_state_dict", "optim_ffhevaluator_state_dict",
+                               "scheduler_ffhevaluator_state_dict"}
+    m2 = _wrapper("init")
+    m2.load_dexgenerator(3, str(tmp_path))
+    m2.load_dexevaluator(3, str(tmp_path))
+    for n, t in m.DexGANGrasp.state_dict().items():
+        assert torch.equal(t.cpu(), m2.DexGANGrasp.state_dict()[n].cpu()), n
+    d1, d2 = m.DexGANGrasp.discriminator._flat, m2.DexGANGrasp.discriminator._flat
+    assert torch.equal(d1.m, d2.m) and torch.equal(d1.v, d2.v) and d2.step == 2
+    # a third step on both must agree exactly (resume == continue)
+    for mm in (m, m2):
+        mm._z_override = synth.make_z(b, 9)
+    l1 = m.update_dexgangrasp(H.clone_batch(batch))
+    l2 = m2.update_dexgangrasp(H.clone_batch(batch))
+    for k in l1:
+        assert float(l1[k]) == float(l2[k]), k
+
+
+@pytest.mark.parametrize("variant", ["init", "wide"])
+def test_wrapper_inference_vs_reference_goldens(variant):
+    g = H.load("inference_goldens.npz")
+    bps = H.load("bps_real_objects.npz")["dists_red_mug"]
+    key = variant + "/"
+    m = _wrapper(variant, is_train=False)
+    n = 32
+    z = torch.from_numpy(g[key + "z"])
+    # generate_grasps draws Z with torch.randn on the device; inject the reference's latent instead
+    gan = m.DexGANGrasp
+    gan.eval()
+    orig = torch.randn
+    try:
+        torch.randn = lambda *a, **k: z.to(k.get("device", "cpu"))
+        grasps = m.generate_grasps(bps, n_samples=n, return_arr=True)
+    finally:
+        torch.randn = orig
+    for k in ["transl", "joint_conf", "z", "rot_matrix"]:
+        np.testing.assert_allclose(grasps[k], g[key + "gen/" + k], rtol=1e-4, atol=1e-4, err_msg=k)
+    p = m.evaluate_grasps(bps, {k: v.copy() for k, v in grasps.items()})
+    np.testing.assert_allclose(p, g[key + "scores"], rtol=1e-4, atol=1e-4)
+    thresh = float(g[key + "thresh"])
+    filt = m.filter_grasps(bps, {k: v.copy() for k, v in grasps.items()}, thresh=thresh)
+    # scores within 1e-4 of the threshold could legitimately flip membership
+    margin = np.abs(g[key + "scores"] - thresh).min()
+    if margin > 2e-4:
+        for k in ["transl", "joint_conf", "z", "rot_matrix"]:
+            np.testing.assert_allclose(filt[k], g[key + "filt/" + k], rtol=1e-4, atol=1e-4, err_msg=k)
+        assert tuple(filt["bps_object"].shape) == tuple(g[key + "filt/bps_object_shape"])
+    with pytest.raises(ValueError):
+        m.filter_grasps(bps, {k: v.copy() for k, v in grasps.items()}, thresh=1.1)
+    fd = m.filter_grasps_discriminator(bps, {k: v.copy() for k, v in grasps.items()}, thresh=0.0)
+    np.testing.assert_allclose(fd["transl"], g[key + "filt_disc/transl"], rtol=1e-4, atol=1e-4)
+
+
+def test_autograd_path_matches_oracle():
+    """Module forward + torch backward (the non-fused path: e.g. refine_grasps' input gradients)."""
+    from oracle import dexgan_oracle as O
+    m = _wrapper("wide")
+    batch = H.batches()["syn8"]
+    b = 8
+    eva = m.DexEvaluator
+    eva.eval()
+    data = {"bps_object": batch["bps_object"].to(DEV), "rot_matrix": batch["rot_matrix"].float().to(DEV).requires_grad_(True),
+            "transl": batch["transl"].float().to(DEV).requires_grad_(True)}
+    p = eva(data)
+    p.squeeze().backward(torch.ones(b, device=DEV))
+    sde = H.eva_sd("wide")
+    rot = batch["rot_matrix"].float().clone().requires_grad_(True)
+    tr = batch["transl"].float().clone().requires_grad_(True)
+    pr = O.evaluator_forward(sde, batch["bps_object"], rot, tr, False)
+    pr.squeeze().backward(torch.ones(b))
+    np.testing.assert_allclose(p.detach().cpu().numpy(), pr.detach().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(data["transl"].grad.cpu().numpy(), tr.grad.numpy(), rtol=2e-3,
+                               atol=2e-3 * float(tr.grad.abs().max()))
+    np.testing.assert_allclose(data["rot_matrix"].grad.cpu().numpy(), rot.grad.numpy(), rtol=2e-3,
+                               atol=2e-3 * float(rot.grad.abs().max()))
+    # generator through autograd in train mode: parameter gradients land in Parameter.grad
+    gen = m.DexGANGrasp.generator
+    gen.train()
+    z = synth.make_z(b, 3).to(DEV)
+    y = gen(z, batch["bps_object"].to(DEV))
+    loss = (y["transl"] ** 2).sum() + y["joint_conf"].sum() + (y["rot_6D"] * 0.5).sum()
+    loss.backward()
+    sd = _strip(H.gan_sd("wide"), "generator.")
+    for n in O.param_names(sd):
+        sd[n].requires_grad_(True)
+    yr = O.generator_forward(sd, z.cpu(), batch["bps_object"], True)
+    lr = (yr["transl"] ** 2).sum() + yr["joint_conf"].sum() + (yr["rot_6D"] * 0.5).sum()
+    lr.backward()
+    for n, p_ in gen.named_parameters():
+        if H.is_pre_bn_bias(n):
+            continue
+        r = sd[n].grad
+        assert float((p_.grad.cpu() - r).abs().max()) <= 2e-3 * float(r.abs().max()) + 1e-12, n
+
+
+def test_bps_encoder_mirror(tmp_path):
+    from dex_gan_grasp_amd.data.bps_encoder import BPSEncoder
+    d = H.load("bps_real_objects.npz")
+    path = os.path.join(str(tmp_path), "basis_point_set.npy")
+    np.save(path, d["basis"])
+    enc = BPSEncoder(CFG, path)
+    out = enc.encode_pcd_with_bps(d["cloud_red_mug"].astype(np.float64))
+    assert out.shape == (4096,) and out.dtype == np.float32
+    want = d["dists_red_mug"].reshape(-1)
+    assert np.abs(out.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64)).max() <= 2
+    with pytest.raises(AssertionError):
+        enc.encode_pcd_with_bps(d["cloud_red_mug"] + 1.0)
