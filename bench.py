@@ -40,15 +40,15 @@ def gemm_roofline(dev, iters=20):
     A = torch.randn((M, K), generator=g).to(dev)
     W = torch.randn((N, K), generator=g).to(dev)
     out = torch.empty((M, N), device=dev)
-    splits = 10
+    splits = 10   # what the forward's split-K plan picks for this shape: 48 tiles x 10 = 480 workgroups
     slabs = torch.empty((splits * M * N,), device=dev)
     lib = _lib.lib()
     st = torch.cuda.current_stream()
 
     def launch():
-        # mode 0, split-K slabs (the reduce kernel that follows is a separate, tiny launch and is
-        # excluded by timing the GEMM launch alone through splits=0 ... see below)
-        _lib.check(lib.dgg_gemm_f32(0, M, N, K, _lib.ptr(A), K, _lib.ptr(W), K, _lib.ptr(out), N, 0, None, 0,
+        # mode 0 (NT), split-K partial products into slabs; C = NULL leaves out the (separate, HBM-bound)
+        # bias/BN-statistics reduce kernel so that the MFMA kernel alone is timed
+        _lib.check(lib.dgg_gemm_f32(0, M, N, K, _lib.ptr(A), K, _lib.ptr(W), K, None, N, splits, _lib.ptr(slabs), 0,
                                     C.c_void_p(st.cuda_stream)))
     for _ in range(3):
         launch()
@@ -68,11 +68,29 @@ def gemm_roofline(dev, iters=20):
             "ms_per_launch": round(ms, 4)}
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota (a GPU
+    box exposes all host cores through os.cpu_count() but schedules only its share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(round(int(q) / int(p)))))
+    except Exception:
+        pass
+    if n > 64:  # no quota visible: the documented CPU share of a 1-GPU box is 16 cores
+        n = 16
+    return n
+
+
 def cpu_baseline(cfg, budget_s=20.0):
     """The CPU oracle (port of the reference step) on this host's cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import dexgan_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     b = 256
     sd = synth.make_state_dict("dexgangrasp", 0)

@@ -36,10 +36,10 @@ class Entry(C.Structure):
 
 
 class HParams(C.Structure):
-    _fields_ = [("lr_gen", C.c_float), ("lr_dis", C.c_float), ("lr_eva", C.c_float), ("beta1", C.c_float),
-                ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("bce_weight", C.c_float),
-                ("transl_coef", C.c_float), ("rot_coef", C.c_float), ("conf_coef", C.c_float),
-                ("grad_scale", C.c_float)]
+    _fields_ = [("lr_gen", C.c_double), ("lr_dis", C.c_double), ("lr_eva", C.c_double), ("beta1", C.c_double),
+                ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double), ("bce_weight", C.c_double),
+                ("transl_coef", C.c_double), ("rot_coef", C.c_double), ("conf_coef", C.c_double),
+                ("grad_scale", C.c_double)]
 
 
 class GanState(C.Structure):
@@ -50,6 +50,7 @@ class GanState(C.Structure):
 _lib = None
 
 _VP, _I, _U, _F, _SZ, _I64, _U64 = C.c_void_p, C.c_int, C.c_uint, C.c_float, C.c_size_t, C.c_int64, C.c_uint64
+_D = C.c_double
 _CFG = C.POINTER(Cfg)
 
 # name -> (restype, argtypes); must list every symbol include/dgg.h declares (tests check it)
@@ -70,7 +71,7 @@ SIGNATURES = {
     "dgg_ortho6d_forward": (_I, [_VP, _I, _I, _VP, _VP]),
     "dgg_ortho6d_backward": (_I, [_VP, _I, _I, _VP, _VP, _I, _VP]),
     "dgg_bce": (_I, [_VP, _VP, _F, _I, _F, _F, _VP, _VP, _VP]),
-    "dgg_adam_l2": (_I, [_VP, _VP, _VP, _VP, _I64, _I, _F, _F, _F, _F, _F, _F, _VP]),
+    "dgg_adam_l2": (_I, [_VP, _VP, _VP, _VP, _I64, _I, _D, _D, _D, _D, _D, _D, _VP]),
     "dgg_cgan_workspace_bytes": (_I64, [_CFG, _I]),
     "dgg_cgan_d_phase": (_I, [_CFG, C.POINTER(GanState), C.POINTER(HParams), _VP, _SZ, _I, _VP, _VP, _VP, _VP, _VP,
                               _VP, _VP]),

@@ -198,7 +198,11 @@ struct RbW {
     float *mean1, *rstd1, *mean2, *rstd2;
 };
 struct NetW {
-    float *X0, *imean, *irstd;
+    float *X0, *imean, *irstd;   // X0 holds [prefix | x_hat]: the input BatchNorm's gamma/beta are folded into
+                                 // the GEMMs (aff_scale / aff_shift), never applied to the stored operand
+    float *aff_scale, *aff_shift;  // [k0]: [1.. | gamma], [0.. | beta]
+    float *cs13;                 // [n13] column sums of dY13 of the ResBlock being back-propagated
+    float *ibn_part;             // [nrb][12][2][k0] per-tile partials of d gamma / d beta from the wgrad epilogue
     RbW rb[3];
     // scratch (not preserved between calls)
     float *slabs, *part, *sums, *dY13, *dpre, *da2, *dh, *dX0, *dXa, *dXb;
@@ -221,6 +225,7 @@ struct Bump {
 struct Seg {
     const float* p;  // forward operand (B x width, row pitch ld)
     int ld, width, wcol;
+    bool is_x0;      // the [prefix | x_hat] operand: BN affine folded into the GEMMs
     float* dp;       // backward: gradient destination for columns [d_lo, d_hi) of this segment
     int dld, d_lo, d_hi, d_accum;
 };
@@ -230,7 +235,7 @@ static const int kSlabCap = 24;  // upper bound on split-K slabs of one GEMM
 // Split-K plan for the fused fc1||fc3 GEMM over `nseg` column segments.
 static void plan13(int B, int n13, const int* widths, int nseg, int* splits) {
     int bm, bn;
-    gemm_tile_shape(GEMM_NT, B, n13, bm, bn);
+    gemm_tile_shape(GEMM_NT, B, n13, bm, bn, 4096);
     const int tiles = ((B + bm - 1) / bm) * ((n13 + bn - 1) / bn);
     int total_kt = 0;
     for (int i = 0; i < nseg; ++i) total_kt += (widths[i] + 31) / 32;
@@ -259,6 +264,10 @@ static void carve(const NetL& L, int B, void* base, NetW& W) {
     W.X0 = b.take<float>(Bz * L.ldx0);
     W.imean = b.take<float>(2 * (size_t)L.k_in);
     W.irstd = b.take<float>(2 * (size_t)L.k_in);
+    W.aff_scale = b.take<float>((size_t)L.k0);
+    W.aff_shift = b.take<float>((size_t)L.k0);
+    W.cs13 = b.take<float>((size_t)L.n13);
+    W.ibn_part = b.take<float>((size_t)L.nrb * 12 * 2 * L.k0);
     for (int r = 0; r < L.nrb; ++r) {
         RbW& R = W.rb[r];
         R.a13 = b.take<float>(Bz * L.n13);
@@ -279,6 +288,8 @@ static void carve(const NetL& L, int B, void* base, NetW& W) {
         plan13(B, L.n13, widths, 2, sp);
         int64_t need = (int64_t)(sp[0] + sp[1] + 2) * B * L.n13;
         if (need < W.slab_floats) W.slab_floats = need;
+        const int64_t need_w2 = (int64_t)8 * L.nn * L.hid;  // split-K slabs of the fc2 weight gradient
+        if (W.slab_floats < need_w2) W.slab_floats = need_w2;
     }
     W.slabs = b.take<float>((size_t)W.slab_floats);
     const size_t nrb = (Bz + kRowBlock - 1) / kRowBlock + 2;
@@ -355,6 +366,10 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
         prob_init(gb.p[i], segs[i].p, segs[i].ld, c.P + R.w13 + segs[i].wcol, R.fin, c.W.slabs + (size_t)nslab * slab,
                   L.n13, B, L.n13, segs[i].width);
         prob_split(gb.p[i], sp[i], slab);
+        if (segs[i].is_x0) {  // BatchNorm gamma/beta applied while the operand is staged
+            gb.p[i].a_scale = c.W.aff_scale;
+            gb.p[i].a_shift = c.W.aff_shift;
+        }
         nslab += gb.p[i].splits;
     }
     if ((int64_t)nslab * slab > c.W.slab_floats) return DGG_ERR_WORKSPACE;
@@ -390,7 +405,7 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
 // ResBlock backward.  dy: gradient w.r.t. the block output y (B x 512).
 // ------------------------------------------------------------------------------------------------
 static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy, bool had_dropout, bool accum,
-                       bool skip_param) {
+                       bool skip_param, int* ibn_tiles) {
     const NetL& L = *c.L;
     const RbL& R = L.rb[r];
     RbW& A = c.W.rb[r];
@@ -403,27 +418,42 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     DGG_TRY(res_out_bwd_launch(dy, L.nn, A.y, L.nn, had_dropout ? A.keep : nullptr, A.a13 + L.hid, L.n13, A.a2, L.nn,
                                A.mean2, A.rstd2, B, B, L.nn, c.W.dpre, c.W.dY13 + L.hid, L.n13, c.W.part, c.st));
     DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 3, L.nn, c.W.sums, gp(R.bn2b), gp(R.bn2w), gp(R.b13 + L.hid),
-                                   acc, c.st));
+                                   acc, c.st, 0, 0, nullptr, c.W.cs13 + L.hid));
     // 2. bn2 backward -> da2; its column sums are fc2.bias' gradient
     DGG_TRY(bn_bwd_apply_launch(c.W.dpre, L.nn, A.a2, L.nn, A.mean2, A.rstd2, c.P + R.bn2w, c.W.sums, c.train, B, B,
                                 L.nn, c.W.da2, L.nn, c.W.part, c.st));
-    if (!skip_param)
-        DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 1, L.nn, nullptr, G + R.b2, nullptr, nullptr, acc, c.st));
-    // 3. fc2: dW2 = da2^T h ; dh = da2 W2
+    // fc2.bias feeds a BatchNorm: in train mode the batch-mean subtraction makes its gradient EXACTLY zero
+    // (sum_m da2 = 0 analytically); the reference stores fp32 rounding noise there.  We store the exact
+    // value in train mode and the real column sum in eval mode (running statistics).
+    if (!skip_param) {
+        if (!c.train)
+            DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 1, L.nn, nullptr, G + R.b2, nullptr, nullptr, acc, c.st));
+        else if (!accum && hipMemsetAsync(G + R.b2, 0, sizeof(float) * L.nn, c.st) != hipSuccess)
+            return DGG_ERR_LAUNCH;
+    }
+    // 3. fc2: dW2 = da2^T h ; dh = da2 W2.  Small outputs (512x256, Bx256): split-K over slabs fills the chip.
     if (!skip_param) {
         GemmBatch g;
         memset(&g, 0, sizeof(g));
         g.nprob = 1;
-        prob_init(g.p[0], c.W.da2, L.nn, A.h, L.hid, G + R.w2, L.hid, L.nn, L.hid, B);
-        g.p[0].accumulate = acc;
+        prob_init(g.p[0], c.W.da2, L.nn, A.h, L.hid, c.W.slabs, L.hid, L.nn, L.hid, B);
+        const long long slab = (long long)L.nn * L.hid;
+        prob_split(g.p[0], 8, slab);
+        if ((int64_t)g.p[0].splits * slab > c.W.slab_floats) return DGG_ERR_WORKSPACE;
         DGG_TRY(gemm_launch(GEMM_TN, g, c.st));
+        DGG_TRY(reduce_bias_launch(c.W.slabs, g.p[0].splits, slab, L.hid, nullptr, G + R.w2, L.hid, L.nn, L.nn, 1,
+                                   L.hid, 0, 0, 0, 0, nullptr, c.st, acc));
     }
     {
         GemmBatch g;
         memset(&g, 0, sizeof(g));
         g.nprob = 1;
-        prob_init(g.p[0], c.W.da2, L.nn, c.P + R.w2, L.hid, c.W.dh, L.hid, B, L.hid, L.nn);
+        prob_init(g.p[0], c.W.da2, L.nn, c.P + R.w2, L.hid, c.W.slabs, L.hid, B, L.hid, L.nn);
+        const long long slab = (long long)B * L.hid;
+        prob_split(g.p[0], 4, slab);
         DGG_TRY(gemm_launch(GEMM_NN, g, c.st));
+        DGG_TRY(reduce_bias_launch(c.W.slabs, g.p[0].splits, slab, L.hid, nullptr, c.W.dh, L.hid, B, B, 1, L.hid, 0, 0,
+                                   0, 0, nullptr, c.st));
     }
     // 4. through lrelu and bn1 -> da1 into dY13[:, 0:256]
     DGG_TRY(act_bwd_launch(c.W.dh, L.hid, A.h, L.hid, A.a13, L.n13, A.mean1, A.rstd1, B, B, L.hid, c.W.dh, L.hid,
@@ -431,20 +461,43 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 2, L.hid, c.W.sums, gp(R.bn1b), gp(R.bn1w), nullptr, acc, c.st));
     DGG_TRY(bn_bwd_apply_launch(c.W.dh, L.hid, A.a13, L.n13, A.mean1, A.rstd1, c.P + R.bn1w, c.W.sums, c.train, B, B,
                                 L.hid, c.W.dY13, L.n13, c.W.part, c.st));
-    if (!skip_param)
-        DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 1, L.hid, nullptr, G + R.b13, nullptr, nullptr, acc, c.st));
-    // 5. wgrad of [fc1;fc3]: dW13[:, wcol:] = dY13^T X_seg
+    // fc1.bias: same argument as fc2.bias above; in eval mode the real column sum is also kept in cs13[0:hid]
+    // for the BatchNorm-aware wgrad epilogue (train mode: exactly zero -> ep_cs0 = NULL)
+    if (!c.train)
+        DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 1, L.hid, nullptr, gp(R.b13), nullptr, nullptr, acc, c.st, 0,
+                                       0, c.W.cs13, nullptr));
+    else if (!skip_param && !accum && hipMemsetAsync(G + R.b13, 0, sizeof(float) * L.hid, c.st) != hipSuccess)
+        return DGG_ERR_LAUNCH;
+    // 5. wgrad of [fc1;fc3]: dW13[:, wcol:] = dY13^T X_seg.  For the [prefix | x_hat] segment the epilogue
+    //    turns T = dY13^T x_hat into dW = gamma T + beta cs and emits the partials of d gamma / d beta of the
+    //    input BatchNorm, so dX0 is never needed for parameter gradients.
     if (!skip_param) {
         GemmBatch g;
         memset(&g, 0, sizeof(g));
         g.nprob = nseg;
+        int ix0 = -1;
         for (int i = 0; i < nseg; ++i) {
             prob_init(g.p[i], c.W.dY13, L.n13, segs[i].p, segs[i].ld, G + R.w13 + segs[i].wcol, R.fin, L.n13,
                       segs[i].width, B);
             g.p[i].accumulate = acc;
+            if (segs[i].is_x0) {
+                ix0 = i;
+                g.p[i].ep_gamma = c.W.aff_scale;
+                g.p[i].ep_beta = c.W.aff_shift;
+                g.p[i].ep_cs0 = c.train ? nullptr : c.W.cs13;
+                g.p[i].ep_cs1 = c.W.cs13 + L.hid;
+                g.p[i].ep_split = L.hid;
+                g.p[i].ep_w = c.P + R.w13 + segs[i].wcol;
+                g.p[i].ep_ldw = R.fin;
+                g.p[i].ep_part = c.W.ibn_part + (size_t)r * 12 * 2 * L.k0;
+            }
         }
         // the widest segment decides the tile shape
         if (nseg == 2 && g.p[1].N > g.p[0].N) { GemmProb t = g.p[0]; g.p[0] = g.p[1]; g.p[1] = t; }
+        int bm, bn;
+        gemm_tile_shape(GEMM_TN, g.p[0].M, g.p[0].N, bm, bn, g.p[0].K);
+        ibn_tiles[r] = (L.n13 + bm - 1) / bm;
+        if (ibn_tiles[r] > 12 || ix0 < 0) return DGG_ERR_INVALID;
         DGG_TRY(gemm_launch(GEMM_TN, g, c.st));
     }
     // 6. dgrad: dX_seg[:, lo:hi] (+)= dY13 W13[:, wcol+lo : wcol+hi]
@@ -473,12 +526,13 @@ static void make_segs(const NetL& L, NetW& W, int r, Seg* segs, int& nseg) {
     memset(segs, 0, 2 * sizeof(Seg));
     if (r == 0) {
         nseg = 1;
-        segs[0].p = W.X0; segs[0].ld = L.ldx0; segs[0].width = L.k0; segs[0].wcol = 0;
+        segs[0].p = W.X0; segs[0].ld = L.ldx0; segs[0].width = L.k0; segs[0].wcol = 0; segs[0].is_x0 = true;
         return;
     }
     nseg = 2;
     const int ix0 = L.x1_first ? 1 : 0, ix1 = L.x1_first ? 0 : 1;
     segs[ix0].p = W.X0; segs[ix0].ld = L.ldx0; segs[ix0].width = L.k0; segs[ix0].wcol = L.x1_first ? L.nn : 0;
+    segs[ix0].is_x0 = true;
     segs[ix1].p = W.rb[r - 1].y; segs[ix1].ld = L.nn; segs[ix1].width = L.nn; segs[ix1].wcol = L.x1_first ? 0 : L.k0;
 }
 
@@ -493,8 +547,8 @@ static int net_forward(const NetL& L, const float* params, float* bn, void* ws, 
     if (!bn) return DGG_ERR_INVALID;
     if (c.train) DGG_TRY(ibn_stats_launch(srcs, B, 1, c.W.part, st));
     DGG_TRY(bn_finalize_launch(c.W.part, B, 1, L.k_in, c.train, bn + L.irm, bn + L.irv, c.W.imean, c.W.irstd, st));
-    DGG_TRY(ibn_apply_launch(srcs, B, B, c.W.imean, c.W.irstd, params + L.ibnw, params + L.ibnb, prefix, L.nprefix,
-                             c.W.X0, L.ldx0, st));
+    DGG_TRY(ibn_apply_launch(srcs, B, B, c.W.imean, c.W.irstd, nullptr, nullptr, prefix, L.nprefix, c.W.X0, L.ldx0,
+                             params + L.ibnw, params + L.ibnb, c.W.aff_scale, c.W.aff_shift, st));
     const bool drop = (L.net == DGG_NET_EVA) && c.train;
     for (int r = 0; r < L.nrb; ++r) {
         Seg segs[2];
@@ -544,17 +598,15 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     carve(L, B, ws, c.W);
     if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
     const bool want_in = d_in && d_in_hi > d_in_lo;
-    // columns of X0 whose gradient is needed
-    int x_lo, x_hi;
-    if (!skip) { x_lo = 0; x_hi = L.k0; }
-    else {
-        x_lo = L.k0; x_hi = 0;
-        if (d_prefix && L.nprefix > 0) { x_lo = 0; x_hi = L.nprefix; }
-        if (want_in) {
-            if (L.nprefix + d_in_lo < x_lo) x_lo = L.nprefix + d_in_lo;
-            if (L.nprefix + d_in_hi > x_hi) x_hi = L.nprefix + d_in_hi;
-        }
+    // columns of X0 whose gradient is needed: only those for which the caller wants INPUT gradients —
+    // the input BatchNorm's parameter gradients come out of the wgrad epilogue
+    int x_lo = L.k0, x_hi = 0;
+    if (d_prefix && L.nprefix > 0) { x_lo = 0; x_hi = L.nprefix; }
+    if (want_in) {
+        if (L.nprefix + d_in_lo < x_lo) x_lo = L.nprefix + d_in_lo;
+        if (L.nprefix + d_in_hi > x_hi) x_hi = L.nprefix + d_in_hi;
     }
+    int ibn_tiles[3] = {0, 0, 0};
     const bool drop = (L.net == DGG_NET_EVA) && c.train;
     // heads
     float* dy = c.W.dXa;
@@ -576,33 +628,19 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
                 segs[i].dp = other; segs[i].dld = L.nn; segs[i].d_lo = 0; segs[i].d_hi = L.nn; segs[i].d_accum = 0;
             }
         }
-        DGG_TRY(rb_backward(c, r, segs, nseg, dy, drop, accum, skip));
+        DGG_TRY(rb_backward(c, r, segs, nseg, dy, drop, accum, skip, ibn_tiles));
         float* t = dy; dy = other; other = t;
     }
-    // input BatchNorm backward
+    // input BatchNorm backward: parameter gradients = sum over ResBlocks and row tiles of the epilogue partials
     const int nrb = (B + kRowBlock - 1) / kRowBlock;
     if (!skip) {
-        DGG_TRY(ibn_bwd_stats_launch(srcs, c.W.dX0, L.ldx0, L.nprefix, c.W.imean, c.W.irstd, B, 1, c.W.part, st));
-        DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 2, L.k_in, c.W.sums, grads + L.ibnb, grads + L.ibnw, nullptr,
-                                       accum ? 1 : 0, st));
-        if (want_in) {
-            // sums laid out [2][k_in]; the apply kernel indexes them with the sub-list's width, so give it
-            // per-quantity pointers through a compacted copy when a sub-range is requested
-            if (d_in_lo == 0 && d_in_hi == L.k_in) {
-                DGG_TRY(ibn_bwd_apply_launch(srcs, c.W.dX0, L.ldx0, L.nprefix, c.W.imean, c.W.irstd, params + L.ibnw,
-                                             c.W.sums, c.train, B, B, 0, L.k_in, d_in, L.k_in, st));
-            } else {
-                ColSrcs sub = sub_srcs(srcs, d_in_lo, d_in_hi);
-                DGG_TRY(ibn_bwd_stats_launch(sub, c.W.dX0, L.ldx0, L.nprefix + d_in_lo, c.W.imean + d_in_lo,
-                                             c.W.irstd + d_in_lo, B, 1, c.W.part, st));
-                DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 2, sub.total, c.W.sums, nullptr, nullptr, nullptr, 0,
-                                               st));
-                DGG_TRY(ibn_bwd_apply_launch(sub, c.W.dX0, L.ldx0, L.nprefix + d_in_lo, c.W.imean + d_in_lo,
-                                             c.W.irstd + d_in_lo, params + L.ibnw + d_in_lo, c.W.sums, c.train, B, B,
-                                             0, sub.total, d_in, sub.total, st));
-            }
+        for (int r = 0; r < L.nrb; ++r) {  // part layout per block: [tiles][2][k0]; q0 -> d gamma, q1 -> d beta
+            DGG_TRY(colsum_finalize_launch(c.W.ibn_part + (size_t)r * 12 * 2 * L.k0, 1, ibn_tiles[r], 2, L.k_in, nullptr,
+                                           grads + L.ibnw, grads + L.ibnb, nullptr, (accum || r > 0) ? 1 : 0, st, L.k0,
+                                           L.nprefix));
         }
-    } else if (want_in) {
+    }
+    if (want_in) {  // input gradients for the requested columns through the (train: batch-statistics) BN backward
         ColSrcs sub = sub_srcs(srcs, d_in_lo, d_in_hi);
         if (c.train) {
             DGG_TRY(ibn_bwd_stats_launch(sub, c.W.dX0, L.ldx0, L.nprefix + d_in_lo, c.W.imean + d_in_lo,
@@ -810,8 +848,8 @@ int dgg_bce(const float* p, const float* labels, float target_const, int B, floa
     return bce_launch(p, labels, target_const, B, weight, loss_scale, loss_out, d_logit, (hipStream_t)stream);
 }
 
-int dgg_adam_l2(float* params, const float* grads, float* m, float* v, int64_t n, int step, float lr, float beta1,
-                float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+int dgg_adam_l2(float* params, const float* grads, float* m, float* v, int64_t n, int step, double lr, double beta1,
+                double beta2, double eps, double weight_decay, double grad_scale, void* stream) {
     if (!params || !grads || !m || !v) return DGG_ERR_INVALID;
     return adam_launch(params, grads, m, v, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale,
                        (hipStream_t)stream);
@@ -862,8 +900,8 @@ int dgg_cgan_d_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
     DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN, bps, S.rfake, f_transl,
                              f_joint, S.p_fake, stream));
     // :213-232 loss = (BCE(real,1) + BCE(fake,0)) / 2
-    DGG_TRY(bce_launch(S.p_real, nullptr, 1.f, B, hp->bce_weight, 0.5f, losses + DGG_L_BCE_REAL, S.dl_real, st));
-    DGG_TRY(bce_launch(S.p_fake, nullptr, 0.f, B, hp->bce_weight, 0.5f, losses + DGG_L_BCE_FAKE, S.dl_fake, st));
+    DGG_TRY(bce_launch(S.p_real, nullptr, 1.f, B, (float)hp->bce_weight, 0.5f, losses + DGG_L_BCE_REAL, S.dl_real, st));
+    DGG_TRY(bce_launch(S.p_fake, nullptr, 0.f, B, (float)hp->bce_weight, 0.5f, losses + DGG_L_BCE_FAKE, S.dl_fake, st));
     DGG_TRY(disc_loss_combine_launch(losses, st));
     // :792-793 zero_grad + backward: real pass overwrites, fake pass accumulates
     DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint,
@@ -890,7 +928,7 @@ int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
     DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN, bps, S.rfake, g_transl,
                              g_joint, S.p_gen, stream));
     // :293-296 BCE(fake_score, 1) and its gradient; backward through D for the pose inputs only
-    DGG_TRY(bce_launch(S.p_gen, nullptr, 1.f, B, hp->bce_weight, 1.0f, losses + DGG_L_GEN_FAKE, S.dl_gen, st));
+    DGG_TRY(bce_launch(S.p_gen, nullptr, 1.f, B, (float)hp->bce_weight, 1.0f, losses + DGG_L_GEN_FAKE, S.dl_gen, st));
     DGG_TRY(dgg_disc_backward(cfg, s->d_params, nullptr, S.ws_df, S.d_bytes, B,
                               DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_NEED_INPUT_GRADS, bps, S.rfake, g_transl, g_joint,
                               S.dl_gen, S.d_pose, stream));
@@ -932,7 +970,7 @@ int dgg_eva_phase(const dgg_cfg* cfg, const float* e_params, float* e_grads, flo
     hipStream_t st = (hipStream_t)stream;
     DGG_TRY(dgg_eva_forward(cfg, e_params, e_bn, ws, W.bytes, B, DGG_TRAIN, bps, rot9, transl, drop_keep, seed, p,
                             stream));
-    DGG_TRY(bce_launch(p, label, 0.f, B, hp->bce_weight, 1.0f, losses + DGG_L_TOTAL_EVA, dl, st));
+    DGG_TRY(bce_launch(p, label, 0.f, B, (float)hp->bce_weight, 1.0f, losses + DGG_L_TOTAL_EVA, dl, st));
     DGG_TRY(copy_cols_launch(losses + DGG_L_TOTAL_EVA, 1, losses + DGG_L_BCE_EVA, 1, 1, 1, st));
     DGG_TRY(dgg_eva_backward(cfg, e_params, e_grads, ws, W.bytes, B, DGG_TRAIN, bps, rot9, transl, dl, nullptr, stream));
     return DGG_OK;
@@ -940,7 +978,7 @@ int dgg_eva_phase(const dgg_cfg* cfg, const float* e_params, float* e_grads, flo
 
 int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc,
                  int splits, float* slabs, int accumulate, void* stream) {
-    if (!A || !Bm || !C || M < 1 || N < 1 || K < 1 || mode < 0 || mode > 2) return DGG_ERR_INVALID;
+    if (!A || !Bm || (!C && splits < 1) || M < 1 || N < 1 || K < 1 || mode < 0 || mode > 2) return DGG_ERR_INVALID;
     GemmBatch g;
     memset(&g, 0, sizeof(g));
     g.nprob = 1;
@@ -950,6 +988,7 @@ int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const f
         prob_init(g.p[0], A, lda, Bm, ldb, slabs, N, M, N, K);
         prob_split(g.p[0], splits, (long long)M * N);
         DGG_TRY(gemm_launch(mode, g, st));
+        if (!C) return DGG_OK;  // slabs only (bench: times the MFMA kernel alone)
         return reduce_bias_launch(slabs, g.p[0].splits, (long long)M * N, N, nullptr, C, ldc, M, M, 1, N, 0, 0, 0, 0,
                                   nullptr, st);
     }

@@ -31,6 +31,23 @@ struct GemmProb {
     int accumulate;
     int tiles_m, tiles_n;
     int blk_begin;     // first block id of this problem in the grouped launch
+    // NT only (may be NULL): per-k affine applied to the A operand while it is staged,
+    //   A'(m,k) = A(m,k) * a_scale[k] + a_shift[k]   — the input BatchNorm's gamma/beta folded into the
+    //   forward GEMM, so the stored operand is the un-affined normalised input x_hat.
+    const float* a_scale;
+    const float* a_shift;
+    // TN only (ep_gamma != NULL): BatchNorm-aware weight-gradient epilogue.  The accumulator holds
+    //   T[n][k] = sum_m dY[m][n] x_hat[m][k];  the kernel stores dW[n][k] = gamma[k] T + beta[k] cs[n]
+    //   and emits per-tile column partials  sum_n W[n][k] T[n][k]  (-> d gamma[k])  and
+    //   sum_n W[n][k] cs[n]  (-> d beta[k]), so the input gradient dX0 is never formed.
+    const float* ep_gamma;
+    const float* ep_beta;
+    const float* ep_cs0;   // column sums of dY for output rows < ep_split (NULL = exactly zero)
+    const float* ep_cs1;   // ... for rows >= ep_split (indexed row - ep_split)
+    int ep_split;
+    const float* ep_w;     // weights, indexed like C (row n, column k), pitch ep_ldw
+    int ep_ldw;
+    float* ep_part;        // [tiles_m][2][N]
 };
 struct GemmBatch {
     GemmProb p[4];
@@ -42,7 +59,7 @@ enum GemmMode { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
 int gemm_plan(GemmProb& p, int mode, int splits);
 int gemm_launch(int mode, GemmBatch& batch, hipStream_t st);
 int gemm_pick_splits(int mode, int M, int N, int K, int other_blocks);
-void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn);
+void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn, int K = 1 << 30);
 
 // ---------------------------------------------------------------- BPS encode (bps_encode.hip)
 int bps_encode_launch(const float* clouds, int B, int N, const float* basis, int P, float* dists, int32_t* ids,
@@ -70,13 +87,14 @@ int bn_finalize_launch(const float* part, int rows_per_group, int groups, int nc
 // (B, nprefix) into columns [0, nprefix).
 int ibn_apply_launch(const ColSrcs& srcs, int B, int rows_per_group, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, const float* prefix, int nprefix, float* X0, int ldx,
+                     const float* aff_gamma, const float* aff_beta, float* aff_scale, float* aff_shift,
                      hipStream_t st);
 
 // out[m][c] = sum_s slabs[s][m][c] + bias[c];  columns [stat_lo, stat_hi) get partial statistics,
 // columns [act_lo, act_hi) get LeakyReLU applied before the store.
 int reduce_bias_launch(const float* slabs, int nslab, long long slab_stride, int ld_slab, const float* bias,
                        float* out, int ld_out, int B, int rows_per_group, int groups, int N, int stat_lo,
-                       int stat_hi, int act_lo, int act_hi, float* part, hipStream_t st);
+                       int stat_hi, int act_lo, int act_hi, float* part, hipStream_t st, int accumulate = 0);
 // h[m][c] = lrelu((a[m][c]-mean)*rstd*gamma+beta)
 int bn_act_launch(const float* a, int lda, int B, int rows_per_group, int N, const float* mean, const float* rstd,
                   const float* gamma, const float* beta, float* h, int ldh, hipStream_t st);
@@ -113,8 +131,11 @@ int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const flo
 // Sum partial column sums over row blocks: part [groups][nrb][nq][ncols] ->
 //   sums_out [groups][nq][ncols] (may be NULL) and, summed over groups, into up to 3 gradient
 //   destinations (NULL to skip): dst[q][c] (+)= sum.
+//   ld / c_lo: row pitch of `part` (0 = ncols) and first column; copy0 / copy2: extra plain copies of the
+//   q == 0 / q == 2 totals.
 int colsum_finalize_launch(const float* part, int groups, int nrb, int nq, int ncols, float* sums_out, float* dst0,
-                           float* dst1, float* dst2, int accumulate, hipStream_t st);
+                           float* dst1, float* dst2, int accumulate, hipStream_t st, int ld = 0, int c_lo = 0,
+                           float* copy0 = nullptr, float* copy2 = nullptr);
 // Input BN backward: partial sums of dX0 and dX0*xhat over the concat sources.
 int ibn_bwd_stats_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col_off, const float* mean,
                          const float* rstd, int rows_per_group, int groups, float* part, hipStream_t st);
@@ -132,8 +153,8 @@ int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const floa
                     const float* gt_transl, const float* gt_joint, const float* fake_score, const float* d_pose,
                     float* losses, float* d_heads, hipStream_t st);
 int disc_loss_combine_launch(float* losses, hipStream_t st);
-int adam_launch(float* params, const float* grads, float* m, float* v, int64_t n, int step, float lr, float b1,
-                float b2, float eps, float wd, float grad_scale, hipStream_t st);
+int adam_launch(float* params, const float* grads, float* m, float* v, int64_t n, int step, double lr, double b1,
+                double b2, double eps, double wd, double grad_scale, hipStream_t st);
 int translate_axis_launch(float* transl, const float* rot9, int B, int axis, float offset, hipStream_t st);
 int copy_cols_launch(const float* src, int lds, float* dst, int ldd, int B, int n, hipStream_t st);
 

@@ -4,10 +4,12 @@
 // (dexgangrasp.py:142-147,213-232,272-307; losses.py:61-76), rot_matrix_from_ortho6d
 // (utils/utils.py:380-394) and Adam (dexgangrasp.py:97-112).
 //
-// These are HBM/L2-bound column kernels: one thread owns one feature column for a block of
-// kRowBlock rows, so a wave reads 64 consecutive floats of a row (coalesced 256 B), keeps its
-// 32 samples in registers and produces exact two-pass partial statistics (mean, M2) that a tiny
-// finalize kernel merges with Chan's formula — deterministic, no atomics.
+// These are HBM/L2-bound column kernels.  A 256-thread workgroup owns 64 feature columns x one block of
+// kRowBlock (32) rows: lane = column (a wave reads 64 consecutive floats of a row: coalesced 256 B),
+// the 4 waves take 8 rows each, keep their samples in registers and produce exact two-pass partial
+// statistics (mean, M2) / partial sums that are merged across the 4 waves through LDS in a fixed order
+// and across row blocks by tiny finalize kernels (Chan's formula) — deterministic, no atomics.
+// Grids are (ceil(N/64), row blocks): 384 workgroups for a 1024 x 768 activation.
 // A batch may consist of `groups` independent BatchNorm batches of rows_per_group rows
 // (the discriminator's real/fake pair, dexgangrasp.py:788-789).
 #include "dgg_internal.h"
@@ -15,6 +17,8 @@
 namespace dgg {
 
 constexpr int RB = kRowBlock;
+constexpr int SUB = 4;          // waves per workgroup, each takes RB/SUB rows of the row block
+constexpr int RS = RB / SUB;    // rows per wave
 
 __device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : kLrelu * x; }
 __device__ __forceinline__ float lrelu_grad(float y) { return y > 0.f ? 1.f : kLrelu; }
@@ -51,48 +55,100 @@ __device__ __forceinline__ void partial_stats(const float (&v)[RB], int n, float
     m2 = q;
 }
 
-// grid: (ceil(ncols/256), groups*nrb)
+// merge the per-wave (mean, M2) of RS-row sub-blocks into the row block's partial (thread sub == 0 writes)
+__device__ __forceinline__ void merge_sub_stats(float mean, float m2, int nsub, int lane, int sub, float (*sh)[2][64],
+                                                int n, float& out_mean, float& out_m2) {
+    sh[sub][0][lane] = mean;
+    sh[sub][1][lane] = m2;
+    __syncthreads();
+    float cnt = 0.f, mu = 0.f, q = 0.f;
+    if (sub == 0) {
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) {
+            const int ns = min(RS, max(0, n - s * RS));
+            if (ns > 0) {
+                const float nb = (float)ns, tot = cnt + nb;
+                const float d = sh[s][0][lane] - mu;
+                mu += d * (nb / tot);
+                q += sh[s][1][lane] + d * d * (cnt * nb / tot);
+                cnt = tot;
+            }
+        }
+    }
+    (void)nsub;
+    out_mean = mu;
+    out_m2 = q;
+}
+
+__device__ __forceinline__ void sub_stats(const float (&v)[RS], int n, float& mean, float& m2) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < RS; ++r) s += (r < n) ? v[r] : 0.f;
+    mean = n > 0 ? s / (float)n : 0.f;
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        const float d = v[r] - mean;
+        q += (r < n) ? d * d : 0.f;
+    }
+    m2 = q;
+}
+
+// grid: (ceil(ncols/64), groups*nrb)
 __global__ __launch_bounds__(256) void ibn_stats_kernel(ColSrcs S, int rpg, int nrb, float* __restrict__ part) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= S.total) return;
+    __shared__ float sh[SUB][2][64];
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool cok = c < S.total;
     const int g = blockIdx.y / nrb, rb = blockIdx.y % nrb;
     const int r0 = rb * RB;
     const int n = min(RB, rpg - r0);
-    int ld;
-    const float* p = src_col(S, c, ld);
-    p += (size_t)(g * rpg + r0) * ld;
-    float v[RB];
+    const int ns = min(RS, max(0, n - sub * RS));
+    int ld = 0;
+    const float* p = cok ? src_col(S, c, ld) : nullptr;
+    float v[RS];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) v[r] = (r < n) ? p[(size_t)r * ld] : 0.f;
-    float mean, m2;
-    partial_stats(v, n, mean, m2);
-    float* o = part + (size_t)blockIdx.y * 2 * S.total;
-    o[c] = mean;
-    o[S.total + c] = m2;
+    for (int r = 0; r < RS; ++r)
+        v[r] = (cok && r < ns) ? p[(size_t)(g * rpg + r0 + sub * RS + r) * ld] : 0.f;
+    float mean, m2, om, oq;
+    sub_stats(v, ns, mean, m2);
+    merge_sub_stats(mean, m2, ns, lane, sub, sh, n, om, oq);
+    if (sub == 0 && cok) {
+        float* o = part + (size_t)blockIdx.y * 2 * S.total;
+        o[c] = om;
+        o[S.total + c] = oq;
+    }
 }
 
-// one thread per column; groups processed in order so running statistics see the reference's
-// call order (real batch first, then fake).
+// 64 columns per workgroup; the 4 waves merge disjoint ranges of row blocks, wave 0 merges those in order.
+// Groups are processed in order so running statistics see the reference's call order.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rpg, int groups,
                                                           int nrb, int ncols, int train,
                                                           float* __restrict__ run_mean,
                                                           float* __restrict__ run_var, float* __restrict__ mean_out,
                                                           float* __restrict__ rstd_out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= ncols) return;
+    __shared__ float sh[SUB][3][64];
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 64 + lane;
+    const bool cok = c0 < ncols;
+    const int c = cok ? c0 : ncols - 1;
     if (!train) {
-        const float m = run_mean[c];
-        const float rs = 1.0f / sqrtf(run_var[c] + kBnEps);
-        for (int g = 0; g < groups; ++g) {
-            mean_out[g * ncols + c] = m;
-            rstd_out[g * ncols + c] = rs;
+        if (sub == 0 && cok) {
+            const float m = run_mean[c];
+            const float rs = 1.0f / sqrtf(run_var[c] + kBnEps);
+            for (int g = 0; g < groups; ++g) {
+                mean_out[g * ncols + c] = m;
+                rstd_out[g * ncols + c] = rs;
+            }
         }
         return;
     }
     float rm = run_mean ? run_mean[c] : 0.f, rv = run_var ? run_var[c] : 0.f;
+    const int per = (nrb + SUB - 1) / SUB;
+    const int rb_lo = min(nrb, sub * per), rb_hi = min(nrb, rb_lo + per);
     for (int g = 0; g < groups; ++g) {
         float cnt = 0.f, mean = 0.f, m2 = 0.f;
-        for (int rb = 0; rb < nrb; ++rb) {
+        for (int rb = rb_lo; rb < rb_hi; ++rb) {
             const float* p = part + (size_t)(g * nrb + rb) * 2 * ncols;
             const float nb = (float)min(RB, rpg - rb * RB);
             const float mb = p[c], qb = p[ncols + c];
@@ -102,28 +158,59 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
             m2 += qb + d * d * (cnt * nb / tot);
             cnt = tot;
         }
-        const float var_b = m2 / cnt;
-        mean_out[g * ncols + c] = mean;
-        rstd_out[g * ncols + c] = 1.0f / sqrtf(var_b + kBnEps);
-        const float var_u = m2 / (cnt - 1.f);
-        rm = (1.f - kBnMom) * rm + kBnMom * mean;
-        rv = (1.f - kBnMom) * rv + kBnMom * var_u;
+        __syncthreads();
+        sh[sub][0][lane] = cnt;
+        sh[sub][1][lane] = mean;
+        sh[sub][2][lane] = m2;
+        __syncthreads();
+        if (sub == 0 && cok) {
+            cnt = 0.f; mean = 0.f; m2 = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < SUB; ++s2) {
+                const float nb = sh[s2][0][lane];
+                if (nb > 0.f) {
+                    const float tot = cnt + nb;
+                    const float d = sh[s2][1][lane] - mean;
+                    mean += d * (nb / tot);
+                    m2 += sh[s2][2][lane] + d * d * (cnt * nb / tot);
+                    cnt = tot;
+                }
+            }
+            const float var_b = m2 / cnt;
+            mean_out[g * ncols + c] = mean;
+            rstd_out[g * ncols + c] = 1.0f / sqrtf(var_b + kBnEps);
+            const float var_u = m2 / (cnt - 1.f);
+            rm = (1.f - kBnMom) * rm + kBnMom * mean;
+            rv = (1.f - kBnMom) * rv + kBnMom * var_u;
+        }
     }
-    if (run_mean) run_mean[c] = rm;
-    if (run_var) run_var[c] = rv;
+    if (sub == 0 && cok) {
+        if (run_mean) run_mean[c] = rm;
+        if (run_var) run_var[c] = rv;
+    }
 }
 
-// grid: (ceil((nprefix+ncols)/256), ceil(B/RB))
+// grid: (ceil((nprefix+ncols)/64), ceil(B/RB)).  gamma == NULL: store the un-affined x_hat = (x-mean)*rstd
+// (the forward GEMM then folds gamma/beta into its operand staging, see GemmProb::a_scale) and emit the
+// per-column affine vectors aff_scale = [1.. | gamma], aff_shift = [0.. | beta] over prefix + BN columns.
 __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rpg, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         const float* __restrict__ prefix, int nprefix,
-                                                        float* __restrict__ X0, int ldx) {
-    const int oc = blockIdx.x * 256 + threadIdx.x;
+                                                        float* __restrict__ X0, int ldx,
+                                                        const float* __restrict__ aff_gamma,
+                                                        const float* __restrict__ aff_beta,
+                                                        float* __restrict__ aff_scale, float* __restrict__ aff_shift) {
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int oc = blockIdx.x * 64 + lane;
     if (oc >= nprefix + S.total) return;
-    const int r0 = blockIdx.y * RB;
-    const int n = min(RB, B - r0);
+    const int r0 = blockIdx.y * RB + sub * RS;
+    const int n = min(RS, B - r0);
+    if (aff_scale && blockIdx.y == 0 && sub == 0) {
+        aff_scale[oc] = oc < nprefix ? 1.f : aff_gamma[oc - nprefix];
+        aff_shift[oc] = oc < nprefix ? 0.f : aff_beta[oc - nprefix];
+    }
     if (oc < nprefix) {
         for (int r = 0; r < n; ++r) X0[(size_t)(r0 + r) * ldx + oc] = prefix[(size_t)(r0 + r) * nprefix + oc];
         return;
@@ -131,7 +218,7 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
     const int c = oc - nprefix;
     int ld;
     const float* p = src_col(S, c, ld);
-    const float ga = gamma[c], be = beta[c];
+    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
     for (int r = 0; r < n; ++r) {
         const int row = r0 + r;
         const int g = row / rpg;
@@ -141,52 +228,84 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
     }
 }
 
-// grid: (ceil(N/256), groups*nrb)
+// grid: (ceil(N/64), groups*nrb)
 __global__ __launch_bounds__(256) void reduce_bias_kernel(const float* __restrict__ slabs, int nslab,
                                                           long long slab_stride, int ld_slab,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           int ld_out, int rpg, int nrb, int N, int stat_lo,
                                                           int stat_hi, int act_lo, int act_hi,
-                                                          float* __restrict__ part) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+                                                          float* __restrict__ part, int accumulate) {
+    __shared__ float sh[SUB][2][64];
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool cok = c < N;
     const int g = blockIdx.y / nrb, rb = blockIdx.y % nrb;
     const int r0 = rb * RB;
     const int n = min(RB, rpg - r0);
-    const size_t row0 = (size_t)(g * rpg + r0);
-    const float b = bias ? bias[c] : 0.f;
+    const int ns = min(RS, max(0, n - sub * RS));
+    const size_t row0 = (size_t)(g * rpg + r0 + sub * RS);
+    const float b = (bias && cok) ? bias[c] : 0.f;
     const bool act = c >= act_lo && c < act_hi;
-    float v[RB];
+    float v[RS];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-        float a = 0.f;
-        if (r < n) {
-            const float* p = slabs + (row0 + r) * ld_slab + c;
-            for (int s = 0; s < nslab; ++s) a += p[(size_t)s * slab_stride];
-            a += b;
-            out[(row0 + r) * ld_out + c] = act ? lrelu(a) : a;
+    for (int r = 0; r < RS; ++r) v[r] = 0.f;
+    if (cok) {
+        // slab order = k order: fixed summation order.  Four slabs (32 independent loads) are in flight per
+        // iteration: the kernel is latency-bound, not bandwidth-bound, at these sizes.
+        int s = 0;
+        for (; s + 4 <= nslab; s += 4) {
+            float t[4][RS];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* p = slabs + (size_t)(s + u) * slab_stride + row0 * ld_slab + c;
+#pragma unroll
+                for (int r = 0; r < RS; ++r) t[u][r] = (r < ns) ? p[(size_t)r * ld_slab] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < RS; ++r) v[r] += t[u][r];
         }
-        v[r] = a;
+        for (; s < nslab; ++s) {
+            const float* p = slabs + (size_t)s * slab_stride + row0 * ld_slab + c;
+#pragma unroll
+            for (int r = 0; r < RS; ++r)
+                if (r < ns) v[r] += p[(size_t)r * ld_slab];
+        }
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            if (r < ns) {
+                v[r] += b;
+                float* o = out + (row0 + r) * ld_out + c;
+                if (accumulate) v[r] += *o;
+                *o = act ? lrelu(v[r]) : v[r];
+            }
+        }
     }
-    if (c >= stat_lo && c < stat_hi) {
-        float mean, m2;
-        partial_stats(v, n, mean, m2);
-        const int ns = stat_hi - stat_lo;
-        float* o = part + (size_t)blockIdx.y * 2 * ns;
-        o[c - stat_lo] = mean;
-        o[ns + c - stat_lo] = m2;
+    const bool any_stat = stat_hi > stat_lo;  // uniform
+    if (any_stat) {
+        float mean, m2, om, oq;
+        sub_stats(v, ns, mean, m2);
+        merge_sub_stats(mean, m2, ns, lane, sub, sh, n, om, oq);
+        if (sub == 0 && c >= stat_lo && c < stat_hi) {
+            const int nst = stat_hi - stat_lo;
+            float* o = part + (size_t)blockIdx.y * 2 * nst;
+            o[c - stat_lo] = om;
+            o[nst + c - stat_lo] = oq;
+        }
     }
 }
 
-// grid: (ceil(N/256), ceil(B/RB))
+// grid: (ceil(N/64), ceil(B/RB))
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ a, int lda, int B, int rpg, int N,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ h, int ldh) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     if (c >= N) return;
-    const int r0 = blockIdx.y * RB;
-    const int n = min(RB, B - r0);
+    const int r0 = blockIdx.y * RB + sub * RS;
+    const int n = min(RS, B - r0);
     const float ga = gamma[c], be = beta[c];
     for (int r = 0; r < n; ++r) {
         const int row = r0 + r;
@@ -223,7 +342,7 @@ __device__ __forceinline__ float philox_keep(uint64_t seed, uint64_t elem) {
     return ((float)(w >> 8) * (1.0f / 16777216.0f)) >= kDropP ? 1.f : 0.f;
 }
 
-// grid: (ceil(N/256), ceil(B/RB))
+// grid: (ceil(N/64), ceil(B/RB))
 __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ s, int lds,
                                                       const float* __restrict__ a2, int lda2, int B, int rpg, int N,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -231,10 +350,11 @@ __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ 
                                                       int drop_mode, const float* __restrict__ keep_in, uint64_t seed,
                                                       uint64_t seed_off, uint8_t* __restrict__ keep_out,
                                                       float* __restrict__ y, int ldy) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     if (c >= N) return;
-    const int r0 = blockIdx.y * RB;
-    const int n = min(RB, B - r0);
+    const int r0 = blockIdx.y * RB + sub * RS;
+    const int n = min(RS, B - r0);
     const float ga = gamma[c], be = beta[c];
     const float inv_keep = 1.0f / (1.0f - kDropP);
     for (int r = 0; r < n; ++r) {
@@ -341,11 +461,14 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
                                                           const float* __restrict__ rstd, int rpg, int nrb, int N,
                                                           float* __restrict__ dpre, float* __restrict__ da3,
                                                           int ldda3, float* __restrict__ part) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+    __shared__ float sh[SUB][3][64];
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 64 + lane;
+    const bool cok = c0 < N;
+    const int c = cok ? c0 : N - 1;
     const int g = blockIdx.y / nrb, rb = blockIdx.y % nrb;
-    const int r0 = rb * RB;
-    const int n = min(RB, rpg - r0);
+    const int r0 = rb * RB + sub * RS;
+    const int n = min(RS, max(0, rpg - r0));
     const float mu = mean[g * N + c], rs = rstd[g * N + c];
     const float inv_keep = 1.0f / (1.0f - kDropP);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -354,18 +477,24 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
         float d = dy[row * lddy + c];
         if (keep) d = keep[row * N + c] ? d * inv_keep : 0.f;
         d *= lrelu_grad(y[row * ldy + c]);
-        dpre[row * N + c] = d;
+        if (cok) dpre[row * N + c] = d;
         const float xh = (a2[row * lda2 + c] - mu) * rs;
         const float d3 = d * lrelu_grad(s[row * lds + c]);
-        da3[row * ldda3 + c] = d3;
+        if (cok) da3[row * ldda3 + c] = d3;
         s0 += d;
         s1 = fmaf(d, xh, s1);
         s2 += d3;
     }
-    float* o = part + (size_t)blockIdx.y * 3 * N;
-    o[c] = s0;
-    o[N + c] = s1;
-    o[2 * N + c] = s2;
+    sh[sub][0][lane] = s0;
+    sh[sub][1][lane] = s1;
+    sh[sub][2][lane] = s2;
+    __syncthreads();
+    if (sub == 0 && cok) {
+        float* o = part + (size_t)blockIdx.y * 3 * N;
+        o[c] = ((sh[0][0][lane] + sh[1][0][lane]) + sh[2][0][lane]) + sh[3][0][lane];
+        o[N + c] = ((sh[0][1][lane] + sh[1][1][lane]) + sh[2][1][lane]) + sh[3][1][lane];
+        o[2 * N + c] = ((sh[0][2][lane] + sh[1][2][lane]) + sh[2][2][lane]) + sh[3][2][lane];
+    }
 }
 
 // grid: (ceil(N/256), groups*nrb)
@@ -377,11 +506,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ sums, int train, int rpg,
                                                            int nrb, int N, float* __restrict__ dx, int lddx,
                                                            float* __restrict__ part) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+    __shared__ float sh[SUB][1][64];
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 64 + lane;
+    const bool cok = c0 < N;
+    const int c = cok ? c0 : N - 1;
     const int g = blockIdx.y / nrb, rb = blockIdx.y % nrb;
-    const int r0 = rb * RB;
-    const int n = min(RB, rpg - r0);
+    const int r0 = rb * RB + sub * RS;
+    const int n = min(RS, max(0, rpg - r0));
     const float mu = mean[g * N + c], rs = rstd[g * N + c];
     const float k = gamma[c] * rs;
     const float inv_n = 1.0f / (float)rpg;
@@ -393,10 +525,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const float d = dz[row * lddz + c];
         const float xh = (a[row * lda + c] - mu) * rs;
         const float v = k * (d - m0 - xh * m1);
-        dx[row * lddx + c] = v;
+        if (cok) dx[row * lddx + c] = v;
         sb += v;
     }
-    part[(size_t)blockIdx.y * N + c] = sb;
+    sh[sub][0][lane] = sb;
+    __syncthreads();
+    if (sub == 0 && cok)
+        part[(size_t)blockIdx.y * N + c] = ((sh[0][0][lane] + sh[1][0][lane]) + sh[2][0][lane]) + sh[3][0][lane];
 }
 
 // grid: (ceil(N/256), groups*nrb)
@@ -406,43 +541,69 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       int rpg, int nrb, int N, float* __restrict__ dq, int lddq,
                                                       float* __restrict__ part) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+    __shared__ float sh[SUB][2][64];
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 64 + lane;
+    const bool cok = c0 < N;
+    const int c = cok ? c0 : N - 1;
     const int g = blockIdx.y / nrb, rb = blockIdx.y % nrb;
-    const int r0 = rb * RB;
-    const int n = min(RB, rpg - r0);
+    const int r0 = rb * RB + sub * RS;
+    const int n = min(RS, max(0, rpg - r0));
     const float mu = mean[g * N + c], rs = rstd[g * N + c];
     float s0 = 0.f, s1 = 0.f;
     for (int r = 0; r < n; ++r) {
         const size_t row = (size_t)(g * rpg + r0 + r);
         const float d = dh[row * lddh + c] * lrelu_grad(h[row * ldh + c]);
-        dq[row * lddq + c] = d;
+        if (cok) dq[row * lddq + c] = d;
         const float xh = (a1[row * lda1 + c] - mu) * rs;
         s0 += d;
         s1 = fmaf(d, xh, s1);
     }
-    float* o = part + (size_t)blockIdx.y * 2 * N;
-    o[c] = s0;
-    o[N + c] = s1;
+    sh[sub][0][lane] = s0;
+    sh[sub][1][lane] = s1;
+    __syncthreads();
+    if (sub == 0 && cok) {
+        float* o = part + (size_t)blockIdx.y * 2 * N;
+        o[c] = ((sh[0][0][lane] + sh[1][0][lane]) + sh[2][0][lane]) + sh[3][0][lane];
+        o[N + c] = ((sh[0][1][lane] + sh[1][1][lane]) + sh[2][1][lane]) + sh[3][1][lane];
+    }
 }
 
-// grid: ceil(nq*ncols/256)
+// grid: ceil(nq*ncols/64): 64 (quantity,column) pairs per workgroup, the 4 waves sum disjoint row-block ranges.
+// part[((g*nrb + rb)*nq + q)*ld + c_lo + c], c in [0, ncols)
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int groups, int nrb,
-                                                              int nq, int ncols, float* __restrict__ sums_out,
-                                                              float* __restrict__ d0, float* __restrict__ d1,
-                                                              float* __restrict__ d2, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nq * ncols) return;
+                                                              int nq, int ncols, int ld, int c_lo,
+                                                              float* __restrict__ sums_out, float* __restrict__ d0,
+                                                              float* __restrict__ d1, float* __restrict__ d2,
+                                                              int accumulate, float* __restrict__ copy0,
+                                                              float* __restrict__ copy2) {
+    __shared__ float sh[SUB][64];
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int i0 = blockIdx.x * 64 + lane;
+    const bool ok = i0 < nq * ncols;
+    const int i = ok ? i0 : nq * ncols - 1;
     const int q = i / ncols, c = i - q * ncols;
+    const int per = (nrb + SUB - 1) / SUB;
+    const int rb_lo = min(nrb, sub * per), rb_hi = min(nrb, rb_lo + per);
     float tot = 0.f;
     for (int g = 0; g < groups; ++g) {
         float sg = 0.f;
-        for (int rb = 0; rb < nrb; ++rb) sg += part[((size_t)(g * nrb + rb) * nq + q) * ncols + c];
-        if (sums_out) sums_out[((size_t)g * nq + q) * ncols + c] = sg;
-        tot += sg;
+        for (int rb = rb_lo; rb < rb_hi; ++rb) sg += part[((size_t)(g * nrb + rb) * nq + q) * ld + c_lo + c];
+        __syncthreads();
+        sh[sub][lane] = sg;
+        __syncthreads();
+        if (sub == 0) {
+            sg = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+            if (sums_out && ok) sums_out[((size_t)g * nq + q) * ncols + c] = sg;
+            tot += sg;
+        }
     }
-    float* d = q == 0 ? d0 : q == 1 ? d1 : d2;
-    if (d) d[c] = accumulate ? d[c] + tot : tot;
+    if (sub == 0 && ok) {
+        float* d = q == 0 ? d0 : q == 1 ? d1 : d2;
+        if (d) d[c] = accumulate ? d[c] + tot : tot;
+        if (q == 0 && copy0) copy0[c] = tot;
+        if (q == 2 && copy2) copy2[c] = tot;
+    }
 }
 
 // grid: (ceil(ncols/256), groups*nrb)
@@ -450,11 +611,14 @@ __global__ __launch_bounds__(256) void ibn_bwd_stats_kernel(ColSrcs S, const flo
                                                             int col_off, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int rpg, int nrb,
                                                             float* __restrict__ part) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= S.total) return;
+    __shared__ float sh[SUB][2][64];
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 64 + lane;
+    const bool cok = c0 < S.total;
+    const int c = cok ? c0 : S.total - 1;
     const int g = blockIdx.y / nrb, rb = blockIdx.y % nrb;
-    const int r0 = rb * RB;
-    const int n = min(RB, rpg - r0);
+    const int r0 = rb * RB + sub * RS;
+    const int n = min(RS, max(0, rpg - r0));
     int ld;
     const float* p = src_col(S, c, ld);
     const float mu = mean[g * S.total + c], rs = rstd[g * S.total + c];
@@ -466,9 +630,14 @@ __global__ __launch_bounds__(256) void ibn_bwd_stats_kernel(ColSrcs S, const flo
         s0 += d;
         s1 = fmaf(d, xh, s1);
     }
-    float* o = part + (size_t)blockIdx.y * 2 * S.total;
-    o[c] = s0;
-    o[S.total + c] = s1;
+    sh[sub][0][lane] = s0;
+    sh[sub][1][lane] = s1;
+    __syncthreads();
+    if (sub == 0 && cok) {
+        float* o = part + (size_t)blockIdx.y * 2 * S.total;
+        o[c] = ((sh[0][0][lane] + sh[1][0][lane]) + sh[2][0][lane]) + sh[3][0][lane];
+        o[S.total + c] = ((sh[0][1][lane] + sh[1][1][lane]) + sh[2][1][lane]) + sh[3][1][lane];
+    }
 }
 
 // grid: (ceil((c_hi-c_lo)/256), ceil(B/RB))
@@ -478,10 +647,11 @@ __global__ __launch_bounds__(256) void ibn_bwd_apply_kernel(ColSrcs S, const flo
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ sums, int train, int B, int rpg,
                                                             int c_lo, int c_hi, float* __restrict__ dst, int ldd) {
-    const int c = c_lo + blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c = c_lo + blockIdx.x * 64 + lane;
     if (c >= c_hi) return;
-    const int r0 = blockIdx.y * RB;
-    const int n = min(RB, B - r0);
+    const int r0 = blockIdx.y * RB + sub * RS;
+    const int n = min(RS, B - r0);
     int ld;
     const float* p = src_col(S, c, ld);
     const float ga = gamma[c];
@@ -703,8 +873,8 @@ __global__ void disc_loss_combine_kernel(float* losses) {
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                   float step_size, float bc2_sqrt, float b1, float b2, float eps,
-                                                   float wd, float gscale) {
+                                                   float step_size, float bc2_sqrt, float omb1, float b2, float omb2,
+                                                   float eps, float wd, float gscale) {
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -716,8 +886,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float gr = fmaf(wd, pa[e], ga[e] * gscale);
-            ma[e] = ma[e] + (gr - ma[e]) * (1.f - b1);
-            va[e] = b2 * va[e] + (1.f - b2) * gr * gr;
+            ma[e] = ma[e] + (gr - ma[e]) * omb1;
+            va[e] = b2 * va[e] + omb2 * gr * gr;
             const float den = sqrtf(va[e]) / bc2_sqrt + eps;
             pa[e] = pa[e] - step_size * (ma[e] / den);
         }
@@ -729,8 +899,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) {
         const float gr = fmaf(wd, p[t], g[t] * gscale);
-        const float mn = m[t] + (gr - m[t]) * (1.f - b1);
-        const float vn = b2 * v[t] + (1.f - b2) * gr * gr;
+        const float mn = m[t] + (gr - m[t]) * omb1;
+        const float vn = b2 * v[t] + omb2 * gr * gr;
         m[t] = mn;
         v[t] = vn;
         p[t] = p[t] - step_size * (mn / (sqrtf(vn) / bc2_sqrt + eps));
@@ -759,7 +929,7 @@ static inline int nrb_of(int rpg) { return (rpg + RB - 1) / RB; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 int ibn_stats_launch(const ColSrcs& srcs, int rpg, int groups, float* part, hipStream_t st) {
-    dim3 grid(cdiv(srcs.total, 256), groups * nrb_of(rpg));
+    dim3 grid(cdiv(srcs.total, 64), groups * nrb_of(rpg));
     hipLaunchKernelGGL(ibn_stats_kernel, grid, dim3(256), 0, st, srcs, rpg, nrb_of(rpg), part);
     return check_launch("ibn_stats");
 }
@@ -767,32 +937,33 @@ int ibn_stats_launch(const ColSrcs& srcs, int rpg, int groups, float* part, hipS
 int bn_finalize_launch(const float* part, int rpg, int groups, int ncols, int train, float* run_mean, float* run_var,
                        float* mean, float* rstd, hipStream_t st) {
     if (train && rpg < 2) return DGG_ERR_INVALID;  // torch: "Expected more than 1 value per channel when training"
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(ncols, 256)), dim3(256), 0, st, part, rpg, groups, nrb_of(rpg),
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(ncols, 64)), dim3(256), 0, st, part, rpg, groups, nrb_of(rpg),
                        ncols, train, run_mean, run_var, mean, rstd);
     return check_launch("bn_finalize");
 }
 
 int ibn_apply_launch(const ColSrcs& srcs, int B, int rpg, const float* mean, const float* rstd, const float* gamma,
-                     const float* beta, const float* prefix, int nprefix, float* X0, int ldx, hipStream_t st) {
-    dim3 grid(cdiv(nprefix + srcs.total, 256), cdiv(B, RB));
+                     const float* beta, const float* prefix, int nprefix, float* X0, int ldx, const float* aff_gamma,
+                     const float* aff_beta, float* aff_scale, float* aff_shift, hipStream_t st) {
+    dim3 grid(cdiv(nprefix + srcs.total, 64), cdiv(B, RB));
     hipLaunchKernelGGL(ibn_apply_kernel, grid, dim3(256), 0, st, srcs, B, rpg, mean, rstd, gamma, beta, prefix,
-                       nprefix, X0, ldx);
+                       nprefix, X0, ldx, aff_gamma, aff_beta, aff_scale, aff_shift);
     return check_launch("ibn_apply");
 }
 
 int reduce_bias_launch(const float* slabs, int nslab, long long slab_stride, int ld_slab, const float* bias,
                        float* out, int ld_out, int B, int rpg, int groups, int N, int stat_lo, int stat_hi,
-                       int act_lo, int act_hi, float* part, hipStream_t st) {
+                       int act_lo, int act_hi, float* part, hipStream_t st, int accumulate) {
     (void)B;
-    dim3 grid(cdiv(N, 256), groups * nrb_of(rpg));
+    dim3 grid(cdiv(N, 64), groups * nrb_of(rpg));
     hipLaunchKernelGGL(reduce_bias_kernel, grid, dim3(256), 0, st, slabs, nslab, slab_stride, ld_slab, bias, out,
-                       ld_out, rpg, nrb_of(rpg), N, stat_lo, stat_hi, act_lo, act_hi, part);
+                       ld_out, rpg, nrb_of(rpg), N, stat_lo, stat_hi, act_lo, act_hi, part, accumulate);
     return check_launch("reduce_bias");
 }
 
 int bn_act_launch(const float* a, int lda, int B, int rpg, int N, const float* mean, const float* rstd,
                   const float* gamma, const float* beta, float* h, int ldh, hipStream_t st) {
-    dim3 grid(cdiv(N, 256), cdiv(B, RB));
+    dim3 grid(cdiv(N, 64), cdiv(B, RB));
     hipLaunchKernelGGL(bn_act_kernel, grid, dim3(256), 0, st, a, lda, B, rpg, N, mean, rstd, gamma, beta, h, ldh);
     return check_launch("bn_act");
 }
@@ -800,7 +971,7 @@ int bn_act_launch(const float* a, int lda, int B, int rpg, int N, const float* m
 int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, int rpg, int N, const float* mean,
                    const float* rstd, const float* gamma, const float* beta, int drop_mode, const float* keep_in,
                    uint64_t seed, uint64_t seed_off, uint8_t* keep_out, float* y, int ldy, hipStream_t st) {
-    dim3 grid(cdiv(N, 256), cdiv(B, RB));
+    dim3 grid(cdiv(N, 64), cdiv(B, RB));
     hipLaunchKernelGGL(res_out_kernel, grid, dim3(256), 0, st, s, lds, a2, lda2, B, rpg, N, mean, rstd, gamma, beta,
                        drop_mode, keep_in, seed, seed_off, keep_out, y, ldy);
     return check_launch("res_out");
@@ -845,7 +1016,7 @@ int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const
                        int lds, const float* a2, int lda2, const float* mean, const float* rstd, int B, int rpg, int N,
                        float* dpre, float* da3, int ldda3, float* part, hipStream_t st) {
     const int groups = B / rpg;
-    dim3 grid(cdiv(N, 256), groups * nrb_of(rpg));
+    dim3 grid(cdiv(N, 64), groups * nrb_of(rpg));
     hipLaunchKernelGGL(res_out_bwd_kernel, grid, dim3(256), 0, st, dy, lddy, y, ldy, keep, s, lds, a2, lda2, mean,
                        rstd, rpg, nrb_of(rpg), N, dpre, da3, ldda3, part);
     return check_launch("res_out_bwd");
@@ -855,7 +1026,7 @@ int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, cons
                         const float* gamma, const float* sums, int train, int B, int rpg, int N, float* dx, int lddx,
                         float* part, hipStream_t st) {
     const int groups = B / rpg;
-    dim3 grid(cdiv(N, 256), groups * nrb_of(rpg));
+    dim3 grid(cdiv(N, 64), groups * nrb_of(rpg));
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, dz, lddz, a, lda, mean, rstd, gamma, sums, train,
                        rpg, nrb_of(rpg), N, dx, lddx, part);
     return check_launch("bn_bwd_apply");
@@ -864,22 +1035,24 @@ int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, cons
 int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const float* a1, int lda1, const float* mean,
                    const float* rstd, int B, int rpg, int N, float* dq, int lddq, float* part, hipStream_t st) {
     const int groups = B / rpg;
-    dim3 grid(cdiv(N, 256), groups * nrb_of(rpg));
+    dim3 grid(cdiv(N, 64), groups * nrb_of(rpg));
     hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, st, dh, lddh, h, ldh, a1, lda1, mean, rstd, rpg,
                        nrb_of(rpg), N, dq, lddq, part);
     return check_launch("act_bwd");
 }
 
 int colsum_finalize_launch(const float* part, int groups, int nrb, int nq, int ncols, float* sums_out, float* dst0,
-                           float* dst1, float* dst2, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(nq * ncols, 256)), dim3(256), 0, st, part, groups, nrb, nq,
-                       ncols, sums_out, dst0, dst1, dst2, accumulate);
+                           float* dst1, float* dst2, int accumulate, hipStream_t st, int ld, int c_lo, float* copy0,
+                           float* copy2) {
+    if (ld <= 0) ld = ncols;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(nq * ncols, 64)), dim3(256), 0, st, part, groups, nrb, nq,
+                       ncols, ld, c_lo, sums_out, dst0, dst1, dst2, accumulate, copy0, copy2);
     return check_launch("colsum_finalize");
 }
 
 int ibn_bwd_stats_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col_off, const float* mean,
                          const float* rstd, int rpg, int groups, float* part, hipStream_t st) {
-    dim3 grid(cdiv(srcs.total, 256), groups * nrb_of(rpg));
+    dim3 grid(cdiv(srcs.total, 64), groups * nrb_of(rpg));
     hipLaunchKernelGGL(ibn_bwd_stats_kernel, grid, dim3(256), 0, st, srcs, dX0, ldx, col_off, mean, rstd, rpg,
                        nrb_of(rpg), part);
     return check_launch("ibn_bwd_stats");
@@ -889,7 +1062,7 @@ int ibn_bwd_apply_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col
                          const float* rstd, const float* gamma, const float* sums, int train, int B, int rpg, int c_lo,
                          int c_hi, float* dst, int ldd, hipStream_t st) {
     if (c_hi <= c_lo) return DGG_OK;
-    dim3 grid(cdiv(c_hi - c_lo, 256), cdiv(B, RB));
+    dim3 grid(cdiv(c_hi - c_lo, 64), cdiv(B, RB));
     hipLaunchKernelGGL(ibn_bwd_apply_kernel, grid, dim3(256), 0, st, srcs, dX0, ldx, col_off, mean, rstd, gamma, sums,
                        train, B, rpg, c_lo, c_hi, dst, ldd);
     return check_launch("ibn_bwd_apply");
@@ -915,8 +1088,8 @@ int ortho6d_bwd_launch(const float* o6, int ld, int B, const float* d_rot9, floa
 int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const float* heads, const float* gt_rot9,
                     const float* gt_transl, const float* gt_joint, const float* fake_score, const float* d_pose,
                     float* losses, float* d_heads, hipStream_t st) {
-    hipLaunchKernelGGL(gen_loss_kernel, dim3(1), dim3(1024), 0, st, cfg->n_hand_joints, hp->bce_weight,
-                       hp->transl_coef, hp->rot_coef, hp->conf_coef, B, heads, gt_rot9, gt_transl, gt_joint,
+    hipLaunchKernelGGL(gen_loss_kernel, dim3(1), dim3(1024), 0, st, cfg->n_hand_joints, (float)hp->bce_weight,
+                       (float)hp->transl_coef, (float)hp->rot_coef, (float)hp->conf_coef, B, heads, gt_rot9, gt_transl, gt_joint,
                        fake_score, d_pose, losses, d_heads);
     return check_launch("gen_loss");
 }
@@ -926,18 +1099,20 @@ int disc_loss_combine_launch(float* losses, hipStream_t st) {
     return check_launch("disc_loss_combine");
 }
 
-int adam_launch(float* params, const float* grads, float* m, float* v, int64_t n, int step, float lr, float b1,
-                float b2, float eps, float wd, float grad_scale, hipStream_t st) {
+int adam_launch(float* params, const float* grads, float* m, float* v, int64_t n, int step, double lr, double b1,
+                double b2, double eps, double wd, double grad_scale, hipStream_t st) {
     if (n <= 0 || step < 1) return DGG_ERR_INVALID;
-    const double bc1 = 1.0 - pow((double)b1, (double)step);
-    const double bc2 = 1.0 - pow((double)b2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
+    // everything that involves 1-beta or beta^t is formed in double (like torch) and rounded once
+    const double bc1 = 1.0 - pow(b1, (double)step);
+    const double bc2 = 1.0 - pow(b2, (double)step);
+    const float step_size = (float)(lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     int64_t blocks = ((n >> 2) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, m, v, n, step_size,
-                       bc2_sqrt, b1, b2, eps, wd, grad_scale);
+                       bc2_sqrt, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)wd,
+                       (float)grad_scale);
     return check_launch("adam");
 }
 

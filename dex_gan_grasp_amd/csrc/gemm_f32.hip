@@ -23,31 +23,73 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int BK = 32;
 
-template <int BR, bool KC>
+// Global -> register staging of one BR x 32 operand tile.
+//  FAST: the tile lies fully inside the matrix and the k-tile inside [kbeg,kend): every address is a
+//        wave-uniform base (SGPR pair, advanced with scalar adds) + one loop-invariant per-lane offset,
+//        so a load is a single `global_load_dword v, v_off, s[base]` with no predicate — the whole
+//        k-tile body stays one basic block and the scheduler can sink the loads between the MFMAs.
+//  !FAST: tails (last M/N tile, last k-tile of a split): indices are clamped into the matrix and the k
+//        tail is zeroed with a select — branch-free, never out of bounds.  Rows/columns beyond M/N only
+//        feed accumulator rows/columns that the epilogue never stores, so they need no zeroing.
+template <int BR, bool KC, bool FAST>
 __device__ __forceinline__ void load_tile(const float* __restrict__ G, int ld, int row0, int nrows, int k0, int kend,
-                                          float (&r)[BR * BK / 256]) {
+                                          float (&r)[BR * BK / 256], const float* __restrict__ scale = nullptr,
+                                          const float* __restrict__ shift = nullptr) {
     const int tid = threadIdx.x;
     constexpr int NE = BR * BK / 256;
     if constexpr (KC) {
         // global [row][k]: a half-wave reads 32 consecutive k of one row (128 B)
-        const int k = tid & 31;
-        const int gk = k0 + k;
-        const bool kok = gk < kend;
+        const int k = tid & 31, rl = tid >> 5;
+        if constexpr (FAST) {
+            const unsigned lane_byte = ((unsigned)rl * (unsigned)ld + (unsigned)k) * 4u;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int gr = row0 + (tid >> 5) + 8 * e;
-            r[e] = (kok && gr < nrows) ? G[(size_t)gr * ld + gk] : 0.f;
+            for (int e = 0; e < NE; ++e) {
+                const char* pu = reinterpret_cast<const char*>(G + ((size_t)(row0 + 8 * e) * ld + k0));  // uniform
+                r[e] = *reinterpret_cast<const float*>(pu + lane_byte);
+            }
+            if (scale) {  // wave-uniform branch
+                const float sc = scale[k0 + k], sh = shift[k0 + k];
+#pragma unroll
+                for (int e = 0; e < NE; ++e) r[e] = __builtin_fmaf(r[e], sc, sh);
+            }
+        } else {
+            const int gk = k0 + k;
+            const bool kok = gk < kend;
+            const int ck = kok ? gk : kend - 1;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                int gr = row0 + rl + 8 * e;
+                gr = gr < nrows ? gr : nrows - 1;
+                const float v = G[(size_t)gr * ld + ck];
+                r[e] = kok ? v : 0.f;
+            }
+            if (scale) {
+                const float sc = scale[ck], sh = shift[ck];
+#pragma unroll
+                for (int e = 0; e < NE; ++e) r[e] = kok ? __builtin_fmaf(r[e], sc, sh) : 0.f;
+            }
         }
     } else {
         // global [k][col]: a wave reads 64 consecutive columns of one k row (256 B)
         constexpr int KSTEP = 256 / BR;
-        const int col = tid % BR;
-        const int gc = row0 + col;
-        const bool cok = gc < nrows;
+        const int col = tid % BR, kl = tid / BR;
+        if constexpr (FAST) {
+            const unsigned lane_byte = ((unsigned)kl * (unsigned)ld + (unsigned)col) * 4u;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int gk = k0 + tid / BR + KSTEP * e;
-            r[e] = (cok && gk < kend) ? G[(size_t)gk * ld + gc] : 0.f;
+            for (int e = 0; e < NE; ++e) {
+                const char* pu = reinterpret_cast<const char*>(G + ((size_t)(k0 + KSTEP * e) * ld + row0));  // uniform
+                r[e] = *reinterpret_cast<const float*>(pu + lane_byte);
+            }
+        } else {
+            int gc = row0 + col;
+            gc = gc < nrows ? gc : nrows - 1;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int gk = k0 + kl + KSTEP * e;
+                const bool kok = gk < kend;
+                const float v = G[(size_t)(kok ? gk : kend - 1) * ld + gc];
+                r[e] = kok ? v : 0.f;
+            }
         }
     }
 }
@@ -77,11 +119,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
     __shared__ float smem[2 * BUF];
 
     // ---- which problem / tile / k-split does this workgroup own (all wave-uniform)
-    int pi = 0;
+    // (copy by scalar selects, not by a dynamic index: every field stays in SGPRs)
+    GemmProb P = batch.p[0];
 #pragma unroll
     for (int q = 1; q < 4; ++q)
-        if (q < batch.nprob && (int)blockIdx.x >= batch.p[q].blk_begin) pi = q;
-    const GemmProb& P = batch.p[pi];
+        if (q < batch.nprob && (int)blockIdx.x >= batch.p[q].blk_begin) P = batch.p[q];
     const int local = (int)blockIdx.x - P.blk_begin;
     const int ntile = P.tiles_m * P.tiles_n;
     const int split = local / ntile;
@@ -111,9 +153,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     float ra[BM * BK / 256], rb[BN * BK / 256];
+    const bool mn_full = (m0 + BM <= M) && (n0 + BN <= N);  // wave-uniform
+    auto fetch = [&](int k0) {
+        if (mn_full && k0 + BK <= kend) {
+            load_tile<BM, A_KC, true>(P.A, P.lda, m0, M, k0, kend, ra, A_KC ? P.a_scale : nullptr, P.a_shift);
+            load_tile<BN, B_KC, true>(P.B, P.ldb, n0, N, k0, kend, rb);
+        } else {
+            load_tile<BM, A_KC, false>(P.A, P.lda, m0, M, k0, kend, ra, A_KC ? P.a_scale : nullptr, P.a_shift);
+            load_tile<BN, B_KC, false>(P.B, P.ldb, n0, N, k0, kend, rb);
+        }
+    };
     if (nkt > 0) {
-        load_tile<BM, A_KC>(P.A, P.lda, m0, M, kbeg, kend, ra);
-        load_tile<BN, B_KC>(P.B, P.ldb, n0, N, kbeg, kend, rb);
+        fetch(kbeg);
         store_tile<BM, A_KC>(smem, ra);
         store_tile<BN, B_KC>(smem + BK * LDA_S, rb);
     }
@@ -123,12 +174,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
         const float* As = smem + (kt & 1) * BUF;
         const float* Bs = As + BK * LDA_S;
         const bool more = kt + 1 < nkt;
-        if (more) {  // prefetch the next k-tile into registers; latency hides under the MFMAs below
-            const int k0 = kbeg + (kt + 1) * BK;
-            load_tile<BM, A_KC>(P.A, P.lda, m0, M, k0, kend, ra);
-            load_tile<BN, B_KC>(P.B, P.ldb, n0, N, k0, kend, rb);
-        }
-#pragma unroll 4
+        if (more) fetch(kbeg + (kt + 1) * BK);  // next k-tile -> registers; latency hides under the MFMAs below
+#pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
             const int k = 2 * kp + lh;
             float a[TM], b[TN];
@@ -153,6 +200,58 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
     // ---- epilogue: D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     float* Cb = P.C + (P.splits > 0 ? (size_t)split * (size_t)P.slab_stride : (size_t)0);
     const bool accum = (P.splits == 0) && P.accumulate;
+    if constexpr (!A_KC && !B_KC) {
+        if (P.ep_gamma) {  // BatchNorm-aware wgrad epilogue (see GemmProb); wave-uniform branch
+            float* red = smem;  // [2 m-waves][2][BN], free after the last barrier of the k loop
+            float csn[TM][16];
+#pragma unroll
+            for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float v = 0.f;
+                    if (row < M) v = row < P.ep_split ? (P.ep_cs0 ? P.ep_cs0[row] : 0.f) : P.ep_cs1[row - P.ep_split];
+                    csn[ta][r] = v;
+                }
+#pragma unroll
+            for (int tb = 0; tb < TN; ++tb) {
+                const int col = n0 + wn0 + tb * 32 + li;
+                const bool colok = col < N;
+                const float ga = colok ? P.ep_gamma[col] : 0.f, be = colok ? P.ep_beta[col] : 0.f;
+                float pg = 0.f, pb = 0.f;
+#pragma unroll
+                for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (row < M && colok) {
+                            const float t = acc[ta][tb][r];
+                            const float w = P.ep_w[(size_t)row * P.ep_ldw + col];
+                            pg = __builtin_fmaf(w, t, pg);
+                            pb = __builtin_fmaf(w, csn[ta][r], pb);
+                            float* p = Cb + (size_t)row * P.ldc + col;
+                            float v = __builtin_fmaf(ga, t, be * csn[ta][r]);
+                            if (accum) v += *p;
+                            *p = v;
+                        }
+                    }
+                pg += __shfl_xor(pg, 32);
+                pb += __shfl_xor(pb, 32);
+                if (lh == 0) {
+                    red[((wave >> 1) * 2 + 0) * BN + wn0 + tb * 32 + li] = pg;
+                    red[((wave >> 1) * 2 + 1) * BN + wn0 + tb * 32 + li] = pb;
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < 2 * BN; idx += 256) {
+                const int q = idx / BN, cidx = idx - q * BN;
+                const int col = n0 + cidx;
+                if (col < N)
+                    P.ep_part[((size_t)tm_i * 2 + q) * N + col] = red[(0 * 2 + q) * BN + cidx] + red[(1 * 2 + q) * BN + cidx];
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int ta = 0; ta < TM; ++ta)
 #pragma unroll
@@ -172,13 +271,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
 }
 
 // ------------------------------------------------------------------------------------------------
-void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn) {
+void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn, int K) {
     // Big tiles when they alone (or with split-K in NT mode) can fill 256 CUs; otherwise 64-wide.
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     bm = 128;
     bn = 128;
     if (mode == GEMM_NT) {
-        if (t128 < 24) { bm = 64; bn = 64; }
+        const long ksteps = (K + BK - 1) / BK;
+        const long maxs = ksteps / 4 > 0 ? ksteps / 4 : 1;  // split-K keeps >= 4 k-tiles per workgroup
+        if (t128 * maxs < 200) { bm = 64; bn = 64; }
         return;
     }
     if (t128 < 200) {
@@ -191,7 +292,7 @@ void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn) {
 
 int gemm_pick_splits(int mode, int M, int N, int K, int other_blocks) {
     int bm, bn;
-    gemm_tile_shape(mode, M, N, bm, bn);
+    gemm_tile_shape(mode, M, N, bm, bn, K);
     const int tiles = ((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     const int ksteps = (K + BK - 1) / BK;
     static int target = -1;
@@ -209,7 +310,7 @@ int gemm_pick_splits(int mode, int M, int N, int K, int other_blocks) {
 
 int gemm_plan(GemmProb& p, int mode, int splits) {
     int bm, bn;
-    gemm_tile_shape(mode, p.M, p.N, bm, bn);
+    gemm_tile_shape(mode, p.M, p.N, bm, bn, p.K);
     p.tiles_m = (p.M + bm - 1) / bm;
     p.tiles_n = (p.N + bn - 1) / bn;
     p.splits = splits;
@@ -245,7 +346,7 @@ static void launch_shape(int bm, int bn, const GemmBatch& b, hipStream_t st) {
 int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
     if (batch.nprob < 1 || batch.nprob > 4) return DGG_ERR_INVALID;
     int bm, bn;
-    gemm_tile_shape(mode, batch.p[0].M, batch.p[0].N, bm, bn);
+    gemm_tile_shape(mode, batch.p[0].M, batch.p[0].N, bm, bn, batch.p[0].K);
     int blocks = 0;
     for (int i = 0; i < batch.nprob; ++i) {
         GemmProb& p = batch.p[i];

@@ -130,20 +130,22 @@ int dgg_bce(const float* p, const float* labels, float target_const, int B, floa
 
 /* A12 — torch.optim.Adam as configured at dexgangrasp.py:97-112 (L2-coupled weight decay):
  * g += wd*theta; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
- * theta -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  `step` is t (1-based). */
-int dgg_adam_l2(float* params, const float* grads, float* m, float* v, int64_t n, int step, float lr,
-                float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+ * theta -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  `step` is t (1-based).  Hyper-parameters
+ * are doubles, as in torch: 1-beta and the bias corrections are formed in double on the host and only
+ * then rounded to the fp32 the kernel computes in (1.f - 0.999f would be off by 1.3e-5). */
+int dgg_adam_l2(float* params, const float* grads, float* m, float* v, int64_t n, int step, double lr,
+                double beta1, double beta2, double eps, double weight_decay, double grad_scale, void* stream);
 
 /* A10 — DexGanGrasp.update_dexgangrasp, dexgangrasp.py:757-823, split at the two points where a
  * data-parallel run all-reduces gradients (between backward and Adam).
  *
  * Hyper-parameters of one step. */
 typedef struct {
-    float lr_gen, lr_dis, lr_eva; /* cfg lr_gen / lr_dis / lr */
-    float beta1, beta2, eps, weight_decay;
-    float bce_weight;
-    float transl_coef, rot_coef, conf_coef; /* 100, 1, 10 (dexgangrasp.py:92-94) */
-    float grad_scale; /* 1/world_size after a sum all-reduce, else 1 */
+    double lr_gen, lr_dis, lr_eva; /* cfg lr_gen / lr_dis / lr */
+    double beta1, beta2, eps, weight_decay;
+    double bce_weight;
+    double transl_coef, rot_coef, conf_coef; /* 100, 1, 10 (dexgangrasp.py:92-94) */
+    double grad_scale; /* 1/world_size after a sum all-reduce, else 1 */
 } dgg_hparams;
 
 /* State of the GAN pair (device pointers, layouts from dgg_table). */
@@ -197,7 +199,8 @@ int dgg_translate_along_axis(float* transl, const float* rot9, int B, int axis, 
 
 /* Plain GEMM entry used by the unit tests of the MFMA kernel (not part of the reference surface):
  * mode 0: C[M,N] = A[M,K] * B[N,K]^T;  1: C[M,N] = A[M,K] * B[K,N];  2: C[M,N] = A[K,M]^T * B[K,N].
- * splits >= 1 (split-K through `slabs`, S*M*N floats; reduced into C); accumulate: C += . */
+ * splits >= 1 (split-K through `slabs`, S*M*N floats; reduced into C, or left as slabs when C is
+ * NULL); accumulate: C += . */
 int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C,
                  int ldc, int splits, float* slabs, int accumulate, void* stream);
 

@@ -216,7 +216,7 @@ def adam_step(sd, grads, st, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8, wd=5e-4):
             if st.m[n] is None:
                 st.m[n] = torch.zeros_like(p)
                 st.v[n] = torch.zeros_like(p)
-            st.m[n].mul_(b1).add_(g, alpha=1 - b1)
+            st.m[n].lerp_(g, 1 - b1)  # torch.optim.Adam's form: m + (1-b1) (g - m)
             st.v[n].mul_(b2).addcmul_(g, g, value=1 - b2)
             denom = (st.v[n].sqrt() / math.sqrt(bc2)).add_(eps)
             p.addcdiv_(st.m[n], denom, value=-(lr / bc1))

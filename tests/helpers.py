@@ -94,26 +94,49 @@ def rms_of_summary(s):
 
 
 def assert_state_close(name, t, golden, step, rtol=1e-4, atol=1e-4, lr=1e-4):
-    """Post-step parameter / buffer check.  Pre-BN biases (analytically-zero gradient, see
-    is_pre_bn_bias): Adam divides the gradient by its own magnitude, so where weight_decay*theta is
-    as small as the rounding noise the SIGN of the update is noise-driven and two correct
-    implementations can differ by up to ~2*lr per step on single elements.  Those tensors are
-    therefore pinned only to |delta| <= 2.5*lr per step; all other tensors tightly."""
+    """Post-step parameter / buffer check against a golden summary (sum, sumsq, numel, 16 samples).
+
+    What can be pinned after an Adam step: in its first steps Adam's update is lr * g/(|g|+eps), a
+    function that AMPLIFIES gradient differences wherever |g| is within a few eps (1e-8) of zero:
+    d(update)/dg = lr * eps/(|g|+eps)^2.  Gradients themselves are pinned tightly elsewhere (2e-3 of the
+    tensor maximum on every tensor of every phase), and dgg_adam_l2 is pinned exactly by its own
+    unit test; but a parameter whose gradient element is ~1e-9 (reference-style 0.02-gain weights put
+    whole tensors there; every tensor has a few such elements; the pre-BN biases are analytically zero)
+    legitimately moves by a different fraction of lr in two correct implementations.  Hence:
+      - hard bound on every sample: |delta| <= 2.5*lr per step (Adam cannot move a parameter further);
+      - tight bound (rtol/atol + 5e-3*lr per step) on at least 12 of the 16 samples;
+      - the tensor sum within numel * 5e-2 * lr per step (mean update deviates by < 5% of lr).
+    BatchNorm running statistics do not pass through Adam and are checked tightly, except the
+    ResBlock running means, which integrate the (noise-driven) pre-BN bias."""
     from summ import summarize
+    s = summarize(t)
+    assert s[2] == golden[2], name + ": numel"
+    hard = 2.5 * lr * (step + 1)
+    if "running_var" in name or "num_batches" in name or (name.endswith("running_mean") and "rb" not in name):
+        assert_summary_close(t, golden, rtol, atol, "state " + name, abs_floor=1e-7)
+        return
+    d = np.abs(s[3:] - golden[3:])
+    assert d.max() <= hard, "%s: sample beyond the hard bound: %.3e" % (name, d.max())
+    if is_pre_bn_bias(name) or name.endswith("running_mean"):
+        return
+    scale = max(np.sqrt(golden[1] / max(golden[2], 1.0)), 1e-30)
+    tight = rtol * np.abs(golden[3:]) + atol * scale + 5e-3 * lr * (step + 1)
+    assert int((d <= tight).sum()) >= 12, "%s: only %d/16 samples within the tight tolerance" % (
+        name, int((d <= tight).sum()))
+    assert abs(s[0] - golden[0]) <= golden[2] * 5e-2 * lr * (step + 1) + rtol * abs(golden[0]), name + ": sum"
+
+
+def assert_update_close(name, t, r, prev, step, lr=1e-4):
+    """Full-tensor post-step check against the oracle (t: ours, r: oracle, prev: oracle before the
+    step).  See assert_state_close for why single elements cannot be pinned tightly after Adam:
+    every element within the hard bound, and the update as a whole within 2% in the L2 sense
+    (|| t - r || <= 2e-2 * || r - prev ||): sign-like +-lr updates with a handful of noise-driven
+    elements pass, a wrong gradient or a wrong Adam does not."""
+    d = (t - r).abs()
+    hard = 2.5 * lr * (step + 1)
+    assert float(d.max()) <= hard, "%s: max err %.3e beyond the hard bound" % (name, float(d.max()))
     if is_pre_bn_bias(name):
-        s = summarize(t)
-        bound = 2.5 * lr * (step + 1)
-        assert np.abs(s[3:] - golden[3:]).max() <= bound, name
-        assert abs(s[0] - golden[0]) <= bound * golden[2], name
         return
-    if ".rb" in "." + name.replace("_rb", ".rb") and name.endswith("running_mean"):
-        # running_mean of a ResBlock BN = EMA of mean(x W^T) + (pre-BN bias): it inherits the
-        # noise-driven bias delta above (times momentum), e.g. 0.1 * 2e-4 = 2e-5 after step 2.
-        s = summarize(t)
-        bound = 2.5 * lr * (step + 1)
-        np.testing.assert_allclose(s[3:], golden[3:], rtol=rtol, atol=bound, err_msg=name)
-        return
-    # Everything else: tight, plus an absolute floor lr * 5e-3 per step — Adam's update is
-    # lr * g/(|g|+eps), so a 5e-3 relative gradient difference (the gradient tolerance) moves a
-    # parameter by at most that much.
-    assert_summary_close(t, golden, rtol, atol, "state " + name, abs_floor=5e-3 * lr * (step + 1))
+    upd = float((r - prev).double().pow(2).sum().sqrt())
+    err = float((t - r).double().pow(2).sum().sqrt())
+    assert err <= 2e-2 * upd + 1e-12, "%s: update L2 error %.3e vs update norm %.3e" % (name, err, upd)

@@ -38,16 +38,37 @@ def _cmp_grads(flat, ref, prefix=""):
         assert err <= 2e-3 * scale, "%s: err %.3e scale %.3e" % (n, err, scale)
 
 
-def _cmp_state(flat, sd_ref, prefix, step, lr=1e-4):
+def _cmp_state(flat, sd_ref, prev, prefix, step, lr=1e-4):
+    """Full-tensor post-step comparison with the oracle (helpers.assert_update_close explains the
+    tolerance model); BatchNorm running statistics tightly."""
     sd = flat.state_dict()
     for n, t in sd.items():
         r = sd_ref[prefix + n]
-        d = (t - r).abs()
-        if H.is_pre_bn_bias(n) or ("rb" in n and n.endswith("running_mean")):
-            assert float(d.max()) <= 2.5 * lr * (step + 1), n   # see helpers.assert_state_close
+        if "running_" in n:
+            d = (t - r).abs()
+            if "rb" in n and n.endswith("running_mean"):
+                assert float(d.max()) <= 2.5 * lr * (step + 1), n   # integrates the pre-BN bias
+            else:
+                tol = 1e-4 * r.abs() + 1e-5 * float(r.pow(2).mean().sqrt()) + 1e-7
+                assert bool((d <= tol).all()), "%s: max err %.3e" % (n, float(d.max()))
             continue
-        tol = 1e-4 * r.abs() + 1e-4 * float(r.pow(2).mean().sqrt()) + 5e-3 * lr * (step + 1)
-        assert bool((d <= tol).all()), "%s: max err %.3e" % (n, float(d.max()))
+        H.assert_update_close(n, t, r, prev[prefix + n], step, lr)
+
+
+def _snap(sd):
+    return {k: v.detach().clone() for k, v in sd.items()}
+
+
+def _sync_from_oracle(flat, sd, adam, prefix=""):
+    """Load the oracle's parameters, BN statistics and Adam moments into the flat buffers so that the
+    next step starts from IDENTICAL state on both sides (otherwise the noise-driven Adam elements of
+    step t perturb the gradients of step t+1 by percents in the eps-dominated reference-init regime)."""
+    flat.load_state_dict(sd, prefix)
+    mv, vv = flat.views("m"), flat.views("v")
+    for n in mv:
+        mv[n].copy_(adam.m[prefix + n].to(mv[n].device))
+        vv[n].copy_(adam.v[prefix + n].to(vv[n].device))
+    flat.step = adam.t
 
 
 @pytest.mark.parametrize("variant,bname", [("wide", "syn64"), ("init", "real16"), ("init", "syn64")])
@@ -76,6 +97,7 @@ def test_cgan_and_eva_steps_vs_oracle_and_goldens(variant, bname):
     hp = ops.make_hparams(CFG)
     for step in range(2):
         z = torch.from_numpy(g[key + "cgan%d/z" % step]) if has_golden else synth.make_z(b, 100 + step)
+        prev = _snap(sd)
         ref_losses, g_d, g_g, _ = O.cgan_step(sd, H.clone_batch(batch), z, ag, ad, CFG, True, return_grads=True)
         # phases by hand so the gradients can be inspected before each Adam
         ws = eng._cgan_ws(b)
@@ -98,19 +120,22 @@ def test_cgan_and_eva_steps_vs_oracle_and_goldens(variant, bname):
             if has_golden:  # the reference's own numbers
                 np.testing.assert_allclose(got[i], float(g[key + "cgan%d/loss/%s" % (step, n)]), rtol=1e-4, atol=1e-6,
                                            err_msg="golden " + n)
-        _cmp_state(fg, sd, "generator.", step)
-        _cmp_state(fd, sd, "discriminator.", step)
+        _cmp_state(fg, sd, prev, "generator.", step)
+        _cmp_state(fd, sd, prev, "discriminator.", step)
         if has_golden:
             cur = fg.state_dict("generator.")
             cur.update(fd.state_dict("discriminator."))
             for n, t in cur.items():
                 H.assert_state_close(n, t, g[key + "cgan%d/state/%s" % (step, n)], step)
+        _sync_from_oracle(fg, sd, ag, "generator.")
+        _sync_from_oracle(fd, sd, ad, "discriminator.")
     # evaluator
     ae = O.AdamState(O.param_names(sde))
     eb = H.eva_batch(bname)
     for step in range(2):
         masks = unpack_mask(g[key + "eva%d/masks" % step], (3, b, 512)) if has_golden else \
             synth.make_dropout_masks(b, 50 + step)
+        prev = _snap(sde)
         ref_losses, g_e, _ = O.eva_step(sde, H.clone_batch(eb), ae, CFG, masks, return_grads=True)
         ws = eng._eva_ws(b)
         ebps, erot = eb["bps_object"].to(DEV), eb["rot_matrix"].float().reshape(b, 9).to(DEV)
@@ -129,7 +154,8 @@ def test_cgan_and_eva_steps_vs_oracle_and_goldens(variant, bname):
                                        rtol=1e-4, atol=1e-6)
             for n, t in fe.state_dict().items():
                 H.assert_state_close(n, t, g[key + "eva%d/state/%s" % (step, n)], step)
-        _cmp_state(fe, sde, "", step)
+        _cmp_state(fe, sde, prev, "", step)
+        _sync_from_oracle(fe, sde, ae)
 
 
 def test_step_properties_at_full_size():
@@ -250,7 +276,7 @@ def test_wrapper_update_steps_vs_reference_goldens(variant, bname, tmp_path):
                               "scheduler_ffhgan_discriminator_state_dict"}
     assert len(ck["ffhgenerator_state_dict"]) == 82
     st = ck["optim_ffhgan_discriminator_state_dict"]["state"]
-    assert len(st) == 34 and float(st[0]["step"]) == 2.0
+    assert len(st) == 24 and float(st[0]["step"]) == 2.0  # 24 trainable tensors in the discriminator
     cke = torch.load(os.path.join(str(tmp_path), "3_eva_net.pt"), map_location="cpu", weights_only=False)
     assert set(cke.keys()) == {"epoch", "ffhevaluator_state_dict", "optim_ffhevaluator_state_dict",
                                "scheduler_ffhevaluator_state_dict"}
