@@ -83,6 +83,7 @@ SIGNATURES = {
                            _VP]),
     "dgg_gen_loss": (_I, [_CFG, C.POINTER(HParams), _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "dgg_translate_along_axis": (_I, [_VP, _VP, _I, _I, _F, _VP]),
+    "dgg_gemm_occupancy": (_I, [_I, _I, _I]),
     "dgg_gemm_f32": (_I, [_I, _I, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _VP, _I, _VP]),
 }
 

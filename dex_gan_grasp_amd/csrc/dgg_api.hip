@@ -976,6 +976,8 @@ int dgg_eva_phase(const dgg_cfg* cfg, const float* e_params, float* e_grads, flo
     return DGG_OK;
 }
 
+int dgg_gemm_occupancy(int mode, int bm, int bn) { return gemm_occupancy(mode, bm, bn); }
+
 int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc,
                  int splits, float* slabs, int accumulate, void* stream) {
     if (!A || !Bm || (!C && splits < 1) || M < 1 || N < 1 || K < 1 || mode < 0 || mode > 2) return DGG_ERR_INVALID;

@@ -60,6 +60,7 @@ int gemm_plan(GemmProb& p, int mode, int splits);
 int gemm_launch(int mode, GemmBatch& batch, hipStream_t st);
 int gemm_pick_splits(int mode, int M, int N, int K, int other_blocks);
 void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn, int K = 1 << 30);
+int gemm_occupancy(int mode, int bm, int bn);
 
 // ---------------------------------------------------------------- BPS encode (bps_encode.hip)
 int bps_encode_launch(const float* clouds, int B, int N, const float* basis, int P, float* dists, int32_t* ids,

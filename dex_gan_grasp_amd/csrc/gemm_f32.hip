@@ -15,6 +15,7 @@
 // A launch carries up to 4 independent problems (grouped GEMM) so the two column segments of a
 // concatenated ResBlock input ([X0 | X1], networks.py:95,154,330) share one grid, and split-K
 // partial products go to slabs that the bias/BN-statistics reduce kernel sums.
+#include <type_traits>
 #include "dgg_internal.h"
 
 namespace dgg {
@@ -33,8 +34,7 @@ constexpr int BK = 32;
 //        feed accumulator rows/columns that the epilogue never stores, so they need no zeroing.
 template <int BR, bool KC, bool FAST>
 __device__ __forceinline__ void load_tile(const float* __restrict__ G, int ld, int row0, int nrows, int k0, int kend,
-                                          float (&r)[BR * BK / 256], const float* __restrict__ scale = nullptr,
-                                          const float* __restrict__ shift = nullptr) {
+                                          float (&r)[BR * BK / 256]) {
     const int tid = threadIdx.x;
     constexpr int NE = BR * BK / 256;
     if constexpr (KC) {
@@ -47,11 +47,6 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ G, int ld, i
                 const char* pu = reinterpret_cast<const char*>(G + ((size_t)(row0 + 8 * e) * ld + k0));  // uniform
                 r[e] = *reinterpret_cast<const float*>(pu + lane_byte);
             }
-            if (scale) {  // wave-uniform branch
-                const float sc = scale[k0 + k], sh = shift[k0 + k];
-#pragma unroll
-                for (int e = 0; e < NE; ++e) r[e] = __builtin_fmaf(r[e], sc, sh);
-            }
         } else {
             const int gk = k0 + k;
             const bool kok = gk < kend;
@@ -62,11 +57,6 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ G, int ld, i
                 gr = gr < nrows ? gr : nrows - 1;
                 const float v = G[(size_t)gr * ld + ck];
                 r[e] = kok ? v : 0.f;
-            }
-            if (scale) {
-                const float sc = scale[ck], sh = shift[ck];
-#pragma unroll
-                for (int e = 0; e < NE; ++e) r[e] = kok ? __builtin_fmaf(r[e], sc, sh) : 0.f;
             }
         }
     } else {
@@ -92,6 +82,20 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ G, int ld, i
             }
         }
     }
+}
+
+// Per-k affine of a k-contiguous operand (the input BatchNorm's gamma/beta folded into the forward GEMM),
+// applied when the staged registers are parked in LDS — NOT right after the loads, which would put a
+// vmcnt(0) in front of the MFMAs and expose the full memory latency on every k-tile.  Zero-filled k tails
+// (k >= kend) must stay zero.
+template <int BR>
+__device__ __forceinline__ void affine_tile(float (&r)[BR * BK / 256], const float* __restrict__ scale,
+                                            const float* __restrict__ shift, int k0, int kend) {
+    const int gk = k0 + (threadIdx.x & 31);
+    const bool kok = gk < kend;
+    const float sc = kok ? scale[gk] : 0.f, sh = kok ? shift[gk] : 0.f;
+#pragma unroll
+    for (int e = 0; e < BR * BK / 256; ++e) r[e] = __builtin_fmaf(r[e], sc, sh);
 }
 
 template <int BR, bool KC>
@@ -124,7 +128,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
 #pragma unroll
     for (int q = 1; q < 4; ++q)
         if (q < batch.nprob && (int)blockIdx.x >= batch.p[q].blk_begin) P = batch.p[q];
-    const int local = (int)blockIdx.x - P.blk_begin;
+    // XCD-aware work assignment: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with
+    // its own 4 MiB L2), so ids congruent mod 8 share an L2.  Give each XCD a CONTIGUOUS run of work items
+    // (split-major, then tile): the 48 tiles of one k-split re-read the same A/W k-chunk (~3.3 MB), which then
+    // stays in that XCD's L2 instead of being fetched by all eight.  Bijective for any block count; affects
+    // speed only, never results.
+    int local = (int)blockIdx.x - P.blk_begin;
+    {
+        const int nb = P.tiles_m * P.tiles_n * (P.splits > 0 ? P.splits : 1);
+        const int q = nb >> 3, r = nb & 7;
+        const int xcd = local & 7, pos = local >> 3;
+        local = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    }
     const int ntile = P.tiles_m * P.tiles_n;
     const int split = local / ntile;
     const int tile = local - split * ntile;
@@ -154,48 +169,83 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
 
     float ra[BM * BK / 256], rb[BN * BK / 256];
     const bool mn_full = (m0 + BM <= M) && (n0 + BN <= N);  // wave-uniform
-    auto fetch = [&](int k0) {
-        if (mn_full && k0 + BK <= kend) {
-            load_tile<BM, A_KC, true>(P.A, P.lda, m0, M, k0, kend, ra, A_KC ? P.a_scale : nullptr, P.a_shift);
-            load_tile<BN, B_KC, true>(P.B, P.ldb, n0, N, k0, kend, rb);
-        } else {
-            load_tile<BM, A_KC, false>(P.A, P.lda, m0, M, k0, kend, ra, A_KC ? P.a_scale : nullptr, P.a_shift);
-            load_tile<BN, B_KC, false>(P.B, P.ldb, n0, N, k0, kend, rb);
-        }
-    };
-    if (nkt > 0) {
-        fetch(kbeg);
-        store_tile<BM, A_KC>(smem, ra);
-        store_tile<BN, B_KC>(smem + BK * LDA_S, rb);
-    }
-    __syncthreads();
+    const bool aff = A_KC && P.a_scale != nullptr;          // wave-uniform
+    // k-tiles [0, nfull) can use the predicate-free loads; tile nfull (if any) is the zero-filled tail
+    const int nfull = mn_full ? (kend - kbeg) / BK : 0;
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    // One k-tile: prefetch tile kt+1 (PF: 1 = fast loads, 2 = tail loads, 0 = none), MFMAs on tile kt, park the
+    // prefetched registers in the other LDS buffer, barrier.  The three prefetch kinds are separate
+    // instantiations on purpose: merging fast and tail loads behind one branch makes the compiler copy the
+    // loaded registers at the join, i.e. wait vmcnt(0) BEFORE the MFMAs and expose the memory latency.
+    auto ktile = [&](int kt, auto pf_tag) {
+        constexpr int PF = decltype(pf_tag)::value;
         const float* As = smem + (kt & 1) * BUF;
         const float* Bs = As + BK * LDA_S;
-        const bool more = kt + 1 < nkt;
-        if (more) fetch(kbeg + (kt + 1) * BK);  // next k-tile -> registers; latency hides under the MFMAs below
+        const int k0n = kbeg + (kt + 1) * BK;
+        if constexpr (PF == 1) {
+            load_tile<BM, A_KC, true>(P.A, P.lda, m0, M, k0n, kend, ra);
+            load_tile<BN, B_KC, true>(P.B, P.ldb, n0, N, k0n, kend, rb);
+        } else if constexpr (PF == 2) {
+            load_tile<BM, A_KC, false>(P.A, P.lda, m0, M, k0n, kend, ra);
+            load_tile<BN, B_KC, false>(P.B, P.ldb, n0, N, k0n, kend, rb);
+        }
+        // LDS -> register operand fetch runs one k-pair ahead of the MFMAs that consume it, so the ~100-cycle
+        // ds_read latency overlaps the 4 x 64 cycles the matrix pipe spends on the previous k-pair
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) a[0][t] = As[lh * LDA_S + wm0 + t * 32 + li];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) b[0][t] = Bs[lh * LDB_S + wn0 + t * 32 + li];
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
-            const int k = 2 * kp + lh;
-            float a[TM], b[TN];
+            const int cur = kp & 1, nxt = cur ^ 1;
+            if (kp + 1 < BK / 2) {
+                const int k = 2 * (kp + 1) + lh;
 #pragma unroll
-            for (int t = 0; t < TM; ++t) a[t] = As[k * LDA_S + wm0 + t * 32 + li];
+                for (int t = 0; t < TM; ++t) a[nxt][t] = As[k * LDA_S + wm0 + t * 32 + li];
 #pragma unroll
-            for (int t = 0; t < TN; ++t) b[t] = Bs[k * LDB_S + wn0 + t * 32 + li];
+                for (int t = 0; t < TN; ++t) b[nxt][t] = Bs[k * LDB_S + wn0 + t * 32 + li];
+            }
+            // pin the order in the emitted code: next pair's LDS reads are issued BEFORE this pair's MFMAs
+            // (left alone, the scheduler sinks the reads below the MFMAs into the same registers and waits
+            // lgkmcnt(0) on every pair, exposing the LDS latency 16 times per k-tile)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ta = 0; ta < TM; ++ta)
 #pragma unroll
                 for (int tb = 0; tb < TN; ++tb)
-                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][ta], b[cur][tb], acc[ta][tb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) {
+        if constexpr (PF != 0) {
             float* Sn = smem + ((kt + 1) & 1) * BUF;
+            if constexpr (A_KC) { if (aff) affine_tile<BM>(ra, P.a_scale, P.a_shift, k0n, kend); }
             store_tile<BM, A_KC>(Sn, ra);
             store_tile<BN, B_KC>(Sn + BK * LDA_S, rb);
         }
         __syncthreads();
+    };
+    using PF0 = std::integral_constant<int, 0>;
+    using PF1 = std::integral_constant<int, 1>;
+    using PF2 = std::integral_constant<int, 2>;
+
+    if (nkt > 0) {  // prologue: tile 0
+        if (nfull > 0) {
+            load_tile<BM, A_KC, true>(P.A, P.lda, m0, M, kbeg, kend, ra);
+            load_tile<BN, B_KC, true>(P.B, P.ldb, n0, N, kbeg, kend, rb);
+        } else {
+            load_tile<BM, A_KC, false>(P.A, P.lda, m0, M, kbeg, kend, ra);
+            load_tile<BN, B_KC, false>(P.B, P.ldb, n0, N, kbeg, kend, rb);
+        }
+        if constexpr (A_KC) { if (aff) affine_tile<BM>(ra, P.a_scale, P.a_shift, kbeg, kend); }
+        store_tile<BM, A_KC>(smem, ra);
+        store_tile<BN, B_KC>(smem + BK * LDA_S, rb);
     }
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nfull; ++kt) ktile(kt, PF1{});   // next tile full
+    for (; kt + 1 < nkt; ++kt) ktile(kt, PF2{});     // next tile is a tail (or the M/N edge)
+    if (kt < nkt) ktile(kt, PF0{});                  // last tile: nothing to prefetch
 
     // ---- epilogue: D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     float* Cb = P.C + (P.splits > 0 ? (size_t)split * (size_t)P.slab_stride : (size_t)0);
@@ -362,6 +412,21 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
     else if (mode == GEMM_TN) launch_shape<false, false>(bm, bn, batch, st);
     else return DGG_ERR_INVALID;
     return check_launch("gemm_f32");
+}
+
+// Residency query (advisory, see MI355X notes on the occupancy API): workgroups of the given GEMM variant that
+// fit one CU at once.
+int gemm_occupancy(int mode, int bm, int bn) {
+    int n = -1;
+    const void* f = nullptr;
+    if (mode == GEMM_NT && bm == 128 && bn == 128) f = (const void*)gemm_f32_kernel<128, 128, true, true>;
+    else if (mode == GEMM_NT) f = (const void*)gemm_f32_kernel<64, 64, true, true>;
+    else if (mode == GEMM_NN && bm == 128 && bn == 128) f = (const void*)gemm_f32_kernel<128, 128, true, false>;
+    else if (mode == GEMM_NN) f = (const void*)gemm_f32_kernel<64, 64, true, false>;
+    else if (mode == GEMM_TN && bm == 128 && bn == 128) f = (const void*)gemm_f32_kernel<128, 128, false, false>;
+    else f = (const void*)gemm_f32_kernel<64, 64, false, false>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 256, 0) != hipSuccess) return -1;
+    return n;
 }
 
 }  // namespace dgg

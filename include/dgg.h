@@ -201,6 +201,8 @@ int dgg_translate_along_axis(float* transl, const float* rot9, int B, int axis, 
  * mode 0: C[M,N] = A[M,K] * B[N,K]^T;  1: C[M,N] = A[M,K] * B[K,N];  2: C[M,N] = A[K,M]^T * B[K,N].
  * splits >= 1 (split-K through `slabs`, S*M*N floats; reduced into C, or left as slabs when C is
  * NULL); accumulate: C += . */
+/* Diagnostic: workgroups of the GEMM variant (mode, tile) resident per CU according to the HIP occupancy API. */
+int dgg_gemm_occupancy(int mode, int bm, int bn);
 int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C,
                  int ldc, int splits, float* slabs, int accumulate, void* stream);
 
