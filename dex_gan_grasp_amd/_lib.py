@@ -13,7 +13,7 @@ from collections import OrderedDict
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdgg.so")
+LIB_PATH = os.environ.get("DGG_LIB", os.path.join(_HERE, "libdgg.so"))  # DGG_LIB: diagnostic builds only
 
 NET_GEN, NET_DISC, NET_EVA = 0, 1, 2
 TRAIN, ACCUM_GRADS, SKIP_PARAM_GRADS, NEED_INPUT_GRADS = 1, 2, 4, 8
