@@ -27,7 +27,10 @@ sys.path.insert(0, ROOT)
 from dex_gan_grasp_amd import _lib, engine, ops, parallel, synth  # noqa: E402
 
 MFLOP_PER_GRASP_FULL = 231.38   # cGAN 167.51 + evaluator 63.87 as the reference executes it
-MFLOP_PER_GRASP_EXEC = 217.41   # the never-applied discriminator dW of the G phase is skipped (153.54 + 63.87)
+# What this implementation executes: no input-gradient GEMM of the BN'd BPS columns (the
+# input-BN parameter gradients come out of the wgrad epilogue), no discriminator dW in the G phase:
+# MACs/sample G 14.6 M + D 36.9 M + E 22.5 M = 74.0 M  ->  148 MFLOP
+MFLOP_PER_GRASP_EXEC = 148.0
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
