@@ -129,8 +129,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank, world, local = parallel.init_from_env()
+    # DGG_REHEARSE=1: rehearsal of the multi-rank code path on a 1-GPU box (gloo backend, all ranks on cuda:0);
+    # never used for reported numbers
+    rehearse = os.environ.get("DGG_REHEARSE") == "1"
+    rank, world, local = parallel.init_from_env(backend="gloo" if rehearse else None)
     assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cfg = dict(synth.DEFAULT_CFG)
@@ -151,8 +156,9 @@ def main():
     zs = [synth.make_z(B, 3 + 100 * rank + i).to(dev) for i in range(4)]
 
     def step(i):
-        eng.cgan_step(*g_in, zs[i % 4], True)
-        eng.eva_step(*e_in, None, 1234 + i)
+        # one update_dexgangrasp + one update_dexevaluator; gradient all-reduces (N > 1) overlap with the
+        # independent phase, see engine.TrainEngine.joint_step
+        eng.joint_step(g_in, zs[i % 4], e_in, True, None, 1234 + i)
 
     for i in range(args.warmup):
         step(i)

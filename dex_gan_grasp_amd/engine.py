@@ -93,3 +93,51 @@ class TrainEngine:
         parallel.allreduce_sum_(E.grads)
         E.adam_step(hp.lr_eva, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
         return self.losses.clone()
+
+    # ---- gen + eval step with communication/compute overlap (the unit bench.py times)
+    def joint_step(self, gan_inputs, z, eva_inputs, is_train_gen=True, drop_keep=None, seed=0, lr_gen=None,
+                   lr_dis=None, lr_eva=None):
+        """One update_dexgangrasp + one update_dexevaluator (independent networks and batches), ordered so that on
+        N > 1 GPUs every gradient all-reduce overlaps with compute that does not depend on it:
+            D phase | AR(D) || E phase | AR(E) || Adam(D), G phase | AR(G) || Adam(E) | Adam(G)
+        (RCCL runs the collectives on its own stream; `wait()` is a stream-level dependency, no host sync).
+        Single GPU: the same launches without collectives.  Results are identical to cgan_step + eva_step."""
+        dev = self.device
+        bps, rot9, transl, joint = (f32c(t, dev) for t in gan_inputs)
+        rot9 = rot9.reshape(-1, 9)
+        z = f32c(z, dev)
+        ebps, erot9, etransl, elabel = (f32c(t, dev) for t in eva_inputs)
+        erot9, elabel = erot9.reshape(-1, 9), elabel.reshape(-1)
+        dk = f32c(drop_keep, dev) if drop_keep is not None else None
+        B, Be = bps.shape[0], ebps.shape[0]
+        ws, wse = self._cgan_ws(B), self._eva_ws(Be)
+        hp = self._hp(lr_gen, lr_dis, lr_eva)
+        st = self._state()
+        cfg_p = C.byref(self.ccfg)
+        args = (ptr(bps), ptr(rot9), ptr(transl), ptr(joint), ptr(z))
+        G, D, E = self.G, self.D, self.E
+        adam = lambda net, lr: net.adam_step(lr, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
+
+        check(lib().dgg_cgan_d_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(self.losses),
+                                     stream_ptr()), "dgg_cgan_d_phase")
+        w_d = parallel.allreduce_sum_(D.grads, async_op=True)
+        check(lib().dgg_eva_phase(cfg_p, ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(wse), wse.numel(), Be,
+                                  ptr(ebps), ptr(erot9), ptr(etransl), ptr(elabel), ptr(dk), int(seed), ptr(self.losses),
+                                  stream_ptr()), "dgg_eva_phase")
+        w_e = parallel.allreduce_sum_(E.grads, async_op=True)
+        if w_d is not None:
+            w_d.wait()
+        adam(D, hp.lr_dis)
+        w_g = None
+        if is_train_gen:
+            check(lib().dgg_cgan_g_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args,
+                                         ptr(self.losses), stream_ptr()), "dgg_cgan_g_phase")
+            w_g = parallel.allreduce_sum_(G.grads, async_op=True)
+        if w_e is not None:
+            w_e.wait()
+        adam(E, hp.lr_eva)
+        if is_train_gen:
+            if w_g is not None:
+                w_g.wait()
+            adam(G, hp.lr_gen)
+        return self.losses

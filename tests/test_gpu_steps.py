@@ -200,6 +200,32 @@ def test_step_properties_at_full_size():
     assert torch.equal(fd3.params, fd1.params)  # D is only updated in the D phase
 
 
+def test_joint_step_equals_separate_steps():
+    L, ops, engine = _mods()
+    b = 64
+    gb, eb = synth.make_batch(b, 1), synth.make_batch(b, 2, with_label=True)
+    z = synth.make_z(b, 3)
+
+    def fresh():
+        fg, fd, fe = (L.FlatNet(k, CFG, DEV) for k in (L.NET_GEN, L.NET_DISC, L.NET_EVA))
+        sd = H.gan_sd("wide")
+        fg.load_state_dict(sd, "generator.")
+        fd.load_state_dict(sd, "discriminator.")
+        fe.load_state_dict(H.eva_sd("wide"))
+        return engine.TrainEngine(CFG, fg, fd, fe, DEV)
+    f = lambda t: t.float().to(DEV)
+    g_in = (f(gb["bps_object"]), f(gb["rot_matrix"]).reshape(b, 9), f(gb["transl"]), f(gb["joint_conf"]))
+    e_in = (f(eb["bps_object"]), f(eb["rot_matrix"]).reshape(b, 9), f(eb["transl"]), f(eb["label"]))
+    e1, e2 = fresh(), fresh()
+    for i in range(2):
+        e1.cgan_step(*g_in, z.to(DEV), True)
+        l1 = e1.eva_step(*e_in, None, 77 + i).clone()
+        l2 = e2.joint_step(g_in, z.to(DEV), e_in, True, None, 77 + i).clone()
+        assert torch.equal(l1[:10], l2[:10])
+    for a, c in ((e1.G, e2.G), (e1.D, e2.D), (e1.E, e2.E)):
+        assert torch.equal(a.params, c.params) and torch.equal(a.m, c.m) and torch.equal(a.bn, c.bn)
+
+
 # ------------------------------------------------------------------ drop-in Python surface
 def _wrapper(variant, is_train=True):
     from dex_gan_grasp_amd.models.dexgangrasp import DexGanGrasp
