@@ -139,6 +139,14 @@ def f32c(t, device):
     return torch.as_tensor(t).to(device=device, dtype=torch.float32).contiguous()
 
 
+def new_workspace(nbytes, device):
+    """Caller-owned scratch for the C-ABI.  DGG_POISON_WS=1 (tests): fill with 0xFF bytes (= NaN floats) so that
+    any kernel reading workspace memory it has not written shows up as NaN instead of depending on leftovers."""
+    if os.environ.get("DGG_POISON_WS") == "1":
+        return torch.full((nbytes,), 255, dtype=torch.uint8, device=device)
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
 class FlatNet:
     """Flat device buffers of one network in the library's layout (dgg_table) with named views.
 
@@ -198,7 +206,7 @@ class FlatNet:
             n = int(lib().dgg_workspace_bytes(self.net, C.byref(self.ccfg), batch))
             if n < 0:
                 raise DggError("dgg_workspace_bytes: %d" % n)
-            ws = torch.empty(n + 4096 + 8 * batch, dtype=torch.uint8, device=self.device)
+            ws = new_workspace(n + 4096 + 8 * batch, self.device)
             self._ws[batch] = ws
         return ws
 

@@ -39,7 +39,7 @@ class TrainEngine:
             n = int(lib().dgg_cgan_workspace_bytes(C.byref(self.ccfg), B))
             if n < 0:
                 raise _lib.DggError("dgg_cgan_workspace_bytes: %d" % n)
-            ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            ws = _lib.new_workspace(n, self.device)
             self._ws[B] = ws
         return ws
 
@@ -47,7 +47,7 @@ class TrainEngine:
         ws = self._ws_e.get(B)
         if ws is None:
             n = int(lib().dgg_workspace_bytes(_lib.NET_EVA, C.byref(self.ccfg), B)) + 8 * B + 4096
-            ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            ws = _lib.new_workspace(n, self.device)
             self._ws_e[B] = ws
         return ws
 

@@ -153,7 +153,7 @@ class _NetFn(torch.autograd.Function):
         flat = mod._flat
         dev = flat.device
         B = ins[-1].shape[0] if kind == "gen" else ins[0].shape[0]
-        ws = torch.empty(flat.workspace(B).numel(), dtype=torch.uint8, device=dev)
+        ws = _lib.new_workspace(flat.workspace(B).numel(), dev)
         ctx.mod, ctx.kind, ctx.train, ctx.ws, ctx.n_in = mod, kind, train, ws, n_in
         ins = [_lib.f32c(t, dev) for t in ins]
         if kind == "gen":

@@ -24,18 +24,10 @@ def _strip(sd, prefix):
     return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
 
 
-def _cmp_grads(flat, ref, prefix=""):
+def _cmp_grads(flat, ref, prefix="", batch=64):
     gv = {k: v.cpu() for k, v in flat.views("grads").items()}
     for n, r in ref.items():
-        n = n[len(prefix):]
-        got = gv[n]
-        if H.is_pre_bn_bias(n):
-            sib = float(ref[prefix + H.sibling_bn_bias(n)].pow(2).mean().sqrt())
-            assert float(got.abs().max()) <= 1e-3 * sib, n
-            continue
-        scale = float(r.abs().max()) + 1e-30
-        err = float((got - r).abs().max())
-        assert err <= 2e-3 * scale, "%s: err %.3e scale %.3e" % (n, err, scale)
+        H.assert_grad_tensor_close(n[len(prefix):], gv[n[len(prefix):]], r, train=True, batch=batch)
 
 
 def _cmp_state(flat, sd_ref, prev, prefix, step, lr=1e-4):
@@ -106,11 +98,11 @@ def test_cgan_and_eva_steps_vs_oracle_and_goldens(variant, bname):
         args = (L.ptr(bps), L.ptr(rot9), L.ptr(tr), L.ptr(jt), L.ptr(zd))
         L.check(L.lib().dgg_cgan_d_phase(C.byref(eng.ccfg), C.byref(st), C.byref(hp), L.ptr(ws), ws.numel(), b, *args,
                                          L.ptr(eng.losses), L.stream_ptr()))
-        _cmp_grads(fd, g_d, "discriminator.")
+        _cmp_grads(fd, g_d, "discriminator.", b)
         fd.adam_step(hp.lr_dis)
         L.check(L.lib().dgg_cgan_g_phase(C.byref(eng.ccfg), C.byref(st), C.byref(hp), L.ptr(ws), ws.numel(), b, *args,
                                          L.ptr(eng.losses), L.stream_ptr()))
-        _cmp_grads(fg, g_g, "generator.")
+        _cmp_grads(fg, g_g, "generator.", b)
         fg.adam_step(hp.lr_gen)
         got = eng.losses.cpu().numpy()
         names = ["total_loss_disc", "bce_loss_real", "bce_loss_fake", "gen_loss_fake", "transl_loss", "rot_loss",
@@ -144,7 +136,7 @@ def test_cgan_and_eva_steps_vs_oracle_and_goldens(variant, bname):
         L.check(L.lib().dgg_eva_phase(C.byref(eng.ccfg), L.ptr(fe.params), L.ptr(fe.grads), L.ptr(fe.bn), C.byref(hp),
                                       L.ptr(ws), ws.numel(), b, L.ptr(ebps), L.ptr(erot), L.ptr(etr), L.ptr(elab),
                                       L.ptr(md), 0, L.ptr(eng.losses), L.stream_ptr()))
-        _cmp_grads(fe, g_e)
+        _cmp_grads(fe, g_e, "", b)
         fe.adam_step(hp.lr_eva)
         got = eng.losses.cpu().numpy()
         np.testing.assert_allclose(got[L.L_TOTAL_EVA], float(ref_losses["total_loss_eva"]), rtol=1e-4, atol=1e-6)
