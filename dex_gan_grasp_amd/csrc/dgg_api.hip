@@ -876,9 +876,22 @@ int64_t dgg_cgan_workspace_bytes(const dgg_cfg* cfg, int batch) {
     return (int64_t)S.bytes;
 }
 
-int dgg_cgan_d_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, void* ws, size_t ws_bytes,
-                     int B, const float* bps, const float* rot9, const float* transl, const float* joint,
-                     const float* z, float* losses, void* stream) {
+// Events for the optional two-stream D phase (created once per thread; events are not caller memory).
+static int fork_events(hipEvent_t* ev, int n) {
+    static thread_local hipEvent_t cache[4];
+    static thread_local bool ready = false;
+    if (!ready) {
+        for (int i = 0; i < 4; ++i)
+            if (hipEventCreateWithFlags(&cache[i], hipEventDisableTiming) != hipSuccess) return DGG_ERR_LAUNCH;
+        ready = true;
+    }
+    for (int i = 0; i < n; ++i) ev[i] = cache[i];
+    return DGG_OK;
+}
+
+int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, void* ws, size_t ws_bytes,
+                      int B, const float* bps, const float* rot9, const float* transl, const float* joint,
+                      const float* z, float* losses, void* stream, void* stream2) {
     if (!s || !hp || !ws || !bps || !rot9 || !transl || !joint || !z || !losses) return DGG_ERR_INVALID;
     StepW S;
     DGG_TRY(carve_step(cfg, B, ws, S));
@@ -886,29 +899,45 @@ int dgg_cgan_d_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
     const int nj = cfg->n_hand_joints;
     const int nh = nj + 9;
     hipStream_t st = (hipStream_t)stream;
-    // :772-776 generator forward (train mode, activations kept for the G phase), R = ortho6d(rot_6D)
+    hipStream_t sb = stream2 ? (hipStream_t)stream2 : st;  // the real-batch pass of D
+    const bool fork = stream2 && stream2 != stream;
+    hipEvent_t ev[3];
+    if (fork) {
+        DGG_TRY(fork_events(ev, 3));
+        if (hipEventRecord(ev[0], st) != hipSuccess || hipStreamWaitEvent(sb, ev[0], 0) != hipSuccess)
+            return DGG_ERR_LAUNCH;
+    }
+    // ---- stream B: D(real) forward, BCE(real, 1), D backward(real) overwriting d_grads        (:788, :215-218, :793)
+    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint,
+                             S.p_real, sb));
+    if (fork && hipEventRecord(ev[1], sb) != hipSuccess) return DGG_ERR_LAUNCH;
+    DGG_TRY(bce_launch(S.p_real, nullptr, 1.f, B, (float)hp->bce_weight, 0.5f, losses + DGG_L_BCE_REAL, S.dl_real, sb));
+    DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint,
+                              S.dl_real, nullptr, sb));
+    if (fork && hipEventRecord(ev[2], sb) != hipSuccess) return DGG_ERR_LAUNCH;
+    // ---- stream A: :772-776 generator forward (train mode, activations kept for the G phase), R = ortho6d(rot_6D)
     DGG_TRY(dgg_gen_forward(cfg, s->g_params, s->g_bn, S.ws_g, S.g_bytes, B, DGG_TRAIN, z, bps, S.heads, stream));
     DGG_TRY(ortho6d_fwd_launch(S.heads + nj, nh, B, S.rfake, st));
     // fake transl / joint live inside the heads buffer with pitch nh: pack contiguous copies for D
-    float* f_transl = S.f_transl;
-    float* f_joint = S.f_joint;
-    DGG_TRY(copy_cols_launch(S.heads + nj + 6, nh, f_transl, 3, B, 3, st));
-    DGG_TRY(copy_cols_launch(S.heads, nh, f_joint, nj, B, nj, st));
-    // :788-789 D(real) then D(fake.detach()): BN running statistics advance in this order
-    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint,
-                             S.p_real, stream));
-    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN, bps, S.rfake, f_transl,
-                             f_joint, S.p_fake, stream));
-    // :213-232 loss = (BCE(real,1) + BCE(fake,0)) / 2
-    DGG_TRY(bce_launch(S.p_real, nullptr, 1.f, B, (float)hp->bce_weight, 0.5f, losses + DGG_L_BCE_REAL, S.dl_real, st));
+    DGG_TRY(copy_cols_launch(S.heads + nj + 6, nh, S.f_transl, 3, B, 3, st));
+    DGG_TRY(copy_cols_launch(S.heads, nh, S.f_joint, nj, B, nj, st));
+    // :789 D(fake.detach()): its BatchNorm running-statistic updates must follow those of the real pass
+    if (fork && hipStreamWaitEvent(st, ev[1], 0) != hipSuccess) return DGG_ERR_LAUNCH;
+    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN, bps, S.rfake, S.f_transl,
+                             S.f_joint, S.p_fake, stream));
     DGG_TRY(bce_launch(S.p_fake, nullptr, 0.f, B, (float)hp->bce_weight, 0.5f, losses + DGG_L_BCE_FAKE, S.dl_fake, st));
+    // :792-793 the fake pass accumulates onto the real pass' gradients
+    if (fork && hipStreamWaitEvent(st, ev[2], 0) != hipSuccess) return DGG_ERR_LAUNCH;
     DGG_TRY(disc_loss_combine_launch(losses, st));
-    // :792-793 zero_grad + backward: real pass overwrites, fake pass accumulates
-    DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint,
-                              S.dl_real, nullptr, stream));
     DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_df, S.d_bytes, B, DGG_TRAIN | DGG_ACCUM_GRADS, bps,
-                              S.rfake, f_transl, f_joint, S.dl_fake, nullptr, stream));
+                              S.rfake, S.f_transl, S.f_joint, S.dl_fake, nullptr, stream));
     return DGG_OK;
+}
+
+int dgg_cgan_d_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, void* ws, size_t ws_bytes,
+                     int B, const float* bps, const float* rot9, const float* transl, const float* joint,
+                     const float* z, float* losses, void* stream) {
+    return dgg_cgan_d_phase2(cfg, s, hp, ws, ws_bytes, B, bps, rot9, transl, joint, z, losses, stream, nullptr);
 }
 
 int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, void* ws, size_t ws_bytes,

@@ -96,12 +96,15 @@ class TrainEngine:
 
     # ---- gen + eval step with communication/compute overlap (the unit bench.py times)
     def joint_step(self, gan_inputs, z, eva_inputs, is_train_gen=True, drop_keep=None, seed=0, lr_gen=None,
-                   lr_dis=None, lr_eva=None):
-        """One update_dexgangrasp + one update_dexevaluator (independent networks and batches), ordered so that on
-        N > 1 GPUs every gradient all-reduce overlaps with compute that does not depend on it:
-            D phase | AR(D) || E phase | AR(E) || Adam(D), G phase | AR(G) || Adam(E) | Adam(G)
-        (RCCL runs the collectives on its own stream; `wait()` is a stream-level dependency, no host sync).
-        Single GPU: the same launches without collectives.  Results are identical to cgan_step + eva_step."""
+                   lr_dis=None, lr_eva=None, two_streams=True):
+        """One update_dexgangrasp + one update_dexevaluator.  The two updates touch disjoint networks, batches
+        and workspaces, so the evaluator update runs on a SECOND HIP stream concurrently with the cGAN update:
+        most launches of either (column kernels, split-K reduces, the K=256 GEMMs) occupy a fraction of the 256
+        CUs, and on N > 1 GPUs each gradient all-reduce overlaps with the other stream's compute:
+            stream A:  D phase | AR(D) | Adam(D) | G phase | AR(G) | Adam(G)
+            stream B:  E phase | AR(E) | Adam(E)
+        (RCCL runs the collectives on its own stream; `wait()` is a stream-level dependency, no host sync; all
+        ranks enqueue the collectives in the same host order.)  Results are bit-identical to cgan_step + eva_step."""
         dev = self.device
         bps, rot9, transl, joint = (f32c(t, dev) for t in gan_inputs)
         rot9 = rot9.reshape(-1, 9)
@@ -117,14 +120,29 @@ class TrainEngine:
         args = (ptr(bps), ptr(rot9), ptr(transl), ptr(joint), ptr(z))
         G, D, E = self.G, self.D, self.E
         adam = lambda net, lr: net.adam_step(lr, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
+        main = torch.cuda.current_stream(dev)
+        if two_streams:
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=dev)
+            side = self._side
+            side.wait_stream(main)          # inputs / previous step are ordered before the evaluator update
+        else:
+            side = main
 
-        check(lib().dgg_cgan_d_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(self.losses),
-                                     stream_ptr()), "dgg_cgan_d_phase")
+        if two_streams:
+            if getattr(self, "_side2", None) is None:
+                self._side2 = torch.cuda.Stream(device=dev)
+            s2 = C.c_void_p(self._side2.cuda_stream)
+        else:
+            s2 = None
+        check(lib().dgg_cgan_d_phase2(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(self.losses),
+                                      stream_ptr(), s2), "dgg_cgan_d_phase2")
         w_d = parallel.allreduce_sum_(D.grads, async_op=True)
-        check(lib().dgg_eva_phase(cfg_p, ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(wse), wse.numel(), Be,
-                                  ptr(ebps), ptr(erot9), ptr(etransl), ptr(elabel), ptr(dk), int(seed), ptr(self.losses),
-                                  stream_ptr()), "dgg_eva_phase")
-        w_e = parallel.allreduce_sum_(E.grads, async_op=True)
+        with torch.cuda.stream(side):
+            check(lib().dgg_eva_phase(cfg_p, ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(wse),
+                                      wse.numel(), Be, ptr(ebps), ptr(erot9), ptr(etransl), ptr(elabel), ptr(dk),
+                                      int(seed), ptr(self.losses), stream_ptr()), "dgg_eva_phase")
+            w_e = parallel.allreduce_sum_(E.grads, async_op=True)
         if w_d is not None:
             w_d.wait()
         adam(D, hp.lr_dis)
@@ -133,11 +151,14 @@ class TrainEngine:
             check(lib().dgg_cgan_g_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args,
                                          ptr(self.losses), stream_ptr()), "dgg_cgan_g_phase")
             w_g = parallel.allreduce_sum_(G.grads, async_op=True)
-        if w_e is not None:
-            w_e.wait()
-        adam(E, hp.lr_eva)
+        with torch.cuda.stream(side):
+            if w_e is not None:
+                w_e.wait()
+            adam(E, hp.lr_eva)
         if is_train_gen:
             if w_g is not None:
                 w_g.wait()
             adam(G, hp.lr_gen)
+        if two_streams:
+            main.wait_stream(side)
         return self.losses

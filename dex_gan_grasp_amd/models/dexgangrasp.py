@@ -279,6 +279,34 @@ class DexGanGrasp(object):
             filt_grasps = {k: v.cpu().detach().numpy() for k, v in filt_grasps.items()}
         return filt_grasps
 
+    def filter_grasps_multi(self, bps, grasps, thresholds=(0.5, 0.75, 0.90), return_arr=True, scorer=None):
+        """The three-stage filter of dexgangrasp_offline.py:27-92 / eval.py:139-204 — filter_grasps called once
+        per threshold on the SAME grasps — with ONE evaluator pass: the reference re-tiles the BPS row and
+        re-runs the evaluator for every threshold (dexgangrasp.py:406-411), the scores are identical each time.
+        Returns a list with, per threshold, the filtered dict (sorted by descending score, entries as
+        filter_grasps returns them) or None where filter_grasps would raise ValueError (best score < thresh)."""
+        scorer = scorer or self.DexEvaluator
+        n_samples = grasps['rot_matrix'].shape[0]
+        if len(bps.shape) > 1:
+            bps = bps.squeeze()
+        grasps = dict(grasps)
+        grasps['bps_object'] = np.tile(bps, (n_samples, 1))
+        grasps_t = utils.dict_to_tensor(grasps, device=self.device, dtype=self.dtype)
+        with torch.no_grad():
+            p_success = scorer(grasps_t).squeeze(-1)
+        sorted_score, indices = p_success.sort(descending=True)
+        out = []
+        for thresh in thresholds:
+            if sorted_score[0] < thresh:
+                out.append(None)
+                continue
+            idx = indices[sorted_score > thresh]
+            f = {k: torch.index_select(v, 0, idx) for k, v in grasps_t.items()}
+            if return_arr:
+                f = {k: v.cpu().detach().numpy() for k, v in f.items()}
+            out.append(f)
+        return out
+
     def filter_grasps(self, bps, grasps, thresh=0.5, return_arr=True):
         """dexgangrasp.py:393-442."""
         return self._filter(self.DexEvaluator, bps, grasps, thresh, return_arr)

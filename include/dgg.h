@@ -169,6 +169,12 @@ enum {
 int dgg_cgan_d_phase(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hparams* hp, void* ws,
                      size_t ws_bytes, int B, const float* bps, const float* rot9, const float* transl,
                      const float* joint, const float* z, float* losses, void* stream);
+/* Same, with the real-batch pass of D (forward, BCE, backward) enqueued on `stream2` so that it overlaps the
+ * generator forward and the fake-batch pass on `stream` (fork/join with HIP events; BatchNorm running statistics
+ * still advance real-then-fake).  stream2 == NULL or == stream: identical to dgg_cgan_d_phase. */
+int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hparams* hp, void* ws,
+                      size_t ws_bytes, int B, const float* bps, const float* rot9, const float* transl,
+                      const float* joint, const float* z, float* losses, void* stream, void* stream2);
 /* Steps 9-12 up to (not including) optim_G.step: D forward #3 with the updated discriminator,
  * generator loss, backward through D (input gradients only) and G -> st->g_grads.
  * Must follow dgg_cgan_d_phase on the same workspace (reuses the saved generator activations). */

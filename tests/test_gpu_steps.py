@@ -345,6 +345,15 @@ def test_wrapper_inference_vs_reference_goldens(variant):
         assert tuple(filt["bps_object"].shape) == tuple(g[key + "filt/bps_object_shape"])
     with pytest.raises(ValueError):
         m.filter_grasps(bps, {k: v.copy() for k, v in grasps.items()}, thresh=1.1)
+    # N1: the three-threshold pipeline with a single evaluator pass == three filter_grasps calls
+    ths = [float(np.quantile(p, q)) for q in (0.2, 0.5, 0.8)] + [1.1]
+    multi = m.filter_grasps_multi(bps, {k: v.copy() for k, v in grasps.items()}, ths)
+    assert multi[3] is None
+    for th, fm in zip(ths[:3], multi[:3]):
+        single = m.filter_grasps(bps, {k: v.copy() for k, v in grasps.items()}, thresh=th)
+        assert set(single.keys()) == set(fm.keys())
+        for k in single:
+            np.testing.assert_array_equal(single[k], fm[k])
     fd = m.filter_grasps_discriminator(bps, {k: v.copy() for k, v in grasps.items()}, thresh=0.0)
     np.testing.assert_allclose(fd["transl"], g[key + "filt_disc/transl"], rtol=1e-4, atol=1e-4)
 

@@ -175,3 +175,15 @@ def test_magd_vs_reference():
     gt = {k: g["gt_" + k] for k in ["rot_matrix", "transl", "joint_conf"]}
     r = O.magd(gt, pred)
     np.testing.assert_allclose([r["transl"], r["rot"], r["joint"], r["coverage"]], g["result"], rtol=1e-5)
+
+
+def test_magd_mirror_vs_reference():
+    """dex_gan_grasp_amd.eval.metrics (mirror of eval.py:47-137) against the reference's own output."""
+    from dex_gan_grasp_amd.eval import metrics
+    g = H.load("magd_golden.npz")
+    pred = {k: g["pred_" + k].copy() for k in ["rot_matrix", "transl", "joint_conf"]}
+    gt = {k: g["gt_" + k].copy() for k in ["rot_matrix", "transl", "joint_conf"]}
+    t, r, j, c = metrics.magd_for_grasp_distribution(pred, gt)
+    np.testing.assert_allclose([t, r, j, c], g["result"], rtol=1e-6)
+    t2, r2, j2, c2 = metrics.magd_for_grasp_distribution({k: torch.from_numpy(v) for k, v in pred.items()}, gt)
+    assert (t2, c2) == (t, c)
