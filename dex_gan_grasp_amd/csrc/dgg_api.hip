@@ -201,11 +201,15 @@ struct NetW {
     float *X0, *imean, *irstd;   // X0 holds [prefix | x_hat]: the input BatchNorm's gamma/beta are folded into
                                  // the GEMMs (aff_scale / aff_shift), never applied to the stored operand
     float *aff_scale, *aff_shift;  // [k0]: [1.. | gamma], [0.. | beta]
-    float *cs13;                 // [n13] column sums of dY13 of the ResBlock being back-propagated
+    float *cs13[3];              // [n13] column sums of dY13, per ResBlock (read by the wgrad epilogue)
     float *ibn_part;             // [nrb][12][2][k0] per-tile partials of d gamma / d beta from the wgrad epilogue
     RbW rb[3];
     // scratch (not preserved between calls)
-    float *slabs, *part, *sums, *dY13, *dpre, *da2, *dh, *dX0, *dXa, *dXb;
+    float *slabs, *part, *sums, *dpre, *dh, *dX0, *dXa, *dXb;
+    // per-ResBlock backward operands: the weight-gradient GEMMs may run on a side stream while the main
+    // stream already back-propagates the next block, so they are not shared scratch
+    float *dY13[3], *da2[3];
+    float *slabs_w;              // split-K slabs of the fc2 weight gradient
     int64_t slab_floats;
     size_t bytes;
 };
@@ -266,7 +270,7 @@ static void carve(const NetL& L, int B, void* base, NetW& W) {
     W.irstd = b.take<float>(2 * (size_t)L.k_in);
     W.aff_scale = b.take<float>((size_t)L.k0);
     W.aff_shift = b.take<float>((size_t)L.k0);
-    W.cs13 = b.take<float>((size_t)L.n13);
+    for (int r = 0; r < L.nrb; ++r) W.cs13[r] = b.take<float>((size_t)L.n13);
     W.ibn_part = b.take<float>((size_t)L.nrb * 12 * 2 * L.k0);
     for (int r = 0; r < L.nrb; ++r) {
         RbW& R = W.rb[r];
@@ -300,9 +304,12 @@ static void carve(const NetL& L, int B, void* base, NetW& W) {
     size_t sums = 2 * 3 * (size_t)L.n13;
     if (2 * 2 * (size_t)L.k_in > sums) sums = 2 * 2 * (size_t)L.k_in;
     W.sums = b.take<float>(sums);
-    W.dY13 = b.take<float>(Bz * L.n13);
+    for (int r = 0; r < L.nrb; ++r) {
+        W.dY13[r] = b.take<float>(Bz * L.n13);
+        W.da2[r] = b.take<float>(Bz * L.nn);
+    }
+    W.slabs_w = b.take<float>((size_t)8 * L.nn * L.hid);
     W.dpre = b.take<float>(Bz * L.nn);
-    W.da2 = b.take<float>(Bz * L.nn);
     W.dh = b.take<float>(Bz * L.hid);
     W.dX0 = b.take<float>(Bz * L.ldx0);
     W.dXa = b.take<float>(Bz * L.nn);
@@ -334,6 +341,33 @@ static void prob_split(GemmProb& p, int splits, long long slab_stride) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Cross-stream plumbing: a per-thread pool of timing-disabled events (a wait captures the record that
+// precedes it on the host, so round-robin reuse is safe) and the stream -> weight-gradient side stream map.
+// ------------------------------------------------------------------------------------------------
+static hipEvent_t next_event() {
+    static thread_local hipEvent_t pool[64];
+    static thread_local int made = 0, cur = 0;
+    if (made < 64) {
+        if (hipEventCreateWithFlags(&pool[made], hipEventDisableTiming) != hipSuccess) return nullptr;
+        return pool[made++];
+    }
+    cur = (cur + 1) & 63;
+    return pool[cur];
+}
+
+struct AuxMap {
+    hipStream_t key[8], aux[8];
+    int n;
+};
+static thread_local AuxMap g_aux = {{}, {}, 0};
+
+static hipStream_t wgrad_stream_of(hipStream_t st) {
+    for (int i = 0; i < g_aux.n; ++i)
+        if (g_aux.key[i] == st) return g_aux.aux[i];
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
 // ResBlock forward (networks.py:43-56) on column segments of the (virtual) concatenated input.
 // ------------------------------------------------------------------------------------------------
 struct Ctx {
@@ -345,6 +379,7 @@ struct Ctx {
     int B;
     bool train;
     hipStream_t st;
+    hipStream_t sw;   // side stream for weight-gradient GEMMs (NULL: same stream)
 };
 
 static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, const float* keep_in, uint64_t seed,
@@ -414,14 +449,17 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     float* G = c.G;
     auto gp = [&](int64_t off) -> float* { return skip_param ? nullptr : G + off; };
     const int acc = accum ? 1 : 0;
+    float* dY13 = c.W.dY13[r];
+    float* da2 = c.W.da2[r];
+    float* cs13 = c.W.cs13[r];
     // 1. through the output LeakyReLU / dropout; split into the bn2 branch (dpre) and the fc3 branch (da3)
     DGG_TRY(res_out_bwd_launch(dy, L.nn, A.y, L.nn, had_dropout ? A.keep : nullptr, A.a13 + L.hid, L.n13, A.a2, L.nn,
-                               A.mean2, A.rstd2, B, B, L.nn, c.W.dpre, c.W.dY13 + L.hid, L.n13, c.W.part, c.st));
+                               A.mean2, A.rstd2, B, B, L.nn, c.W.dpre, dY13 + L.hid, L.n13, c.W.part, c.st));
     DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 3, L.nn, c.W.sums, gp(R.bn2b), gp(R.bn2w), gp(R.b13 + L.hid),
-                                   acc, c.st, 0, 0, nullptr, c.W.cs13 + L.hid));
+                                   acc, c.st, 0, 0, nullptr, cs13 + L.hid));
     // 2. bn2 backward -> da2; its column sums are fc2.bias' gradient
     DGG_TRY(bn_bwd_apply_launch(c.W.dpre, L.nn, A.a2, L.nn, A.mean2, A.rstd2, c.P + R.bn2w, c.W.sums, c.train, B, B,
-                                L.nn, c.W.da2, L.nn, c.W.part, c.st));
+                                L.nn, da2, L.nn, c.W.part, c.st));
     // fc2.bias feeds a BatchNorm: in train mode the batch-mean subtraction makes its gradient EXACTLY zero
     // (sum_m da2 = 0 analytically); the reference stores fp32 rounding noise there.  We store the exact
     // value in train mode and the real column sum in eval mode (running statistics).
@@ -431,24 +469,12 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
         else if (!accum && hipMemsetAsync(G + R.b2, 0, sizeof(float) * L.nn, c.st) != hipSuccess)
             return DGG_ERR_LAUNCH;
     }
-    // 3. fc2: dW2 = da2^T h ; dh = da2 W2.  Small outputs (512x256, Bx256): split-K over slabs fills the chip.
-    if (!skip_param) {
-        GemmBatch g;
-        memset(&g, 0, sizeof(g));
-        g.nprob = 1;
-        prob_init(g.p[0], c.W.da2, L.nn, A.h, L.hid, c.W.slabs, L.hid, L.nn, L.hid, B);
-        const long long slab = (long long)L.nn * L.hid;
-        prob_split(g.p[0], 8, slab);
-        if ((int64_t)g.p[0].splits * slab > c.W.slab_floats) return DGG_ERR_WORKSPACE;
-        DGG_TRY(gemm_launch(GEMM_TN, g, c.st));
-        DGG_TRY(reduce_bias_launch(c.W.slabs, g.p[0].splits, slab, L.hid, nullptr, G + R.w2, L.hid, L.nn, L.nn, 1,
-                                   L.hid, 0, 0, 0, 0, nullptr, c.st, acc));
-    }
+    // 3. fc2: dh = da2 W2 (B x 256 output: split-K over slabs fills the chip)
     {
         GemmBatch g;
         memset(&g, 0, sizeof(g));
         g.nprob = 1;
-        prob_init(g.p[0], c.W.da2, L.nn, c.P + R.w2, L.hid, c.W.slabs, L.hid, B, L.hid, L.nn);
+        prob_init(g.p[0], da2, L.nn, c.P + R.w2, L.hid, c.W.slabs, L.hid, B, L.hid, L.nn);
         const long long slab = (long long)B * L.hid;
         prob_split(g.p[0], 4, slab);
         DGG_TRY(gemm_launch(GEMM_NN, g, c.st));
@@ -460,32 +486,52 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
                            c.W.part, c.st));
     DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 2, L.hid, c.W.sums, gp(R.bn1b), gp(R.bn1w), nullptr, acc, c.st));
     DGG_TRY(bn_bwd_apply_launch(c.W.dh, L.hid, A.a13, L.n13, A.mean1, A.rstd1, c.P + R.bn1w, c.W.sums, c.train, B, B,
-                                L.hid, c.W.dY13, L.n13, c.W.part, c.st));
+                                L.hid, dY13, L.n13, c.W.part, c.st));
     // fc1.bias: same argument as fc2.bias above; in eval mode the real column sum is also kept in cs13[0:hid]
     // for the BatchNorm-aware wgrad epilogue (train mode: exactly zero -> ep_cs0 = NULL)
     if (!c.train)
         DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 1, L.hid, nullptr, gp(R.b13), nullptr, nullptr, acc, c.st, 0,
-                                       0, c.W.cs13, nullptr));
+                                       0, cs13, nullptr));
     else if (!skip_param && !accum && hipMemsetAsync(G + R.b13, 0, sizeof(float) * L.hid, c.st) != hipSuccess)
         return DGG_ERR_LAUNCH;
     // 5. wgrad of [fc1;fc3]: dW13[:, wcol:] = dY13^T X_seg.  For the [prefix | x_hat] segment the epilogue
     //    turns T = dY13^T x_hat into dW = gamma T + beta cs and emits the partials of d gamma / d beta of the
     //    input BatchNorm, so dX0 is never needed for parameter gradients.
+    //    The weight-gradient GEMMs have no consumer before the optimiser step: with a side stream configured
+    //    (dgg_set_wgrad_stream) they run there, concurrently with the dgrad chain of the following blocks.
+    hipStream_t sw = c.st;
+    if (!skip_param && c.sw) {
+        hipEvent_t e = next_event();
+        if (!e || hipEventRecord(e, c.st) != hipSuccess || hipStreamWaitEvent(c.sw, e, 0) != hipSuccess)
+            return DGG_ERR_LAUNCH;
+        sw = c.sw;
+    }
+    if (!skip_param) {  // fc2: dW2 = da2^T h (512 x 256 output, split-K)
+        GemmBatch g;
+        memset(&g, 0, sizeof(g));
+        g.nprob = 1;
+        prob_init(g.p[0], da2, L.nn, A.h, L.hid, c.W.slabs_w, L.hid, L.nn, L.hid, B);
+        const long long slab = (long long)L.nn * L.hid;
+        prob_split(g.p[0], 8, slab);
+        DGG_TRY(gemm_launch(GEMM_TN, g, sw));
+        DGG_TRY(reduce_bias_launch(c.W.slabs_w, g.p[0].splits, slab, L.hid, nullptr, G + R.w2, L.hid, L.nn, L.nn, 1,
+                                   L.hid, 0, 0, 0, 0, nullptr, sw, acc));
+    }
     if (!skip_param) {
         GemmBatch g;
         memset(&g, 0, sizeof(g));
         g.nprob = nseg;
         int ix0 = -1;
         for (int i = 0; i < nseg; ++i) {
-            prob_init(g.p[i], c.W.dY13, L.n13, segs[i].p, segs[i].ld, G + R.w13 + segs[i].wcol, R.fin, L.n13,
+            prob_init(g.p[i], dY13, L.n13, segs[i].p, segs[i].ld, G + R.w13 + segs[i].wcol, R.fin, L.n13,
                       segs[i].width, B);
             g.p[i].accumulate = acc;
             if (segs[i].is_x0) {
                 ix0 = i;
                 g.p[i].ep_gamma = c.W.aff_scale;
                 g.p[i].ep_beta = c.W.aff_shift;
-                g.p[i].ep_cs0 = c.train ? nullptr : c.W.cs13;
-                g.p[i].ep_cs1 = c.W.cs13 + L.hid;
+                g.p[i].ep_cs0 = c.train ? nullptr : cs13;
+                g.p[i].ep_cs1 = cs13 + L.hid;
                 g.p[i].ep_split = L.hid;
                 g.p[i].ep_w = c.P + R.w13 + segs[i].wcol;
                 g.p[i].ep_ldw = R.fin;
@@ -498,7 +544,7 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
         gemm_tile_shape(GEMM_TN, g.p[0].M, g.p[0].N, bm, bn, g.p[0].K);
         ibn_tiles[r] = (L.n13 + bm - 1) / bm;
         if (ibn_tiles[r] > 12 || ix0 < 0) return DGG_ERR_INVALID;
-        DGG_TRY(gemm_launch(GEMM_TN, g, c.st));
+        DGG_TRY(gemm_launch(GEMM_TN, g, sw));
     }
     // 6. dgrad: dX_seg[:, lo:hi] (+)= dY13 W13[:, wcol+lo : wcol+hi]
     {
@@ -507,7 +553,7 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
         int np = 0;
         for (int i = 0; i < nseg; ++i) {
             if (!segs[i].dp || segs[i].d_hi <= segs[i].d_lo) continue;
-            prob_init(g.p[np], c.W.dY13, L.n13, c.P + R.w13 + segs[i].wcol + segs[i].d_lo, R.fin,
+            prob_init(g.p[np], dY13, L.n13, c.P + R.w13 + segs[i].wcol + segs[i].d_lo, R.fin,
                       segs[i].dp + segs[i].d_lo, segs[i].dld, B, segs[i].d_hi - segs[i].d_lo, L.n13);
             g.p[np].accumulate = segs[i].d_accum;
             ++np;
@@ -542,6 +588,7 @@ static int net_forward(const NetL& L, const float* params, float* bn, void* ws, 
     if (!params || !ws || !out || B < 1) return DGG_ERR_INVALID;
     Ctx c;
     c.L = &L; c.P = params; c.G = nullptr; c.bn = bn; c.B = B; c.train = (flags & DGG_TRAIN) != 0; c.st = st;
+    c.sw = nullptr;
     carve(L, B, ws, c.W);
     if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
     if (!bn) return DGG_ERR_INVALID;
@@ -595,6 +642,8 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     if (!skip && !grads) return DGG_ERR_INVALID;
     Ctx c;
     c.L = &L; c.P = params; c.G = grads; c.bn = nullptr; c.B = B; c.train = (flags & DGG_TRAIN) != 0; c.st = st;
+    c.sw = skip ? nullptr : wgrad_stream_of(st);
+    if (c.sw == st) c.sw = nullptr;
     carve(L, B, ws, c.W);
     if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
     const bool want_in = d_in && d_in_hi > d_in_lo;
@@ -633,6 +682,11 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     }
     // input BatchNorm backward: parameter gradients = sum over ResBlocks and row tiles of the epilogue partials
     const int nrb = (B + kRowBlock - 1) / kRowBlock;
+    if (c.sw) {  // join: everything queued after this call on `st` sees the complete gradient buffer
+        hipEvent_t e = next_event();
+        if (!e || hipEventRecord(e, c.sw) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess)
+            return DGG_ERR_LAUNCH;
+    }
     if (!skip) {
         for (int r = 0; r < L.nrb; ++r) {  // part layout per block: [tiles][2][k0]; q0 -> d gamma, q1 -> d beta
             DGG_TRY(colsum_finalize_launch(c.W.ibn_part + (size_t)r * 12 * 2 * L.k0, 1, ibn_tiles[r], 2, L.k_in, nullptr,
@@ -876,16 +930,21 @@ int64_t dgg_cgan_workspace_bytes(const dgg_cfg* cfg, int batch) {
     return (int64_t)S.bytes;
 }
 
-// Events for the optional two-stream D phase (created once per thread; events are not caller memory).
-static int fork_events(hipEvent_t* ev, int n) {
-    static thread_local hipEvent_t cache[4];
-    static thread_local bool ready = false;
-    if (!ready) {
-        for (int i = 0; i < 4; ++i)
-            if (hipEventCreateWithFlags(&cache[i], hipEventDisableTiming) != hipSuccess) return DGG_ERR_LAUNCH;
-        ready = true;
-    }
-    for (int i = 0; i < n; ++i) ev[i] = cache[i];
+int dgg_set_wgrad_stream(void* stream, void* wgrad_stream) {
+    hipStream_t k = (hipStream_t)stream, a = (hipStream_t)wgrad_stream;
+    for (int i = 0; i < g_aux.n; ++i)
+        if (g_aux.key[i] == k) {
+            if (a) { g_aux.aux[i] = a; return DGG_OK; }
+            g_aux.key[i] = g_aux.key[g_aux.n - 1];
+            g_aux.aux[i] = g_aux.aux[g_aux.n - 1];
+            --g_aux.n;
+            return DGG_OK;
+        }
+    if (!a) return DGG_OK;
+    if (g_aux.n >= 8) return DGG_ERR_INVALID;
+    g_aux.key[g_aux.n] = k;
+    g_aux.aux[g_aux.n] = a;
+    ++g_aux.n;
     return DGG_OK;
 }
 
@@ -903,7 +962,8 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
     const bool fork = stream2 && stream2 != stream;
     hipEvent_t ev[3];
     if (fork) {
-        DGG_TRY(fork_events(ev, 3));
+        for (int i = 0; i < 3; ++i)
+            if (!(ev[i] = next_event())) return DGG_ERR_LAUNCH;
         if (hipEventRecord(ev[0], st) != hipSuccess || hipStreamWaitEvent(sb, ev[0], 0) != hipSuccess)
             return DGG_ERR_LAUNCH;
     }
@@ -1005,7 +1065,16 @@ int dgg_eva_phase(const dgg_cfg* cfg, const float* e_params, float* e_grads, flo
     return DGG_OK;
 }
 
-int dgg_gemm_occupancy(int mode, int bm, int bn) { return gemm_occupancy(mode, bm, bn); }
+int dgg_gemm_occupancy(int mode, int bm, int bn) {
+    return gemm_algo() == 1 && bm == 128 && bn == 128 ? gemm_x3_occupancy(mode) : gemm_occupancy(mode, bm, bn);
+}
+
+int dgg_set_gemm_algo(int algo) {
+    if (algo != DGG_GEMM_F32 && algo != DGG_GEMM_BF16X3) return DGG_ERR_INVALID;
+    gemm_set_algo(algo);
+    return DGG_OK;
+}
+int dgg_get_gemm_algo(void) { return gemm_algo(); }
 
 int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc,
                  int splits, float* slabs, int accumulate, void* stream) {

@@ -61,6 +61,10 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st);
 int gemm_pick_splits(int mode, int M, int N, int K, int other_blocks);
 void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn, int K = 1 << 30);
 int gemm_occupancy(int mode, int bm, int bn);
+int gemm_algo();
+void gemm_set_algo(int a);
+void gemm_x3_dispatch(int mode, const GemmBatch& batch, hipStream_t st);  // gemm_x3.hip, 128 x 128 tiles
+int gemm_x3_occupancy(int mode);
 
 // ---------------------------------------------------------------- BPS encode (bps_encode.hip)
 int bps_encode_launch(const float* clouds, int B, int N, const float* basis, int P, float* dists, int32_t* ids,

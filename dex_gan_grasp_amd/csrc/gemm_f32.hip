@@ -15,12 +15,12 @@
 // A launch carries up to 4 independent problems (grouped GEMM) so the two column segments of a
 // concatenated ResBlock input ([X0 | X1], networks.py:95,154,330) share one grid, and split-K
 // partial products go to slabs that the bias/BN-statistics reduce kernel sums.
+#include <stdlib.h>
 #include <type_traits>
 #include "dgg_internal.h"
+#include "gemm_epilogue.h"
 
 namespace dgg {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int BK = 32;
 #ifndef DGG_ABLATE
@@ -250,77 +250,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
     for (; kt + 1 < nkt; ++kt) ktile(kt, PF2{});     // next tile is a tail (or the M/N edge)
     if (kt < nkt) ktile(kt, PF0{});                  // last tile: nothing to prefetch
 
-    // ---- epilogue: D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    float* Cb = P.C + (P.splits > 0 ? (size_t)split * (size_t)P.slab_stride : (size_t)0);
-    const bool accum = (P.splits == 0) && P.accumulate;
-    if constexpr (!A_KC && !B_KC) {
-        if (P.ep_gamma) {  // BatchNorm-aware wgrad epilogue (see GemmProb); wave-uniform branch
-            float* red = smem;  // [2 m-waves][2][BN], free after the last barrier of the k loop
-            float csn[TM][16];
-#pragma unroll
-            for (int ta = 0; ta < TM; ++ta)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    float v = 0.f;
-                    if (row < M) v = row < P.ep_split ? (P.ep_cs0 ? P.ep_cs0[row] : 0.f) : P.ep_cs1[row - P.ep_split];
-                    csn[ta][r] = v;
-                }
-#pragma unroll
-            for (int tb = 0; tb < TN; ++tb) {
-                const int col = n0 + wn0 + tb * 32 + li;
-                const bool colok = col < N;
-                const float ga = colok ? P.ep_gamma[col] : 0.f, be = colok ? P.ep_beta[col] : 0.f;
-                float pg = 0.f, pb = 0.f;
-#pragma unroll
-                for (int ta = 0; ta < TM; ++ta)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (row < M && colok) {
-                            const float t = acc[ta][tb][r];
-                            const float w = P.ep_w[(size_t)row * P.ep_ldw + col];
-                            pg = __builtin_fmaf(w, t, pg);
-                            pb = __builtin_fmaf(w, csn[ta][r], pb);
-                            float* p = Cb + (size_t)row * P.ldc + col;
-                            float v = __builtin_fmaf(ga, t, be * csn[ta][r]);
-                            if (accum) v += *p;
-                            *p = v;
-                        }
-                    }
-                pg += __shfl_xor(pg, 32);
-                pb += __shfl_xor(pb, 32);
-                if (lh == 0) {
-                    red[((wave >> 1) * 2 + 0) * BN + wn0 + tb * 32 + li] = pg;
-                    red[((wave >> 1) * 2 + 1) * BN + wn0 + tb * 32 + li] = pb;
-                }
-            }
-            __syncthreads();
-            for (int idx = tid; idx < 2 * BN; idx += 256) {
-                const int q = idx / BN, cidx = idx - q * BN;
-                const int col = n0 + cidx;
-                if (col < N)
-                    P.ep_part[((size_t)tm_i * 2 + q) * N + col] = red[(0 * 2 + q) * BN + cidx] + red[(1 * 2 + q) * BN + cidx];
-            }
-            return;
-        }
-    }
-#pragma unroll
-    for (int ta = 0; ta < TM; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < TN; ++tb) {
-            const int col = n0 + wn0 + tb * 32 + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < M && col < N) {
-                    float* p = Cb + (size_t)row * P.ldc + col;
-                    float v = acc[ta][tb][r];
-                    if (accum) v += *p;
-                    *p = v;
-                }
-            }
-        }
+    gemm_epilogue<BM, BN, 2, 2, !A_KC && !B_KC>(P, acc, smem, split, tm_i, m0, n0, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -394,6 +324,18 @@ static void launch_shape(int bm, int bn, const GemmBatch& b, hipStream_t st) {
         hipLaunchKernelGGL((gemm_f32_kernel<64, 64, A_KC, B_KC>), grid, block, 0, st, b);
 }
 
+// Which kernel family executes the GEMMs: 1 = bf16x3 split on the bf16 matrix pipe (gemm_x3.hip, default),
+// 0 = native f32 MFMA (this file).  Process-wide; DGG_GEMM_ALGO=f32 selects 0 at start-up.
+static int g_algo = -1;
+int gemm_algo() {
+    if (g_algo < 0) {
+        const char* e = getenv("DGG_GEMM_ALGO");
+        g_algo = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;
+    }
+    return g_algo;
+}
+void gemm_set_algo(int a) { g_algo = a ? 1 : 0; }
+
 // All problems of one grouped launch must use the same tile shape: the launcher derives it from
 // problem 0 and re-plans the others with it.
 int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
@@ -410,6 +352,11 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
         blocks += p.tiles_m * p.tiles_n * (p.splits > 0 ? p.splits : 1);
     }
     batch.total_blocks = blocks;
+    if (mode != GEMM_NT && mode != GEMM_NN && mode != GEMM_TN) return DGG_ERR_INVALID;
+    if (gemm_algo() == 1 && bm == 128 && bn == 128) {
+        gemm_x3_dispatch(mode, batch, st);
+        return check_launch("gemm_x3");
+    }
     if (mode == GEMM_NT) launch_shape<true, true>(bm, bn, batch, st);
     else if (mode == GEMM_NN) launch_shape<true, false>(bm, bn, batch, st);
     else if (mode == GEMM_TN) launch_shape<false, false>(bm, bn, batch, st);

@@ -5,6 +5,7 @@ DexGanGrasp.update_dexgangrasp / update_dexevaluator (dexgangrasp.py:739-823); s
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -94,6 +95,28 @@ class TrainEngine:
         E.adam_step(hp.lr_eva, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
         return self.losses.clone()
 
+    def _map_wgrad_streams(self, *streams):
+        """Give each compute stream a weight-gradient side stream (dgg_set_wgrad_stream): dW GEMMs have no
+        consumer before Adam, so they overlap the dgrad chain of the following ResBlocks."""
+        mode = int(os.environ.get("DGG_WGRAD_STREAMS", "1"))
+        if mode == 0:
+            return
+        if getattr(self, "_wg", None) is None:
+            self._wg, self._wg_mapped = {}, set()
+        shared = None
+        for s in streams:
+            key = s.cuda_stream
+            if key in self._wg_mapped:
+                continue
+            if mode == 1:       # one side stream per compute stream
+                w = torch.cuda.Stream(device=self.device)
+            else:               # a single side stream shared by all
+                shared = shared or next(iter(self._wg.values()), None) or torch.cuda.Stream(device=self.device)
+                w = shared
+            self._wg[key] = w
+            check(lib().dgg_set_wgrad_stream(C.c_void_p(key), C.c_void_p(w.cuda_stream)), "dgg_set_wgrad_stream")
+            self._wg_mapped.add(key)
+
     # ---- gen + eval step with communication/compute overlap (the unit bench.py times)
     def joint_step(self, gan_inputs, z, eva_inputs, is_train_gen=True, drop_keep=None, seed=0, lr_gen=None,
                    lr_dis=None, lr_eva=None, two_streams=True):
@@ -135,6 +158,8 @@ class TrainEngine:
             s2 = C.c_void_p(self._side2.cuda_stream)
         else:
             s2 = None
+        if two_streams:
+            self._map_wgrad_streams(main, self._side2, side)
         check(lib().dgg_cgan_d_phase2(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(self.losses),
                                       stream_ptr(), s2), "dgg_cgan_d_phase2")
         w_d = parallel.allreduce_sum_(D.grads, async_op=True)

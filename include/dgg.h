@@ -163,6 +163,12 @@ enum {
     DGG_L_TOTAL_EVA = 8, DGG_L_BCE_EVA = 9
 };
 
+/* Optional concurrency hint (per calling thread): while set, every *_backward / phase call enqueued on `stream`
+ * launches its weight-gradient GEMMs (dW13, dW2 — no consumer before the optimiser step) on `wgrad_stream`,
+ * overlapping the dgrad chain; the call joins `wgrad_stream` back into `stream` before it returns, so callers
+ * keep single-stream semantics.  wgrad_stream == NULL removes the mapping.  Results are bit-identical. */
+int dgg_set_wgrad_stream(void* stream, void* wgrad_stream);
+
 /* Steps 1-8 of SURVEY.md 3.1 up to (not including) optim_D.step: G forward (train), ortho6d,
  * D forward on real then on fake.detach(), discriminator loss, D backward (both) -> st->d_grads.
  * Inputs: bps (B,4096), rot9 (B,9), transl (B,3), joint (B,nj) = the real batch; z (B,latent). */
@@ -207,6 +213,14 @@ int dgg_translate_along_axis(float* transl, const float* rot9, int B, int axis, 
  * mode 0: C[M,N] = A[M,K] * B[N,K]^T;  1: C[M,N] = A[M,K] * B[K,N];  2: C[M,N] = A[K,M]^T * B[K,N].
  * splits >= 1 (split-K through `slabs`, S*M*N floats; reduced into C, or left as slabs when C is
  * NULL); accumulate: C += . */
+/* GEMM arithmetic (process-wide; default DGG_GEMM_BF16X3, or DGG_GEMM_ALGO=f32 in the environment):
+ *   DGG_GEMM_F32    : v_mfma_f32_32x32x2_f32, a k-ordered fp32 fma chain (157 TFLOP/s peak on MI355X);
+ *   DGG_GEMM_BF16X3 : each fp32 operand split exactly into three bf16 pieces, the six leading partial products
+ *                     accumulated in fp32 on v_mfma_f32_32x32x16_bf16 — error below the fp32 accumulation's own
+ *                     rounding, 6/16 of the f32-MFMA cost. */
+enum { DGG_GEMM_F32 = 0, DGG_GEMM_BF16X3 = 1 };
+int dgg_set_gemm_algo(int algo);
+int dgg_get_gemm_algo(void);
 /* Diagnostic: workgroups of the GEMM variant (mode, tile) resident per CU according to the HIP occupancy API. */
 int dgg_gemm_occupancy(int mode, int bm, int bn);
 int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C,
