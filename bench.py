@@ -31,27 +31,31 @@ MFLOP_PER_GRASP_FULL = 231.38   # cGAN 167.51 + evaluator 63.87 
 # input-BN parameter gradients come out of the wgrad epilogue), no discriminator dW in the G phase:
 # MACs/sample G 14.6 M + D 36.9 M + E 22.5 M = 74.0 M  ->  148 MFLOP
 MFLOP_PER_GRASP_EXEC = 148.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
 def gemm_roofline(dev, iters=20):
-    """Dominant kernel: gemm_f32_kernel<128,128,NT> on the fused fc1||fc3 layer of a ResBlock at the
-    bench batch: C[1024,768] = X[1024,4613] W[768,4613]^T, split-K as the forward uses it.
-    achieved = algorithmic FLOPs (2*M*N*K) / mean launch duration (HIP events on the launch stream)."""
-    M, N, K = 1024, 768, 4613
+    """Dominant kernel: gemm_x3_kernel<NT, 16-byte staging> on the fused fc1||fc3 layer of a ResBlock at the bench
+    batch, shaped as the discriminator's second ResBlock runs it: C[1024,768] = X0[1024,4120] W13[768,0:4120]^T with
+    the weight rows 4632 floats apart, split-K 5 as the forward plans it (48 tiles x 5 = 240 workgroups, one per CU).
+    achieved = algorithmic FLOPs (2*M*N*K, fp32-equivalent) / mean launch duration (HIP events on the launch stream).
+    The kernel computes every fp32 product as six bf16 partial products on v_mfma_f32_32x32x16_bf16, so the matrix-
+    pipe bound for it is the dense bf16 peak / 6; the native f32-MFMA peak is reported next to it."""
+    M, N, K, LDB = 1024, 768, 4120, 4632
     g = torch.Generator().manual_seed(0)
     A = torch.randn((M, K), generator=g).to(dev)
-    W = torch.randn((N, K), generator=g).to(dev)
-    out = torch.empty((M, N), device=dev)
-    splits = 10   # what the forward's split-K plan picks for this shape: 48 tiles x 10 = 480 workgroups
+    W = torch.randn((N, LDB), generator=g).to(dev)
+    splits = 5
     slabs = torch.empty((splits * M * N,), device=dev)
     lib = _lib.lib()
     st = torch.cuda.current_stream()
+    algo = int(lib.dgg_get_gemm_algo())
 
     def launch():
         # mode 0 (NT), split-K partial products into slabs; C = NULL leaves out the (separate, HBM-bound)
         # bias/BN-statistics reduce kernel so that the MFMA kernel alone is timed
-        _lib.check(lib.dgg_gemm_f32(0, M, N, K, _lib.ptr(A), K, _lib.ptr(W), K, None, N, splits, _lib.ptr(slabs), 0,
+        _lib.check(lib.dgg_gemm_f32(0, M, N, K, _lib.ptr(A), K, _lib.ptr(W), LDB, None, N, splits, _lib.ptr(slabs), 0,
                                     C.c_void_p(st.cuda_stream)))
     for _ in range(3):
         launch()
@@ -65,9 +69,15 @@ def gemm_roofline(dev, iters=20):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * M * N * K
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "kernel": "gemm_f32_kernel<128,128,NT> M=1024 N=768 K=4613 (fc1||fc3 of a ResBlock)",
+    if algo == 1:
+        peak, kern = PEAK_BF16_MFMA_TFLOPS / 6.0, "gemm_x3_kernel<NT,vec16,vec16> (bf16x3: 6 bf16 MFMA products per fp32 product)"
+    else:
+        peak, kern = PEAK_F32_MFMA_TFLOPS, "gemm_f32_kernel<128,128,NT>"
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "kernel": kern + " M=1024 N=768 K=4120 split-K 5 (fc1||fc3 of a ResBlock)",
+            "peak_basis": "dense bf16 MFMA 2500 TFLOP/s / 6 products" if algo == 1 else "dense f32 MFMA",
+            "f32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "ms_per_launch": round(ms, 4)}
 
 
@@ -191,7 +201,10 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "mflop_per_grasp_as_reference": MFLOP_PER_GRASP_FULL,
                        "mflop_per_grasp_executed": MFLOP_PER_GRASP_EXEC,
-                       "step_tflops_executed": round(value * MFLOP_PER_GRASP_EXEC * 1e6 / 1e12 / world, 2)},
+                       "step_tflops_executed": round(value * MFLOP_PER_GRASP_EXEC * 1e6 / 1e12 / world, 2),
+                       "gemm_arithmetic": ("fp32 operands split exactly into 3 bf16 pieces, 6 partial products on the "
+                                           "bf16 MFMA, fp32 accumulate (fp32-accurate)"
+                                           if int(_lib.lib().dgg_get_gemm_algo()) == 1 else "f32 MFMA")},
         }
         res["roofline"] = gemm_roofline(dev)
         if world == 1 and not args.no_cpu_baseline:

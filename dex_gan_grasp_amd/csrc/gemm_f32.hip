@@ -265,7 +265,10 @@ void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn, int K) {
         if (t128 * maxs < 200) { bm = 64; bn = 64; }
         return;
     }
-    if (t128 < 200) {
+    // the bf16x3 kernel (128 x 128 only, one workgroup per CU) is worth a partly filled chip: 198 tiles of the
+    // 768 x 4101 weight gradient at 128 x 128 beat 780 tiles of 64 x 64 on the f32 pipe by 1.5x
+    const long enough = gemm_algo() == 1 ? 128 : 200;
+    if (t128 < enough) {
         bm = (M >= 1024) ? 128 : 64;
         bn = 64;
         const long t = (long)((M + bm - 1) / bm) * ((N + 63) / 64);
@@ -281,7 +284,7 @@ int gemm_pick_splits(int mode, int M, int N, int K, int other_blocks) {
     static int target = -1;
     if (target < 0) {
         const char* e = getenv("DGG_SPLITK_TARGET");
-        target = e ? atoi(e) : 512;
+        target = e ? atoi(e) : (gemm_algo() == 1 ? 256 : 512);  // bf16x3: one workgroup per CU
     }
     int s = (target - other_blocks) / (tiles > 0 ? tiles : 1);
     if (s < 1) s = 1;
@@ -341,7 +344,10 @@ void gemm_set_algo(int a) { g_algo = a ? 1 : 0; }
 int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
     if (batch.nprob < 1 || batch.nprob > 4) return DGG_ERR_INVALID;
     int bm, bn;
-    gemm_tile_shape(mode, batch.p[0].M, batch.p[0].N, bm, bn, batch.p[0].K);
+    int big = 0;  // the problem with the most work decides the tile shape
+    for (int i = 1; i < batch.nprob; ++i)
+        if ((double)batch.p[i].M * batch.p[i].N * batch.p[i].K > (double)batch.p[big].M * batch.p[big].N * batch.p[big].K) big = i;
+    gemm_tile_shape(mode, batch.p[big].M, batch.p[big].N, bm, bn, batch.p[big].K);
     int blocks = 0;
     for (int i = 0; i < batch.nprob; ++i) {
         GemmProb& p = batch.p[i];

@@ -417,6 +417,9 @@ __global__ __launch_bounds__(1024, 1) void gemm_x3_kernel(const GemmBatch batch)
     // operand fragment addresses: row li of the wave's piece, 16-byte k chunk lh (+2 for the second k16 step)
     const int offA = (wm0 + li) * XP + lh * 16;
     const int offB = 3 * XPL + (wn0 + li) * XP + lh * 16;
+#ifdef DGG_X3_PRIO
+    __builtin_amdgcn_s_setprio(DGG_X3_PRIO);
+#endif
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         if constexpr (DGG_X3_ABLATE != 3) {

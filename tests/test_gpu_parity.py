@@ -69,6 +69,66 @@ def test_gemm_splitk_and_accumulate():
     assert ((out - ref2).abs() <= 4e-7 * scale + 1e-6).all()
 
 
+def _strided(t, ld, off):
+    """Device copy of the 2-D tensor `t` with row pitch `ld` floats, starting `off` floats into its storage
+    (off % 4 != 0 or ld % 4 != 0 -> rows are not 16-byte aligned: the dword staging path of the bf16x3 kernel)."""
+    buf = torch.zeros((t.shape[0] * ld + off + 8,), dtype=torch.float32, device=DEV)
+    v = buf[off:off + t.shape[0] * ld].view(t.shape[0], ld)[:, :t.shape[1]]
+    v.copy_(t.to(DEV))
+    return v
+
+
+@pytest.mark.parametrize("mode,shape", [(0, (300, 768, 2003)), (0, (1024, 768, 701)),      # NT: forward
+                                        (1, (2048, 1100, 200)), (1, (1300, 1664, 77)),      # NN: dgrad
+                                        (2, (768, 4101, 300)), (2, (1664, 1300, 129))])     # TN: wgrad
+@pytest.mark.parametrize("align", ["vv", "vu", "uv", "uu"])
+def test_gemm_bf16x3_variants(mode, shape, align):
+    """128 x 128-tile shapes (the ones gemm_x3_kernel serves) in every operand orientation and every combination of
+    16-byte / 4-byte aligned operands, ragged M / N / K tails included; against fp64 and next to the native f32-MFMA
+    kernel on the same data: exact on integers, and on real data — N(0,1) and 12-decade log-normal scales — within
+    1.5x of the error of the k-ordered f32 fma chain (measured: 2.6-3.1e-7 vs 2.9-3.6e-7 of sum|a||b|)."""
+    ops, _lib = _ops()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + mode)
+    lib = _lib.lib()
+    assert lib.dgg_get_gemm_algo() == 1, "bf16x3 must be the default GEMM arithmetic"
+    try:
+        for kind in ["int", "real", "wide"]:
+            if kind == "int":
+                A = torch.randint(-3, 4, (M, K), generator=g).float()
+                Bm = torch.randint(-3, 4, (K, N), generator=g).float()
+            elif kind == "real":
+                A, Bm = torch.randn((M, K), generator=g), torch.randn((K, N), generator=g)
+            else:   # 12 decades of dynamic range inside one dot product
+                A = torch.randn((M, K), generator=g) * torch.exp(torch.randn((M, K), generator=g) * 4)
+                Bm = torch.randn((K, N), generator=g) * torch.exp(torch.randn((K, N), generator=g) * 4)
+            ref = A.double() @ Bm.double()
+            scale = A.abs().double() @ Bm.abs().double()
+            a_host = A if mode in (0, 1) else A.t().contiguous()
+            b_host = Bm.t().contiguous() if mode == 0 else Bm
+            pa = (a_host.shape[1] + 3) // 4 * 4
+            pb = (b_host.shape[1] + 3) // 4 * 4
+            a_dev = _strided(a_host, pa if align[0] == "v" else pa + 1, 0 if align[0] == "v" else 1)
+            b_dev = _strided(b_host, pb if align[1] == "v" else pb + 3, 0 if align[1] == "v" else 3)
+            errs = {}
+            for algo in (1, 0):
+                assert lib.dgg_set_gemm_algo(algo) == 0
+                for splits in (0, 3):
+                    out = ops.gemm(mode, a_dev, b_dev, M, N, K, splits=splits).cpu().double()
+                    if kind == "int":
+                        assert torch.equal(out, ref), (algo, splits)
+                    e = ((out - ref).abs() / (scale + 1e-300)).max().item()
+                    errs[(algo, splits)] = e
+                    # relative to sum |a||b|: < 4e-7 on well-scaled data; with 12 decades inside one dot product a
+                    # single term carries the sum and either arithmetic sits at a few 2^-24 of it
+                    assert e <= (4e-6 if kind == "wide" else 4e-7), (kind, algo, splits, e)
+            if kind != "int":   # the split is an fp32-accurate GEMM: same error level as the k-ordered f32 fma chain
+                assert errs[(1, 0)] <= 1.5 * errs[(0, 0)] + 2e-8, errs
+            print("gemm error / sum|a||b|  mode %d %s %s: bf16x3 %.2e  f32 %.2e" % (mode, align, kind, errs[(1, 0)], errs[(0, 0)]))
+    finally:
+        lib.dgg_set_gemm_algo(1)
+
+
 # ------------------------------------------------------------------ A1: BPS encode
 def _ulp(a, b):
     return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmarks used for the rocprofv3 runs under profiles/ (GEMM roofline shape, BPS encode).
-    python tools/microbench.py gemm [--iters N]     # gemm_f32_kernel<128,128,NT> M=1024 N=768 K=4613, split-K 10
+    python tools/microbench.py gemm [--iters N]     # the 128x128 NT GEMM kernel (bf16x3 by default, DGG_GEMM_ALGO=f32 for the f32 MFMA) M=1024 N=768 K=4613
     python tools/microbench.py bps  [--iters N]     # bps_batched_kernel: 1024 clouds x 2048 points x 4096 basis
 """
 import argparse
@@ -52,7 +52,7 @@ def main():
                                                  _lib.stream_ptr()))
         ms = time_it(fn, a.iters)
         fl = 2.0 * M * N * K
-        print(json.dumps({"kernel": "gemm_f32_kernel<128,128,NT>", "M": M, "N": N, "K": K, "splits": S, "ms": ms,
+        print(json.dumps({"kernel": ("gemm_x3_kernel<NT>" if lib.dgg_get_gemm_algo() == 1 else "gemm_f32_kernel<128,128,NT>"), "M": M, "N": N, "K": K, "splits": S, "ms": ms,
                           "tflops": fl / ms / 1e9, "algorithmic_bytes": 4 * (M * K + N * K + S * M * N)}))
     else:
         B, Np = (1024, 2048) if a.what == "bps" else (1, 73000)
