@@ -38,7 +38,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 def gemm_roofline(dev, iters=20):
     """Dominant kernel: gemm_x3_kernel<NT, 16-byte staging> on the fused fc1||fc3 layer of a ResBlock at the bench
     batch, shaped as the discriminator's second ResBlock runs it: C[1024,768] = X0[1024,4120] W13[768,0:4120]^T with
-    the weight rows 4632 floats apart, split-K 5 as the forward plans it (48 tiles x 5 = 240 workgroups, one per CU).
+    the weight rows 4632 floats apart, split-K 4 as the forward plans it (48 tiles x 4 = 192 one-per-CU workgroups; the rest of the chip is left to the other streams of the step).
     achieved = algorithmic FLOPs (2*M*N*K, fp32-equivalent) / mean launch duration (HIP events on the launch stream).
     The kernel computes every fp32 product as six bf16 partial products on v_mfma_f32_32x32x16_bf16, so the matrix-
     pipe bound for it is the dense bf16 peak / 6; the native f32-MFMA peak is reported next to it."""
@@ -46,7 +46,7 @@ def gemm_roofline(dev, iters=20):
     g = torch.Generator().manual_seed(0)
     A = torch.randn((M, K), generator=g).to(dev)
     W = torch.randn((N, LDB), generator=g).to(dev)
-    splits = 5
+    splits = 4
     slabs = torch.empty((splits * M * N,), device=dev)
     lib = _lib.lib()
     st = torch.cuda.current_stream()
@@ -75,7 +75,7 @@ def gemm_roofline(dev, iters=20):
         peak, kern = PEAK_F32_MFMA_TFLOPS, "gemm_f32_kernel<128,128,NT>"
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": None,
-            "kernel": kern + " M=1024 N=768 K=4120 split-K 5 (fc1||fc3 of a ResBlock)",
+            "kernel": kern + " M=1024 N=768 K=4120 split-K 4 (fc1||fc3 of a ResBlock)",
             "peak_basis": "dense bf16 MFMA 2500 TFLOP/s / 6 products" if algo == 1 else "dense f32 MFMA",
             "f32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "ms_per_launch": round(ms, 4)}

@@ -246,7 +246,7 @@ static void plan13(int B, int n13, const int* widths, int nseg, int* splits) {
     static int target = -1;
     if (target < 0) {
         const char* e = getenv("DGG_SPLITK_TARGET");
-        target = e ? atoi(e) : (gemm_algo() == 1 ? 256 : 512);  // bf16x3 kernel: one workgroup per CU
+        target = e ? atoi(e) : (gemm_algo() == 1 ? 192 : 512);  // bf16x3 kernel: one workgroup per CU; measured best at 144-192 (other streams keep CUs)
         if (target < 1) target = 1;
     }
     int s_total = target / (tiles > 0 ? tiles : 1);

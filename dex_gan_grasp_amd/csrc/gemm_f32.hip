@@ -284,7 +284,7 @@ int gemm_pick_splits(int mode, int M, int N, int K, int other_blocks) {
     static int target = -1;
     if (target < 0) {
         const char* e = getenv("DGG_SPLITK_TARGET");
-        target = e ? atoi(e) : (gemm_algo() == 1 ? 256 : 512);  // bf16x3: one workgroup per CU
+        target = e ? atoi(e) : (gemm_algo() == 1 ? 192 : 512);  // bf16x3: one workgroup per CU, a quarter of the chip left to the other streams
     }
     int s = (target - other_blocks) / (tiles > 0 ? tiles : 1);
     if (s < 1) s = 1;
