@@ -73,8 +73,17 @@ def gemm_roofline(dev, iters=20):
         peak, kern = PEAK_BF16_MFMA_TFLOPS / 6.0, "gemm_x3_kernel<NT,vec16,vec16> (bf16x3: 6 bf16 MFMA products per fp32 product)"
     else:
         peak, kern = PEAK_F32_MFMA_TFLOPS, "gemm_f32_kernel<128,128,NT>"
+    # HBM-side bytes per launch of this kernel at this shape come from separate rocprofv3 --pmc passes (FETCH_SIZE,
+    # WRITE_SIZE with the gfx950 correction), recorded in profiles/; PMC counters cannot be read from inside a run
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_x3_pmc.json")))
+        if algo == 1 and pmc["shape"] == {"M": M, "N": N, "K": K, "splits": splits}:
+            traffic = int(pmc["traffic_bytes"])
+    except Exception:
+        traffic = None
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": None,
+            "frac": round(achieved / peak, 4), "traffic": traffic, "algorithmic_bytes": 4 * (M * K + N * K + splits * M * N),
             "kernel": kern + " M=1024 N=768 K=4120 split-K 4 (fc1||fc3 of a ResBlock)",
             "peak_basis": "dense bf16 MFMA 2500 TFLOP/s / 6 products" if algo == 1 else "dense f32 MFMA",
             "f32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),

@@ -75,107 +75,77 @@ __device__ __forceinline__ void split3x4(const f32x2 (&v)[4], unsigned (&h)[4], 
 
 // ------------------------------------------------------------------------------------------------
 // Staging of one 128 x 32 operand tile by 512 threads, 8 elements each.  KC: operand stored [row][k] (k contiguous);
-// !KC: stored [k][row].  V: 16-byte loads (base, pitch 16-byte aligned).  FAST: tile and k-tile fully inside the
-// matrix (predicate-free, wave-uniform base + per-lane offset); else indices are clamped and k tails zeroed.
+// !KC: stored [k][row].  V: 16-byte loads (base, pitch 16-byte aligned).  FAST: the k-tile lies fully inside
+// [kbeg, kend) (no k predication); else k tails are clamped and zeroed.  Row indices are always clamped.
 //   KC  V : lane = (k quad tid&7, row tid>>3 (+64));           r[4e + j] = (row + 64e, k 4*k4 + j)
 //   KC !V : lane = (k tid&31,     row tid>>5 (+16e, e < 8));   r[e]
-//  !KC  V : lane = (k quad tid&7, row quad (tid>>3)&31, k half tid>>8);  r[4i + j] = (k 4*kq + 2*ih + i, row 4*n4 + j)
+//  !KC  V : lane = (k half ih = tid&1, k quad kq = tid[1:2] + 4 tid[6], row quad n4 = tid[3:5] + 8 tid[7:8]);
+//           r[4i + j] = (k 4*kq + 2*ih + i, row 4*n4 + j); a wave-load reads 8 k rows x 128 contiguous bytes
 //  !KC !V : lane = (row tid&127,  k octet tid>>7);             r[e] = (k 8*kb + e)
 // ------------------------------------------------------------------------------------------------
 template <bool KC, bool V, bool FAST>
 __device__ __forceinline__ void stage_load(const float* __restrict__ G, int ld, int row0, int nrows, int k0, int kend,
                                            float (&r)[XE]) {
     const int tid = threadIdx.x;
+    // Row (column) indices are clamped into the matrix in both variants: the per-lane part of every address is
+    // loop-invariant, so the last M / N tile costs nothing extra (rows beyond the edge only feed accumulator rows
+    // that are never stored).  !FAST additionally predicates and zero-fills k >= kend, element by element.
     if constexpr (KC && V) {
         const int k4 = tid & 7, rl = tid >> 3;
-        if constexpr (FAST) {
-            const unsigned lane_byte = ((unsigned)rl * (unsigned)ld + 4u * (unsigned)k4) * 4u;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const char* pu = reinterpret_cast<const char*>(G + ((size_t)(row0 + 64 * e) * ld + k0));  // uniform
-                const f32x4 v = *reinterpret_cast<const f32x4*>(pu + lane_byte);
+        for (int e = 0; e < 2; ++e) {
+            int gr = row0 + rl + 64 * e;
+            gr = gr < nrows ? gr : nrows - 1;
+            const float* p = G + (size_t)gr * ld + (k0 + 4 * k4);
+            if constexpr (FAST) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) r[4 * e + j] = v[j];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                int gr = row0 + rl + 64 * e;
-                gr = gr < nrows ? gr : nrows - 1;
+            } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int gk = k0 + 4 * k4 + j;
-                    const bool kok = gk < kend;
-                    const float v = G[(size_t)gr * ld + (kok ? gk : kend - 1)];
+                    const bool kok = k0 + 4 * k4 + j < kend;
+                    const float v = kok ? p[j] : p[kend - 1 - (k0 + 4 * k4)];
                     r[4 * e + j] = kok ? v : 0.f;
                 }
             }
         }
     } else if constexpr (KC) {
         const int k = tid & 31, rl = tid >> 5;
-        if constexpr (FAST) {
-            const unsigned lane_byte = ((unsigned)rl * (unsigned)ld + (unsigned)k) * 4u;
+        const int gk = k0 + k;
+        const bool kok = FAST || gk < kend;
+        const int ck = kok ? gk : kend - 1;
 #pragma unroll
-            for (int e = 0; e < XE; ++e) {
-                const char* pu = reinterpret_cast<const char*>(G + ((size_t)(row0 + 16 * e) * ld + k0));  // uniform
-                r[e] = *reinterpret_cast<const float*>(pu + lane_byte);
-            }
-        } else {
-            const int gk = k0 + k;
-            const bool kok = gk < kend;
-            const int ck = kok ? gk : kend - 1;
-#pragma unroll
-            for (int e = 0; e < XE; ++e) {
-                int gr = row0 + rl + 16 * e;
-                gr = gr < nrows ? gr : nrows - 1;
-                const float v = G[(size_t)gr * ld + ck];
-                r[e] = kok ? v : 0.f;
-            }
+        for (int e = 0; e < XE; ++e) {
+            int gr = row0 + rl + 16 * e;
+            gr = gr < nrows ? gr : nrows - 1;
+            const float v = G[(size_t)gr * ld + ck];
+            r[e] = kok ? v : 0.f;
         }
     } else if constexpr (V) {
-        const int kq = tid & 7, n4 = (tid >> 3) & 31, ih = tid >> 8;
-        if constexpr (FAST) {
-            const unsigned lane_byte = ((unsigned)(4 * kq + 2 * ih) * (unsigned)ld + 4u * (unsigned)n4) * 4u;
+        const int ih = tid & 1, kq = ((tid >> 1) & 3) + 4 * ((tid >> 6) & 1), n4 = ((tid >> 3) & 7) + 8 * (tid >> 7);
+        // the aligned column quad holding the last valid column lies inside the pitch (ld % 4 == 0, ld >= nrows)
+        int gc = row0 + 4 * n4;
+        const int last4 = (nrows - 1) & ~3;
+        gc = gc < last4 ? gc : last4;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const char* pu = reinterpret_cast<const char*>(G + ((size_t)(k0 + i) * ld + row0));  // uniform
-                const f32x4 v = *reinterpret_cast<const f32x4*>(pu + lane_byte);
+        for (int i = 0; i < 2; ++i) {
+            const int gk = k0 + 4 * kq + 2 * ih + i;
+            const bool kok = FAST || gk < kend;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(G + (size_t)(kok ? gk : kend - 1) * ld + gc);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) r[4 * i + j] = v[j];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int gk = k0 + 4 * kq + 2 * ih + i;
-                const bool kok = gk < kend;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int gc = row0 + 4 * n4 + j;
-                    gc = gc < nrows ? gc : nrows - 1;
-                    const float v = G[(size_t)(kok ? gk : kend - 1) * ld + gc];
-                    r[4 * i + j] = kok ? v : 0.f;
-                }
-            }
+            for (int j = 0; j < 4; ++j) r[4 * i + j] = kok ? v[j] : 0.f;
         }
     } else {
         const int col = tid & 127, kb = (tid >> 7) * XE;
-        if constexpr (FAST) {
-            const unsigned lane_byte = ((unsigned)kb * (unsigned)ld + (unsigned)col) * 4u;
+        int gc = row0 + col;
+        gc = gc < nrows ? gc : nrows - 1;
 #pragma unroll
-            for (int e = 0; e < XE; ++e) {
-                const char* pu = reinterpret_cast<const char*>(G + ((size_t)(k0 + e) * ld + row0));  // uniform
-                r[e] = *reinterpret_cast<const float*>(pu + lane_byte);
-            }
-        } else {
-            int gc = row0 + col;
-            gc = gc < nrows ? gc : nrows - 1;
-#pragma unroll
-            for (int e = 0; e < XE; ++e) {
-                const int gk = k0 + kb + e;
-                const bool kok = gk < kend;
-                const float v = G[(size_t)(kok ? gk : kend - 1) * ld + gc];
-                r[e] = kok ? v : 0.f;
-            }
+        for (int e = 0; e < XE; ++e) {
+            const int gk = k0 + kb + e;
+            const bool kok = FAST || gk < kend;
+            const float v = G[(size_t)(kok ? gk : kend - 1) * ld + gc];
+            r[e] = kok ? v : 0.f;
         }
     }
 }
@@ -277,20 +247,34 @@ __device__ __forceinline__ void stage_park(char* __restrict__ planes, const floa
             *reinterpret_cast<unsigned*>(p + 2 * XPL) = l[i];
         }
     } else if constexpr (V) {
+        // lanes l, l^1 hold the two k halves (ih) of the same 4 rows: they swap two rows each (DPP quad_perm), after
+        // which a lane owns 2 rows x 4 consecutive k = one 8-byte store per row and plane
+        const bool hi = (tid & 1) != 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j].x = r[j];
-            v[j].y = r[4 + j];
+        for (int jj = 0; jj < 2; ++jj) {
+            float keep[2], recv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                keep[i] = hi ? r[4 * i + 2 + jj] : r[4 * i + jj];
+                const float send = hi ? r[4 * i + jj] : r[4 * i + 2 + jj];
+                recv[i] = __builtin_bit_cast(
+                    float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
+            }
+            v[2 * jj].x = hi ? recv[0] : keep[0];      // k = 4 kq + 0, 1
+            v[2 * jj].y = hi ? recv[1] : keep[1];
+            v[2 * jj + 1].x = hi ? keep[0] : recv[0];  // k = 4 kq + 2, 3
+            v[2 * jj + 1].y = hi ? keep[1] : recv[1];
         }
         split3x4(v, h, m, l);
-        const int kq = tid & 7, n4 = (tid >> 3) & 31, ih = tid >> 8;
-        char* base = planes + (4 * n4) * XP + kq * 8 + ih * 4;
+        const int kq = ((tid >> 1) & 3) + 4 * ((tid >> 6) & 1), n4 = ((tid >> 3) & 7) + 8 * (tid >> 7);
+        char* base = planes + (4 * n4 + (hi ? 2 : 0)) * XP + kq * 8;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {  // 4-byte stores: the 8 kq x 4 n4 of a 32-lane group touch each bank twice
-            char* p = base + j * XP;
-            *reinterpret_cast<unsigned*>(p) = h[j];
-            *reinterpret_cast<unsigned*>(p + XPL) = m[j];
-            *reinterpret_cast<unsigned*>(p + 2 * XPL) = l[j];
+        for (int jj = 0; jj < 2; ++jj) {  // a 16-lane group (2 ih x 4 kq x 2 n4) covers all 32 banks once
+            char* p = base + jj * XP;
+            const u32x2 hh = {h[2 * jj], h[2 * jj + 1]}, mm = {m[2 * jj], m[2 * jj + 1]}, ll = {l[2 * jj], l[2 * jj + 1]};
+            *reinterpret_cast<u32x2*>(p) = hh;
+            *reinterpret_cast<u32x2*>(p + XPL) = mm;
+            *reinterpret_cast<u32x2*>(p + 2 * XPL) = ll;
         }
     } else {
 #pragma unroll
@@ -344,11 +328,10 @@ __global__ __launch_bounds__(1024, 1) void gemm_x3_kernel(const GemmBatch batch)
     if (threadIdx.x < 512) {
         // ================= producer waves 0-7 (two per SIMD): global -> register ring -> split3 -> LDS planes
         float ra[XNS][XE], rb[XNS][XE], rq[XNS][XE];  // k-tile t lives in set t % XNS (rq: affine scale / shift)
-        const bool mn_full = (m0 + XT <= M) && (n0 + XT <= N);
         const bool aff = A_KC && P.a_scale != nullptr;
         const float* const sc_p = aff ? P.a_scale : P.A;  // valid either way, see affine_load
         const float* const sh_p = aff ? P.a_shift : P.A;
-        const int nfull = mn_full ? (kend - kbeg) / XK : 0;  // k-tiles [0, nfull) take the predicate-free loads
+        const int nfull = (kend - kbeg) / XK;  // k-tiles [0, nfull) are full: loads without k predication
         auto fetch = [&](int kt, float (&a)[XE], float (&b)[XE], float (&q)[XE]) {
             if constexpr (DGG_X3_ABLATE == 1) return;
             const int k0 = kbeg + kt * XK;

@@ -35,24 +35,29 @@ def main():
     ap.add_argument("what", choices=["gemm", "bps", "bps1"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--k", type=int, default=4613)
+    ap.add_argument("--m", type=int, default=1024)
+    ap.add_argument("--n", type=int, default=768)
     ap.add_argument("--mode", type=int, default=0)
     ap.add_argument("--splits", type=int, default=10)
     a = ap.parse_args()
     dev = "cuda"
     if a.what == "gemm":
-        M, N, K, S = 1024, 768, a.k, a.splits
+        M, N, K, S = a.m, a.n, a.k, a.splits
         g = torch.Generator().manual_seed(0)
-        A = torch.randn((M, K), generator=g).to(dev)
-        W = torch.randn((N, K), generator=g).to(dev)
-        slabs = torch.empty((S * M * N,), device=dev)
+        # mode 0: A[M][K] B[N][K];  1: A[M][K] B[K][N];  2: A[K][M] B[K][N]
+        A = (torch.randn((M, K), generator=g) if a.mode != 2 else torch.randn((K, M), generator=g)).to(dev)
+        W = (torch.randn((N, K), generator=g) if a.mode == 0 else torch.randn((K, N), generator=g)).to(dev)
+        slabs = torch.empty((max(S, 1) * M * N,), device=dev)
+        out = torch.empty((M, N), device=dev)
         lib = _lib.lib()
         print("occupancy (WG/CU) NT128 %d NT64 %d TN128 %d TN64 %d" % (lib.dgg_gemm_occupancy(0, 128, 128),
               lib.dgg_gemm_occupancy(0, 64, 64), lib.dgg_gemm_occupancy(2, 128, 128), lib.dgg_gemm_occupancy(2, 64, 64)))
-        fn = lambda: _lib.check(lib.dgg_gemm_f32(0, M, N, K, _lib.ptr(A), K, _lib.ptr(W), K, None, N, S, _lib.ptr(slabs), 0,
+        fn = lambda: _lib.check(lib.dgg_gemm_f32(a.mode, M, N, K, _lib.ptr(A), A.stride(0), _lib.ptr(W), W.stride(0),
+                                                 None if S >= 1 else _lib.ptr(out), N, S, _lib.ptr(slabs), 0,
                                                  _lib.stream_ptr()))
         ms = time_it(fn, a.iters)
         fl = 2.0 * M * N * K
-        print(json.dumps({"kernel": ("gemm_x3_kernel<NT>" if lib.dgg_get_gemm_algo() == 1 else "gemm_f32_kernel<128,128,NT>"), "M": M, "N": N, "K": K, "splits": S, "ms": ms,
+        print(json.dumps({"kernel": ("gemm_x3_kernel<NT>" if lib.dgg_get_gemm_algo() == 1 else "gemm_f32_kernel<128,128,NT>"), "mode": a.mode, "M": M, "N": N, "K": K, "splits": S, "ms": ms,
                           "tflops": fl / ms / 1e9, "algorithmic_bytes": 4 * (M * K + N * K + S * M * N)}))
     else:
         B, Np = (1024, 2048) if a.what == "bps" else (1, 73000)
