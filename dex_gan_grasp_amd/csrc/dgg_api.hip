@@ -607,7 +607,7 @@ static int net_forward(const NetL& L, const float* params, float* bn, void* ws, 
     }
     const int sig = L.net != DGG_NET_GEN;
     DGG_TRY(heads_fwd_launch(c.W.rb[L.nrb - 1].y, L.nn, B, L.nn, params + L.wh, params + L.bh, L.nh, sig, out, L.nh,
-                             st));
+                             c.W.slabs, st));
     return DGG_OK;
 }
 

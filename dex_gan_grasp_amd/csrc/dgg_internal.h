@@ -111,7 +111,7 @@ int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, in
                    hipStream_t st);
 // heads: out[m][j] = sum_k y[m][k] Wh[j][k] + bh[j]; sigmoid optionally.
 int heads_fwd_launch(const float* y, int ldy, int B, int K, const float* wh, const float* bh, int nh, int sigmoid,
-                     float* out, int ldo, hipStream_t st);
+                     float* out, int ldo, float* scratch, hipStream_t st);
 // heads backward: dy = dout * Wh (written), partial dWh/dbh -> finalize into grads.
 int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B, int K, const float* wh, int nh,
                      float* dy, int lddy, float* gwh, float* gbh, int accumulate, int skip_param, float* scratch,

@@ -12,6 +12,7 @@
 // Grids are (ceil(N/64), row blocks): 384 workgroups for a 1024 x 768 activation.
 // A batch may consist of `groups` independent BatchNorm batches of rows_per_group rows
 // (the discriminator's real/fake pair, dexgangrasp.py:788-789).
+#include <string.h>
 #include "dgg_internal.h"
 
 namespace dgg {
@@ -979,30 +980,88 @@ int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, in
 
 constexpr int kNhMax = 32;
 
-int heads_fwd_launch(const float* y, int ldy, int B, int K, const float* wh, const float* bh, int nh, int sigmoid,
-                     float* out, int ldo, hipStream_t st) {
-    if (nh > kNhMax) return DGG_ERR_UNSUPPORTED;
-    if (nh == 1)
-        hipLaunchKernelGGL((heads_fwd_kernel<1>), dim3(cdiv(B, 4)), dim3(256), 0, st, y, ldy, B, K, wh, bh, nh, sigmoid,
-                           out, ldo);
-    else
-        hipLaunchKernelGGL((heads_fwd_kernel<kNhMax>), dim3(cdiv(B, 4)), dim3(256), 0, st, y, ldy, B, K, wh, bh, nh,
-                           sigmoid, out, ldo);
-    return check_launch("heads_fwd");
+// column sums of a narrow (B x n <= 32) matrix; one workgroup, fixed summation order
+__global__ __launch_bounds__(256) void narrow_colsum_kernel(const float* __restrict__ x, int ld, int B, int n,
+                                                            float* __restrict__ dst, int accumulate) {
+    __shared__ float sh[8][32];
+    const int j = threadIdx.x & 31, s8 = threadIdx.x >> 5;
+    float a = 0.f;
+    if (j < n)
+        for (int r = s8; r < B; r += 8) a += x[(size_t)r * ld + j];
+    sh[s8][j] = a;
+    __syncthreads();
+    if (s8 == 0 && j < n) {
+        float t = sh[0][j];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += sh[q][j];
+        dst[j] = accumulate ? dst[j] + t : t;
+    }
 }
 
+static void one_problem(GemmBatch& g, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N,
+                        int K, int splits, long long slab_stride) {
+    memset(&g, 0, sizeof(g));
+    g.nprob = 1;
+    GemmProb& p = g.p[0];
+    p.A = A; p.B = Bm; p.C = C;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K;
+    p.kchunk = K;
+    if (splits > 0) {
+        const int ksteps = (K + 31) / 32;
+        const int per = (ksteps + splits - 1) / splits;
+        p.kchunk = per * 32;
+        p.splits = (K + p.kchunk - 1) / p.kchunk;
+        p.slab_stride = slab_stride;
+    }
+}
+
+// nh == 1 (discriminator / evaluator score): one wave per row.  nh > 1 (the generator's 21 pose outputs,
+// networks.py:98-100): the heads are a (B x K)(K x nh) product — MFMA GEMM with split-K slabs + the bias reduce;
+// the per-row kernel spent its time in nh x 6 cross-lane reduction steps (53 us at B = 1024 against 12).
+// scratch: >= 4 * B * nh floats (nh > 1 only).
+int heads_fwd_launch(const float* y, int ldy, int B, int K, const float* wh, const float* bh, int nh, int sigmoid,
+                     float* out, int ldo, float* scratch, hipStream_t st) {
+    if (nh > kNhMax) return DGG_ERR_UNSUPPORTED;
+    if (nh == 1) {
+        hipLaunchKernelGGL((heads_fwd_kernel<1>), dim3(cdiv(B, 4)), dim3(256), 0, st, y, ldy, B, K, wh, bh, nh, sigmoid,
+                           out, ldo);
+        return check_launch("heads_fwd");
+    }
+    if (sigmoid || !scratch) return DGG_ERR_UNSUPPORTED;
+    GemmBatch g;
+    one_problem(g, y, ldy, wh, K, scratch, nh, B, nh, K, 4, (long long)B * nh);
+    int rc = gemm_launch(GEMM_NT, g, st);
+    if (rc) return rc;
+    return reduce_bias_launch(scratch, g.p[0].splits, (long long)B * nh, nh, bh, out, ldo, B, B, 1, nh, 0, 0, 0, 0,
+                              nullptr, st);
+}
+
+// scratch: nh == 1: per-row-block partials; nh > 1: >= 8 * nh * K floats of split-K slabs
 int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B, int K, const float* wh, int nh,
                      float* dy, int lddy, float* gwh, float* gbh, int accumulate, int skip_param, float* scratch,
                      hipStream_t st) {
     if (nh > kNhMax) return DGG_ERR_UNSUPPORTED;
+    if (nh > 1) {
+        GemmBatch g;
+        // dy = dout Wh  (B x K, reduction over the nh heads)
+        one_problem(g, dout, ldd, wh, K, dy, lddy, B, K, nh, 0, 0);
+        int rc = gemm_launch(GEMM_NN, g, st);
+        if (rc || skip_param) return rc;
+        // dWh (+)= dout^T y  (nh x K, reduction over the batch: split-K slabs + reduce), dbh (+)= column sums of dout
+        one_problem(g, dout, ldd, y, ldy, scratch, K, nh, K, B, 8, (long long)nh * K);
+        rc = gemm_launch(GEMM_TN, g, st);
+        if (rc) return rc;
+        rc = reduce_bias_launch(scratch, g.p[0].splits, (long long)nh * K, K, nullptr, gwh, K, nh, nh, 1, K, 0, 0, 0, 0,
+                                nullptr, st, accumulate);
+        if (rc) return rc;
+        hipLaunchKernelGGL(narrow_colsum_kernel, dim3(1), dim3(256), 0, st, dout, ldd, B, nh, gbh, accumulate);
+        return check_launch("narrow_colsum");
+    }
     const int nrb = cdiv(B, RB);
     dim3 grid(cdiv(K, 256), nrb);
-    if (nh == 1)
-        hipLaunchKernelGGL((heads_bwd_kernel<1>), grid, dim3(256), 0, st, y, ldy, dout, ldd, B, K, wh, nh, dy, lddy,
-                           skip_param, scratch);
-    else
-        hipLaunchKernelGGL((heads_bwd_kernel<kNhMax>), grid, dim3(256), 0, st, y, ldy, dout, ldd, B, K, wh, nh, dy,
-                           lddy, skip_param, scratch);
+    hipLaunchKernelGGL((heads_bwd_kernel<1>), grid, dim3(256), 0, st, y, ldy, dout, ldd, B, K, wh, nh, dy, lddy,
+                       skip_param, scratch);
     int rc = check_launch("heads_bwd");
     if (rc || skip_param) return rc;
     // weights and biases are adjacent in the flat layout iff gbh == gwh + nh*K; finalize separately otherwise
