@@ -324,6 +324,42 @@ class DexGanGrasp(object):
         with torch.no_grad():
             return self.DexGANGrasp.generate_poses(bps_tensor, return_arr=return_arr, z_offset=z_offset)
 
+    # ------------------------------------------------------------------ N4: gradient-based refinement
+    def improve_grasps_gradient_based(self, data, last_success):
+        """dexgangrasp.py:516-541: one ascent step on the evaluator's success probability, each sample's step scaled
+        so that the palm translation moves at most 1 cm.  The input gradients come from `dgg_eva_backward`
+        (DGG_NEED_INPUT_GRADS) through the module's autograd bridge and — as in the reference, which never zeroes
+        them — accumulate in `.grad` over the steps of one `refine_grasps` call.
+        The reference also steps `joint_conf`, whose `.grad` is None because DexEvaluator does not read it
+        (networks.py:307-338), i.e. its line 539 raises TypeError; here joint_conf is left unchanged."""
+        p_success = self.DexEvaluator(data)
+        p_success.squeeze(-1).backward(torch.ones(p_success.shape[0], device=p_success.device))
+        norm_transl = torch.norm(data["transl"].grad, p=2, dim=-1)
+        alpha = torch.min(0.01 / norm_transl, torch.tensor(1.0, device=norm_transl.device))
+        data["transl"].data += data["transl"].grad * alpha[:, None]
+        data["rot_matrix"].data += data["rot_matrix"].grad * alpha.view(-1, *([1] * (data["rot_matrix"].dim() - 1)))
+        if data["joint_conf"].grad is not None:
+            data["joint_conf"].data += data["joint_conf"].grad * alpha[:, None]
+        return p_success.squeeze(), None
+
+    def refine_grasps(self, data, refine_method, num_refine_steps=10, dtype=torch.float32):
+        """dexgangrasp.py:619-660.  `refine_method == "gradient"` only: the sampling-based variant of the reference
+        calls helpers that do not exist in its tree (`utils.control_points_from_rot_and_trans`, `self.grasp_evaluator`)."""
+        data = utils.data_dict_to_dtype(data, dtype)
+        if refine_method != "gradient":
+            raise NotImplementedError("refine method [%s] is not implemented" % refine_method)
+        for k in ("rot_matrix", "transl", "joint_conf"):
+            data[k] = data[k].to(self.device).detach().clone().requires_grad_(True)
+        refined_success, refined_data = [], [utils.grasp_numpy_from_data_dict(data)]
+        last_success = None
+        for _ in range(num_refine_steps):
+            p_success, last_success = self.improve_grasps_gradient_based(data, last_success)
+            refined_success.append(p_success.cpu().data.numpy())
+            refined_data.append(utils.grasp_numpy_from_data_dict(data))
+        with torch.no_grad():
+            refined_success.append(self.DexEvaluator(data).squeeze().cpu().data.numpy())
+        return refined_data, refined_success
+
     # ------------------------------------------------------------------ checkpoints
     def load_dexevaluator(self, epoch, load_path=None):
         """dexgangrasp.py:571-592."""

@@ -93,3 +93,12 @@ def dict_to_tensor(in_dict, device, dtype):
         else:
             out_dict[k] = torch.tensor(v, dtype=dtype, device=device)
     return out_dict
+
+
+def grasp_numpy_from_data_dict(data):
+    """utils.py:199-204."""
+    return {
+        "rot_matrix": data["rot_matrix"].cpu().data.numpy(),
+        "transl": data["transl"].cpu().data.numpy(),
+        "joint_conf": data["joint_conf"].cpu().data.numpy(),
+    }

@@ -358,6 +358,42 @@ def test_wrapper_inference_vs_reference_goldens(variant):
     np.testing.assert_allclose(fd["transl"], g[key + "filt_disc/transl"], rtol=1e-4, atol=1e-4)
 
 
+def test_refine_grasps_gradient_matches_oracle():
+    """N4 (dexgangrasp.py:516-541, 619-660): the gradient-refinement loop, step for step, against the same loop
+    written with torch autograd over the oracle's evaluator (gradients accumulate in .grad, as in the reference)."""
+    from oracle import dexgan_oracle as O
+    m = _wrapper("wide", is_train=False)
+    m.DexEvaluator.eval()
+    batch = H.batches()["syn8"]
+    steps = 3
+    data = {"bps_object": batch["bps_object"].clone(), "rot_matrix": batch["rot_matrix"].clone(),
+            "transl": batch["transl"].clone(), "joint_conf": batch["joint_conf"].clone()}
+    refined_data, refined_success = m.refine_grasps(data, "gradient", num_refine_steps=steps)
+    assert len(refined_data) == steps + 1 and len(refined_success) == steps + 1
+    # oracle loop
+    sde = H.eva_sd("wide")
+    rot = batch["rot_matrix"].float().clone().requires_grad_(True)
+    tr = batch["transl"].float().clone().requires_grad_(True)
+    want_p = []
+    for _ in range(steps):
+        p = O.evaluator_forward(sde, batch["bps_object"].float(), rot, tr, False)
+        p.squeeze(-1).backward(torch.ones(p.shape[0]))
+        alpha = torch.min(0.01 / torch.norm(tr.grad, p=2, dim=-1), torch.tensor(1.0))
+        tr.data += tr.grad * alpha[:, None]
+        rot.data += rot.grad * alpha.view(-1, *([1] * (rot.dim() - 1)))
+        want_p.append(p.detach().squeeze().numpy())
+    want_p.append(O.evaluator_forward(sde, batch["bps_object"].float(), rot, tr, False).detach().squeeze().numpy())
+    for got, want in zip(refined_success, want_p):
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(refined_data[-1]["transl"], tr.detach().numpy(), rtol=0, atol=2e-5)   # steps are <= 1 cm
+    np.testing.assert_allclose(refined_data[-1]["rot_matrix"].reshape(8, -1), rot.detach().numpy().reshape(8, -1),
+                               rtol=0, atol=2e-4)
+    np.testing.assert_array_equal(refined_data[-1]["joint_conf"], refined_data[0]["joint_conf"])
+    assert np.abs(refined_data[-1]["transl"] - refined_data[0]["transl"]).max() > 1e-4      # it did move
+    with pytest.raises(NotImplementedError):
+        m.refine_grasps(dict(data), "sampling")
+
+
 def test_autograd_path_matches_oracle():
     """Module forward + torch backward (the non-fused path: e.g. refine_grasps' input gradients)."""
     from oracle import dexgan_oracle as O
