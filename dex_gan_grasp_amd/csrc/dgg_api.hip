@@ -455,8 +455,12 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     // 1. through the output LeakyReLU / dropout; split into the bn2 branch (dpre) and the fc3 branch (da3)
     DGG_TRY(res_out_bwd_launch(dy, L.nn, A.y, L.nn, had_dropout ? A.keep : nullptr, A.a13 + L.hid, L.n13, A.a2, L.nn,
                                A.mean2, A.rstd2, B, B, L.nn, c.W.dpre, dY13 + L.hid, L.n13, c.W.part, c.st));
+    // fc1.bias / fc2.bias feed a train-mode BatchNorm: their gradient is EXACTLY zero (the batch-mean subtraction
+    // removes any per-column constant; the reference stores fp32 rounding noise there) — cleared by this launch
+    const bool zero_pre_bn = c.train && !skip_param && !accum;
     DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 3, L.nn, c.W.sums, gp(R.bn2b), gp(R.bn2w), gp(R.b13 + L.hid),
-                                   acc, c.st, 0, 0, nullptr, cs13 + L.hid));
+                                   acc, c.st, 0, 0, nullptr, cs13 + L.hid, zero_pre_bn ? G + R.b2 : nullptr, L.nn,
+                                   zero_pre_bn ? G + R.b13 : nullptr, L.hid));
     // 2. bn2 backward -> da2; its column sums are fc2.bias' gradient
     DGG_TRY(bn_bwd_apply_launch(c.W.dpre, L.nn, A.a2, L.nn, A.mean2, A.rstd2, c.P + R.bn2w, c.W.sums, c.train, B, B,
                                 L.nn, da2, L.nn, c.W.part, c.st));
@@ -466,8 +470,6 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     if (!skip_param) {
         if (!c.train)
             DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 1, L.nn, nullptr, G + R.b2, nullptr, nullptr, acc, c.st));
-        else if (!accum && hipMemsetAsync(G + R.b2, 0, sizeof(float) * L.nn, c.st) != hipSuccess)
-            return DGG_ERR_LAUNCH;
     }
     // 3. fc2: dh = da2 W2 (B x 256 output: split-K over slabs fills the chip)
     {
@@ -492,8 +494,6 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     if (!c.train)
         DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 1, L.hid, nullptr, gp(R.b13), nullptr, nullptr, acc, c.st, 0,
                                        0, cs13, nullptr));
-    else if (!skip_param && !accum && hipMemsetAsync(G + R.b13, 0, sizeof(float) * L.hid, c.st) != hipSuccess)
-        return DGG_ERR_LAUNCH;
     // 5. wgrad of [fc1;fc3]: dW13[:, wcol:] = dY13^T X_seg.  For the [prefix | x_hat] segment the epilogue
     //    turns T = dY13^T x_hat into dW = gamma T + beta cs and emits the partials of d gamma / d beta of the
     //    input BatchNorm, so dX0 is never needed for parameter gradients.

@@ -137,10 +137,11 @@ int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const flo
 //   sums_out [groups][nq][ncols] (may be NULL) and, summed over groups, into up to 3 gradient
 //   destinations (NULL to skip): dst[q][c] (+)= sum.
 //   ld / c_lo: row pitch of `part` (0 = ncols) and first column; copy0 / copy2: extra plain copies of the
-//   q == 0 / q == 2 totals.
+//   q == 0 / q == 2 totals; zero0 / zero1: ranges cleared alongside.
 int colsum_finalize_launch(const float* part, int groups, int nrb, int nq, int ncols, float* sums_out, float* dst0,
                            float* dst1, float* dst2, int accumulate, hipStream_t st, int ld = 0, int c_lo = 0,
-                           float* copy0 = nullptr, float* copy2 = nullptr);
+                           float* copy0 = nullptr, float* copy2 = nullptr, float* zero0 = nullptr, int nz0 = 0,
+                           float* zero1 = nullptr, int nz1 = 0);
 // Input BN backward: partial sums of dX0 and dX0*xhat over the concat sources.
 int ibn_bwd_stats_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col_off, const float* mean,
                          const float* rstd, int rows_per_group, int groups, float* part, hipStream_t st);

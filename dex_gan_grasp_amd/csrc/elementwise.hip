@@ -577,8 +577,13 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
                                                               float* __restrict__ sums_out, float* __restrict__ d0,
                                                               float* __restrict__ d1, float* __restrict__ d2,
                                                               int accumulate, float* __restrict__ copy0,
-                                                              float* __restrict__ copy2) {
+                                                              float* __restrict__ copy2, float* __restrict__ zero0,
+                                                              int nz0, float* __restrict__ zero1, int nz1) {
     __shared__ float sh[SUB][64];
+    if (blockIdx.x == 0) {  // ranges the caller wants cleared alongside (saves separate memset launches)
+        for (int z = threadIdx.x; z < nz0; z += 256) zero0[z] = 0.f;
+        for (int z = threadIdx.x; z < nz1; z += 256) zero1[z] = 0.f;
+    }
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int i0 = blockIdx.x * 64 + lane;
     const bool ok = i0 < nq * ncols;
@@ -1102,10 +1107,11 @@ int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const flo
 
 int colsum_finalize_launch(const float* part, int groups, int nrb, int nq, int ncols, float* sums_out, float* dst0,
                            float* dst1, float* dst2, int accumulate, hipStream_t st, int ld, int c_lo, float* copy0,
-                           float* copy2) {
+                           float* copy2, float* zero0, int nz0, float* zero1, int nz1) {
     if (ld <= 0) ld = ncols;
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(nq * ncols, 64)), dim3(256), 0, st, part, groups, nrb, nq,
-                       ncols, ld, c_lo, sums_out, dst0, dst1, dst2, accumulate, copy0, copy2);
+                       ncols, ld, c_lo, sums_out, dst0, dst1, dst2, accumulate, copy0, copy2, zero0, zero0 ? nz0 : 0,
+                       zero1, zero1 ? nz1 : 0);
     return check_launch("colsum_finalize");
 }
 
