@@ -370,7 +370,21 @@ static hipStream_t wgrad_stream_of(hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // ResBlock forward (networks.py:43-56) on column segments of the (virtual) concatenated input.
 // ------------------------------------------------------------------------------------------------
+// The BPS columns of the discriminator's input — and their batch statistics, hence x_hat — are the same in the real
+// and the fake pass of a D phase (dexgangrasp.py:788-789 feed the same bps_object twice): the partial product
+// x_hat_bps W13[:, bps]^T of every ResBlock is computed once, by the real pass, and summed into both passes.
+struct Share {
+    int mode;             // 1: produce (real pass), 2: consume (fake pass)
+    int ncols;            // leading columns of X0 that are shared
+    float* slabs[3];      // per ResBlock: up to kShareSlabs slabs of B x n13
+    int nslab[3];         // set by the producer
+    hipEvent_t ready[3];  // two-stream form: recorded by the producer after its GEMM, awaited by the consumer
+    bool events;
+};
+static const int kShareSlabs = 16;  // plan13 never gives one piece more
+
 struct Ctx {
+    Share* share;
     const NetL* L;
     const float* P;   // params
     float* G;         // grads (backward)
@@ -388,30 +402,64 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
     const RbL& R = L.rb[r];
     RbW& A = c.W.rb[r];
     const int B = c.B;
-    // 1. [a1 | a3] partial products: X_seg (B x width) * W13[:, wcol:wcol+width]^T -> split-K slabs
+    // 1. [a1 | a3] partial products: X_piece (B x width) * W13[:, wcol:wcol+width]^T -> split-K slabs.
+    //    A piece is a column segment of the concatenated input; with a Share the [prefix | x_hat] segment is cut at
+    //    share->ncols into the shared BPS piece and the pass' own pose piece.
+    struct Piece { const float* p; int ld, width, wcol, x0_off; bool x0, shared; };
+    Piece pc[4];
+    int np = 0;
+    Share* sh = c.share;
+    for (int i = 0; i < nseg; ++i) {
+        if (sh && segs[i].is_x0 && L.nprefix == 0 && sh->ncols > 0 && sh->ncols < segs[i].width) {
+            pc[np++] = Piece{segs[i].p, segs[i].ld, sh->ncols, segs[i].wcol, 0, true, true};
+            pc[np++] = Piece{segs[i].p + sh->ncols, segs[i].ld, segs[i].width - sh->ncols, segs[i].wcol + sh->ncols,
+                             sh->ncols, true, false};
+        } else {
+            pc[np++] = Piece{segs[i].p, segs[i].ld, segs[i].width, segs[i].wcol, 0, segs[i].is_x0, false};
+        }
+    }
     int widths[4], sp[4];
-    for (int i = 0; i < nseg; ++i) widths[i] = segs[i].width;
-    plan13(B, L.n13, widths, nseg, sp);
+    for (int i = 0; i < np; ++i) widths[i] = pc[i].width;
+    plan13(B, L.n13, widths, np, sp);
     GemmBatch gb;
     memset(&gb, 0, sizeof(gb));
-    gb.nprob = nseg;
     const long long slab = (long long)B * L.n13;
-    int nslab = 0;
-    for (int i = 0; i < nseg; ++i) {
-        prob_init(gb.p[i], segs[i].p, segs[i].ld, c.P + R.w13 + segs[i].wcol, R.fin, c.W.slabs + (size_t)nslab * slab,
-                  L.n13, B, L.n13, segs[i].width);
-        prob_split(gb.p[i], sp[i], slab);
-        if (segs[i].is_x0) {  // BatchNorm gamma/beta applied while the operand is staged
-            gb.p[i].a_scale = c.W.aff_scale;
-            gb.p[i].a_shift = c.W.aff_shift;
+    int nslab = 0, nq = 0;
+    for (int i = 0; i < np; ++i) {
+        float* dst = c.W.slabs + (size_t)nslab * slab;
+        if (pc[i].shared) {
+            if (sh->mode == 2) continue;  // consumer: the producer's slabs are summed in below
+            dst = sh->slabs[r];
         }
-        nslab += gb.p[i].splits;
+        GemmProb& q = gb.p[nq++];
+        prob_init(q, pc[i].p, pc[i].ld, c.P + R.w13 + pc[i].wcol, R.fin, dst, L.n13, B, L.n13, pc[i].width);
+        prob_split(q, sp[i], slab);
+        if (pc[i].x0) {  // BatchNorm gamma/beta applied while the operand is staged
+            q.a_scale = c.W.aff_scale + pc[i].x0_off;
+            q.a_shift = c.W.aff_shift + pc[i].x0_off;
+        }
+        if (pc[i].shared) {
+            if (q.splits > kShareSlabs) return DGG_ERR_WORKSPACE;
+            sh->nslab[r] = q.splits;
+        } else {
+            nslab += q.splits;
+        }
     }
+    gb.nprob = nq;
     if ((int64_t)nslab * slab > c.W.slab_floats) return DGG_ERR_WORKSPACE;
     DGG_TRY(gemm_launch(GEMM_NT, gb, c.st));
-    // 2. sum slabs + bias; a1 -> statistics, a3 -> s = lrelu(a3)
-    DGG_TRY(reduce_bias_launch(c.W.slabs, nslab, slab, L.n13, c.P + R.b13, A.a13, L.n13, B, B, 1, L.n13, 0, L.hid,
-                               L.hid, L.n13, c.W.part, c.st));
+    const bool shared_here = sh && np > nseg;
+    if (shared_here && sh->events) {
+        if (sh->mode == 1 && hipEventRecord(sh->ready[r], c.st) != hipSuccess) return DGG_ERR_LAUNCH;
+        if (sh->mode == 2 && hipStreamWaitEvent(c.st, sh->ready[r], 0) != hipSuccess) return DGG_ERR_LAUNCH;
+    }
+    // 2. sum slabs (k order: shared BPS chunks first) + bias; a1 -> statistics, a3 -> s = lrelu(a3)
+    if (shared_here)
+        DGG_TRY(reduce_bias_launch(sh->slabs[r], sh->nslab[r], slab, L.n13, c.P + R.b13, A.a13, L.n13, B, B, 1, L.n13,
+                                   0, L.hid, L.hid, L.n13, c.W.part, c.st, 0, c.W.slabs, nslab));
+    else
+        DGG_TRY(reduce_bias_launch(c.W.slabs, nslab, slab, L.n13, c.P + R.b13, A.a13, L.n13, B, B, 1, L.n13, 0, L.hid,
+                                   L.hid, L.n13, c.W.part, c.st));
     DGG_TRY(bn_finalize_launch(c.W.part, B, 1, L.hid, c.train, c.bn ? c.bn + R.rm1 : nullptr,
                                c.bn ? c.bn + R.rv1 : nullptr, A.mean1, A.rstd1, c.st));
     // 3. h = lrelu(bn1(a1))
@@ -584,9 +632,10 @@ static void make_segs(const NetL& L, NetW& W, int r, Seg* segs, int& nseg) {
 
 static int net_forward(const NetL& L, const float* params, float* bn, void* ws, size_t ws_bytes, int B, unsigned flags,
                        const ColSrcs& srcs, const float* prefix, const float* drop_keep, uint64_t seed, float* out,
-                       hipStream_t st) {
+                       hipStream_t st, Share* share = nullptr) {
     if (!params || !ws || !out || B < 1) return DGG_ERR_INVALID;
     Ctx c;
+    c.share = share;
     c.L = &L; c.P = params; c.G = nullptr; c.bn = bn; c.B = B; c.train = (flags & DGG_TRAIN) != 0; c.st = st;
     c.sw = nullptr;
     carve(L, B, ws, c.W);
@@ -641,6 +690,7 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     const bool accum = (flags & DGG_ACCUM_GRADS) != 0;
     if (!skip && !grads) return DGG_ERR_INVALID;
     Ctx c;
+    c.share = nullptr;
     c.L = &L; c.P = params; c.G = grads; c.bn = nullptr; c.B = B; c.train = (flags & DGG_TRAIN) != 0; c.st = st;
     c.sw = skip ? nullptr : wgrad_stream_of(st);
     if (c.sw == st) c.sw = nullptr;
@@ -743,6 +793,8 @@ struct StepW {
     size_t g_bytes, d_bytes;
     float *heads, *rfake, *f_transl, *f_joint, *p_real, *p_fake, *p_gen, *dl_real, *dl_fake, *dl_gen, *d_pose,
         *d_heads;
+    float* dshare[3];  // per ResBlock of D: split-K slabs of the BPS-column product shared by the real and fake pass
+    int d_nrb, d_n13;
     size_t bytes;
 };
 
@@ -773,6 +825,16 @@ static int carve_step(const dgg_cfg* cfg, int B, void* base, StepW& S) {
     S.dl_gen = b.take<float>(Bz);
     S.d_pose = b.take<float>(Bz * (12 + nj));
     S.d_heads = b.take<float>(Bz * (nj + 9));
+    S.d_nrb = Ld.nrb;
+    S.d_n13 = Ld.n13;
+    for (int r = 0; r < 3; ++r) {
+        S.dshare[r] = nullptr;
+        if (r >= Ld.nrb) continue;
+        // as rb_forward cuts the pieces: [BPS | pose] (+ the previous block's output)
+        int widths[3] = {cfg->in_bps, Ld.k0 - cfg->in_bps, Ld.nn}, sp[3];
+        plan13(B, Ld.n13, widths, r == 0 ? 2 : 3, sp);
+        S.dshare[r] = b.take<float>((size_t)sp[0] * Bz * Ld.n13);
+    }
     S.bytes = (b.off + 255) & ~(size_t)255;
     return DGG_OK;
 }
@@ -967,9 +1029,21 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
         if (hipEventRecord(ev[0], st) != hipSuccess || hipStreamWaitEvent(sb, ev[0], 0) != hipSuccess)
             return DGG_ERR_LAUNCH;
     }
+    // the BPS-column partial products of D's ResBlocks are computed by the real pass and reused by the fake pass
+    NetL Ld;
+    DGG_TRY(build_layout(DGG_NET_DISC, cfg, Ld));
+    Share share;
+    memset(&share, 0, sizeof(share));
+    share.ncols = cfg->in_bps;
+    share.events = fork;
+    for (int r = 0; r < S.d_nrb; ++r) {
+        share.slabs[r] = S.dshare[r];
+        if (fork && !(share.ready[r] = next_event())) return DGG_ERR_LAUNCH;
+    }
     // ---- stream B: D(real) forward, BCE(real, 1), D backward(real) overwriting d_grads        (:788, :215-218, :793)
-    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint,
-                             S.p_real, sb));
+    share.mode = 1;
+    DGG_TRY(net_forward(Ld, s->d_params, s->d_bn, S.ws_dr, S.d_bytes, B, DGG_TRAIN,
+                        srcs_pose(cfg, bps, rot9, transl, joint), nullptr, nullptr, 0, S.p_real, sb, &share));
     if (fork && hipEventRecord(ev[1], sb) != hipSuccess) return DGG_ERR_LAUNCH;
     DGG_TRY(bce_launch(S.p_real, nullptr, 1.f, B, (float)hp->bce_weight, 0.5f, losses + DGG_L_BCE_REAL, S.dl_real, sb));
     DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint,
@@ -983,8 +1057,9 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
     DGG_TRY(copy_cols_launch(S.heads, nh, S.f_joint, nj, B, nj, st));
     // :789 D(fake.detach()): its BatchNorm running-statistic updates must follow those of the real pass
     if (fork && hipStreamWaitEvent(st, ev[1], 0) != hipSuccess) return DGG_ERR_LAUNCH;
-    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN, bps, S.rfake, S.f_transl,
-                             S.f_joint, S.p_fake, stream));
+    share.mode = 2;
+    DGG_TRY(net_forward(Ld, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN,
+                        srcs_pose(cfg, bps, S.rfake, S.f_transl, S.f_joint), nullptr, nullptr, 0, S.p_fake, st, &share));
     DGG_TRY(bce_launch(S.p_fake, nullptr, 0.f, B, (float)hp->bce_weight, 0.5f, losses + DGG_L_BCE_FAKE, S.dl_fake, st));
     // :792-793 the fake pass accumulates onto the real pass' gradients
     if (fork && hipStreamWaitEvent(st, ev[2], 0) != hipSuccess) return DGG_ERR_LAUNCH;

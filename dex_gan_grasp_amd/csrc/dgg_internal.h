@@ -95,11 +95,12 @@ int ibn_apply_launch(const ColSrcs& srcs, int B, int rows_per_group, const float
                      const float* aff_gamma, const float* aff_beta, float* aff_scale, float* aff_shift,
                      hipStream_t st);
 
-// out[m][c] = sum_s slabs[s][m][c] + bias[c];  columns [stat_lo, stat_hi) get partial statistics,
+// out[m][c] = sum_s slabs[s][m][c] (+ sum_s slabs2[s][m][c], same stride / pitch) + bias[c];  columns [stat_lo, stat_hi) get partial statistics,
 // columns [act_lo, act_hi) get LeakyReLU applied before the store.
 int reduce_bias_launch(const float* slabs, int nslab, long long slab_stride, int ld_slab, const float* bias,
                        float* out, int ld_out, int B, int rows_per_group, int groups, int N, int stat_lo,
-                       int stat_hi, int act_lo, int act_hi, float* part, hipStream_t st, int accumulate = 0);
+                       int stat_hi, int act_lo, int act_hi, float* part, hipStream_t st, int accumulate = 0,
+                       const float* slabs2 = nullptr, int nslab2 = 0);
 // h[m][c] = lrelu((a[m][c]-mean)*rstd*gamma+beta)
 int bn_act_launch(const float* a, int lda, int B, int rows_per_group, int N, const float* mean, const float* rstd,
                   const float* gamma, const float* beta, float* h, int ldh, hipStream_t st);

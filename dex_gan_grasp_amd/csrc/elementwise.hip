@@ -235,7 +235,8 @@ __global__ __launch_bounds__(256) void reduce_bias_kernel(const float* __restric
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           int ld_out, int rpg, int nrb, int N, int stat_lo,
                                                           int stat_hi, int act_lo, int act_hi,
-                                                          float* __restrict__ part, int accumulate) {
+                                                          float* __restrict__ part, int accumulate,
+                                                          const float* __restrict__ slabs2, int nslab2) {
     __shared__ float sh[SUB][2][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -253,12 +254,19 @@ __global__ __launch_bounds__(256) void reduce_bias_kernel(const float* __restric
     if (cok) {
         // slab order = k order: fixed summation order.  Four slabs (32 independent loads) are in flight per
         // iteration: the kernel is latency-bound, not bandwidth-bound, at these sizes.
+        // slabs [0, nslab) come from `slabs`, [nslab, nslab + nslab2) from `slabs2` (same stride and pitch): a
+        // partial product computed once and shared by two reduces (D real / fake pass) needs no copy
+        const int ntot = nslab + nslab2;
+        auto slab = [&](int i) -> const float* {
+            return (i < nslab ? slabs + (size_t)i * slab_stride : slabs2 + (size_t)(i - nslab) * slab_stride) +
+                   row0 * ld_slab + c;
+        };
         int s = 0;
-        for (; s + 4 <= nslab; s += 4) {
+        for (; s + 4 <= ntot; s += 4) {
             float t[4][RS];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float* p = slabs + (size_t)(s + u) * slab_stride + row0 * ld_slab + c;
+                const float* p = slab(s + u);
 #pragma unroll
                 for (int r = 0; r < RS; ++r) t[u][r] = (r < ns) ? p[(size_t)r * ld_slab] : 0.f;
             }
@@ -267,8 +275,8 @@ __global__ __launch_bounds__(256) void reduce_bias_kernel(const float* __restric
 #pragma unroll
                 for (int r = 0; r < RS; ++r) v[r] += t[u][r];
         }
-        for (; s < nslab; ++s) {
-            const float* p = slabs + (size_t)s * slab_stride + row0 * ld_slab + c;
+        for (; s < ntot; ++s) {
+            const float* p = slab(s);
 #pragma unroll
             for (int r = 0; r < RS; ++r)
                 if (r < ns) v[r] += p[(size_t)r * ld_slab];
@@ -959,11 +967,13 @@ int ibn_apply_launch(const ColSrcs& srcs, int B, int rpg, const float* mean, con
 
 int reduce_bias_launch(const float* slabs, int nslab, long long slab_stride, int ld_slab, const float* bias,
                        float* out, int ld_out, int B, int rpg, int groups, int N, int stat_lo, int stat_hi,
-                       int act_lo, int act_hi, float* part, hipStream_t st, int accumulate) {
+                       int act_lo, int act_hi, float* part, hipStream_t st, int accumulate, const float* slabs2,
+                       int nslab2) {
     (void)B;
     dim3 grid(cdiv(N, 64), groups * nrb_of(rpg));
     hipLaunchKernelGGL(reduce_bias_kernel, grid, dim3(256), 0, st, slabs, nslab, slab_stride, ld_slab, bias, out,
-                       ld_out, rpg, nrb_of(rpg), N, stat_lo, stat_hi, act_lo, act_hi, part, accumulate);
+                       ld_out, rpg, nrb_of(rpg), N, stat_lo, stat_hi, act_lo, act_hi, part, accumulate, slabs2,
+                       slabs2 ? nslab2 : 0);
     return check_launch("reduce_bias");
 }
 
