@@ -1097,7 +1097,9 @@ int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
                               DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_NEED_INPUT_GRADS, bps, S.rfake, g_transl, g_joint,
                               S.dl_gen, S.d_pose, stream));
     // :272-307 reconstruction losses + total; d_heads combines the MSE gradients with D's input gradient
-    DGG_TRY(gen_loss_launch(cfg, hp, B, S.heads, rot9, transl, joint, S.p_gen, S.d_pose, losses, S.d_heads, st));
+    // S.dl_gen (B floats) is free again: D's backward has consumed it
+    DGG_TRY(gen_loss_launch(cfg, hp, B, S.heads, rot9, transl, joint, S.p_gen, S.d_pose, losses, S.d_heads, st,
+                            B >= 4 * ((B + 63) / 64) ? S.dl_gen : nullptr));
     // :814-815 zero_grad + backward through G
     DGG_TRY(dgg_gen_backward(cfg, s->g_params, s->g_grads, S.ws_g, S.g_bytes, B, DGG_TRAIN, z, bps, S.d_heads, nullptr,
                              nullptr, stream));

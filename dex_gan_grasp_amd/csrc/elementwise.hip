@@ -815,7 +815,11 @@ __global__ __launch_bounds__(256) void ortho6d_bwd_kernel(const float* __restric
     for (int k = 0; k < 6; ++k) d_o6[(size_t)i * ldd + k] = go[k];
 }
 
-// single block.  heads (B, nj+9) = [joint | rot6 | transl];  d_pose (B, 12+nj) = [d rot9 | d transl | d joint]
+// heads (B, nj+9) = [joint | rot6 | transl];  d_pose (B, 12+nj) = [d rot9 | d transl | d joint].
+// One row per thread, rows strided by 21 / 24 floats: a single workgroup pushes ~70 uncoalesced wave-loads of 64
+// cache lines each through one CU's address unit (44 us at B = 1024).  With `partial` the grid spreads the rows
+// over CUs (64 rows per workgroup), writes the four partial sums per workgroup, and gen_loss_final_kernel adds them
+// in workgroup order (deterministic); without it: one workgroup, final values written directly.
 __global__ __launch_bounds__(1024) void gen_loss_kernel(int nj, float bce_w, float c_tr, float c_rot, float c_cf,
                                                         int B, const float* __restrict__ heads,
                                                         const float* __restrict__ gt_rot9,
@@ -823,11 +827,11 @@ __global__ __launch_bounds__(1024) void gen_loss_kernel(int nj, float bce_w, flo
                                                         const float* __restrict__ gt_joint,
                                                         const float* __restrict__ fake_score,
                                                         const float* __restrict__ d_pose, float* __restrict__ losses,
-                                                        float* __restrict__ d_heads) {
+                                                        float* __restrict__ d_heads, float* __restrict__ partial) {
     __shared__ float sh[16];
     const int nh = nj + 9;
     float l_tr = 0.f, l_rot = 0.f, l_cf = 0.f, l_f = 0.f;
-    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
         const float* hrow = heads + (size_t)i * nh;
         Rot R;
         ortho6d(hrow + nj, R);
@@ -868,6 +872,13 @@ __global__ __launch_bounds__(1024) void gen_loss_kernel(int nj, float bce_w, flo
     const float t_rot = block_sum_1024(l_rot, sh);
     const float t_cf = block_sum_1024(l_cf, sh);
     const float t_f = block_sum_1024(l_f, sh);
+    if (partial) {
+        if (threadIdx.x == 0) {
+            float* o = partial + 4 * blockIdx.x;
+            o[0] = t_tr; o[1] = t_rot; o[2] = t_cf; o[3] = t_f;
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
         const float lf = bce_w * (t_f / (float)B);
         const float ltr = c_tr * (t_tr / (3.f * (float)B));
@@ -879,6 +890,22 @@ __global__ __launch_bounds__(1024) void gen_loss_kernel(int nj, float bce_w, flo
         losses[DGG_L_CONF] = lcf;
         losses[DGG_L_TOTAL_GEN] = lf + (ltr + lrot + lcf);
     }
+}
+
+__global__ void gen_loss_final_kernel(int nj, float bce_w, float c_tr, float c_rot, float c_cf, int B, int nblk,
+                                      const float* __restrict__ partial, float* __restrict__ losses) {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < nblk; ++b)
+        for (int q = 0; q < 4; ++q) t[q] += partial[4 * b + q];
+    const float lf = bce_w * (t[3] / (float)B);
+    const float ltr = c_tr * (t[0] / (3.f * (float)B));
+    const float lrot = c_rot * (t[1] / (9.f * (float)B));
+    const float lcf = c_cf * (t[2] / ((float)nj * (float)B));
+    losses[DGG_L_GEN_FAKE] = lf;
+    losses[DGG_L_TRANSL] = ltr;
+    losses[DGG_L_ROT] = lrot;
+    losses[DGG_L_CONF] = lcf;
+    losses[DGG_L_TOTAL_GEN] = lf + (ltr + lrot + lcf);
 }
 
 __global__ void disc_loss_combine_kernel(float* losses) {
@@ -1162,10 +1189,19 @@ int ortho6d_bwd_launch(const float* o6, int ld, int B, const float* d_rot9, floa
 
 int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const float* heads, const float* gt_rot9,
                     const float* gt_transl, const float* gt_joint, const float* fake_score, const float* d_pose,
-                    float* losses, float* d_heads, hipStream_t st) {
-    hipLaunchKernelGGL(gen_loss_kernel, dim3(1), dim3(1024), 0, st, cfg->n_hand_joints, (float)hp->bce_weight,
-                       (float)hp->transl_coef, (float)hp->rot_coef, (float)hp->conf_coef, B, heads, gt_rot9, gt_transl, gt_joint,
-                       fake_score, d_pose, losses, d_heads);
+                    float* losses, float* d_heads, hipStream_t st, float* scratch) {
+    const float bw = (float)hp->bce_weight, ct = (float)hp->transl_coef, cr = (float)hp->rot_coef,
+                cc = (float)hp->conf_coef;
+    const int nblk = cdiv(B, 64);
+    if (!scratch || nblk < 2) {
+        hipLaunchKernelGGL(gen_loss_kernel, dim3(1), dim3(1024), 0, st, cfg->n_hand_joints, bw, ct, cr, cc, B, heads,
+                           gt_rot9, gt_transl, gt_joint, fake_score, d_pose, losses, d_heads, (float*)nullptr);
+        return check_launch("gen_loss");
+    }
+    hipLaunchKernelGGL(gen_loss_kernel, dim3(nblk), dim3(64), 0, st, cfg->n_hand_joints, bw, ct, cr, cc, B, heads,
+                       gt_rot9, gt_transl, gt_joint, fake_score, d_pose, losses, d_heads, scratch);
+    hipLaunchKernelGGL(gen_loss_final_kernel, dim3(1), dim3(1), 0, st, cfg->n_hand_joints, bw, ct, cr, cc, B, nblk,
+                       scratch, losses);
     return check_launch("gen_loss");
 }
 
