@@ -487,8 +487,16 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
 // ------------------------------------------------------------------------------------------------
 // ResBlock backward.  dy: gradient w.r.t. the block output y (B x 512).
 // ------------------------------------------------------------------------------------------------
+// Single-score head (D / E) folded into the last ResBlock's backward: d_score (B), the head's weights and the
+// destinations of its parameter gradients.
+struct HeadBwd {
+    const float* d_score;
+    const float* w;
+    float *gw, *gb;
+};
+
 static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy, bool had_dropout, bool accum,
-                       bool skip_param, int* ibn_tiles) {
+                       bool skip_param, int* ibn_tiles, const HeadBwd* hb = nullptr) {
     const NetL& L = *c.L;
     const RbL& R = L.rb[r];
     RbW& A = c.W.rb[r];
@@ -501,14 +509,17 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     float* da2 = c.W.da2[r];
     float* cs13 = c.W.cs13[r];
     // 1. through the output LeakyReLU / dropout; split into the bn2 branch (dpre) and the fc3 branch (da3)
-    DGG_TRY(res_out_bwd_launch(dy, L.nn, A.y, L.nn, had_dropout ? A.keep : nullptr, A.a13 + L.hid, L.n13, A.a2, L.nn,
-                               A.mean2, A.rstd2, B, B, L.nn, c.W.dpre, dY13 + L.hid, L.n13, c.W.part, c.st));
+    const int nq1 = (hb && !skip_param) ? 5 : 3;
+    DGG_TRY(res_out_bwd_launch(hb ? nullptr : dy, L.nn, A.y, L.nn, had_dropout ? A.keep : nullptr, A.a13 + L.hid, L.n13,
+                               A.a2, L.nn, A.mean2, A.rstd2, B, B, L.nn, c.W.dpre, dY13 + L.hid, L.n13, c.W.part, c.st,
+                               hb ? hb->d_score : nullptr, hb ? hb->w : nullptr, nq1));
     // fc1.bias / fc2.bias feed a train-mode BatchNorm: their gradient is EXACTLY zero (the batch-mean subtraction
     // removes any per-column constant; the reference stores fp32 rounding noise there) — cleared by this launch
     const bool zero_pre_bn = c.train && !skip_param && !accum;
-    DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 3, L.nn, c.W.sums, gp(R.bn2b), gp(R.bn2w), gp(R.b13 + L.hid),
+    DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, nq1, L.nn, c.W.sums, gp(R.bn2b), gp(R.bn2w), gp(R.b13 + L.hid),
                                    acc, c.st, 0, 0, nullptr, cs13 + L.hid, zero_pre_bn ? G + R.b2 : nullptr, L.nn,
-                                   zero_pre_bn ? G + R.b13 : nullptr, L.hid));
+                                   zero_pre_bn ? G + R.b13 : nullptr, L.hid, nq1 == 5 ? hb->gw : nullptr,
+                                   nq1 == 5 ? hb->gb : nullptr));
     // 2. bn2 backward -> da2; its column sums are fc2.bias' gradient
     DGG_TRY(bn_bwd_apply_launch(c.W.dpre, L.nn, A.a2, L.nn, A.mean2, A.rstd2, c.P + R.bn2w, c.W.sums, c.train, B, B,
                                 L.nn, da2, L.nn, c.W.part, c.st));
@@ -710,9 +721,12 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     // heads
     float* dy = c.W.dXa;
     float* other = c.W.dXb;
-    DGG_TRY(heads_bwd_launch(c.W.rb[L.nrb - 1].y, L.nn, d_out, L.nh, B, L.nn, params + L.wh, L.nh, dy, L.nn,
-                             skip ? nullptr : grads + L.wh, skip ? nullptr : grads + L.bh, accum ? 1 : 0, skip ? 1 : 0,
-                             c.W.part, st));
+    HeadBwd hb{d_out, params + L.wh, skip ? nullptr : grads + L.wh, skip ? nullptr : grads + L.bh};
+    const bool fold_head = L.nh == 1;  // the outer product d_score (x) w is formed inside the last block's backward
+    if (!fold_head)
+        DGG_TRY(heads_bwd_launch(c.W.rb[L.nrb - 1].y, L.nn, d_out, L.nh, B, L.nn, params + L.wh, L.nh, dy, L.nn,
+                                 skip ? nullptr : grads + L.wh, skip ? nullptr : grads + L.bh, accum ? 1 : 0,
+                                 skip ? 1 : 0, c.W.part, st));
     for (int r = L.nrb - 1; r >= 0; --r) {
         Seg segs[2];
         int nseg;
@@ -727,7 +741,8 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
                 segs[i].dp = other; segs[i].dld = L.nn; segs[i].d_lo = 0; segs[i].d_hi = L.nn; segs[i].d_accum = 0;
             }
         }
-        DGG_TRY(rb_backward(c, r, segs, nseg, dy, drop, accum, skip, ibn_tiles));
+        DGG_TRY(rb_backward(c, r, segs, nseg, dy, drop, accum, skip, ibn_tiles,
+                            (fold_head && r == L.nrb - 1) ? &hb : nullptr));
         float* t = dy; dy = other; other = t;
     }
     // input BatchNorm backward: parameter gradients = sum over ResBlocks and row tiles of the epilogue partials

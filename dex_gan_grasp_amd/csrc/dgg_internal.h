@@ -119,12 +119,13 @@ int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B,
                      hipStream_t st);
 
 // ResBlock backward element-wise stages ----------------------------------------------------
-// Stage 1: dpre = dy * [keep/(1-p)] * lrelu'(y);  da3 = dpre * lrelu'(s) -> dY13[:, c3off + c];
+// Stage 1 (head mode: dy = hd_dout (x) hd_w formed on the fly, nq == 5 adds the head's parameter-gradient sums):
+//          dpre = dy * [keep/(1-p)] * lrelu'(y);  da3 = dpre * lrelu'(s) -> dY13[:, c3off + c];
 //          partial sums: sum dpre, sum dpre*xhat2, sum da3.
 int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const uint8_t* keep, const float* s,
                        int lds, const float* a2, int lda2, const float* mean, const float* rstd, int B,
                        int rows_per_group, int N, float* dpre, float* da3, int ldda3, float* part,
-                       hipStream_t st);
+                       hipStream_t st, const float* hd_dout = nullptr, const float* hd_w = nullptr, int nq = 3);
 // Stage 2/4 (BN backward apply): dx = gamma*rstd*(dz - sum_dz/B - xhat*sum_dzx/B) (train) or
 //          gamma*rstd*dz (eval);  partial sums of dx (-> bias gradient of the preceding Linear).
 int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, const float* mean, const float* rstd,
@@ -142,7 +143,7 @@ int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const flo
 int colsum_finalize_launch(const float* part, int groups, int nrb, int nq, int ncols, float* sums_out, float* dst0,
                            float* dst1, float* dst2, int accumulate, hipStream_t st, int ld = 0, int c_lo = 0,
                            float* copy0 = nullptr, float* copy2 = nullptr, float* zero0 = nullptr, int nz0 = 0,
-                           float* zero1 = nullptr, int nz1 = 0);
+                           float* zero1 = nullptr, int nz1 = 0, float* dst3 = nullptr, float* dst4 = nullptr);
 // Input BN backward: partial sums of dX0 and dX0*xhat over the concat sources.
 int ibn_bwd_stats_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col_off, const float* mean,
                          const float* rstd, int rows_per_group, int groups, float* part, hipStream_t st);

@@ -461,6 +461,10 @@ __global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict_
 
 // ---------------------------------------------------------------- ResBlock backward stages
 // grid: (ceil(N/256), groups*nrb)
+// Head mode (hd_dout != NULL; single-score head of D / E, networks.py:121,293): the block output's gradient is the
+// outer product dy[row][c] = d_score[row] * w_head[c], formed here instead of being materialised by a heads kernel;
+// with nq == 5 two more partial sums give the head's parameter gradients, sum_row d_score*y (q 3) and sum_row
+// d_score (q 4, the same in every column).
 __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restrict__ dy, int lddy,
                                                           const float* __restrict__ y, int ldy,
                                                           const uint8_t* __restrict__ keep,
@@ -469,8 +473,10 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, int rpg, int nrb, int N,
                                                           float* __restrict__ dpre, float* __restrict__ da3,
-                                                          int ldda3, float* __restrict__ part) {
-    __shared__ float sh[SUB][3][64];
+                                                          int ldda3, float* __restrict__ part,
+                                                          const float* __restrict__ hd_dout,
+                                                          const float* __restrict__ hd_w, int nq) {
+    __shared__ float sh[SUB][5][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 64 + lane;
     const bool cok = c0 < N;
@@ -480,12 +486,22 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
     const int n = min(RS, max(0, rpg - r0));
     const float mu = mean[g * N + c], rs = rstd[g * N + c];
     const float inv_keep = 1.0f / (1.0f - kDropP);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    const float wv = hd_dout ? hd_w[c] : 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
     for (int r = 0; r < n; ++r) {
         const size_t row = (size_t)(g * rpg + r0 + r);
-        float d = dy[row * lddy + c];
+        const float yv = y[row * ldy + c];
+        float d;
+        if (hd_dout) {
+            const float ds = hd_dout[row];
+            d = ds * wv;
+            s3 = fmaf(ds, yv, s3);
+            s4 += ds;
+        } else {
+            d = dy[row * lddy + c];
+        }
         if (keep) d = keep[row * N + c] ? d * inv_keep : 0.f;
-        d *= lrelu_grad(y[row * ldy + c]);
+        d *= lrelu_grad(yv);
         if (cok) dpre[row * N + c] = d;
         const float xh = (a2[row * lda2 + c] - mu) * rs;
         const float d3 = d * lrelu_grad(s[row * lds + c]);
@@ -497,12 +513,13 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
     sh[sub][0][lane] = s0;
     sh[sub][1][lane] = s1;
     sh[sub][2][lane] = s2;
+    sh[sub][3][lane] = s3;
+    sh[sub][4][lane] = s4;
     __syncthreads();
     if (sub == 0 && cok) {
-        float* o = part + (size_t)blockIdx.y * 3 * N;
-        o[c] = ((sh[0][0][lane] + sh[1][0][lane]) + sh[2][0][lane]) + sh[3][0][lane];
-        o[N + c] = ((sh[0][1][lane] + sh[1][1][lane]) + sh[2][1][lane]) + sh[3][1][lane];
-        o[2 * N + c] = ((sh[0][2][lane] + sh[1][2][lane]) + sh[2][2][lane]) + sh[3][2][lane];
+        float* o = part + (size_t)blockIdx.y * nq * N;
+        for (int q = 0; q < nq; ++q)
+            o[q * N + c] = ((sh[0][q][lane] + sh[1][q][lane]) + sh[2][q][lane]) + sh[3][q][lane];
     }
 }
 
@@ -586,7 +603,8 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
                                                               float* __restrict__ d1, float* __restrict__ d2,
                                                               int accumulate, float* __restrict__ copy0,
                                                               float* __restrict__ copy2, float* __restrict__ zero0,
-                                                              int nz0, float* __restrict__ zero1, int nz1) {
+                                                              int nz0, float* __restrict__ zero1, int nz1,
+                                                              float* __restrict__ d3, float* __restrict__ d4) {
     __shared__ float sh[SUB][64];
     if (blockIdx.x == 0) {  // ranges the caller wants cleared alongside (saves separate memset launches)
         for (int z = threadIdx.x; z < nz0; z += 256) zero0[z] = 0.f;
@@ -613,7 +631,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
         }
     }
     if (sub == 0 && ok) {
-        float* d = q == 0 ? d0 : q == 1 ? d1 : d2;
+        float* d = q == 0 ? d0 : q == 1 ? d1 : q == 2 ? d2 : q == 3 ? d3 : (c == 0 ? d4 : nullptr);  // q 4: one scalar
         if (d) d[c] = accumulate ? d[c] + tot : tot;
         if (q == 0 && copy0) copy0[c] = tot;
         if (q == 2 && copy2) copy2[c] = tot;
@@ -1115,11 +1133,13 @@ int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B,
 
 int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const uint8_t* keep, const float* s,
                        int lds, const float* a2, int lda2, const float* mean, const float* rstd, int B, int rpg, int N,
-                       float* dpre, float* da3, int ldda3, float* part, hipStream_t st) {
+                       float* dpre, float* da3, int ldda3, float* part, hipStream_t st, const float* hd_dout,
+                       const float* hd_w, int nq) {
+    if (!dy && !hd_dout) return DGG_ERR_INVALID;
     const int groups = B / rpg;
     dim3 grid(cdiv(N, 64), groups * nrb_of(rpg));
     hipLaunchKernelGGL(res_out_bwd_kernel, grid, dim3(256), 0, st, dy, lddy, y, ldy, keep, s, lds, a2, lda2, mean,
-                       rstd, rpg, nrb_of(rpg), N, dpre, da3, ldda3, part);
+                       rstd, rpg, nrb_of(rpg), N, dpre, da3, ldda3, part, hd_dout, hd_w, nq);
     return check_launch("res_out_bwd");
 }
 
@@ -1144,11 +1164,11 @@ int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const flo
 
 int colsum_finalize_launch(const float* part, int groups, int nrb, int nq, int ncols, float* sums_out, float* dst0,
                            float* dst1, float* dst2, int accumulate, hipStream_t st, int ld, int c_lo, float* copy0,
-                           float* copy2, float* zero0, int nz0, float* zero1, int nz1) {
+                           float* copy2, float* zero0, int nz0, float* zero1, int nz1, float* dst3, float* dst4) {
     if (ld <= 0) ld = ncols;
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(nq * ncols, 64)), dim3(256), 0, st, part, groups, nrb, nq,
                        ncols, ld, c_lo, sums_out, dst0, dst1, dst2, accumulate, copy0, copy2, zero0, zero0 ? nz0 : 0,
-                       zero1, zero1 ? nz1 : 0);
+                       zero1, zero1 ? nz1 : 0, dst3, dst4);
     return check_launch("colsum_finalize");
 }
 
