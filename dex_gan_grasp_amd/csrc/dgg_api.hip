@@ -539,12 +539,10 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
         const long long slab = (long long)B * L.hid;
         prob_split(g.p[0], 4, slab);
         DGG_TRY(gemm_launch(GEMM_NN, g, c.st));
-        DGG_TRY(reduce_bias_launch(c.W.slabs, g.p[0].splits, slab, L.hid, nullptr, c.W.dh, L.hid, B, B, 1, L.hid, 0, 0,
-                                   0, 0, nullptr, c.st));
+        // 4. slabs -> dh, through lrelu and bn1 -> da1 into dY13[:, 0:256] (the slab sum happens inside act_bwd)
+        DGG_TRY(act_bwd_launch(c.W.slabs, L.hid, A.h, L.hid, A.a13, L.n13, A.mean1, A.rstd1, B, B, L.hid, c.W.dh, L.hid,
+                               c.W.part, c.st, g.p[0].splits, slab));
     }
-    // 4. through lrelu and bn1 -> da1 into dY13[:, 0:256]
-    DGG_TRY(act_bwd_launch(c.W.dh, L.hid, A.h, L.hid, A.a13, L.n13, A.mean1, A.rstd1, B, B, L.hid, c.W.dh, L.hid,
-                           c.W.part, c.st));
     DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 2, L.hid, c.W.sums, gp(R.bn1b), gp(R.bn1w), nullptr, acc, c.st));
     DGG_TRY(bn_bwd_apply_launch(c.W.dh, L.hid, A.a13, L.n13, A.mean1, A.rstd1, c.P + R.bn1w, c.W.sums, c.train, B, B,
                                 L.hid, dY13, L.n13, c.W.part, c.st));

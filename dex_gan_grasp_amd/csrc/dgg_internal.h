@@ -134,7 +134,8 @@ int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, cons
 // Stage 3: dq = dh * lrelu'(h) (in place on dh allowed); partial sums: sum dq, sum dq*xhat1.
 int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const float* a1, int lda1, const float* mean,
                    const float* rstd, int B, int rows_per_group, int N, float* dq, int lddq, float* part,
-                   hipStream_t st);
+                   hipStream_t st,
+                   int nslab = 0, long long slab_stride = 0);
 // Sum partial column sums over row blocks: part [groups][nrb][nq][ncols] ->
 //   sums_out [groups][nq][ncols] (may be NULL) and, summed over groups, into up to 3 gradient
 //   destinations (NULL to skip): dst[q][c] (+)= sum.

@@ -566,7 +566,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ a1, int lda1,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       int rpg, int nrb, int N, float* __restrict__ dq, int lddq,
-                                                      float* __restrict__ part) {
+                                                      float* __restrict__ part, int nslab, long long slab_stride) {
+    // nslab > 0: `dh` is a stack of split-K slabs (pitch lddh, slab_stride apart) summed here in slab (= k) order —
+    // the separate reduce launch between the dh GEMM and this kernel is gone
     __shared__ float sh[SUB][2][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 64 + lane;
@@ -579,7 +581,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     float s0 = 0.f, s1 = 0.f;
     for (int r = 0; r < n; ++r) {
         const size_t row = (size_t)(g * rpg + r0 + r);
-        const float d = dh[row * lddh + c] * lrelu_grad(h[row * ldh + c]);
+        float dv = dh[row * lddh + c];
+        for (int q = 1; q < nslab; ++q) dv += dh[(size_t)q * slab_stride + row * lddh + c];
+        const float d = dv * lrelu_grad(h[row * ldh + c]);
         if (cok) dq[row * lddq + c] = d;
         const float xh = (a1[row * lda1 + c] - mu) * rs;
         s0 += d;
@@ -1154,11 +1158,12 @@ int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, cons
 }
 
 int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const float* a1, int lda1, const float* mean,
-                   const float* rstd, int B, int rpg, int N, float* dq, int lddq, float* part, hipStream_t st) {
+                   const float* rstd, int B, int rpg, int N, float* dq, int lddq, float* part, hipStream_t st,
+                   int nslab, long long slab_stride) {
     const int groups = B / rpg;
     dim3 grid(cdiv(N, 64), groups * nrb_of(rpg));
     hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, st, dh, lddh, h, ldh, a1, lda1, mean, rstd, rpg,
-                       nrb_of(rpg), N, dq, lddq, part);
+                       nrb_of(rpg), N, dq, lddq, part, nslab, slab_stride);
     return check_launch("act_bwd");
 }
 
