@@ -460,10 +460,13 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
     else
         DGG_TRY(reduce_bias_launch(c.W.slabs, nslab, slab, L.n13, c.P + R.b13, A.a13, L.n13, B, B, 1, L.n13, 0, L.hid,
                                    L.hid, L.n13, c.W.part, c.st));
-    DGG_TRY(bn_finalize_launch(c.W.part, B, 1, L.hid, c.train, c.bn ? c.bn + R.rm1 : nullptr,
-                               c.bn ? c.bn + R.rv1 : nullptr, A.mean1, A.rstd1, c.st));
-    // 3. h = lrelu(bn1(a1))
-    DGG_TRY(bn_act_launch(A.a13, L.n13, B, B, L.hid, A.mean1, A.rstd1, c.P + R.bn1w, c.P + R.bn1b, A.h, L.hid, c.st));
+    // 3. h = lrelu(bn1(a1)); the statistics are finalized inside the kernel (mean1 / rstd1 kept for the backward)
+    {
+        BnFused fz{c.W.part, c.train ? 1 : 0, c.bn ? c.bn + R.rm1 : nullptr, c.bn ? c.bn + R.rv1 : nullptr, A.mean1,
+                   A.rstd1};
+        DGG_TRY(bn_act_launch(A.a13, L.n13, B, B, L.hid, A.mean1, A.rstd1, c.P + R.bn1w, c.P + R.bn1b, A.h, L.hid, c.st,
+                              &fz));
+    }
     // 4. a2 = h W2^T + b2 (K = 256)
     {
         GemmBatch g2;
@@ -476,11 +479,13 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
         DGG_TRY(reduce_bias_launch(c.W.slabs, g2.p[0].splits, slab2, L.nn, c.P + R.b2, A.a2, L.nn, B, B, 1, L.nn, 0,
                                    L.nn, 0, 0, c.W.part, c.st));
     }
-    DGG_TRY(bn_finalize_launch(c.W.part, B, 1, L.nn, c.train, c.bn ? c.bn + R.rm2 : nullptr,
-                               c.bn ? c.bn + R.rv2 : nullptr, A.mean2, A.rstd2, c.st));
-    // 5. y = lrelu(s + bn2(a2)) [dropout]
-    DGG_TRY(res_out_launch(A.a13 + L.hid, L.n13, A.a2, L.nn, B, B, L.nn, A.mean2, A.rstd2, c.P + R.bn2w, c.P + R.bn2b,
-                           drop_mode, keep_in, seed, seed_off, A.keep, A.y, L.nn, c.st));
+    // 5. y = lrelu(s + bn2(a2)) [dropout]; bn2's statistics finalized inside
+    {
+        BnFused fz{c.W.part, c.train ? 1 : 0, c.bn ? c.bn + R.rm2 : nullptr, c.bn ? c.bn + R.rv2 : nullptr, A.mean2,
+                   A.rstd2};
+        DGG_TRY(res_out_launch(A.a13 + L.hid, L.n13, A.a2, L.nn, B, B, L.nn, A.mean2, A.rstd2, c.P + R.bn2w,
+                               c.P + R.bn2b, drop_mode, keep_in, seed, seed_off, A.keep, A.y, L.nn, c.st, &fz));
+    }
     return DGG_OK;
 }
 
@@ -651,9 +656,11 @@ static int net_forward(const NetL& L, const float* params, float* bn, void* ws, 
     if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
     if (!bn) return DGG_ERR_INVALID;
     if (c.train) DGG_TRY(ibn_stats_launch(srcs, B, 1, c.W.part, st));
-    DGG_TRY(bn_finalize_launch(c.W.part, B, 1, L.k_in, c.train, bn + L.irm, bn + L.irv, c.W.imean, c.W.irstd, st));
-    DGG_TRY(ibn_apply_launch(srcs, B, B, c.W.imean, c.W.irstd, nullptr, nullptr, prefix, L.nprefix, c.W.X0, L.ldx0,
-                             params + L.ibnw, params + L.ibnb, c.W.aff_scale, c.W.aff_shift, st));
+    {
+        BnFused fz{c.W.part, c.train ? 1 : 0, bn + L.irm, bn + L.irv, c.W.imean, c.W.irstd};
+        DGG_TRY(ibn_apply_launch(srcs, B, B, c.W.imean, c.W.irstd, nullptr, nullptr, prefix, L.nprefix, c.W.X0, L.ldx0,
+                                 params + L.ibnw, params + L.ibnb, c.W.aff_scale, c.W.aff_shift, st, &fz));
+    }
     const bool drop = (L.net == DGG_NET_EVA) && c.train;
     for (int r = 0; r < L.nrb; ++r) {
         Seg segs[2];

@@ -84,6 +84,14 @@ struct ColSrcs {
 
 // Partial batch statistics (mean, M2) of the virtual concat of `srcs` per (group,row block,column).
 int ibn_stats_launch(const ColSrcs& srcs, int rows_per_group, int groups, float* part, hipStream_t st);
+// Finalize fused into the consumer (ibn_apply / bn_act / res_out): the kernel merges the partials of its own columns
+// (train) or reads the running statistics (eval), uses them, and its first row of workgroups stores mean / rstd
+// (mean_out / rstd_out: [groups][ncols]) and advances the running statistics.
+struct BnFused {
+    const float* part;
+    int train;
+    float *run_mean, *run_var, *mean_out, *rstd_out;
+};
 // Merge partials -> mean/rstd (train) or take running stats (eval); update running stats.
 //   part: [groups][nrb][2][ncols];  mean/rstd out: [groups][ncols]
 int bn_finalize_launch(const float* part, int rows_per_group, int groups, int ncols, int train, float* run_mean,
@@ -93,7 +101,7 @@ int bn_finalize_launch(const float* part, int rows_per_group, int groups, int nc
 int ibn_apply_launch(const ColSrcs& srcs, int B, int rows_per_group, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, const float* prefix, int nprefix, float* X0, int ldx,
                      const float* aff_gamma, const float* aff_beta, float* aff_scale, float* aff_shift,
-                     hipStream_t st);
+                     hipStream_t st, const BnFused* fused = nullptr);
 
 // out[m][c] = sum_s slabs[s][m][c] (+ sum_s slabs2[s][m][c], same stride / pitch) + bias[c];  columns [stat_lo, stat_hi) get partial statistics,
 // columns [act_lo, act_hi) get LeakyReLU applied before the store.
@@ -103,13 +111,14 @@ int reduce_bias_launch(const float* slabs, int nslab, long long slab_stride, int
                        const float* slabs2 = nullptr, int nslab2 = 0);
 // h[m][c] = lrelu((a[m][c]-mean)*rstd*gamma+beta)
 int bn_act_launch(const float* a, int lda, int B, int rows_per_group, int N, const float* mean, const float* rstd,
-                  const float* gamma, const float* beta, float* h, int ldh, hipStream_t st);
+                  const float* gamma, const float* beta, float* h, int ldh, hipStream_t st,
+                  const BnFused* fused = nullptr);
 // y = lrelu(s + bn2(a2)) then dropout (keep mask given as floats, or drawn from Philox when
 // drop_mode == 2); writes the keep mask (bytes) when dropping.  drop_mode: 0 none, 1 given, 2 rng.
 int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, int rows_per_group, int N,
                    const float* mean, const float* rstd, const float* gamma, const float* beta, int drop_mode,
                    const float* keep_in, uint64_t seed, uint64_t seed_off, uint8_t* keep_out, float* y, int ldy,
-                   hipStream_t st);
+                   hipStream_t st, const BnFused* fused = nullptr);
 // heads: out[m][j] = sum_k y[m][k] Wh[j][k] + bh[j]; sigmoid optionally.
 int heads_fwd_launch(const float* y, int ldy, int B, int K, const float* wh, const float* bh, int nh, int sigmoid,
                      float* out, int ldo, float* scratch, hipStream_t st);

@@ -121,6 +121,87 @@ __global__ __launch_bounds__(256) void ibn_stats_kernel(ColSrcs S, int rpg, int 
     }
 }
 
+// Fused form of bn_finalize_kernel for the kernels that consume the statistics: every workgroup merges the
+// row-block partials of ITS 64 columns (same order, same arithmetic, hence the same bits in every workgroup),
+// leaves mean / rstd of each group in `res`, and the workgroups with `writer` set also store them for the backward
+// and advance the running statistics.  Must be reached by all 256 threads.  c: this lane's column, clamped into
+// [0, ncols); cok: lane owns a real BN column.
+struct BnFin {
+    const float* part;   // NULL: statistics were finalized by an earlier launch (mean / rstd arrays are read)
+    int nrb, train;
+    float *run_mean, *run_var, *mean_out, *rstd_out;
+};
+__device__ __forceinline__ void bn_block_stats(const BnFin& f, int rpg, int groups, int ncols, int c, bool cok,
+                                               bool writer, float (*sh)[3][64], float (*res)[2][64]) {
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    if (!f.train) {
+        if (sub == 0) {
+            const float m = f.run_mean[c];
+            const float rs = 1.0f / sqrtf(f.run_var[c] + kBnEps);
+            for (int g = 0; g < groups; ++g) {
+                res[g][0][lane] = m;
+                res[g][1][lane] = rs;
+                if (writer && cok) {
+                    f.mean_out[g * ncols + c] = m;
+                    f.rstd_out[g * ncols + c] = rs;
+                }
+            }
+        }
+        __syncthreads();
+        return;
+    }
+    float rm = f.run_mean ? f.run_mean[c] : 0.f, rv = f.run_var ? f.run_var[c] : 0.f;
+    const int per = (f.nrb + SUB - 1) / SUB;
+    const int rb_lo = min(f.nrb, sub * per), rb_hi = min(f.nrb, rb_lo + per);
+    for (int g = 0; g < groups; ++g) {
+        float cnt = 0.f, mean = 0.f, m2 = 0.f;
+        for (int rb = rb_lo; rb < rb_hi; ++rb) {
+            const float* p = f.part + (size_t)(g * f.nrb + rb) * 2 * ncols;
+            const float nb = (float)min(RB, rpg - rb * RB);
+            const float mb = p[c], qb = p[ncols + c];
+            const float tot = cnt + nb;
+            const float d = mb - mean;
+            mean += d * (nb / tot);
+            m2 += qb + d * d * (cnt * nb / tot);
+            cnt = tot;
+        }
+        __syncthreads();
+        sh[sub][0][lane] = cnt;
+        sh[sub][1][lane] = mean;
+        sh[sub][2][lane] = m2;
+        __syncthreads();
+        if (sub == 0) {
+            cnt = 0.f; mean = 0.f; m2 = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < SUB; ++s2) {
+                const float nb = sh[s2][0][lane];
+                if (nb > 0.f) {
+                    const float tot = cnt + nb;
+                    const float d = sh[s2][1][lane] - mean;
+                    mean += d * (nb / tot);
+                    m2 += sh[s2][2][lane] + d * d * (cnt * nb / tot);
+                    cnt = tot;
+                }
+            }
+            const float rstd = 1.0f / sqrtf(m2 / cnt + kBnEps);
+            res[g][0][lane] = mean;
+            res[g][1][lane] = rstd;
+            if (writer && cok) {
+                f.mean_out[g * ncols + c] = mean;
+                f.rstd_out[g * ncols + c] = rstd;
+            }
+            const float var_u = m2 / (cnt - 1.f);
+            rm = (1.f - kBnMom) * rm + kBnMom * mean;
+            rv = (1.f - kBnMom) * rv + kBnMom * var_u;
+        }
+    }
+    if (sub == 0 && writer && cok) {
+        if (f.run_mean) f.run_mean[c] = rm;
+        if (f.run_var) f.run_var[c] = rv;
+    }
+    __syncthreads();
+}
+
 // 64 columns per workgroup; the 4 waves merge disjoint ranges of row blocks, wave 0 merges those in order.
 // Groups are processed in order so running statistics see the reference's call order.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rpg, int groups,
@@ -202,10 +283,19 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
                                                         float* __restrict__ X0, int ldx,
                                                         const float* __restrict__ aff_gamma,
                                                         const float* __restrict__ aff_beta,
-                                                        float* __restrict__ aff_scale, float* __restrict__ aff_shift) {
+                                                        float* __restrict__ aff_scale, float* __restrict__ aff_shift,
+                                                        BnFin fin) {
+    __shared__ float sh[SUB][3][64];
+    __shared__ float res[2][2][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int oc = blockIdx.x * 64 + lane;
-    if (oc >= nprefix + S.total) return;
+    const bool ook = oc < nprefix + S.total;
+    const bool bnc = ook && oc >= nprefix;
+    const int c = bnc ? oc - nprefix : 0;
+    const int groups = B / rpg;
+    const bool fused = fin.mean_out != nullptr;
+    if (fused) bn_block_stats(fin, rpg, groups, S.total, c, bnc, blockIdx.y == 0, sh, res);
+    if (!ook) return;
     const int r0 = blockIdx.y * RB + sub * RS;
     const int n = min(RS, B - r0);
     if (aff_scale && blockIdx.y == 0 && sub == 0) {
@@ -216,16 +306,17 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
         for (int r = 0; r < n; ++r) X0[(size_t)(r0 + r) * ldx + oc] = prefix[(size_t)(r0 + r) * nprefix + oc];
         return;
     }
-    const int c = oc - nprefix;
     int ld;
     const float* p = src_col(S, c, ld);
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
     for (int r = 0; r < n; ++r) {
         const int row = r0 + r;
         const int g = row / rpg;
-        const float sc = rstd[g * S.total + c] * ga;
-        const float sh = be - mean[g * S.total + c] * sc;
-        X0[(size_t)row * ldx + oc] = fmaf(p[(size_t)row * ld], sc, sh);
+        const float mu = fused ? res[g][0][lane] : mean[g * S.total + c];
+        const float rs = fused ? res[g][1][lane] : rstd[g * S.total + c];
+        const float sc = rs * ga;
+        const float shf = be - mu * sc;
+        X0[(size_t)row * ldx + oc] = fmaf(p[(size_t)row * ld], sc, shf);
     }
 }
 
@@ -309,19 +400,27 @@ __global__ __launch_bounds__(256) void reduce_bias_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ a, int lda, int B, int rpg, int N,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ h, int ldh) {
+                                                     float* __restrict__ h, int ldh, BnFin fin) {
+    __shared__ float sh[SUB][3][64];
+    __shared__ float res[2][2][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    if (c >= N) return;
+    const int c0 = blockIdx.x * 64 + lane;
+    const bool cok = c0 < N;
+    const int c = cok ? c0 : N - 1;
+    const bool fused = fin.mean_out != nullptr;
+    if (fused) bn_block_stats(fin, rpg, B / rpg, N, c, cok, blockIdx.y == 0, sh, res);
+    if (!cok) return;
     const int r0 = blockIdx.y * RB + sub * RS;
     const int n = min(RS, B - r0);
     const float ga = gamma[c], be = beta[c];
     for (int r = 0; r < n; ++r) {
         const int row = r0 + r;
         const int g = row / rpg;
-        const float sc = rstd[g * N + c] * ga;
-        const float sh = be - mean[g * N + c] * sc;
-        h[(size_t)row * ldh + c] = lrelu(fmaf(a[(size_t)row * lda + c], sc, sh));
+        const float mu = fused ? res[g][0][lane] : mean[g * N + c];
+        const float rs = fused ? res[g][1][lane] : rstd[g * N + c];
+        const float sc = rs * ga;
+        const float shf = be - mu * sc;
+        h[(size_t)row * ldh + c] = lrelu(fmaf(a[(size_t)row * lda + c], sc, shf));
     }
 }
 
@@ -358,10 +457,16 @@ __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ 
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       int drop_mode, const float* __restrict__ keep_in, uint64_t seed,
                                                       uint64_t seed_off, uint8_t* __restrict__ keep_out,
-                                                      float* __restrict__ y, int ldy) {
+                                                      float* __restrict__ y, int ldy, BnFin fin) {
+    __shared__ float sh[SUB][3][64];
+    __shared__ float res[2][2][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    if (c >= N) return;
+    const int c0 = blockIdx.x * 64 + lane;
+    const bool cok = c0 < N;
+    const int c = cok ? c0 : N - 1;
+    const bool fused = fin.mean_out != nullptr;
+    if (fused) bn_block_stats(fin, rpg, B / rpg, N, c, cok, blockIdx.y == 0, sh, res);
+    if (!cok) return;
     const int r0 = blockIdx.y * RB + sub * RS;
     const int n = min(RS, B - r0);
     const float ga = gamma[c], be = beta[c];
@@ -369,9 +474,11 @@ __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ 
     for (int r = 0; r < n; ++r) {
         const int row = r0 + r;
         const int g = row / rpg;
-        const float sc = rstd[g * N + c] * ga;
-        const float sh = be - mean[g * N + c] * sc;
-        float v = lrelu(s[(size_t)row * lds + c] + fmaf(a2[(size_t)row * lda2 + c], sc, sh));
+        const float mu = fused ? res[g][0][lane] : mean[g * N + c];
+        const float rs = fused ? res[g][1][lane] : rstd[g * N + c];
+        const float sc = rs * ga;
+        const float shf = be - mu * sc;
+        float v = lrelu(s[(size_t)row * lds + c] + fmaf(a2[(size_t)row * lda2 + c], sc, shf));
         if (drop_mode) {
             const size_t e = (size_t)row * N + c;
             const float k = drop_mode == 1 ? keep_in[e] : philox_keep(seed, seed_off + e);
@@ -997,6 +1104,21 @@ int ibn_stats_launch(const ColSrcs& srcs, int rpg, int groups, float* part, hipS
     return check_launch("ibn_stats");
 }
 
+// host side of BnFin: NULL -> statistics already finalized (the kernel reads its mean / rstd arguments)
+static int make_fin(const BnFused* fz, int rpg, BnFin& fin) {
+    memset(&fin, 0, sizeof(fin));
+    if (!fz) return DGG_OK;
+    if (fz->train && rpg < 2) return DGG_ERR_INVALID;  // torch: "Expected more than 1 value per channel when training"
+    fin.part = fz->part;
+    fin.nrb = nrb_of(rpg);
+    fin.train = fz->train;
+    fin.run_mean = fz->run_mean;
+    fin.run_var = fz->run_var;
+    fin.mean_out = fz->mean_out;
+    fin.rstd_out = fz->rstd_out;
+    return DGG_OK;
+}
+
 int bn_finalize_launch(const float* part, int rpg, int groups, int ncols, int train, float* run_mean, float* run_var,
                        float* mean, float* rstd, hipStream_t st) {
     if (train && rpg < 2) return DGG_ERR_INVALID;  // torch: "Expected more than 1 value per channel when training"
@@ -1007,10 +1129,12 @@ int bn_finalize_launch(const float* part, int rpg, int groups, int ncols, int tr
 
 int ibn_apply_launch(const ColSrcs& srcs, int B, int rpg, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, const float* prefix, int nprefix, float* X0, int ldx, const float* aff_gamma,
-                     const float* aff_beta, float* aff_scale, float* aff_shift, hipStream_t st) {
+                     const float* aff_beta, float* aff_scale, float* aff_shift, hipStream_t st, const BnFused* fz) {
+    BnFin fin;
+    if (int rc = make_fin(fz, rpg, fin)) return rc;
     dim3 grid(cdiv(nprefix + srcs.total, 64), cdiv(B, RB));
     hipLaunchKernelGGL(ibn_apply_kernel, grid, dim3(256), 0, st, srcs, B, rpg, mean, rstd, gamma, beta, prefix,
-                       nprefix, X0, ldx, aff_gamma, aff_beta, aff_scale, aff_shift);
+                       nprefix, X0, ldx, aff_gamma, aff_beta, aff_scale, aff_shift, fin);
     return check_launch("ibn_apply");
 }
 
@@ -1027,18 +1151,23 @@ int reduce_bias_launch(const float* slabs, int nslab, long long slab_stride, int
 }
 
 int bn_act_launch(const float* a, int lda, int B, int rpg, int N, const float* mean, const float* rstd,
-                  const float* gamma, const float* beta, float* h, int ldh, hipStream_t st) {
+                  const float* gamma, const float* beta, float* h, int ldh, hipStream_t st, const BnFused* fz) {
+    BnFin fin;
+    if (int rc = make_fin(fz, rpg, fin)) return rc;
     dim3 grid(cdiv(N, 64), cdiv(B, RB));
-    hipLaunchKernelGGL(bn_act_kernel, grid, dim3(256), 0, st, a, lda, B, rpg, N, mean, rstd, gamma, beta, h, ldh);
+    hipLaunchKernelGGL(bn_act_kernel, grid, dim3(256), 0, st, a, lda, B, rpg, N, mean, rstd, gamma, beta, h, ldh, fin);
     return check_launch("bn_act");
 }
 
 int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, int rpg, int N, const float* mean,
                    const float* rstd, const float* gamma, const float* beta, int drop_mode, const float* keep_in,
-                   uint64_t seed, uint64_t seed_off, uint8_t* keep_out, float* y, int ldy, hipStream_t st) {
+                   uint64_t seed, uint64_t seed_off, uint8_t* keep_out, float* y, int ldy, hipStream_t st,
+                   const BnFused* fz) {
+    BnFin fin;
+    if (int rc = make_fin(fz, rpg, fin)) return rc;
     dim3 grid(cdiv(N, 64), cdiv(B, RB));
     hipLaunchKernelGGL(res_out_kernel, grid, dim3(256), 0, st, s, lds, a2, lda2, B, rpg, N, mean, rstd, gamma, beta,
-                       drop_mode, keep_in, seed, seed_off, keep_out, y, ldy);
+                       drop_mode, keep_in, seed, seed_off, keep_out, y, ldy, fin);
     return check_launch("res_out");
 }
 
