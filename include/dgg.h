@@ -14,7 +14,7 @@
  *    running statistics and workspaces are caller-owned buffers whose sizes the *_floats / *_bytes
  *    queries return; layouts of the flat buffers are described by dgg_table();
  *  - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = the
- *    null stream); nothing synchronises, so calls are graph-capturable;
+ *    null stream); nothing synchronises with the host;
  *  - return value: DGG_OK (0) or a negative dgg_status; no exceptions cross the boundary;
  *  - re-entrant across streams with distinct workspaces; not thread-safe on one workspace.
  *  - all tensors fp32 row-major contiguous unless a leading dimension is given.
