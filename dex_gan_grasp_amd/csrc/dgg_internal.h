@@ -92,10 +92,6 @@ struct BnFused {
     int train;
     float *run_mean, *run_var, *mean_out, *rstd_out;
 };
-// Merge partials -> mean/rstd (train) or take running stats (eval); update running stats.
-//   part: [groups][nrb][2][ncols];  mean/rstd out: [groups][ncols]
-int bn_finalize_launch(const float* part, int rows_per_group, int groups, int ncols, int train, float* run_mean,
-                       float* run_var, float* mean, float* rstd, hipStream_t st);
 // X0[m][col_off + c] = (x - mean)*rstd*gamma + beta over the concat; optionally copies `prefix`
 // (B, nprefix) into columns [0, nprefix).
 int ibn_apply_launch(const ColSrcs& srcs, int B, int rows_per_group, const float* mean, const float* rstd,

@@ -121,8 +121,10 @@ __global__ __launch_bounds__(256) void ibn_stats_kernel(ColSrcs S, int rpg, int 
     }
 }
 
-// Fused form of bn_finalize_kernel for the kernels that consume the statistics: every workgroup merges the
-// row-block partials of ITS 64 columns (same order, same arithmetic, hence the same bits in every workgroup),
+// BatchNorm statistics are finalized inside the kernels that consume them: every workgroup merges the row-block
+// partials of ITS 64 columns — the 4 waves merge disjoint ranges of row blocks (Chan), wave 0 merges those in order;
+// same order, same arithmetic, hence the same bits in every workgroup; groups in order, so the running statistics
+// see the reference's call order —
 // leaves mean / rstd of each group in `res`, and the workgroups with `writer` set also store them for the backward
 // and advance the running statistics.  Must be reached by all 256 threads.  c: this lane's column, clamped into
 // [0, ncols); cok: lane owns a real BN column.
@@ -200,76 +202,6 @@ __device__ __forceinline__ void bn_block_stats(const BnFin& f, int rpg, int grou
         if (f.run_var) f.run_var[c] = rv;
     }
     __syncthreads();
-}
-
-// 64 columns per workgroup; the 4 waves merge disjoint ranges of row blocks, wave 0 merges those in order.
-// Groups are processed in order so running statistics see the reference's call order.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rpg, int groups,
-                                                          int nrb, int ncols, int train,
-                                                          float* __restrict__ run_mean,
-                                                          float* __restrict__ run_var, float* __restrict__ mean_out,
-                                                          float* __restrict__ rstd_out) {
-    __shared__ float sh[SUB][3][64];
-    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const int c0 = blockIdx.x * 64 + lane;
-    const bool cok = c0 < ncols;
-    const int c = cok ? c0 : ncols - 1;
-    if (!train) {
-        if (sub == 0 && cok) {
-            const float m = run_mean[c];
-            const float rs = 1.0f / sqrtf(run_var[c] + kBnEps);
-            for (int g = 0; g < groups; ++g) {
-                mean_out[g * ncols + c] = m;
-                rstd_out[g * ncols + c] = rs;
-            }
-        }
-        return;
-    }
-    float rm = run_mean ? run_mean[c] : 0.f, rv = run_var ? run_var[c] : 0.f;
-    const int per = (nrb + SUB - 1) / SUB;
-    const int rb_lo = min(nrb, sub * per), rb_hi = min(nrb, rb_lo + per);
-    for (int g = 0; g < groups; ++g) {
-        float cnt = 0.f, mean = 0.f, m2 = 0.f;
-        for (int rb = rb_lo; rb < rb_hi; ++rb) {
-            const float* p = part + (size_t)(g * nrb + rb) * 2 * ncols;
-            const float nb = (float)min(RB, rpg - rb * RB);
-            const float mb = p[c], qb = p[ncols + c];
-            const float tot = cnt + nb;
-            const float d = mb - mean;
-            mean += d * (nb / tot);
-            m2 += qb + d * d * (cnt * nb / tot);
-            cnt = tot;
-        }
-        __syncthreads();
-        sh[sub][0][lane] = cnt;
-        sh[sub][1][lane] = mean;
-        sh[sub][2][lane] = m2;
-        __syncthreads();
-        if (sub == 0 && cok) {
-            cnt = 0.f; mean = 0.f; m2 = 0.f;
-#pragma unroll
-            for (int s2 = 0; s2 < SUB; ++s2) {
-                const float nb = sh[s2][0][lane];
-                if (nb > 0.f) {
-                    const float tot = cnt + nb;
-                    const float d = sh[s2][1][lane] - mean;
-                    mean += d * (nb / tot);
-                    m2 += sh[s2][2][lane] + d * d * (cnt * nb / tot);
-                    cnt = tot;
-                }
-            }
-            const float var_b = m2 / cnt;
-            mean_out[g * ncols + c] = mean;
-            rstd_out[g * ncols + c] = 1.0f / sqrtf(var_b + kBnEps);
-            const float var_u = m2 / (cnt - 1.f);
-            rm = (1.f - kBnMom) * rm + kBnMom * mean;
-            rv = (1.f - kBnMom) * rv + kBnMom * var_u;
-        }
-    }
-    if (sub == 0 && cok) {
-        if (run_mean) run_mean[c] = rm;
-        if (run_var) run_var[c] = rv;
-    }
 }
 
 // grid: (ceil((nprefix+ncols)/64), ceil(B/RB)).  gamma == NULL: store the un-affined x_hat = (x-mean)*rstd
@@ -522,50 +454,6 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
 }
 
 // grid: (ceil(K/256), nrb): dy[m][k] = sum_j dout[m][j] wh[j][k]; partial dWh[j][k], dbh[j]
-template <int NHMAX>
-__global__ __launch_bounds__(256) void heads_bwd_kernel(const float* __restrict__ y, int ldy,
-                                                        const float* __restrict__ dout, int ldd, int B, int K,
-                                                        const float* __restrict__ wh, int nh,
-                                                        float* __restrict__ dy, int lddy, int skip_param,
-                                                        float* __restrict__ part) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    const int r0 = blockIdx.y * RB;
-    const int n = min(RB, B - r0);
-    const bool kok = k < K;
-    float w[NHMAX], gw[NHMAX], gb[NHMAX];
-#pragma unroll
-    for (int j = 0; j < NHMAX; ++j) {
-        w[j] = (kok && j < nh) ? wh[(size_t)j * K + k] : 0.f;
-        gw[j] = 0.f;
-        gb[j] = 0.f;
-    }
-    for (int r = 0; r < n; ++r) {
-        const int row = r0 + r;
-        const float yv = kok ? y[(size_t)row * ldy + k] : 0.f;
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < NHMAX; ++j) {
-            if (j < nh) {
-                const float d = dout[(size_t)row * ldd + j];
-                acc = fmaf(d, w[j], acc);
-                gw[j] = fmaf(d, yv, gw[j]);
-                gb[j] += d;
-            }
-        }
-        if (kok) dy[(size_t)row * lddy + k] = acc;
-    }
-    if (skip_param) return;
-    // part layout per row block: [nh*K weights | nh biases]
-    float* o = part + (size_t)blockIdx.y * ((size_t)nh * K + nh);
-#pragma unroll
-    for (int j = 0; j < NHMAX; ++j) {
-        if (j < nh) {
-            if (kok) o[(size_t)j * K + k] = gw[j];
-            if (k == 0) o[(size_t)nh * K + j] = gb[j];
-        }
-    }
-}
-
 // ---------------------------------------------------------------- ResBlock backward stages
 // grid: (ceil(N/256), groups*nrb)
 // Head mode (hd_dout != NULL; single-score head of D / E, networks.py:121,293): the block output's gradient is the
@@ -1119,14 +1007,6 @@ static int make_fin(const BnFused* fz, int rpg, BnFin& fin) {
     return DGG_OK;
 }
 
-int bn_finalize_launch(const float* part, int rpg, int groups, int ncols, int train, float* run_mean, float* run_var,
-                       float* mean, float* rstd, hipStream_t st) {
-    if (train && rpg < 2) return DGG_ERR_INVALID;  // torch: "Expected more than 1 value per channel when training"
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(ncols, 64)), dim3(256), 0, st, part, rpg, groups, nrb_of(rpg),
-                       ncols, train, run_mean, run_var, mean, rstd);
-    return check_launch("bn_finalize");
-}
-
 int ibn_apply_launch(const ColSrcs& srcs, int B, int rpg, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, const float* prefix, int nprefix, float* X0, int ldx, const float* aff_gamma,
                      const float* aff_beta, float* aff_scale, float* aff_shift, hipStream_t st, const BnFused* fz) {
@@ -1230,7 +1110,7 @@ int heads_fwd_launch(const float* y, int ldy, int B, int K, const float* wh, con
                               nullptr, st);
 }
 
-// scratch: nh == 1: per-row-block partials; nh > 1: >= 8 * nh * K floats of split-K slabs
+// Multi-output heads only (generator).  scratch: >= 8 * nh * K floats of split-K slabs
 int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B, int K, const float* wh, int nh,
                      float* dy, int lddy, float* gwh, float* gbh, int accumulate, int skip_param, float* scratch,
                      hipStream_t st) {
@@ -1251,16 +1131,7 @@ int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B,
         hipLaunchKernelGGL(narrow_colsum_kernel, dim3(1), dim3(256), 0, st, dout, ldd, B, nh, gbh, accumulate);
         return check_launch("narrow_colsum");
     }
-    const int nrb = cdiv(B, RB);
-    dim3 grid(cdiv(K, 256), nrb);
-    hipLaunchKernelGGL((heads_bwd_kernel<1>), grid, dim3(256), 0, st, y, ldy, dout, ldd, B, K, wh, nh, dy, lddy,
-                       skip_param, scratch);
-    int rc = check_launch("heads_bwd");
-    if (rc || skip_param) return rc;
-    // weights and biases are adjacent in the flat layout iff gbh == gwh + nh*K; finalize separately otherwise
-    const int ncols = nh * K + nh;
-    if (gbh == gwh + (size_t)nh * K) return colsum_finalize_launch(scratch, 1, nrb, 1, ncols, nullptr, gwh, nullptr,
-                                                                   nullptr, accumulate, st);
+    // nh == 1: folded into the last ResBlock's backward (res_out_bwd head mode), see net_backward
     return DGG_ERR_INVALID;
 }
 
