@@ -1102,7 +1102,6 @@ int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
     StepW S;
     DGG_TRY(carve_step(cfg, B, ws, S));
     if (S.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
-    const int nj = cfg->n_hand_joints;
     hipStream_t st = (hipStream_t)stream;
     // :808 D forward #3 with the updated discriminator on the (non-detached) fake grasp; the packed
     // fake transl / joint copies written by the D phase are still valid (same generator output)
