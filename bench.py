@@ -31,6 +31,8 @@ MFLOP_PER_GRASP_FULL = 231.38   # cGAN 167.51 + evaluator 63.87 
 # input-BN parameter gradients come out of the wgrad epilogue), no discriminator dW in the G phase:
 # MACs/sample G 14.6 M + D 36.9 M + E 22.5 M = 74.0 M  ->  148 MFLOP
 MFLOP_PER_GRASP_EXEC = 148.0
+# the next step's batch is resident (as with a prefetching loader): its D real pass is enqueued one step ahead
+PIPELINE = os.environ.get("DGG_PIPELINE", "1") == "1"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
@@ -177,7 +179,7 @@ def main():
     def step(i):
         # one update_dexgangrasp + one update_dexevaluator; gradient all-reduces (N > 1) overlap with the
         # independent phase, see engine.TrainEngine.joint_step
-        eng.joint_step(g_in, zs[i % 4], e_in, True, None, 1234 + i)
+        eng.joint_step(g_in, zs[i % 4], e_in, True, None, 1234 + i, next_gan_inputs=g_in if PIPELINE else None)
 
     for i in range(args.warmup):
         step(i)
@@ -211,6 +213,9 @@ def main():
                        "mflop_per_grasp_as_reference": MFLOP_PER_GRASP_FULL,
                        "mflop_per_grasp_executed": MFLOP_PER_GRASP_EXEC,
                        "step_tflops_executed": round(value * MFLOP_PER_GRASP_EXEC * 1e6 / 1e12 / world, 2),
+                       "pipelining": ("the next step's D real-batch pass is enqueued one step ahead (its batch is "
+                                      "resident, as with a prefetching loader); same results bit for bit"
+                                      if PIPELINE else "none"),
                        "gemm_arithmetic": ("fp32 operands split exactly into 3 bf16 pieces, 6 partial products on the "
                                            "bf16 MFMA, fp32 accumulate (fp32-accurate)"
                                            if int(_lib.lib().dgg_get_gemm_algo()) == 1 else "f32 MFMA")},

@@ -80,6 +80,8 @@ SIGNATURES = {
     "dgg_get_gemm_algo": (_I, []),
     "dgg_cgan_d_phase2": (_I, [_CFG, C.POINTER(GanState), C.POINTER(HParams), _VP, _SZ, _I, _VP, _VP, _VP, _VP, _VP,
                                _VP, _VP, _VP]),
+    "dgg_cgan_d_real_prefetch": (_I, [_CFG, C.POINTER(GanState), C.POINTER(HParams), _VP, _SZ, _I, _VP, _VP, _VP, _VP,
+                                      _VP, _VP]),
     "dgg_cgan_g_phase": (_I, [_CFG, C.POINTER(GanState), C.POINTER(HParams), _VP, _SZ, _I, _VP, _VP, _VP, _VP, _VP,
                               _VP, _VP]),
     "dgg_cgan_step": (_I, [_CFG, C.POINTER(GanState), C.POINTER(HParams), _VP, _SZ, _I, _VP, _VP, _VP, _VP, _VP, _I,

@@ -355,8 +355,9 @@ static hipEvent_t next_event() {
     return pool[cur];
 }
 
+static const int kAuxCap = 64;
 struct AuxMap {
-    hipStream_t key[8], aux[8];
+    hipStream_t key[kAuxCap], aux[kAuxCap];
     int n;
 };
 static thread_local AuxMap g_aux = {{}, {}, 0};
@@ -1023,10 +1024,98 @@ int dgg_set_wgrad_stream(void* stream, void* wgrad_stream) {
             return DGG_OK;
         }
     if (!a) return DGG_OK;
-    if (g_aux.n >= 8) return DGG_ERR_INVALID;
+    if (g_aux.n >= kAuxCap) return DGG_ERR_INVALID;
     g_aux.key[g_aux.n] = k;
     g_aux.aux[g_aux.n] = a;
     ++g_aux.n;
+    return DGG_OK;
+}
+
+// ---- pipelining across steps -------------------------------------------------------------------
+// The real-batch pass of the NEXT D phase needs only D's parameters after this step's Adam and D's BatchNorm running
+// statistics after this step's D forward #3 (dexgangrasp.py:788 follows :808 of the previous call): it can be
+// enqueued on the side stream while this step's G phase is still running (dgg_cgan_d_real_prefetch).  The matching
+// dgg_cgan_d_phase2 call then finds it here and launches only the generator / fake-batch half.
+struct PendingReal {
+    const void* ws;       // key: the step workspace this state belongs to (NULL = free slot)
+    bool valid;           // a real pass has been prefetched for (B, bps, rot9, transl, joint)
+    int B;
+    const float *bps, *rot9, *transl, *joint;
+    hipEvent_t ev[6];     // fwd_done, bwd_done, 3 x share.ready, D-free; created with the slot
+    bool events_ok, dfree_set;
+    Share share;
+    unsigned long long stamp;
+};
+static const int kPendingSlots = 4;   // step workspaces that pipeline concurrently on one thread
+static thread_local PendingReal g_pending[kPendingSlots] = {};
+static thread_local unsigned long long g_pending_clock = 0;
+static const int kLossRealNext = 12;  // losses[] slot of a prefetched real pass' BCE term
+
+// the slot of workspace `ws`; with create: a free slot or the least recently used one is (re)assigned
+static PendingReal* pending_slot(const void* ws, bool create) {
+    PendingReal* lru = &g_pending[0];
+    for (int i = 0; i < kPendingSlots; ++i) {
+        PendingReal& p = g_pending[i];
+        if (p.ws == ws) { p.stamp = ++g_pending_clock; return &p; }
+        if (p.stamp < lru->stamp) lru = &p;
+    }
+    if (!create) return nullptr;
+    if (!lru->events_ok) {
+        for (int i = 0; i < 6; ++i)
+            if (hipEventCreateWithFlags(&lru->ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        lru->events_ok = true;
+    }
+    lru->ws = ws;
+    lru->valid = false;
+    lru->dfree_set = false;
+    lru->stamp = ++g_pending_clock;
+    return lru;
+}
+
+// D(real) forward (producing the shared BPS slabs), BCE(real, 1), D backward(real) overwriting d_grads, all on `sb`
+// (dexgangrasp.py:788, :215-218, :793)
+static int real_pass(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, const StepW& S, const NetL& Ld,
+                     int B, const float* bps, const float* rot9, const float* transl, const float* joint,
+                     float* loss_slot, hipStream_t sb, Share& share, hipEvent_t fwd_done, hipEvent_t bwd_done) {
+    share.mode = 1;
+    DGG_TRY(net_forward(Ld, s->d_params, s->d_bn, S.ws_dr, S.d_bytes, B, DGG_TRAIN,
+                        srcs_pose(cfg, bps, rot9, transl, joint), nullptr, nullptr, 0, S.p_real, sb, &share));
+    if (fwd_done && hipEventRecord(fwd_done, sb) != hipSuccess) return DGG_ERR_LAUNCH;
+    DGG_TRY(bce_launch(S.p_real, nullptr, 1.f, B, (float)hp->bce_weight, 0.5f, loss_slot, S.dl_real, sb));
+    DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint,
+                              S.dl_real, nullptr, sb));
+    if (bwd_done && hipEventRecord(bwd_done, sb) != hipSuccess) return DGG_ERR_LAUNCH;
+    return DGG_OK;
+}
+
+int dgg_cgan_d_real_prefetch(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, void* ws,
+                             size_t ws_bytes, int B, const float* bps, const float* rot9, const float* transl,
+                             const float* joint, float* losses, void* stream2) {
+    if (!s || !hp || !ws || !bps || !rot9 || !transl || !joint || !losses || !stream2) return DGG_ERR_INVALID;
+    StepW S;
+    DGG_TRY(carve_step(cfg, B, ws, S));
+    if (S.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
+    hipStream_t sb = (hipStream_t)stream2;
+    PendingReal* Pp = pending_slot(ws, true);
+    if (!Pp) return DGG_ERR_LAUNCH;
+    PendingReal& P = *Pp;
+    // D's running statistics must already hold this step's third forward, its parameters this step's Adam update:
+    // both precede the D-free mark that dgg_cgan_g_phase (same workspace) leaves on its stream
+    if (P.dfree_set && hipStreamWaitEvent(sb, P.ev[5], 0) != hipSuccess) return DGG_ERR_LAUNCH;
+    NetL Ld;
+    DGG_TRY(build_layout(DGG_NET_DISC, cfg, Ld));
+    memset(&P.share, 0, sizeof(P.share));
+    P.share.ncols = cfg->in_bps;
+    P.share.events = true;
+    for (int r = 0; r < S.d_nrb; ++r) {
+        P.share.slabs[r] = S.dshare[r];
+        P.share.ready[r] = P.ev[2 + r];
+    }
+    P.valid = false;
+    DGG_TRY(real_pass(cfg, s, hp, S, Ld, B, bps, rot9, transl, joint, losses + kLossRealNext, sb, P.share, P.ev[0],
+                      P.ev[1]));
+    P.B = B; P.bps = bps; P.rot9 = rot9; P.transl = transl; P.joint = joint;
+    P.valid = true;
     return DGG_OK;
 }
 
@@ -1042,33 +1131,40 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
     hipStream_t st = (hipStream_t)stream;
     hipStream_t sb = stream2 ? (hipStream_t)stream2 : st;  // the real-batch pass of D
     const bool fork = stream2 && stream2 != stream;
-    hipEvent_t ev[3];
-    if (fork) {
-        for (int i = 0; i < 3; ++i)
-            if (!(ev[i] = next_event())) return DGG_ERR_LAUNCH;
-        if (hipEventRecord(ev[0], st) != hipSuccess || hipStreamWaitEvent(sb, ev[0], 0) != hipSuccess)
-            return DGG_ERR_LAUNCH;
-    }
-    // the BPS-column partial products of D's ResBlocks are computed by the real pass and reused by the fake pass
     NetL Ld;
     DGG_TRY(build_layout(DGG_NET_DISC, cfg, Ld));
+    // a real pass prefetched for exactly these buffers? (anything else: it is dropped and redone)
+    PendingReal* Pp = pending_slot(ws, false);
+    const bool pre = fork && Pp && Pp->valid && Pp->B == B && Pp->bps == bps && Pp->rot9 == rot9 &&
+                     Pp->transl == transl && Pp->joint == joint;
+    if (Pp) Pp->valid = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     Share share;
-    memset(&share, 0, sizeof(share));
-    share.ncols = cfg->in_bps;
-    share.events = fork;
-    for (int r = 0; r < S.d_nrb; ++r) {
-        share.slabs[r] = S.dshare[r];
-        if (fork && !(share.ready[r] = next_event())) return DGG_ERR_LAUNCH;
+    int real_slot = DGG_L_BCE_REAL;
+    if (pre) {
+        share = Pp->share;
+        ev[1] = Pp->ev[0];
+        ev[2] = Pp->ev[1];
+        real_slot = kLossRealNext;
+    } else {
+        if (fork) {
+            for (int i = 0; i < 3; ++i)
+                if (!(ev[i] = next_event())) return DGG_ERR_LAUNCH;
+            if (hipEventRecord(ev[0], st) != hipSuccess || hipStreamWaitEvent(sb, ev[0], 0) != hipSuccess)
+                return DGG_ERR_LAUNCH;
+        }
+        // the BPS-column partial products of D's ResBlocks are computed by the real pass and reused by the fake pass
+        memset(&share, 0, sizeof(share));
+        share.ncols = cfg->in_bps;
+        share.events = fork;
+        for (int r = 0; r < S.d_nrb; ++r) {
+            share.slabs[r] = S.dshare[r];
+            if (fork && !(share.ready[r] = next_event())) return DGG_ERR_LAUNCH;
+        }
+        // ---- stream B: the real-batch pass
+        DGG_TRY(real_pass(cfg, s, hp, S, Ld, B, bps, rot9, transl, joint, losses + DGG_L_BCE_REAL, sb, share, ev[1],
+                          ev[2]));
     }
-    // ---- stream B: D(real) forward, BCE(real, 1), D backward(real) overwriting d_grads        (:788, :215-218, :793)
-    share.mode = 1;
-    DGG_TRY(net_forward(Ld, s->d_params, s->d_bn, S.ws_dr, S.d_bytes, B, DGG_TRAIN,
-                        srcs_pose(cfg, bps, rot9, transl, joint), nullptr, nullptr, 0, S.p_real, sb, &share));
-    if (fork && hipEventRecord(ev[1], sb) != hipSuccess) return DGG_ERR_LAUNCH;
-    DGG_TRY(bce_launch(S.p_real, nullptr, 1.f, B, (float)hp->bce_weight, 0.5f, losses + DGG_L_BCE_REAL, S.dl_real, sb));
-    DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint,
-                              S.dl_real, nullptr, sb));
-    if (fork && hipEventRecord(ev[2], sb) != hipSuccess) return DGG_ERR_LAUNCH;
     // ---- stream A: :772-776 generator forward (train mode, activations kept for the G phase), R = ortho6d(rot_6D)
     DGG_TRY(dgg_gen_forward(cfg, s->g_params, s->g_bn, S.ws_g, S.g_bytes, B, DGG_TRAIN, z, bps, S.heads, stream));
     DGG_TRY(ortho6d_fwd_launch(S.heads + nj, nh, B, S.rfake, st));
@@ -1083,7 +1179,7 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
     DGG_TRY(bce_launch(S.p_fake, nullptr, 0.f, B, (float)hp->bce_weight, 0.5f, losses + DGG_L_BCE_FAKE, S.dl_fake, st));
     // :792-793 the fake pass accumulates onto the real pass' gradients
     if (fork && hipStreamWaitEvent(st, ev[2], 0) != hipSuccess) return DGG_ERR_LAUNCH;
-    DGG_TRY(disc_loss_combine_launch(losses, st));
+    DGG_TRY(disc_loss_combine_launch(losses, st, real_slot));
     DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_df, S.d_bytes, B, DGG_TRAIN | DGG_ACCUM_GRADS, bps,
                               S.rfake, S.f_transl, S.f_joint, S.dl_fake, nullptr, stream));
     return DGG_OK;
@@ -1109,6 +1205,13 @@ int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
     float* g_joint = S.f_joint;
     DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN, bps, S.rfake, g_transl,
                              g_joint, S.p_gen, stream));
+    // D-free mark: from here on nothing in this step writes D's parameters or running statistics
+    if (PendingReal* Pp = pending_slot(ws, true)) {
+        if (hipEventRecord(Pp->ev[5], st) != hipSuccess) return DGG_ERR_LAUNCH;
+        Pp->dfree_set = true;
+    } else {
+        return DGG_ERR_LAUNCH;
+    }
     // :293-296 BCE(fake_score, 1) and its gradient; backward through D for the pose inputs only
     DGG_TRY(bce_launch(S.p_gen, nullptr, 1.f, B, (float)hp->bce_weight, 1.0f, losses + DGG_L_GEN_FAKE, S.dl_gen, st));
     DGG_TRY(dgg_disc_backward(cfg, s->d_params, nullptr, S.ws_df, S.d_bytes, B,

@@ -166,7 +166,7 @@ int ortho6d_bwd_launch(const float* o6, int ld, int B, const float* d_rot9, floa
 int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const float* heads, const float* gt_rot9,
                     const float* gt_transl, const float* gt_joint, const float* fake_score, const float* d_pose,
                     float* losses, float* d_heads, hipStream_t st, float* scratch = nullptr /* >= 4*ceil(B/64) floats */);
-int disc_loss_combine_launch(float* losses, hipStream_t st);
+int disc_loss_combine_launch(float* losses, hipStream_t st, int real_slot = DGG_L_BCE_REAL);
 int adam_launch(float* params, const float* grads, float* m, float* v, int64_t n, int step, double lr, double b1,
                 double b2, double eps, double wd, double grad_scale, hipStream_t st);
 int translate_axis_launch(float* transl, const float* rot9, int B, int axis, float offset, hipStream_t st);

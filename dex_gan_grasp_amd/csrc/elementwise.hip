@@ -925,8 +925,10 @@ __global__ void gen_loss_final_kernel(int nj, float bce_w, float c_tr, float c_r
     losses[DGG_L_TOTAL_GEN] = lf + (ltr + lrot + lcf);
 }
 
-__global__ void disc_loss_combine_kernel(float* losses) {
-    losses[DGG_L_TOTAL_DISC] = (losses[DGG_L_BCE_REAL] + losses[DGG_L_BCE_FAKE]) / 2.f;
+__global__ void disc_loss_combine_kernel(float* losses, int real_slot) {
+    const float r = losses[real_slot];   // a prefetched real pass leaves its term in a spare slot
+    losses[DGG_L_BCE_REAL] = r;
+    losses[DGG_L_TOTAL_DISC] = (r + losses[DGG_L_BCE_FAKE]) / 2.f;
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -1230,8 +1232,8 @@ int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const floa
     return check_launch("gen_loss");
 }
 
-int disc_loss_combine_launch(float* losses, hipStream_t st) {
-    hipLaunchKernelGGL(disc_loss_combine_kernel, dim3(1), dim3(1), 0, st, losses);
+int disc_loss_combine_launch(float* losses, hipStream_t st, int real_slot) {
+    hipLaunchKernelGGL(disc_loss_combine_kernel, dim3(1), dim3(1), 0, st, losses, real_slot);
     return check_launch("disc_loss_combine");
 }
 

@@ -95,6 +95,14 @@ class TrainEngine:
         E.adam_step(hp.lr_eva, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
         return self.losses.clone()
 
+    def __del__(self):
+        # the library's stream -> weight-gradient-stream map must not outlive this engine's streams
+        try:
+            for key in getattr(self, "_wg_mapped", ()):
+                lib().dgg_set_wgrad_stream(C.c_void_p(key), None)
+        except Exception:
+            pass
+
     def _map_wgrad_streams(self, *streams):
         """Give each compute stream a weight-gradient side stream (dgg_set_wgrad_stream): dW GEMMs have no
         consumer before Adam, so they overlap the dgrad chain of the following ResBlocks."""
@@ -119,7 +127,7 @@ class TrainEngine:
 
     # ---- gen + eval step with communication/compute overlap (the unit bench.py times)
     def joint_step(self, gan_inputs, z, eva_inputs, is_train_gen=True, drop_keep=None, seed=0, lr_gen=None,
-                   lr_dis=None, lr_eva=None, two_streams=True):
+                   lr_dis=None, lr_eva=None, two_streams=True, next_gan_inputs=None):
         """One update_dexgangrasp + one update_dexevaluator.  The two updates touch disjoint networks, batches
         and workspaces, so the evaluator update runs on a SECOND HIP stream concurrently with the cGAN update:
         most launches of either (column kernels, split-K reduces, the K=256 GEMMs) occupy a fraction of the 256
@@ -127,7 +135,12 @@ class TrainEngine:
             stream A:  D phase | AR(D) | Adam(D) | G phase | AR(G) | Adam(G)
             stream B:  E phase | AR(E) | Adam(E)
         (RCCL runs the collectives on its own stream; `wait()` is a stream-level dependency, no host sync; all
-        ranks enqueue the collectives in the same host order.)  Results are bit-identical to cgan_step + eva_step."""
+        ranks enqueue the collectives in the same host order.)  Results are bit-identical to cgan_step + eva_step.
+
+        next_gan_inputs (optional, is_train_gen only): the NEXT call's gan_inputs, already resident on the device as
+        contiguous float32 tensors (a prefetching data loader has them).  The real-batch pass of the next D phase is
+        then enqueued behind this step's third D forward and overlaps its G phase (dgg_cgan_d_real_prefetch); the next
+        call must pass the very same tensors as gan_inputs.  Same results, bit for bit."""
         dev = self.device
         bps, rot9, transl, joint = (f32c(t, dev) for t in gan_inputs)
         rot9 = rot9.reshape(-1, 9)
@@ -176,6 +189,16 @@ class TrainEngine:
             check(lib().dgg_cgan_g_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args,
                                          ptr(self.losses), stream_ptr()), "dgg_cgan_g_phase")
             w_g = parallel.allreduce_sum_(G.grads, async_op=True)
+            if two_streams and next_gan_inputs is not None:
+                nb, nr, nt, nj_ = next_gan_inputs
+                nr = nr.reshape(-1, 9)
+                for t in (nb, nr, nt, nj_):
+                    if t.dtype != torch.float32 or not t.is_contiguous() or t.device != bps.device:
+                        raise _lib.DggError("next_gan_inputs must be resident contiguous float32 tensors")
+                self._keep_next = (nb, nr, nt, nj_)   # the C side remembers raw pointers
+                check(lib().dgg_cgan_d_real_prefetch(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), nb.shape[0],
+                                                     ptr(nb), ptr(nr), ptr(nt), ptr(nj_), ptr(self.losses), s2),
+                      "dgg_cgan_d_real_prefetch")
         with torch.cuda.stream(side):
             if w_e is not None:
                 w_e.wait()

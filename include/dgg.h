@@ -181,6 +181,16 @@ int dgg_cgan_d_phase(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hpar
 int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hparams* hp, void* ws,
                       size_t ws_bytes, int B, const float* bps, const float* rot9, const float* transl,
                       const float* joint, const float* z, float* losses, void* stream, void* stream2);
+/* Pipelining across steps (optional): enqueue on `stream2` the real-batch pass (forward, BCE, backward) of the NEXT
+ * D phase — its inputs must already be resident — while the current step's G phase is still running; it starts
+ * once this thread's last dgg_cgan_g_phase on the same workspace has passed its D forward (D's parameters and
+ * BatchNorm running statistics are then final for this step).  The next dgg_cgan_d_phase2 call on this thread with
+ * the same workspace, batch size, input pointers and a stream2 picks it up and runs only the generator / fake-batch half; with anything else
+ * the prefetched pass is dropped and redone.  Results are bit-identical to the unpipelined order.  Uses
+ * losses[12] as scratch; up to 4 workspaces per thread can be in flight. */
+int dgg_cgan_d_real_prefetch(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hparams* hp, void* ws,
+                             size_t ws_bytes, int B, const float* bps, const float* rot9, const float* transl,
+                             const float* joint, float* losses, void* stream2);
 /* Steps 9-12 up to (not including) optim_G.step: D forward #3 with the updated discriminator,
  * generator loss, backward through D (input gradients only) and G -> st->g_grads.
  * Must follow dgg_cgan_d_phase on the same workspace (reuses the saved generator activations). */

@@ -208,14 +208,34 @@ def test_joint_step_equals_separate_steps():
     f = lambda t: t.float().to(DEV)
     g_in = (f(gb["bps_object"]), f(gb["rot_matrix"]).reshape(b, 9), f(gb["transl"]), f(gb["joint_conf"]))
     e_in = (f(eb["bps_object"]), f(eb["rot_matrix"]).reshape(b, 9), f(eb["transl"]), f(eb["label"]))
-    e1, e2 = fresh(), fresh()
-    for i in range(2):
-        e1.cgan_step(*g_in, z.to(DEV), True)
+    e1, e2, e3 = fresh(), fresh(), fresh()
+    zd = z.to(DEV)
+    # e3: pipelined across steps — the next step's D real pass is prefetched behind this step's third D forward;
+    # alternating batches (g_in / g_alt) so that a prefetch of the wrong tensors could not go unnoticed
+    gb2 = synth.make_batch(b, 11)
+    g_alt = (f(gb2["bps_object"]), f(gb2["rot_matrix"]).reshape(b, 9), f(gb2["transl"]), f(gb2["joint_conf"]))
+    seq = [g_in, g_alt, g_in, g_in]
+    for i in range(3):
+        cur, nxt = seq[i], seq[i + 1]
+        e1.cgan_step(*cur, zd, True)
         l1 = e1.eva_step(*e_in, None, 77 + i).clone()
-        l2 = e2.joint_step(g_in, z.to(DEV), e_in, True, None, 77 + i).clone()
-        assert torch.equal(l1[:10], l2[:10])
-    for a, c in ((e1.G, e2.G), (e1.D, e2.D), (e1.E, e2.E)):
+        l2 = e2.joint_step(cur, zd, e_in, True, None, 77 + i).clone()
+        l3 = e3.joint_step(cur, zd, e_in, True, None, 77 + i, next_gan_inputs=nxt if i < 2 else None).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(l1[:10], l2[:10]) and torch.equal(l1[:10], l3[:10])
+    for a, c, d in ((e1.G, e2.G, e3.G), (e1.D, e2.D, e3.D), (e1.E, e2.E, e3.E)):
         assert torch.equal(a.params, c.params) and torch.equal(a.m, c.m) and torch.equal(a.bn, c.bn)
+        assert torch.equal(a.params, d.params) and torch.equal(a.m, d.m) and torch.equal(a.bn, d.bn)
+    # a prefetch that is not picked up (different tensors in the next call) is dropped and redone: only D's running
+    # statistics see the extra pass, the update itself is the unpipelined one
+    e4, e5 = fresh(), fresh()
+    e4.joint_step(g_in, zd, e_in, True, None, 5, next_gan_inputs=g_alt)
+    e5.joint_step(g_in, zd, e_in, True, None, 5)
+    g_in2 = tuple(t.clone() for t in g_in)
+    e4.joint_step(g_in2, zd, e_in, True, None, 6)
+    e5.joint_step(g_in2, zd, e_in, True, None, 6)
+    torch.cuda.synchronize()
+    assert torch.equal(e4.G.params, e5.G.params) and torch.equal(e4.E.params, e5.E.params)
 
 
 # ------------------------------------------------------------------ drop-in Python surface
