@@ -76,6 +76,7 @@ SIGNATURES = {
     "dgg_cgan_d_phase": (_I, [_CFG, C.POINTER(GanState), C.POINTER(HParams), _VP, _SZ, _I, _VP, _VP, _VP, _VP, _VP,
                               _VP, _VP]),
     "dgg_set_wgrad_stream": (_I, [_VP, _VP]),
+    "dgg_enable_wgrad_stream": (_I, [_VP, _I]),
     "dgg_set_gemm_algo": (_I, [_I]),
     "dgg_get_gemm_algo": (_I, []),
     "dgg_cgan_d_phase2": (_I, [_CFG, C.POINTER(GanState), C.POINTER(HParams), _VP, _SZ, _I, _VP, _VP, _VP, _VP, _VP,

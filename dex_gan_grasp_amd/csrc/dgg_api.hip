@@ -358,9 +358,10 @@ static hipEvent_t next_event() {
 static const int kAuxCap = 64;
 struct AuxMap {
     hipStream_t key[kAuxCap], aux[kAuxCap];
+    int owned[kAuxCap];   // > 0: library-created side stream, reference count of dgg_enable_wgrad_stream
     int n;
 };
-static thread_local AuxMap g_aux = {{}, {}, 0};
+static thread_local AuxMap g_aux = {{}, {}, {}, 0};
 
 static hipStream_t wgrad_stream_of(hipStream_t st) {
     for (int i = 0; i < g_aux.n; ++i)
@@ -1013,20 +1014,52 @@ int64_t dgg_cgan_workspace_bytes(const dgg_cfg* cfg, int batch) {
     return (int64_t)S.bytes;
 }
 
+static void aux_remove(int i) {
+    g_aux.key[i] = g_aux.key[g_aux.n - 1];
+    g_aux.aux[i] = g_aux.aux[g_aux.n - 1];
+    g_aux.owned[i] = g_aux.owned[g_aux.n - 1];
+    --g_aux.n;
+}
+
 int dgg_set_wgrad_stream(void* stream, void* wgrad_stream) {
     hipStream_t k = (hipStream_t)stream, a = (hipStream_t)wgrad_stream;
+    if (a && a == k) return DGG_ERR_INVALID;
     for (int i = 0; i < g_aux.n; ++i)
         if (g_aux.key[i] == k) {
+            if (g_aux.owned[i]) return DGG_ERR_INVALID;  // managed by dgg_enable_wgrad_stream
             if (a) { g_aux.aux[i] = a; return DGG_OK; }
-            g_aux.key[i] = g_aux.key[g_aux.n - 1];
-            g_aux.aux[i] = g_aux.aux[g_aux.n - 1];
-            --g_aux.n;
+            aux_remove(i);
             return DGG_OK;
         }
     if (!a) return DGG_OK;
     if (g_aux.n >= kAuxCap) return DGG_ERR_INVALID;
     g_aux.key[g_aux.n] = k;
     g_aux.aux[g_aux.n] = a;
+    g_aux.owned[g_aux.n] = 0;
+    ++g_aux.n;
+    return DGG_OK;
+}
+
+int dgg_enable_wgrad_stream(void* stream, int enable) {
+    hipStream_t k = (hipStream_t)stream;
+    for (int i = 0; i < g_aux.n; ++i)
+        if (g_aux.key[i] == k) {
+            if (!g_aux.owned[i]) return DGG_ERR_INVALID;  // an explicit mapping exists
+            if (enable) { ++g_aux.owned[i]; return DGG_OK; }
+            if (--g_aux.owned[i] == 0) {
+                hipStream_t dead = g_aux.aux[i];
+                aux_remove(i);
+                if (hipStreamDestroy(dead) != hipSuccess) return DGG_ERR_LAUNCH;  // pending work completes first
+            }
+            return DGG_OK;
+        }
+    if (!enable) return DGG_OK;
+    if (g_aux.n >= kAuxCap) return DGG_ERR_INVALID;
+    hipStream_t a;
+    if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) return DGG_ERR_LAUNCH;
+    g_aux.key[g_aux.n] = k;
+    g_aux.aux[g_aux.n] = a;
+    g_aux.owned[g_aux.n] = 1;
     ++g_aux.n;
     return DGG_OK;
 }

@@ -96,33 +96,28 @@ class TrainEngine:
         return self.losses.clone()
 
     def __del__(self):
-        # the library's stream -> weight-gradient-stream map must not outlive this engine's streams
+        # one disable per enable: the library frees a side stream when its last user is gone
         try:
             for key in getattr(self, "_wg_mapped", ()):
-                lib().dgg_set_wgrad_stream(C.c_void_p(key), None)
+                lib().dgg_enable_wgrad_stream(C.c_void_p(key), 0)
         except Exception:
             pass
 
     def _map_wgrad_streams(self, *streams):
-        """Give each compute stream a weight-gradient side stream (dgg_set_wgrad_stream): dW GEMMs have no
-        consumer before Adam, so they overlap the dgrad chain of the following ResBlocks."""
-        mode = int(os.environ.get("DGG_WGRAD_STREAMS", "1"))
-        if mode == 0:
+        """Give each compute stream a weight-gradient side stream (dgg_enable_wgrad_stream): dW GEMMs have no
+        consumer before Adam, so they overlap the dgrad chain of the following ResBlocks.  The side streams are
+        created and owned by the library — streams from torch's pool are shared between users, and one that served
+        as a side stream here and as a compute stream (with its own side stream) elsewhere could close a wait
+        cycle."""
+        if os.environ.get("DGG_WGRAD_STREAMS", "1") == "0":
             return
-        if getattr(self, "_wg", None) is None:
-            self._wg, self._wg_mapped = {}, set()
-        shared = None
+        if getattr(self, "_wg_mapped", None) is None:
+            self._wg_mapped = set()
         for s in streams:
             key = s.cuda_stream
             if key in self._wg_mapped:
                 continue
-            if mode == 1:       # one side stream per compute stream
-                w = torch.cuda.Stream(device=self.device)
-            else:               # a single side stream shared by all
-                shared = shared or next(iter(self._wg.values()), None) or torch.cuda.Stream(device=self.device)
-                w = shared
-            self._wg[key] = w
-            check(lib().dgg_set_wgrad_stream(C.c_void_p(key), C.c_void_p(w.cuda_stream)), "dgg_set_wgrad_stream")
+            check(lib().dgg_enable_wgrad_stream(C.c_void_p(key), 1), "dgg_enable_wgrad_stream")
             self._wg_mapped.add(key)
 
     # ---- gen + eval step with communication/compute overlap (the unit bench.py times)

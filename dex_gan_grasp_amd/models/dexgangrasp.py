@@ -307,6 +307,36 @@ class DexGanGrasp(object):
             out.append(f)
         return out
 
+    def sweep_objects(self, bps_objects, n_samples, thresholds=(0.5, 0.75, 0.90), z_offset=0.025, z=None):
+        """Config 5 (BASELINE.json; dexgangrasp_offline.py:27-92 run over many objects) as ONE generator pass and ONE
+        evaluator pass for all objects: the reference loops per object (generate_grasps -> filter_grasps x3), i.e.
+        2 + 3 network passes of 200 rows each per object — launch-bound on any GPU.  Both networks are in eval mode
+        here (running BatchNorm statistics), so rows of different objects do not interact and stacking them changes
+        nothing.  bps_objects (O, 4096); z: optional latents (O * n_samples, latentD) instead of torch.randn.
+        Returns device tensors: 'transl' (O,n,3), 'rot_matrix' (O,n,3,3), 'joint_conf' (O,n,nj), 'z' (O,n,latentD),
+        'score' (O,n), 'order' (O,n: indices by descending score) and 'count' (T,O): grasps with score > threshold —
+        object o's filter_grasps(thresholds[t]) result is rows order[o, :count[t, o]]."""
+        gen, eva = self.DexGANGrasp, self.DexEvaluator
+        gen.eval()
+        eva.eval()
+        bps_objects = torch.as_tensor(bps_objects, dtype=self.dtype, device=self.device)
+        n_obj = bps_objects.shape[0]
+        bps_rows = bps_objects.repeat_interleave(n_samples, dim=0)
+        with torch.no_grad():
+            if z is None:
+                z = torch.randn((n_obj * n_samples, gen.latentD), dtype=self.dtype, device=self.device)
+            res = gen.generator(z.to(self.device, self.dtype), bps_rows)
+            rot = utils.rot_matrix_from_ortho6d(res.pop('rot_6D'))
+            res['rot_matrix'] = rot
+            res = utils.translate_along_axis(res, 0, z_offset)
+            score = eva({'bps_object': bps_rows, 'rot_matrix': res['rot_matrix'], 'transl': res['transl']})
+            score = score.view(n_obj, n_samples)
+            sorted_score, order = score.sort(dim=1, descending=True)
+            count = torch.stack([(sorted_score > t).sum(dim=1) for t in thresholds])
+        out = {k: v.view(n_obj, n_samples, *v.shape[1:]) for k, v in res.items()}
+        out.update(score=score, order=order, count=count)
+        return out
+
     def filter_grasps(self, bps, grasps, thresh=0.5, return_arr=True):
         """dexgangrasp.py:393-442."""
         return self._filter(self.DexEvaluator, bps, grasps, thresh, return_arr)

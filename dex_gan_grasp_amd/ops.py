@@ -160,6 +160,8 @@ def bce(p, target, weight=1.0, loss_scale=1.0, want_grad=True):
 
 def translate_along_axis(transl, rot9, axis, offset):
     dev = _dev(transl)
+    if not transl.is_contiguous() or transl.dtype != torch.float32:
+        raise _lib.DggError("translate_along_axis works in place on a contiguous float32 (N, 3) tensor")
     check(lib().dgg_translate_along_axis(ptr(transl), ptr(f32c(rot9, dev)), transl.shape[0], int(axis), float(offset),
                                          stream_ptr()), "dgg_translate_along_axis")
     return transl

@@ -59,7 +59,10 @@ def translate_along_axis(out, axis, translation):
     t, r = out['transl'], out['rot_matrix']
     if torch.is_tensor(t):
         if t.is_cuda:
-            ops.translate_along_axis(t, r.reshape(-1, 9), axis, translation)
+            # the kernel works on a dense (N, 3) array; the generator's `transl` is a strided view of its heads
+            tc = t if t.is_contiguous() else t.contiguous()
+            ops.translate_along_axis(tc, r.reshape(-1, 9), axis, translation)
+            out['transl'] = tc
         else:
             t -= (r[:, :, axis] * translation).to(t.dtype)
         return out

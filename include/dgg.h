@@ -166,8 +166,13 @@ enum {
 /* Optional concurrency hint (per calling thread): while set, every *_backward / phase call enqueued on `stream`
  * launches its weight-gradient GEMMs (dW13, dW2 — no consumer before the optimiser step) on `wgrad_stream`,
  * overlapping the dgrad chain; the call joins `wgrad_stream` back into `stream` before it returns, so callers
- * keep single-stream semantics.  wgrad_stream == NULL removes the mapping.  Results are bit-identical. */
+ * keep single-stream semantics.  wgrad_stream == NULL removes the mapping.  Results are bit-identical.
+ * `wgrad_stream` must be used for nothing else (in particular not as a compute stream that has a side stream). */
 int dgg_set_wgrad_stream(void* stream, void* wgrad_stream);
+/* Same, with a side stream created and owned by the library (reference-counted per `stream`: every enable needs
+ * one disable).  Prefer this form: a caller-provided side stream that is ALSO some compute stream with a side stream
+ * of its own (easy to get from a pooled stream allocator) can close a wait cycle between the two. */
+int dgg_enable_wgrad_stream(void* stream, int enable);
 
 /* Steps 1-8 of SURVEY.md 3.1 up to (not including) optim_D.step: G forward (train), ortho6d,
  * D forward on real then on fake.detach(), discriminator loss, D backward (both) -> st->d_grads.

@@ -414,6 +414,40 @@ def test_refine_grasps_gradient_matches_oracle():
         m.refine_grasps(dict(data), "sampling")
 
 
+def test_sweep_objects_matches_per_object_pipeline():
+    """Config 5 in one generator + one evaluator pass (sweep_objects) against the reference's per-object sequence
+    generate_grasps -> filter_grasps x3 (here filter_grasps_multi), same latents."""
+    m = _wrapper("wide", is_train=False)
+    n_obj, n = 5, 64
+    rows = H.batches()["syn64"]["bps_object"][:n_obj].float().numpy()
+    thresholds = (0.3, 0.5, 0.7)
+    zs, per_obj = [], []
+    for o in range(n_obj):
+        torch.manual_seed(100 + o)
+        zs.append(torch.randn((n, m.DexGANGrasp.latentD), dtype=torch.float32, device=DEV))
+        torch.manual_seed(100 + o)                       # generate_poses draws the same latents
+        g = m.generate_grasps(rows[o], n, return_arr=True)
+        per_obj.append((g, m.filter_grasps_multi(rows[o], g, thresholds=thresholds)))
+    out = m.sweep_objects(rows, n, thresholds=thresholds, z=torch.cat(zs))
+    assert out["score"].shape == (n_obj, n) and out["count"].shape == (len(thresholds), n_obj)
+    for o in range(n_obj):
+        g, filt = per_obj[o]
+        np.testing.assert_allclose(out["transl"][o].cpu().numpy(), g["transl"], rtol=0, atol=2e-5)  # other split-K plan
+        np.testing.assert_allclose(out["rot_matrix"][o].cpu().numpy(), g["rot_matrix"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(out["joint_conf"][o].cpu().numpy(), g["joint_conf"], rtol=0, atol=2e-5)
+        score = out["score"][o].cpu().numpy()
+        for t, thr in enumerate(thresholds):
+            cnt = int(out["count"][t, o])
+            near = int(((score > thr - 1e-5) & (score < thr + 1e-5)).sum())     # scores within rounding of the cut
+            ref_cnt = 0 if filt[t] is None else filt[t]["transl"].shape[0]
+            assert abs(cnt - ref_cnt) <= near, (o, thr, cnt, ref_cnt)
+            if cnt and filt[t] is not None and near == 0:
+                sel = out["order"][o, :cnt].cpu().numpy()
+                np.testing.assert_allclose(np.sort(out["transl"][o].cpu().numpy()[sel], axis=0),
+                                           np.sort(filt[t]["transl"], axis=0), rtol=0, atol=2e-5)
+    assert int(out["count"].sum()) > 0          # the thresholds actually select something
+
+
 def test_autograd_path_matches_oracle():
     """Module forward + torch backward (the non-fused path: e.g. refine_grasps' input gradients)."""
     from oracle import dexgan_oracle as O
