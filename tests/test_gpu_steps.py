@@ -446,6 +446,12 @@ def test_sweep_objects_matches_per_object_pipeline():
                 np.testing.assert_allclose(np.sort(out["transl"][o].cpu().numpy()[sel], axis=0),
                                            np.sort(filt[t]["transl"], axis=0), rtol=0, atol=2e-5)
     assert int(out["count"].sum()) > 0          # the thresholds actually select something
+    # tensor-returning form of generate_grasps (device-side translate_along_axis on the generator's strided output)
+    torch.manual_seed(100)
+    gt = m.generate_grasps(rows[0], n, return_arr=False)
+    assert gt["transl"].is_cuda
+    np.testing.assert_allclose(gt["transl"].cpu().numpy(), per_obj[0][0]["transl"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(gt["joint_conf"].cpu().numpy(), per_obj[0][0]["joint_conf"], rtol=0, atol=2e-6)
 
 
 def test_autograd_path_matches_oracle():
