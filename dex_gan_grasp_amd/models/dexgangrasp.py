@@ -307,7 +307,8 @@ class DexGanGrasp(object):
             out.append(f)
         return out
 
-    def sweep_objects(self, bps_objects, n_samples, thresholds=(0.5, 0.75, 0.90), z_offset=0.025, z=None):
+    def sweep_objects(self, bps_objects, n_samples, thresholds=(0.5, 0.75, 0.90), z_offset=0.025, z=None,
+                      chunk_objects=256):
         """Config 5 (BASELINE.json; dexgangrasp_offline.py:27-92 run over many objects) as ONE generator pass and ONE
         evaluator pass for all objects: the reference loops per object (generate_grasps -> filter_grasps x3), i.e.
         2 + 3 network passes of 200 rows each per object — launch-bound on any GPU.  Both networks are in eval mode
@@ -315,11 +316,19 @@ class DexGanGrasp(object):
         nothing.  bps_objects (O, 4096); z: optional latents (O * n_samples, latentD) instead of torch.randn.
         Returns device tensors: 'transl' (O,n,3), 'rot_matrix' (O,n,3,3), 'joint_conf' (O,n,nj), 'z' (O,n,latentD),
         'score' (O,n), 'order' (O,n: indices by descending score) and 'count' (T,O): grasps with score > threshold —
-        object o's filter_grasps(thresholds[t]) result is rows order[o, :count[t, o]]."""
+        object o's filter_grasps(thresholds[t]) result is rows order[o, :count[t, o]].  Objects are processed
+        chunk_objects at a time (activations of chunk_objects * n_samples rows live in the workspaces)."""
+        bps_objects = torch.as_tensor(bps_objects, dtype=self.dtype, device=self.device)
+        if bps_objects.shape[0] > chunk_objects:
+            parts = []
+            for lo in range(0, bps_objects.shape[0], chunk_objects):
+                hi = min(lo + chunk_objects, bps_objects.shape[0])
+                zc = None if z is None else z[lo * n_samples:hi * n_samples]
+                parts.append(self.sweep_objects(bps_objects[lo:hi], n_samples, thresholds, z_offset, zc, chunk_objects))
+            return {k: torch.cat([p[k] for p in parts], dim=1 if k == 'count' else 0) for k in parts[0]}
         gen, eva = self.DexGANGrasp, self.DexEvaluator
         gen.eval()
         eva.eval()
-        bps_objects = torch.as_tensor(bps_objects, dtype=self.dtype, device=self.device)
         n_obj = bps_objects.shape[0]
         bps_rows = bps_objects.repeat_interleave(n_samples, dim=0)
         with torch.no_grad():
