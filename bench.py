@@ -8,14 +8,18 @@ update_dexevaluator (fwd, BCE, bwd, Adam) on one batch of synthetic inputs alrea
 
     python bench.py [--gpus N --steps K --warmup W]        # N > 1: launched by torch.distributed.run
 
-Prints ONE JSON line with the contract fields + "roofline" (dominant kernel: the fp32-MFMA GEMM,
-timed live with HIP events on the launch stream) + "cpu_baseline" (the CPU oracle = plain-PyTorch
-restatement of the reference step, timed on this host's cores, rank 0, N = 1 only).
+The timed region is K steps bracketed by barrier + synchronize; it is repeated --repeats times (default 25, so the
+measurement spans > 1 s) and the MEDIAN block gives `value` / `ms_per_step` (min / max are reported next to it).
+Prints ONE JSON line: the contract fields + "roofline" (the dominant kernel: the weight-gradient GEMM; the forward
+GEMM, BPS encode, Adam and the input-BatchNorm kernel under "roofline_kernels"), "sub_results" (BASELINE configs 2, 3,
+5, the BPS encode stage and the drop-in API path) and "cpu_baseline" (the CPU oracle = plain-PyTorch restatement of
+the reference step at the SAME batch, timed on this host's cores; rank 0, N = 1 only).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -35,88 +39,155 @@ MFLOP_PER_GRASP_EXEC = 135.4   # 148.0 minus the BPS-column product that D's fak
 PIPELINE = os.environ.get("DGG_PIPELINE", "1") == "1"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F32_VALU_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 vector peak
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
 
 
-def gemm_roofline(dev, iters=20):
-    """Dominant kernel: gemm_x3_kernel<NT, 16-byte staging> on the fused fc1||fc3 layer of a ResBlock at the bench
-    batch, shaped as the discriminator's second ResBlock runs it: C[1024,768] = X0[1024,4120] W13[768,0:4120]^T with
-    the weight rows 4632 floats apart, split-K 4 as the forward plans it (48 tiles x 4 = 192 one-per-CU workgroups; the rest of the chip is left to the other streams of the step).
-    achieved = algorithmic FLOPs (2*M*N*K, fp32-equivalent) / mean launch duration (HIP events on the launch stream).
-    The kernel computes every fp32 product as six bf16 partial products on v_mfma_f32_32x32x16_bf16, so the matrix-
-    pipe bound for it is the dense bf16 peak / 6; the native f32-MFMA peak is reported next to it."""
-    M, N, K, LDB = 1024, 768, 4120, 4632
+def _time_stream(fn, iters, warm=3):
+    """Mean duration (ms) of fn() over `iters` back-to-back calls, HIP events on the stream the kernels launch on."""
+    st = torch.cuda.current_stream()
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        fn()
+    e1.record(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def _pmc_traffic(name, shape):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction +
+    WRITE_SIZE; separate passes, see profiles/): PMC counters cannot be read from inside a run."""
+    for rnd in ("r02", "r01"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, name))))
+            if pmc.get("shape") == shape:
+                return int(pmc["traffic_bytes"]), "profiles/%s_%s_pmc.json" % (rnd, name)
+        except Exception:
+            continue
+    return None, None
+
+
+def gemm_roofline(dev, mode, M, N, K, lda, ldb, splits, what, pmc_name, iters=20):
+    """One large fc GEMM as the step runs it, alone on the chip.  achieved = algorithmic FLOPs (2*M*N*K, fp32-
+    equivalent) / mean launch duration.  The bf16x3 arithmetic computes every fp32 product as six bf16 partial products
+    on v_mfma_f32_32x32x16_bf16, so its matrix-pipe bound is the dense bf16 peak / 6; the native f32-MFMA peak is
+    reported next to it.  mode 0 (NT): C = A[M,K] B[N,K]^T;  mode 2 (TN): C = A[K,M]^T B[K,N]."""
     g = torch.Generator().manual_seed(0)
-    A = torch.randn((M, K), generator=g).to(dev)
-    W = torch.randn((N, LDB), generator=g).to(dev)
-    splits = 4
-    slabs = torch.empty((splits * M * N,), device=dev)
+    if mode == 0:
+        A = torch.randn((M, lda), generator=g).to(dev)
+        W = torch.randn((N, ldb), generator=g).to(dev)
+    else:
+        A = torch.randn((K, lda), generator=g).to(dev)
+        W = torch.randn((K, ldb), generator=g).to(dev)
+    slabs = torch.empty((max(splits, 1) * M * N,), device=dev)
+    out = torch.empty((M, N), device=dev)
     lib = _lib.lib()
     st = torch.cuda.current_stream()
     algo = int(lib.dgg_get_gemm_algo())
 
     def launch():
-        # mode 0 (NT), split-K partial products into slabs; C = NULL leaves out the (separate, HBM-bound)
-        # bias/BN-statistics reduce kernel so that the MFMA kernel alone is timed
-        _lib.check(lib.dgg_gemm_f32(0, M, N, K, _lib.ptr(A), K, _lib.ptr(W), LDB, None, N, splits, _lib.ptr(slabs), 0,
+        # split-K partial products into slabs with C = NULL: the (separate, HBM-bound) reduce kernel is left out so
+        # that the MFMA kernel alone is timed
+        _lib.check(lib.dgg_gemm_f32(mode, M, N, K, _lib.ptr(A), lda, _lib.ptr(W), ldb,
+                                    None if splits >= 1 else _lib.ptr(out), N, splits, _lib.ptr(slabs), 0,
                                     C.c_void_p(st.cuda_stream)))
-    for _ in range(3):
-        launch()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(iters):
-        launch()
-    e1.record(st)
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    ms = _time_stream(launch, iters)
     flops = 2.0 * M * N * K
     achieved = flops / (ms * 1e-3) / 1e12
-    if algo == 1:
-        peak, kern = PEAK_BF16_MFMA_TFLOPS / 6.0, "gemm_x3_kernel<NT,vec16,vec16> (bf16x3: 6 bf16 MFMA products per fp32 product)"
-    else:
-        peak, kern = PEAK_F32_MFMA_TFLOPS, "gemm_f32_kernel<128,128,NT>"
-    # HBM-side bytes per launch of this kernel at this shape come from separate rocprofv3 --pmc passes (FETCH_SIZE,
-    # WRITE_SIZE with the gfx950 correction), recorded in profiles/; PMC counters cannot be read from inside a run
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_x3_pmc.json")))
-        if algo == 1 and pmc["shape"] == {"M": M, "N": N, "K": K, "splits": splits}:
-            traffic = int(pmc["traffic_bytes"])
-    except Exception:
-        traffic = None
+    peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if algo == 1 else PEAK_F32_MFMA_TFLOPS
+    shape = {"M": M, "N": N, "K": K, "splits": splits}
+    traffic, src = _pmc_traffic(pmc_name, shape)
+    alg_bytes = 4 * (M * K + N * K + max(splits, 1) * M * N)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic, "algorithmic_bytes": 4 * (M * K + N * K + splits * M * N),
-            "kernel": kern + " M=1024 N=768 K=4120 split-K 4 (fc1||fc3 of a ResBlock)",
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": src,
+            "algorithmic_bytes": alg_bytes, "kernel": what, "shape": shape,
             "peak_basis": "dense bf16 MFMA 2500 TFLOP/s / 6 products" if algo == 1 else "dense f32 MFMA",
             "f32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "ms_per_launch": round(ms, 4)}
 
 
+def bps_roofline(dev, B=1024, Np=2048, iters=10):
+    """bps_batched_kernel (A1): 4096 * N pair evaluations per cloud at ~8 flop each against N*12 + 4096*8 bytes:
+    arithmetic intensity ~1e3 flop/B, so the fp32 VECTOR pipe binds, not HBM; both are reported."""
+    g = torch.Generator().manual_seed(0)
+    basis = (torch.rand((4096, 3), generator=g) * 0.2 - 0.1).to(dev)
+    clouds = synth.make_clouds(B, Np, 7).to(dev)
+    d = torch.empty((B, 4096), device=dev)
+    ids = torch.empty((B, 4096), dtype=torch.int32, device=dev)
+    lib = _lib.lib()
+    st = torch.cuda.current_stream()
+    fn = lambda: _lib.check(lib.dgg_bps_encode(_lib.ptr(clouds), B, Np, _lib.ptr(basis), 4096, _lib.ptr(d),
+                                               _lib.ptr(ids), C.c_void_p(st.cuda_stream)))
+    ms = _time_stream(fn, iters)
+    pairs = B * Np * 4096.0
+    byts = B * (Np * 12 + 4096 * 8) + 4096 * 12
+    tf = pairs * 8 / ms / 1e9
+    return {"bound": "valu", "achieved": round(tf, 2), "peak": PEAK_F32_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_F32_VALU_TFLOPS, 4), "kernel": "bps_batched_kernel %d clouds x %d points x 4096 basis" % (B, Np),
+            "ms_per_launch": round(ms, 4), "pairs_per_s": round(pairs / ms * 1e3, 1), "clouds_per_s": round(B / ms * 1e3, 1),
+            "algorithmic_bytes": byts, "hbm_gb_per_s": round(byts / ms / 1e6, 2),
+            "hbm_frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 5),
+            "note": "8 flop per (basis, point) pair; VALU binds (AI ~1e3 flop/B), the HBM fraction is ~0 by construction"}
+
+
+def adam_roofline(dev, n=10661657, iters=20):
+    """adam_kernel (A12) on the evaluator's flat buffer: 16 B read + 12 B written per parameter, pure HBM streaming."""
+    p, g, m, v = (torch.randn(n, device=dev) * 0.01 for _ in range(4))
+    v.abs_()
+    lib = _lib.lib()
+    st = torch.cuda.current_stream()
+    k = [0]
+
+    def fn():
+        k[0] += 1
+        _lib.check(lib.dgg_adam_l2(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n, k[0], 1e-4, 0.9, 0.999,
+                                   1e-8, 5e-4, 1.0, C.c_void_p(st.cuda_stream)))
+    ms = _time_stream(fn, iters)
+    byts = 28.0 * n
+    gbs = byts / ms / 1e6
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(gbs / PEAK_HBM_GBS, 4), "kernel": "adam_kernel, %d parameters (28 B each)" % n,
+            "algorithmic_bytes": int(byts), "ms_per_launch": round(ms, 4)}
+
+
 def usable_cores():
-    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota (a GPU
-    box exposes all host cores through os.cpu_count() but schedules only its share)."""
-    try:
-        n = len(os.sched_getaffinity(0))
-    except AttributeError:
-        n = os.cpu_count() or 1
-    try:
-        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            n = min(n, max(1, int(round(int(q) / int(p)))))
-    except Exception:
-        pass
-    if n > 64:  # no quota visible: the documented CPU share of a 1-GPU box is 16 cores
-        n = 16
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                q, p = txt[0], txt[1]
+            else:
+                q, p = txt[0], open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0]
+            if q not in ("max", "-1"):
+                n = min(n, max(1, int(round(int(q) / int(p)))))
+            break
+        except Exception:
+            continue
     return n
 
 
-def cpu_baseline(cfg, budget_s=20.0):
-    """The CPU oracle (port of the reference step) on this host's cores, bounded sample."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, b):
+    """The CPU oracle (port of the reference step: plain PyTorch fp32) at the SAME batch as the GPU step, on this
+    host's cores: >= 5 timed steps after 2 warm-up with all usable cores, plus a 1-thread figure (2 timed after 1)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import dexgan_oracle as O
     cores = usable_cores()
-    torch.set_num_threads(cores)
-    b = 256
     sd = synth.make_state_dict("dexgangrasp", 0)
     sde = synth.make_state_dict("evaluator", 5)
     batch = synth.make_batch(b, 1, with_label=True)
@@ -125,39 +196,134 @@ def cpu_baseline(cfg, budget_s=20.0):
     ag = O.AdamState([n for n in O.param_names(sd) if n.startswith("generator.")])
     ad = O.AdamState([n for n in O.param_names(sd) if n.startswith("discriminator.")])
     ae = O.AdamState(O.param_names(sde))
+
     def step():
         O.cgan_step(sd, batch, z, ag, ad, cfg, True)
         O.eva_step(sde, batch, ae, cfg, masks)
-    step()
-    t0 = time.time()
-    n = 0
-    while True:
-        step()
-        n += 1
-        if time.time() - t0 > budget_s or n >= 50:
-            break
-    dt = time.time() - t0
+
+    def run(threads, warm, timed, budget):
+        torch.set_num_threads(threads)
+        for _ in range(warm):
+            step()
+        t0, n = time.time(), 0
+        while n < timed or (time.time() - t0 < budget and n < 20):
+            step()
+            n += 1
+        return n, time.time() - t0
+    n, dt = run(cores, 2, 5, 8.0)
+    n1, dt1 = run(1, 1, 2, 6.0)
+    torch.set_num_threads(cores)
     return {"value": round(b * n / dt, 1), "unit": "grasps/s", "cores": cores, "kind": "port",
-            "sample": "%d gen+eval steps at batch %d (same step, smaller batch so the sample stays within ~%ds)" % (n, b, int(budget_s))}
+            "cpu_model": cpu_model(), "ms_per_step": round(dt / n * 1e3, 1),
+            "single_thread": {"value": round(b * n1 / dt1, 1), "unit": "grasps/s", "cores": 1,
+                              "ms_per_step": round(dt1 / n1 * 1e3, 1), "sample": "%d steps after 1 warm-up" % n1},
+            "sample": "%d gen+eval steps at batch %d (the GPU step's batch) after 2 warm-up, %d threads" % (n, b, cores)}
+
+
+def sub_results(cfg, dev, eng):
+    """BASELINE configs 2, 3 and 5 and the pieces around the headline step, each timed on its own (1 GPU)."""
+    out = {}
+    f = lambda t: t.float().to(dev).contiguous()
+
+    def wall(fn, steps, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+    # config 2: cGAN update only, B = 256 (train.py's generator phase)
+    b = 256
+    gb = synth.make_batch(b, 1)
+    g_in = (f(gb["bps_object"]), f(gb["rot_matrix"]).reshape(b, 9), f(gb["transl"]), f(gb["joint_conf"]))
+    z = synth.make_z(b, 3).to(dev)
+    dt = wall(lambda: eng.cgan_step(*g_in, z, True, two_streams=True), 40)
+    out["config2_cgan_step_b256"] = {"ms_per_step": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1),
+                                     "workload": "update_dexgangrasp only, batch 256, fp32"}
+    # config 3: evaluator update only, B = 1024
+    b = 1024
+    eb = synth.make_batch(b, 2, with_label=True)
+    e_in = (f(eb["bps_object"]), f(eb["rot_matrix"]).reshape(b, 9), f(eb["transl"]), f(eb["label"]))
+    k = [0]
+
+    def eva():
+        k[0] += 1
+        eng.eva_step(*e_in, None, 99 + k[0], two_streams=True)
+    dt = wall(eva, 40)
+    out["config3_eva_step_b1024"] = {"ms_per_step": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1),
+                                     "workload": "update_dexevaluator only, batch 1024, in-kernel dropout"}
+    # the cGAN update alone at the headline batch, serial entry with intra-step side streams
+    gb = synth.make_batch(b, 1)
+    g_in = (f(gb["bps_object"]), f(gb["rot_matrix"]).reshape(b, 9), f(gb["transl"]), f(gb["joint_conf"]))
+    z = synth.make_z(b, 3).to(dev)
+    dt = wall(lambda: eng.cgan_step(*g_in, z, True, two_streams=True), 30)
+    out["cgan_step_b1024"] = {"ms_per_step": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1)}
+    # the drop-in API path: DexGanGrasp.update_dexgangrasp + update_dexevaluator through the wrapper, as an unchanged
+    # train.py would call them (one after the other; batches resident on the device as float32)
+    from dex_gan_grasp_amd.models.dexgangrasp import DexGanGrasp
+    wcfg = dict(cfg)
+    wcfg["train_ffhevaluator"] = True
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = DexGanGrasp(wcfg)
+    gd = {"bps_object": g_in[0], "rot_matrix": g_in[1].view(b, 3, 3), "transl": g_in[2], "joint_conf": g_in[3]}
+    ed = {"bps_object": e_in[0], "rot_matrix": e_in[1].view(b, 3, 3), "transl": e_in[2], "label": e_in[3]}
+
+    def api():
+        m.update_dexgangrasp(dict(gd))
+        m.update_dexevaluator(dict(ed))
+    dt = wall(api, 30)
+    out["api_path_b1024"] = {"ms_per_step": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1),
+                             "workload": "DexGanGrasp.update_dexgangrasp + update_dexevaluator (wrapper), batch 1024"}
+    # config 5 (one rank's share): 1250 objects x 200 grasps, encode (N = 2048) + generate + evaluate + 3 thresholds
+    n_obj, n_g, n_pts = 1250, 200, 2048
+    with contextlib.redirect_stdout(io.StringIO()):
+        icfg = dict(cfg)
+        icfg["is_train"] = False
+        mi = DexGanGrasp(icfg)
+    mi.DexGANGrasp.load_state_dict(synth.make_state_dict("dexgangrasp", 10, 1.0, True))
+    mi.DexEvaluator.load_state_dict(synth.make_state_dict("evaluator", 15, 1.0, True))
+    g = torch.Generator().manual_seed(0)
+    basis = (torch.rand((4096, 3), generator=g) * 0.2 - 0.1).to(dev)
+    clouds = synth.make_clouds(n_obj, n_pts, 7).to(dev)
+    kept = [0]
+    stage = {}
+
+    def sweep():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dists, _ = ops.bps_encode(clouds, basis)
+        torch.cuda.synchronize()
+        stage["encode_s"] = time.perf_counter() - t0
+        o = mi.sweep_objects(dists, n_g, thresholds=(0.5, 0.75, 0.90))
+        kept[0] = int(o["count"].sum())
+    dt = wall(sweep, 2, warm=1)
+    out["config5_sweep_1250x200"] = {"seconds": round(dt, 4), "objects_per_s": round(n_obj / dt, 1),
+                                     "grasps_per_s": round(n_obj * n_g / dt, 1), "encode_seconds": round(stage["encode_s"], 5),
+                                     "kept_total": kept[0],
+                                     "workload": "per object: BPS-encode a 2048-point cloud, generate 200 grasps, evaluate, "
+                                                 "filter at 0.5/0.75/0.9; one rank's share (1250 of 10k objects)"}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=25, help="timed blocks of --steps steps; the median is reported")
     ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch (BASELINE: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub", action="store_true")
     args = ap.parse_args()
 
     # DGG_REHEARSE=1: rehearsal of the multi-rank code path on a 1-GPU box (gloo backend, all ranks on cuda:0);
     # never used for reported numbers
-    rehearse = os.environ.get("DGG_REHEARSE") == "1"
-    rank, world, local = parallel.init_from_env(backend="gloo" if rehearse else None)
+    rank, world, local = parallel.init_from_env()
     assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
-    if rehearse:
-        local = 0
-    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cfg = dict(synth.DEFAULT_CFG)
     B = args.batch
@@ -175,28 +341,34 @@ def main():
     g_in = (f(gb["bps_object"]), f(gb["rot_matrix"]).reshape(B, 9), f(gb["transl"]), f(gb["joint_conf"]))
     e_in = (f(eb["bps_object"]), f(eb["rot_matrix"]).reshape(B, 9), f(eb["transl"]), f(eb["label"]))
     zs = [synth.make_z(B, 3 + 100 * rank + i).to(dev) for i in range(4)]
+    it = [0]
 
-    def step(i):
+    def step():
         # one update_dexgangrasp + one update_dexevaluator; gradient all-reduces (N > 1) overlap with the
         # independent phase, see engine.TrainEngine.joint_step
+        i = it[0]
+        it[0] += 1
         eng.joint_step(g_in, zs[i % 4], e_in, True, None, 1234 + i, next_gan_inputs=g_in if PIPELINE else None)
 
-    for i in range(args.warmup):
-        step(i)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    for _ in range(args.warmup):
+        step()
+    blocks = []
+    for _ in range(max(1, args.repeats)):
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        blocks.append(time.perf_counter() - t0)
+    if world > 1:   # MAX over ranks, block by block
+        t = torch.tensor(blocks, device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        blocks = [float(x) for x in t.cpu()]
+    dt = statistics.median(blocks)
     losses = eng.losses.cpu().numpy()
     assert all(map(lambda x: x == x, losses[:10])), "NaN in losses"
 
@@ -210,6 +382,10 @@ def main():
             "config": {"workload": "cGAN step (update_dexgangrasp) + evaluator step (update_dexevaluator), "
                                    "batch %d per GPU, BPS-4096, fp32, Adam included" % B,
                        "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "timed_blocks": len(blocks),
+                       "block_ms_per_step_min_median_max": [round(min(blocks) / args.steps * 1e3, 4),
+                                                            round(dt / args.steps * 1e3, 4),
+                                                            round(max(blocks) / args.steps * 1e3, 4)],
                        "mflop_per_grasp_as_reference": MFLOP_PER_GRASP_FULL,
                        "mflop_per_grasp_executed": MFLOP_PER_GRASP_EXEC,
                        "step_tflops_executed": round(value * MFLOP_PER_GRASP_EXEC * 1e6 / 1e12 / world, 2),
@@ -220,9 +396,21 @@ def main():
                                            "bf16 MFMA, fp32 accumulate (fp32-accurate)"
                                            if int(_lib.lib().dgg_get_gemm_algo()) == 1 else "f32 MFMA")},
         }
-        res["roofline"] = gemm_roofline(dev)
+        # dominant kernel of the step: the weight gradient of a ResBlock's fused fc1||fc3 layer,
+        # dW13[768, 4120] = dY13[1024, 768]^T X0[1024, 4120] (TN); the forward of the same layer (NT, split-K 4) next
+        tn = gemm_roofline(dev, 2, 768, 4120, B, 768, 4120, 0,
+                           "weight gradient of fc1||fc3 (TN): dW13[768,4120] = dY13[%d,768]^T X0[%d,4120]" % (B, B),
+                           "gemm_x3_tn")
+        nt = gemm_roofline(dev, 0, B, 768, 4120, 4120, 4632, 4,
+                           "forward of fc1||fc3 (NT): a13[%d,768] = X0[%d,4120] W13[768,4120]^T, split-K 4" % (B, B),
+                           "gemm_x3")
+        res["roofline"] = tn
+        res["roofline_kernels"] = {"gemm_wgrad_tn": tn, "gemm_forward_nt": nt, "bps_encode": bps_roofline(dev),
+                                   "adam": adam_roofline(dev)}
+        if world == 1 and not args.no_sub:
+            res["sub_results"] = sub_results(cfg, dev, eng)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cfg)
+            res["cpu_baseline"] = cpu_baseline(cfg, B)
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()

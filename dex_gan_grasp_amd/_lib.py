@@ -92,6 +92,15 @@ SIGNATURES = {
     "dgg_gen_loss": (_I, [_CFG, C.POINTER(HParams), _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "dgg_translate_along_axis": (_I, [_VP, _VP, _I, _I, _F, _VP]),
     "dgg_gemm_occupancy": (_I, [_I, _I, _I]),
+    "dgg_cgan_release": (_I, [_VP]),
+    "dgg_reset": (_I, []),
+    "dgg_eva_keep_offset": (_I64, [_CFG, _I, _I]),
+    "dgg_resblock_param_floats": (_I64, [_I]),
+    "dgg_resblock_bnstat_floats": (_I64, [_I]),
+    "dgg_resblock_table": (_I, [_I, C.POINTER(Entry), _I]),
+    "dgg_resblock_workspace_bytes": (_I64, [_I, _I]),
+    "dgg_resblock_forward": (_I, [_I, _VP, _VP, _VP, _SZ, _I, _U, _VP, _I, _VP, _VP]),
+    "dgg_resblock_backward": (_I, [_I, _VP, _VP, _VP, _SZ, _I, _U, _VP, _I, _VP, _VP, _VP]),
     "dgg_gemm_f32": (_I, [_I, _I, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _VP, _I, _VP]),
 }
 
@@ -129,8 +138,9 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream_ptr(device=None):
+    """The current HIP stream of `device` (default: the current device) as a void*."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def table(net, ccfg):
@@ -221,4 +231,4 @@ class FlatNet:
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-4, grad_scale=1.0):
         self.step += 1
         check(lib().dgg_adam_l2(ptr(self.params), ptr(self.grads), ptr(self.m), ptr(self.v), self.n_params, self.step,
-                                lr, beta1, beta2, eps, weight_decay, grad_scale, stream_ptr()), "dgg_adam_l2")
+                                lr, beta1, beta2, eps, weight_decay, grad_scale, stream_ptr(self.device)), "dgg_adam_l2")

@@ -129,6 +129,43 @@ static int build_layout(int net, const dgg_cfg* c, NetL& L) {
     return DGG_OK;
 }
 
+// Stand-alone ResBlock (networks.py:26-56): one block, no input BatchNorm, no heads.  Same parameter order as a
+// block inside a network: [W13 = fc1.weight ; fc3.weight | b13 | bn1.w | bn1.b | W2 | b2 | bn2.w | bn2.b].
+static const int kNetResBlock = 3;
+static int build_rb_layout(int fin, NetL& L) {
+    if (fin < 1) return DGG_ERR_INVALID;
+    memset(&L, 0, sizeof(L));
+    L.net = kNetResBlock;
+    L.hid = 256;
+    L.nn = 512;
+    L.n13 = 768;
+    L.k_in = 0;
+    L.nprefix = 0;
+    L.k0 = fin;
+    L.ldx0 = 4;  // no X0 / dX0 buffers: the block reads the caller's x directly
+    L.nrb = 1;
+    int64_t po = 0, bo = 0;
+    auto P = [&](int64_t n) { int64_t o = po; po = align4(po + n); return o; };
+    auto S = [&](int64_t n) { int64_t o = bo; bo = align4(bo + n); return o; };
+    RbL& R = L.rb[0];
+    R.fin = fin;
+    R.w13 = P((int64_t)L.n13 * fin);
+    R.b13 = P(L.n13);
+    R.bn1w = P(L.hid);
+    R.bn1b = P(L.hid);
+    R.w2 = P((int64_t)L.nn * L.hid);
+    R.b2 = P(L.nn);
+    R.bn2w = P(L.nn);
+    R.bn2b = P(L.nn);
+    R.rm1 = S(L.hid);
+    R.rv1 = S(L.hid);
+    R.rm2 = S(L.nn);
+    R.rv2 = S(L.nn);
+    L.nparam = po;
+    L.nbn = bo;
+    return DGG_OK;
+}
+
 static int add_entry(dgg_entry* out, int cap, int& n, const char* name, int64_t off, int rows, int cols, int kind) {
     if (out && n < cap) {
         memset(&out[n], 0, sizeof(dgg_entry));
@@ -148,17 +185,22 @@ static int fill_table(const NetL& L, const dgg_cfg* c, dgg_entry* out, int cap) 
     const char* ibn = L.net == DGG_NET_GEN ? "gen_bn1" : L.net == DGG_NET_DISC ? "disc_bn1" : "bn1";
     const char* rbp = L.net == DGG_NET_GEN ? "gen_rb" : L.net == DGG_NET_DISC ? "disc_rb" : "rb";
     auto E = [&](const char* a, const char* b, int64_t off, int rows, int cols, int kind) {
-        snprintf(nm, sizeof(nm), "%s.%s", a, b);
+        if (a[0]) snprintf(nm, sizeof(nm), "%s.%s", a, b);
+        else snprintf(nm, sizeof(nm), "%s", b);
         add_entry(out, cap, n, nm, off, rows, cols, kind);
     };
-    E(ibn, "weight", L.ibnw, L.k_in, 1, 0);
-    E(ibn, "bias", L.ibnb, L.k_in, 1, 0);
-    E(ibn, "running_mean", L.irm, L.k_in, 1, 1);
-    E(ibn, "running_var", L.irv, L.k_in, 1, 1);
+    const bool bare = L.net == kNetResBlock;  // stand-alone block: keys "fc1.weight", ... without a prefix
+    if (!bare) {
+        E(ibn, "weight", L.ibnw, L.k_in, 1, 0);
+        E(ibn, "bias", L.ibnb, L.k_in, 1, 0);
+        E(ibn, "running_mean", L.irm, L.k_in, 1, 1);
+        E(ibn, "running_var", L.irv, L.k_in, 1, 1);
+    }
     for (int r = 0; r < L.nrb; ++r) {
         const RbL& R = L.rb[r];
         char pre[32];
-        snprintf(pre, sizeof(pre), "%s%d", rbp, r + 1);
+        if (bare) pre[0] = 0;
+        else snprintf(pre, sizeof(pre), "%s%d", rbp, r + 1);
         E(pre, "fc1.weight", R.w13, L.hid, R.fin, 0);
         E(pre, "fc3.weight", R.w13 + (int64_t)L.hid * R.fin, L.nn, R.fin, 0);
         E(pre, "fc1.bias", R.b13, L.hid, 1, 0);
@@ -174,6 +216,7 @@ static int fill_table(const NetL& L, const dgg_cfg* c, dgg_entry* out, int cap) 
         E(pre, "bn2.running_mean", R.rm2, L.nn, 1, 1);
         E(pre, "bn2.running_var", R.rv2, L.nn, 1, 1);
     }
+    if (bare) return n;
     if (L.net == DGG_NET_GEN) {
         const int nj = c->n_hand_joints;
         add_entry(out, cap, n, "gen_joint_conf.weight", L.wh, nj, L.nn, 0);
@@ -243,12 +286,14 @@ static void plan13(int B, int n13, const int* widths, int nseg, int* splits) {
     const int tiles = ((B + bm - 1) / bm) * ((n13 + bn - 1) / bn);
     int total_kt = 0;
     for (int i = 0; i < nseg; ++i) total_kt += (widths[i] + 31) / 32;
-    static int target = -1;
-    if (target < 0) {
+    // DGG_SPLITK_TARGET is read once (thread-safe static initialisation); the default follows the current algorithm
+    static const int env_target = [] {
         const char* e = getenv("DGG_SPLITK_TARGET");
-        target = e ? atoi(e) : (gemm_algo() == 1 ? 192 : 512);  // bf16x3 kernel: one workgroup per CU; measured best at 144-192 (other streams keep CUs)
-        if (target < 1) target = 1;
-    }
+        const int t = e ? atoi(e) : 0;
+        return t < 0 ? 0 : t;
+    }();
+    // bf16x3 kernel: one workgroup per CU; measured best at 144-192 (other streams keep CUs)
+    const int target = env_target > 0 ? env_target : (gemm_algo() == 1 ? 192 : 512);
     int s_total = target / (tiles > 0 ? tiles : 1);
     if (s_total < 1) s_total = 1;
     if (s_total > 16) s_total = 16;
@@ -607,7 +652,7 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
         int bm, bn;
         gemm_tile_shape(GEMM_TN, g.p[0].M, g.p[0].N, bm, bn, g.p[0].K);
         ibn_tiles[r] = (L.n13 + bm - 1) / bm;
-        if (ibn_tiles[r] > 12 || ix0 < 0) return DGG_ERR_INVALID;
+        if (ibn_tiles[r] > 12 || (ix0 < 0 && L.net != kNetResBlock)) return DGG_ERR_INVALID;
         DGG_TRY(gemm_launch(GEMM_TN, g, sw));
     }
     // 6. dgrad: dX_seg[:, lo:hi] (+)= dY13 W13[:, wcol+lo : wcol+hi]
@@ -868,7 +913,7 @@ using namespace dgg;
 // =================================================================================================
 extern "C" {
 
-const char* dgg_version(void) { return "dgg 0.1 (gfx950, fp32 MFMA)"; }
+const char* dgg_version(void) { return "dgg 0.2 (gfx950)"; }
 const char* dgg_last_error(void) { return g_err; }
 
 int dgg_table(int net, const dgg_cfg* cfg, dgg_entry* out, int cap) {
@@ -1073,7 +1118,9 @@ struct PendingReal {
     const void* ws;       // key: the step workspace this state belongs to (NULL = free slot)
     bool valid;           // a real pass has been prefetched for (B, bps, rot9, transl, joint)
     int B;
+    int step_B;           // batch size of the step whose G phase left the D-free mark (the workspace is carved for it)
     const float *bps, *rot9, *transl, *joint;
+    const float* d_params;  // the discriminator the prefetched pass was computed with
     hipEvent_t ev[6];     // fwd_done, bwd_done, 3 x share.ready, D-free; created with the slot
     bool events_ok, dfree_set;
     Share share;
@@ -1101,6 +1148,7 @@ static PendingReal* pending_slot(const void* ws, bool create) {
     lru->ws = ws;
     lru->valid = false;
     lru->dfree_set = false;
+    lru->step_B = 0;
     lru->stamp = ++g_pending_clock;
     return lru;
 }
@@ -1132,6 +1180,14 @@ int dgg_cgan_d_real_prefetch(const dgg_cfg* cfg, const dgg_gan_state* s, const d
     PendingReal* Pp = pending_slot(ws, true);
     if (!Pp) return DGG_ERR_LAUNCH;
     PendingReal& P = *Pp;
+    // The workspace is carved by batch size: a prefetch for another B would lay its real-pass regions over the
+    // generator / fake-pass regions the running G phase is still reading.  Refuse it (the caller simply skips the
+    // prefetch for a ragged last batch).
+    if (P.dfree_set && P.step_B != B) {
+        snprintf(g_err, sizeof(g_err), "dgg_cgan_d_real_prefetch: batch %d differs from the running step's %d", B,
+                 P.step_B);
+        return DGG_ERR_INVALID;
+    }
     // D's running statistics must already hold this step's third forward, its parameters this step's Adam update:
     // both precede the D-free mark that dgg_cgan_g_phase (same workspace) leaves on its stream
     if (P.dfree_set && hipStreamWaitEvent(sb, P.ev[5], 0) != hipSuccess) return DGG_ERR_LAUNCH;
@@ -1148,6 +1204,7 @@ int dgg_cgan_d_real_prefetch(const dgg_cfg* cfg, const dgg_gan_state* s, const d
     DGG_TRY(real_pass(cfg, s, hp, S, Ld, B, bps, rot9, transl, joint, losses + kLossRealNext, sb, P.share, P.ev[0],
                       P.ev[1]));
     P.B = B; P.bps = bps; P.rot9 = rot9; P.transl = transl; P.joint = joint;
+    P.d_params = s->d_params;
     P.valid = true;
     return DGG_OK;
 }
@@ -1169,7 +1226,7 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
     // a real pass prefetched for exactly these buffers? (anything else: it is dropped and redone)
     PendingReal* Pp = pending_slot(ws, false);
     const bool pre = fork && Pp && Pp->valid && Pp->B == B && Pp->bps == bps && Pp->rot9 == rot9 &&
-                     Pp->transl == transl && Pp->joint == joint;
+                     Pp->transl == transl && Pp->joint == joint && Pp->d_params == s->d_params;
     if (Pp) Pp->valid = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     Share share;
@@ -1242,6 +1299,7 @@ int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
     if (PendingReal* Pp = pending_slot(ws, true)) {
         if (hipEventRecord(Pp->ev[5], st) != hipSuccess) return DGG_ERR_LAUNCH;
         Pp->dfree_set = true;
+        Pp->step_B = B;
     } else {
         return DGG_ERR_LAUNCH;
     }
@@ -1294,6 +1352,112 @@ int dgg_eva_phase(const dgg_cfg* cfg, const float* e_params, float* e_grads, flo
     DGG_TRY(copy_cols_launch(losses + DGG_L_TOTAL_EVA, 1, losses + DGG_L_BCE_EVA, 1, 1, 1, st));
     DGG_TRY(dgg_eva_backward(cfg, e_params, e_grads, ws, W.bytes, B, DGG_TRAIN, bps, rot9, transl, dl, nullptr, stream));
     return DGG_OK;
+}
+
+// ---- hidden-state management -------------------------------------------------------------------
+int dgg_cgan_release(void* ws) {
+    for (int i = 0; i < kPendingSlots; ++i)
+        if (g_pending[i].ws == ws && ws) {
+            g_pending[i].ws = nullptr;
+            g_pending[i].valid = false;
+            g_pending[i].dfree_set = false;
+            g_pending[i].step_B = 0;
+            g_pending[i].stamp = 0;
+        }
+    return DGG_OK;
+}
+
+int dgg_reset(void) {
+    for (int i = 0; i < kPendingSlots; ++i) {
+        g_pending[i].ws = nullptr;
+        g_pending[i].valid = false;
+        g_pending[i].dfree_set = false;
+        g_pending[i].step_B = 0;
+        g_pending[i].stamp = 0;
+    }
+    int rc = DGG_OK;
+    for (int i = g_aux.n - 1; i >= 0; --i) {
+        if (g_aux.owned[i]) {
+            if (hipStreamSynchronize(g_aux.aux[i]) != hipSuccess || hipStreamDestroy(g_aux.aux[i]) != hipSuccess)
+                rc = DGG_ERR_LAUNCH;
+        }
+    }
+    g_aux.n = 0;
+    return rc;
+}
+
+int64_t dgg_eva_keep_offset(const dgg_cfg* cfg, int batch, int r) {
+    NetL L;
+    if (batch < 1 || build_layout(DGG_NET_EVA, cfg, L) || r < 0 || r >= L.nrb) return DGG_ERR_INVALID;
+    // carve against a fake (never dereferenced) base to read the offset back
+    NetW W;
+    char* fake = reinterpret_cast<char*>((uintptr_t)1 << 40);
+    carve(L, batch, fake, W);
+    return (int64_t)(reinterpret_cast<char*>(W.rb[r].keep) - fake);
+}
+
+// ---- A2: stand-alone ResBlock (networks.py:43-56, final_nl = True) ------------------------------
+int64_t dgg_resblock_param_floats(int fin) {
+    NetL L;
+    if (build_rb_layout(fin, L)) return DGG_ERR_INVALID;
+    return L.nparam;
+}
+int64_t dgg_resblock_bnstat_floats(int fin) {
+    NetL L;
+    if (build_rb_layout(fin, L)) return DGG_ERR_INVALID;
+    return L.nbn;
+}
+int dgg_resblock_table(int fin, dgg_entry* out, int cap) {
+    NetL L;
+    int rc = build_rb_layout(fin, L);
+    if (rc) return rc;
+    return fill_table(L, nullptr, out, cap);
+}
+int64_t dgg_resblock_workspace_bytes(int fin, int batch) {
+    NetL L;
+    if (batch < 1 || build_rb_layout(fin, L)) return DGG_ERR_INVALID;
+    NetW W;
+    carve(L, batch, nullptr, W);
+    return (int64_t)W.bytes;
+}
+
+int dgg_resblock_forward(int fin, const float* params, float* bnstats, void* ws, size_t ws_bytes, int B,
+                         unsigned flags, const float* x, int ldx, float* y, void* stream) {
+    NetL L;
+    DGG_TRY(build_rb_layout(fin, L));
+    if (!params || !bnstats || !ws || !x || !y || B < 1 || ldx < fin) return DGG_ERR_INVALID;
+    Ctx c;
+    c.share = nullptr;
+    c.L = &L; c.P = params; c.G = nullptr; c.bn = bnstats; c.B = B; c.train = (flags & DGG_TRAIN) != 0;
+    c.st = (hipStream_t)stream; c.sw = nullptr;
+    if (c.train && B < 2) return DGG_ERR_INVALID;
+    carve(L, B, ws, c.W);
+    if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
+    Seg seg;
+    memset(&seg, 0, sizeof(seg));
+    seg.p = x; seg.ld = ldx; seg.width = fin; seg.wcol = 0; seg.is_x0 = false;
+    DGG_TRY(rb_forward(c, 0, &seg, 1, 0, nullptr, 0, 0));
+    return copy_cols_launch(c.W.rb[0].y, L.nn, y, L.nn, B, L.nn, c.st);
+}
+
+int dgg_resblock_backward(int fin, const float* params, float* grads, void* ws, size_t ws_bytes, int B,
+                          unsigned flags, const float* x, int ldx, const float* dy, float* dx, void* stream) {
+    NetL L;
+    DGG_TRY(build_rb_layout(fin, L));
+    const bool skip = (flags & DGG_SKIP_PARAM_GRADS) != 0;
+    if (!params || !ws || !x || !dy || B < 1 || ldx < fin || (!skip && !grads)) return DGG_ERR_INVALID;
+    Ctx c;
+    c.share = nullptr;
+    c.L = &L; c.P = params; c.G = grads; c.bn = nullptr; c.B = B; c.train = (flags & DGG_TRAIN) != 0;
+    c.st = (hipStream_t)stream; c.sw = nullptr;
+    carve(L, B, ws, c.W);
+    if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
+    Seg seg;
+    memset(&seg, 0, sizeof(seg));
+    seg.p = x; seg.ld = ldx; seg.width = fin; seg.wcol = 0; seg.is_x0 = false;
+    if (dx) { seg.dp = dx; seg.dld = fin; seg.d_lo = 0; seg.d_hi = fin; seg.d_accum = 0; }
+    int ibn_tiles[3] = {0, 0, 0};
+    return rb_backward(c, 0, &seg, 1, dy, false, (flags & DGG_ACCUM_GRADS) != 0, skip, ibn_tiles);
 }
 
 int dgg_gemm_occupancy(int mode, int bm, int bn) {

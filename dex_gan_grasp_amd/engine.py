@@ -22,6 +22,9 @@ class TrainEngine:
         self.losses = torch.zeros(16, dtype=torch.float32, device=self.device)
         self._ws = {}
         self._ws_e = {}
+        self._side = None        # evaluator stream
+        self._side2 = None       # D real-batch pass (fork inside the D phase, prefetch across steps)
+        self._side2_busy = None  # event: last work enqueued on _side2 that the main stream has not joined yet
 
     # ---- helpers
     def _hp(self, lr_gen=None, lr_dis=None, lr_eva=None):
@@ -57,51 +60,96 @@ class TrainEngine:
         vals = [G.params, G.grads, G.m, G.v, G.bn, D.params, D.grads, D.m, D.v, D.bn]
         return _lib.GanState(*[t.data_ptr() for t in vals])
 
+    def flush(self):
+        """Make the current stream wait for everything this engine has enqueued on its side streams (a prefetched
+        real-batch pass of D writes D.grads, D's running statistics and its workspace).  Called by every entry point
+        other than joint_step and by anything that reads the networks' state (checkpoints, eval forwards)."""
+        if self._side2_busy is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._side2_busy)
+            self._side2_busy = None
+
+    def _streams(self, two_streams):
+        """(main, s2 as void* or None): the D phase forks its real-batch pass onto _side2, and every compute
+        stream gets a library-owned weight-gradient side stream."""
+        main = torch.cuda.current_stream(self.device)
+        if not two_streams:
+            return main, None
+        if self._side2 is None:
+            self._side2 = torch.cuda.Stream(device=self.device)
+        self._map_wgrad_streams(main, self._side2)
+        return main, C.c_void_p(self._side2.cuda_stream)
+
     # ---- A10
-    def cgan_step(self, bps, rot9, transl, joint, z, is_train_gen=True, lr_gen=None, lr_dis=None):
+    def cgan_step(self, bps, rot9, transl, joint, z, is_train_gen=True, lr_gen=None, lr_dis=None, two_streams=False):
         """One update_dexgangrasp step on this rank's shard.  Inputs: fp32 device tensors.
-        Returns a (16,) device tensor of losses (slots: _lib.L_*); values are a fresh copy."""
+        Returns a (16,) device tensor of losses (slots: _lib.L_*); values are a fresh copy.
+        two_streams: intra-step concurrency (D's real-batch pass and the weight-gradient GEMMs on side streams,
+        joined before the call returns; bit-identical results)."""
         dev = self.device
+        self.flush()
         bps, rot9, transl, joint, z = (f32c(t, dev) for t in (bps, rot9.reshape(-1, 9), transl, joint, z))
         B = bps.shape[0]
         ws = self._cgan_ws(B)
         hp = self._hp(lr_gen, lr_dis)
         st = self._state()
+        _, s2 = self._streams(two_streams)
         cfg_p, args = C.byref(self.ccfg), (ptr(bps), ptr(rot9), ptr(transl), ptr(joint), ptr(z))
-        check(lib().dgg_cgan_d_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(self.losses),
-                                     stream_ptr()), "dgg_cgan_d_phase")
+        check(lib().dgg_cgan_d_phase2(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(self.losses),
+                                      stream_ptr(dev), s2), "dgg_cgan_d_phase2")
         parallel.allreduce_sum_(self.D.grads)
         self.D.adam_step(hp.lr_dis, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
         if is_train_gen:
             check(lib().dgg_cgan_g_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args,
-                                         ptr(self.losses), stream_ptr()), "dgg_cgan_g_phase")
+                                         ptr(self.losses), stream_ptr(dev)), "dgg_cgan_g_phase")
             parallel.allreduce_sum_(self.G.grads)
             self.G.adam_step(hp.lr_gen, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
         return self.losses.clone()
 
     # ---- A11
-    def eva_step(self, bps, rot9, transl, label, drop_keep=None, seed=0, lr=None):
+    def eva_step(self, bps, rot9, transl, label, drop_keep=None, seed=0, lr=None, two_streams=False):
         dev = self.device
+        self.flush()
         bps, rot9, transl, label = (f32c(t, dev) for t in (bps, rot9.reshape(-1, 9), transl, label.reshape(-1)))
         dk = f32c(drop_keep, dev) if drop_keep is not None else None
         B = bps.shape[0]
         ws = self._eva_ws(B)
         hp = self._hp(lr_eva=lr)
         E = self.E
+        if two_streams:
+            self._map_wgrad_streams(torch.cuda.current_stream(dev))
         check(lib().dgg_eva_phase(C.byref(self.ccfg), ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(ws),
                                   ws.numel(), B, ptr(bps), ptr(rot9), ptr(transl), ptr(label), ptr(dk), int(seed),
-                                  ptr(self.losses), stream_ptr()), "dgg_eva_phase")
+                                  ptr(self.losses), stream_ptr(dev)), "dgg_eva_phase")
         parallel.allreduce_sum_(E.grads)
         E.adam_step(hp.lr_eva, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
         return self.losses.clone()
 
-    def __del__(self):
-        # one disable per enable: the library frees a side stream when its last user is gone
+    def eva_keep_masks(self, B):
+        """The dropout keep masks (3, B, 512) uint8 that the last train-mode evaluator pass at batch B wrote into
+        its workspace (drawn in-kernel from Philox unless masks were given) — what its backward used."""
+        ws = self._eva_ws(B)
+        out = []
+        for r in range(3):
+            off = int(lib().dgg_eva_keep_offset(C.byref(self.ccfg), B, r))
+            if off < 0:
+                raise _lib.DggError("dgg_eva_keep_offset: %d" % off)
+            out.append(ws[off:off + B * 512].view(B, 512).clone())
+        return torch.stack(out)
+
+    def close(self):
+        """Release what the library remembers about this engine: pending-prefetch slots keyed by its workspaces and
+        its weight-gradient side streams (one disable per enable).  Must run on the thread that used the engine."""
         try:
-            for key in getattr(self, "_wg_mapped", ()):
+            for ws in self._ws.values():
+                lib().dgg_cgan_release(ptr(ws))
+            for key in getattr(self, "_wg_mapped", None) or ():
                 lib().dgg_enable_wgrad_stream(C.c_void_p(key), 0)
+            self._wg_mapped = set()
         except Exception:
             pass
+
+    def __del__(self):
+        self.close()
 
     def _map_wgrad_streams(self, *streams):
         """Give each compute stream a weight-gradient side stream (dgg_enable_wgrad_stream): dW GEMMs have no
@@ -138,6 +186,8 @@ class TrainEngine:
         call must pass the very same tensors as gan_inputs.  Same results, bit for bit."""
         dev = self.device
         bps, rot9, transl, joint = (f32c(t, dev) for t in gan_inputs)
+        if not two_streams:
+            self.flush()
         rot9 = rot9.reshape(-1, 9)
         z = f32c(z, dev)
         ebps, erot9, etransl, elabel = (f32c(t, dev) for t in eva_inputs)
@@ -151,30 +201,23 @@ class TrainEngine:
         args = (ptr(bps), ptr(rot9), ptr(transl), ptr(joint), ptr(z))
         G, D, E = self.G, self.D, self.E
         adam = lambda net, lr: net.adam_step(lr, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
-        main = torch.cuda.current_stream(dev)
+        main, s2 = self._streams(two_streams)
         if two_streams:
-            if getattr(self, "_side", None) is None:
+            if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
             side = self._side
             side.wait_stream(main)          # inputs / previous step are ordered before the evaluator update
+            self._map_wgrad_streams(side)
         else:
             side = main
-
-        if two_streams:
-            if getattr(self, "_side2", None) is None:
-                self._side2 = torch.cuda.Stream(device=dev)
-            s2 = C.c_void_p(self._side2.cuda_stream)
-        else:
-            s2 = None
-        if two_streams:
-            self._map_wgrad_streams(main, self._side2, side)
         check(lib().dgg_cgan_d_phase2(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(self.losses),
-                                      stream_ptr(), s2), "dgg_cgan_d_phase2")
+                                      stream_ptr(dev), s2), "dgg_cgan_d_phase2")
+        self._side2_busy = None             # the D phase joins _side2 (a picked-up prefetch included) into main
         w_d = parallel.allreduce_sum_(D.grads, async_op=True)
         with torch.cuda.stream(side):
             check(lib().dgg_eva_phase(cfg_p, ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(wse),
                                       wse.numel(), Be, ptr(ebps), ptr(erot9), ptr(etransl), ptr(elabel), ptr(dk),
-                                      int(seed), ptr(self.losses), stream_ptr()), "dgg_eva_phase")
+                                      int(seed), ptr(self.losses), stream_ptr(dev)), "dgg_eva_phase")
             w_e = parallel.allreduce_sum_(E.grads, async_op=True)
         if w_d is not None:
             w_d.wait()
@@ -182,9 +225,10 @@ class TrainEngine:
         w_g = None
         if is_train_gen:
             check(lib().dgg_cgan_g_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args,
-                                         ptr(self.losses), stream_ptr()), "dgg_cgan_g_phase")
+                                         ptr(self.losses), stream_ptr(dev)), "dgg_cgan_g_phase")
             w_g = parallel.allreduce_sum_(G.grads, async_op=True)
-            if two_streams and next_gan_inputs is not None:
+            # a ragged next batch (last of an epoch) is simply not prefetched: the workspace is carved per batch size
+            if two_streams and next_gan_inputs is not None and next_gan_inputs[0].shape[0] == B:
                 nb, nr, nt, nj_ = next_gan_inputs
                 nr = nr.reshape(-1, 9)
                 for t in (nb, nr, nt, nj_):
@@ -194,6 +238,7 @@ class TrainEngine:
                 check(lib().dgg_cgan_d_real_prefetch(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), nb.shape[0],
                                                      ptr(nb), ptr(nr), ptr(nt), ptr(nj_), ptr(self.losses), s2),
                       "dgg_cgan_d_real_prefetch")
+                self._side2_busy = self._side2.record_event()
         with torch.cuda.stream(side):
             if w_e is not None:
                 w_e.wait()
@@ -204,4 +249,4 @@ class TrainEngine:
             adam(G, hp.lr_gen)
         if two_streams:
             main.wait_stream(side)
-        return self.losses
+        return self.losses.clone()

@@ -21,9 +21,14 @@ from . import losses, networks
 from .networks import DexEvaluator, DexGANGrasp
 
 
+# DGG_API_STREAMS=0: run update_* on the caller's stream only (default: D's real-batch pass and the weight-gradient
+# GEMMs of each update overlap on library side streams, joined before the call returns; bit-identical results)
+_API_STREAMS = os.environ.get("DGG_API_STREAMS", "1") != "0"
+
+
 def define_losses(loss_type_recon):
-    """dexgangrasp.py:13-25."""
-    kl_loss = losses.kl_divergence
+    """dexgangrasp.py:13-25 (the VAE-era KL term is dead code in the reference: not mirrored)."""
+    kl_loss = None
     if loss_type_recon == 'transl_rot_6D_l2':
         reconstruction_loss = losses.transl_rot_6D_l2_loss
     else:
@@ -77,16 +82,23 @@ class DexGanGrasp(object):
         self.cfg = cfg
         self.is_train = cfg["is_train"]
         self.is_wgan = cfg["is_wgan"]
+        world = parallel.env_rank_world()[1]
         if torch.cuda.is_available():
-            # one process per GPU under torchrun (LOCAL_RANK); otherwise the first configured id
-            _, world, local = parallel.env_rank_world()
-            self.device = torch.device('cuda:{}'.format(local if world > 1 else cfg["gpu_ids"][0]))
+            if world > 1:
+                # one process per GPU under torchrun: join the process group and make this rank's GPU the current
+                # device before anything touches HIP (kernels launch on the current device)
+                _, _, idx = parallel.init_from_env()
+                self.device = torch.device('cuda:{}'.format(idx))
+            else:
+                self.device = torch.device('cuda:{}'.format(cfg["gpu_ids"][0]))
+                torch.cuda.set_device(self.device)
         else:
             self.device = torch.device('cpu')
-        if len(cfg["gpu_ids"]) > 1 and parallel.env_rank_world()[1] == 1:
+        if len(cfg["gpu_ids"]) > 1 and world == 1:
             raise NotImplementedError(
                 "multi-GPU runs use one process per GPU: launch with torchrun / torch.distributed.run "
                 "(gradients are all-reduced over RCCL); nn.DataParallel is not used")
+
         if self.is_wgan:
             raise NotImplementedError("is_wgan=True (WGAN-GP, dexgangrasp.py:149-211,234-270) is not built yet")
 
@@ -94,6 +106,7 @@ class DexGanGrasp(object):
             self.DexGANGrasp, self.DexEvaluator = build_network(cfg, self.device, is_train=self.is_train)
         else:
             raise ValueError('Wrong configure model name of', cfg["model"])
+        self._sync_replicas()   # every rank draws its own init (dexgangrasp.py:39-62): rank 0's wins
 
         if self.is_train:
             self.bce_weight = cfg["bce_weight"]
@@ -134,6 +147,24 @@ class DexGanGrasp(object):
         self._drop_keep = None       # tests: explicit evaluator dropout masks
 
     # ------------------------------------------------------------------ engine plumbing
+    def _sync_replicas(self, with_optim=False):
+        """Data-parallel replicas must be identical: broadcast rank 0's parameters and BatchNorm
+        statistics (after init and after every load_*; with_optim: Adam moments and step too)."""
+        if not parallel.is_distributed() or not self.device.type == 'cuda':
+            return
+        for mod in (self.DexGANGrasp.generator, self.DexGANGrasp.discriminator, self.DexEvaluator):
+            flat = mod._require_flat()
+            bufs = [flat.params, flat.bn] + ([flat.m, flat.v] if with_optim and flat.m is not None else [])
+            for t in bufs:
+                parallel.broadcast_(t)
+            if with_optim:
+                st = torch.tensor([flat.step], dtype=torch.int64, device=self.device)
+                parallel.broadcast_(st)
+                flat.step = int(st.item())
+            for m in mod.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    parallel.broadcast_(m.num_batches_tracked)
+
     def _eng(self):
         if self._engine is None:
             g = self.DexGANGrasp.generator._require_flat()
@@ -202,7 +233,7 @@ class DexGanGrasp(object):
         ccfg = _lib.make_cfg(self.cfg)
         _lib.check(_lib.lib().dgg_gen_loss(_lib.C.byref(ccfg), _lib.C.byref(hp), B, _lib.ptr(heads), _lib.ptr(gt_rot),
                                            _lib.ptr(gt_tr), _lib.ptr(gt_j), _lib.ptr(_lib.f32c(fake_score.detach(), dev)),
-                                           None, _lib.ptr(out), None, _lib.stream_ptr()), "dgg_gen_loss")
+                                           None, _lib.ptr(out), None, _lib.stream_ptr(dev)), "dgg_gen_loss")
         loss_dict = {'gen_loss_fake': out[_lib.L_GEN_FAKE], 'transl_loss': out[_lib.L_TRANSL],
                      'rot_loss': out[_lib.L_ROT], 'conf_loss': out[_lib.L_CONF],
                      'total_loss_gen': out[_lib.L_TOTAL_GEN]}
@@ -415,6 +446,7 @@ class DexGanGrasp(object):
             self.DexEvaluator.train()
         else:
             self.DexEvaluator.eval()
+        self._sync_replicas(with_optim=self.cfg["is_train"])
 
     def load_dexgenerator(self, epoch, load_path=None):
         """dexgangrasp.py:594-617 (+ the GAN optimisers, which the reference saves but leaves as a TODO
@@ -439,10 +471,13 @@ class DexGanGrasp(object):
         else:
             print("Network in EVAL mode")
             self.DexGANGrasp.eval()
+        self._sync_replicas(with_optim=self.cfg["is_train"])
 
     def save_dexevaluator(self, net_name, epoch):
         """dexgangrasp.py:662-683: same file name and dict keys."""
         save_path = os.path.join(self.cfg["save_dir"], net_name + '_eva_net.pt')
+        if self._engine is not None:
+            self._engine.flush()
         self._export_adam(self.optim_dexevaluator, self.DexEvaluator, self.DexEvaluator._require_flat())
         sd = {k: v.detach().cpu().clone() for k, v in self.DexEvaluator.state_dict().items()}
         torch.save({'epoch': epoch, 'ffhevaluator_state_dict': sd,
@@ -452,6 +487,8 @@ class DexGanGrasp(object):
     def save_dexgenerator(self, net_name, epoch):
         """dexgangrasp.py:685-712: same file name and dict keys."""
         save_path = os.path.join(self.cfg["save_dir"], net_name + '_gen_net.pt')
+        if self._engine is not None:
+            self._engine.flush()
         self._export_adam(self.optim_dexgangrasp_generator, self.DexGANGrasp.generator,
                           self.DexGANGrasp.generator._require_flat())
         self._export_adam(self.optim_dexgangrasp_discriminator, self.DexGANGrasp.discriminator,
@@ -500,7 +537,8 @@ class DexGanGrasp(object):
         if self._drop_keep is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         lr = self.optim_dexevaluator.param_groups[0]['lr']
-        out = self._eng().eva_step(eva.bps_object, eva.rot_matrix, eva.transl, eva.gt_label, self._drop_keep, seed, lr)
+        out = self._eng().eva_step(eva.bps_object, eva.rot_matrix, eva.transl, eva.gt_label, self._drop_keep, seed, lr,
+                                   two_streams=_API_STREAMS)
         self._bump(eva, 1)
         return {'total_loss_eva': out[_lib.L_TOTAL_EVA], 'bce_loss': out[_lib.L_BCE_EVA]}
 
@@ -518,7 +556,8 @@ class DexGanGrasp(object):
         joint = _lib.f32c(real_data["joint_conf"], dev)
         out = self._eng().cgan_step(bps, rot9, transl, joint, Zgen, is_train_gen,
                                     self.optim_dexgangrasp_generator.param_groups[0]['lr'],
-                                    self.optim_dexgangrasp_discriminator.param_groups[0]['lr'])
+                                    self.optim_dexgangrasp_discriminator.param_groups[0]['lr'],
+                                    two_streams=_API_STREAMS)
         self._bump(gan.generator, 1)
         self._bump(gan.discriminator, 3 if is_train_gen else 2)
         loss_dict = {'total_loss_disc': out[_lib.L_TOTAL_DISC], 'bce_loss_real': out[_lib.L_BCE_REAL],

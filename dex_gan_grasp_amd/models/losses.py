@@ -15,11 +15,6 @@ def accuracy_evaluator(pred_label, gt_label):
     return true_positive, true_negative, acc
 
 
-def kl_divergence(mu, logvar, device="cpu"):
-    """losses.py:54-58 (VAE-era, unused by the GAN path; kept for API parity)."""
-    return torch.mean(-.5 * torch.sum(1. + logvar - mu ** 2 - torch.exp(logvar), dim=-1))
-
-
 def transl_rot_6D_l2_loss(pred_transl_rot_6D, gt_transl_rot_matrix, torch_l2_loss_fn, device='cpu'):
     pred_rot_matrix = utils.rot_matrix_from_ortho6d(pred_transl_rot_6D['rot_6D'])
     pred_rot_matrix = pred_rot_matrix.reshape(pred_rot_matrix.shape[0], -1)

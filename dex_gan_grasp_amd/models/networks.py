@@ -21,7 +21,7 @@ import torch
 from torch import nn
 from torch.optim import lr_scheduler
 
-from .. import _lib, ops
+from .. import _lib, ops, parallel
 from ..utils import utils
 
 
@@ -39,13 +39,77 @@ def get_scheduler(optimizer, cfg):
 
 
 def _default_device(cfg):
-    return torch.device('cuda:{}'.format(cfg["gpu_ids"][0])) if torch.cuda.is_available() else torch.device('cpu')
+    """cfg["gpu_ids"][0] as in the reference (networks.py:170); one process per GPU under torchrun: this rank's GPU."""
+    if not torch.cuda.is_available():
+        return torch.device('cpu')
+    if parallel.env_rank_world()[1] > 1:
+        return torch.device('cuda:{}'.format(parallel.local_device_index()))
+    return torch.device('cuda:{}'.format(cfg["gpu_ids"][0]))
+
+
+class _ResBlockFn(torch.autograd.Function):
+    """Stand-alone ResBlock through dgg_resblock_forward / dgg_resblock_backward.  The block's tensors are packed
+    into the library's flat layout for the call ([fc1.weight ; fc3.weight | biases | bn1 | fc2 | bn2]) — inside a
+    network they already live that way; on its own the module keeps ordinary Parameters."""
+
+    @staticmethod
+    def forward(ctx, mod, train, x, *params):
+        import ctypes as C
+        dev = x.device
+        fin = mod.Fin
+        lib = _lib.lib()
+        n = int(lib.dgg_resblock_table(fin, None, 0))
+        arr = (_lib.Entry * n)()
+        lib.dgg_resblock_table(fin, arr, n)
+        entries = [(e.name.decode(), int(e.offset), int(e.rows) * int(e.cols), int(e.kind)) for e in arr]
+        named = dict(mod.named_parameters())
+        bufs = dict(mod.named_buffers())
+        flat = torch.zeros(int(lib.dgg_resblock_param_floats(fin)), dtype=torch.float32, device=dev)
+        bn = torch.zeros(int(lib.dgg_resblock_bnstat_floats(fin)), dtype=torch.float32, device=dev)
+        for name, off, cnt, kind in entries:
+            src = named[name] if kind == 0 else bufs[name]
+            (flat if kind == 0 else bn)[off:off + cnt].copy_(src.detach().reshape(-1))
+        xc = _lib.f32c(x, dev)
+        B = xc.shape[0]
+        ws = _lib.new_workspace(int(lib.dgg_resblock_workspace_bytes(fin, B)), dev)
+        y = torch.empty((B, mod.Fout), dtype=torch.float32, device=dev)
+        _lib.check(lib.dgg_resblock_forward(fin, _lib.ptr(flat), _lib.ptr(bn), _lib.ptr(ws), ws.numel(), B,
+                                            _lib.TRAIN if train else 0, _lib.ptr(xc), xc.stride(0), _lib.ptr(y),
+                                            _lib.stream_ptr(dev)), "dgg_resblock_forward")
+        if train:  # running statistics advanced in the packed copy: write them back
+            with torch.no_grad():
+                for name, off, cnt, kind in entries:
+                    if kind == 1:
+                        bufs[name].copy_(bn[off:off + cnt].view_as(bufs[name]))
+        ctx.mod, ctx.train, ctx.entries, ctx.ws, ctx.flat = mod, train, entries, ws, flat
+        ctx.save_for_backward(xc)
+        ctx.need_x = x.requires_grad
+        ctx.pnames = [nm for nm, _ in mod.named_parameters()]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        mod, dev = ctx.mod, xc.device
+        lib = _lib.lib()
+        B = xc.shape[0]
+        grads = torch.zeros_like(ctx.flat)
+        dx = torch.empty((B, mod.Fin), dtype=torch.float32, device=dev) if ctx.need_x else None
+        dyc = _lib.f32c(dy, dev)
+        _lib.check(lib.dgg_resblock_backward(mod.Fin, _lib.ptr(ctx.flat), _lib.ptr(grads), _lib.ptr(ctx.ws),
+                                             ctx.ws.numel(), B, _lib.TRAIN if ctx.train else 0, _lib.ptr(xc),
+                                             xc.stride(0), _lib.ptr(dyc), _lib.ptr(dx), _lib.stream_ptr(dev)),
+                   "dgg_resblock_backward")
+        named = dict(mod.named_parameters())
+        off = {name: (o, c) for name, o, c, kind in ctx.entries if kind == 0}
+        pg = [grads[off[nm][0]:off[nm][0] + off[nm][1]].view_as(named[nm]) for nm in ctx.pnames]
+        return (None, None, dx, *pg)
 
 
 class ResBlock(nn.Module):
-    """networks.py:26-56.  Holds the parameters (fc1, bn1, fc2, bn2, fc3) under the reference's
-    names.  Inside Generator/Discriminator/DexEvaluator the block is executed by the fused network
-    kernels; called on its own it is not part of the reference's hot path and is not supported."""
+    """networks.py:26-56.  Holds the parameters (fc1, bn1, fc2, bn2, fc3) under the reference's names.  Inside
+    Generator / Discriminator / DexEvaluator the block is executed by the fused network kernels; called on its own
+    (networks.py:43-56) it runs through dgg_resblock_forward / _backward with full autograd support."""
 
     def __init__(self, Fin, Fout, n_neurons=256):
         super(ResBlock, self).__init__()
@@ -60,8 +124,17 @@ class ResBlock(nn.Module):
         self.ll = nn.LeakyReLU(negative_slope=0.2)
 
     def forward(self, x, final_nl=True):
-        raise _lib.DggError("ResBlock is executed inside the fused network kernels of libdgg.so; "
-                            "a stand-alone ResBlock.forward is outside the accelerated path")
+        if not x.is_cuda:
+            raise _lib.DggError("ResBlock.forward: GPU tensor required (this implementation has no CPU path)")
+        if self.Fin == self.Fout or self.fc1.out_features != 256 or self.Fout != 512 or not final_nl:
+            # every ResBlock the reference builds is (Fin != 512) -> 512 with 256 hidden units and final_nl=True
+            # (networks.py:73-74,119-120,290-292); other shapes have no kernel
+            raise _lib.DggError("stand-alone ResBlock: only Fin != Fout = 512, n_neurons = 256, final_nl=True")
+        y = _ResBlockFn.apply(self, self.training, x, *[p for _, p in self.named_parameters()])
+        if self.training:
+            self.bn1.num_batches_tracked += 1
+            self.bn2.num_batches_tracked += 1
+        return y
 
 
 class _FlatBacked(nn.Module):

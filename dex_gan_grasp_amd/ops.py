@@ -29,7 +29,7 @@ def bps_encode(clouds, basis, return_ids=True):
     P = b.shape[0]
     dists = torch.empty((B, P), dtype=torch.float32, device=dev)
     ids = torch.empty((B, P), dtype=torch.int32, device=dev) if return_ids else None
-    check(lib().dgg_bps_encode(ptr(x), B, N, ptr(b), P, ptr(dists), ptr(ids), stream_ptr()), "dgg_bps_encode")
+    check(lib().dgg_bps_encode(ptr(x), B, N, ptr(b), P, ptr(dists), ptr(ids), stream_ptr(dev)), "dgg_bps_encode")
     return (dists, ids) if return_ids else dists
 
 
@@ -39,7 +39,7 @@ def gemm(mode, A, Bm, M, N, K, splits=0, C_out=None, accumulate=False):
     out = C_out if C_out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
     slabs = torch.empty((max(splits, 1) * M * N,), dtype=torch.float32, device=dev) if splits >= 1 else None
     check(lib().dgg_gemm_f32(mode, M, N, K, ptr(A), A.stride(0), ptr(Bm), Bm.stride(0), ptr(out), out.stride(0),
-                             splits, ptr(slabs), 1 if accumulate else 0, stream_ptr()), "dgg_gemm_f32")
+                             splits, ptr(slabs), 1 if accumulate else 0, stream_ptr(dev)), "dgg_gemm_f32")
     return out
 
 
@@ -51,7 +51,7 @@ def gen_forward(fn, z, bps, train, ws=None):
     ws = ws if ws is not None else fn.workspace(B)
     out = torch.empty((B, fn.ccfg.n_hand_joints + 9), dtype=torch.float32, device=dev)
     check(lib().dgg_gen_forward(C.byref(fn.ccfg), ptr(fn.params), ptr(fn.bn), ptr(ws), ws.numel(), B,
-                                _lib.TRAIN if train else 0, ptr(z), ptr(bps), ptr(out), stream_ptr()), "dgg_gen_forward")
+                                _lib.TRAIN if train else 0, ptr(z), ptr(bps), ptr(out), stream_ptr(dev)), "dgg_gen_forward")
     return out
 
 
@@ -64,7 +64,7 @@ def gen_backward(fn, z, bps, d_heads, train, want_dz=False, want_dbps=False, acc
     dbps = torch.empty((B, fn.ccfg.in_bps), dtype=torch.float32, device=dev) if want_dbps else None
     flags = (_lib.TRAIN if train else 0) | (_lib.ACCUM_GRADS if accumulate else 0)
     check(lib().dgg_gen_backward(C.byref(fn.ccfg), ptr(fn.params), ptr(fn.grads), ptr(ws), ws.numel(), B, flags,
-                                 ptr(z), ptr(bps), ptr(d_heads), ptr(dz), ptr(dbps), stream_ptr()), "dgg_gen_backward")
+                                 ptr(z), ptr(bps), ptr(d_heads), ptr(dz), ptr(dbps), stream_ptr(dev)), "dgg_gen_backward")
     return dz, dbps
 
 
@@ -76,7 +76,7 @@ def disc_forward(fn, bps, rot9, transl, joint, train, ws=None):
     out = torch.empty((B, 1), dtype=torch.float32, device=dev)
     check(lib().dgg_disc_forward(C.byref(fn.ccfg), ptr(fn.params), ptr(fn.bn), ptr(ws), ws.numel(), B,
                                  _lib.TRAIN if train else 0, ptr(bps), ptr(rot9), ptr(transl), ptr(joint), ptr(out),
-                                 stream_ptr()), "dgg_disc_forward")
+                                 stream_ptr(dev)), "dgg_disc_forward")
     return out
 
 
@@ -92,7 +92,7 @@ def disc_backward(fn, bps, rot9, transl, joint, d_logit, train, need_input=False
             (_lib.SKIP_PARAM_GRADS if skip_param else 0) | (_lib.NEED_INPUT_GRADS if need_input else 0)
     check(lib().dgg_disc_backward(C.byref(fn.ccfg), ptr(fn.params), None if skip_param else ptr(fn.grads), ptr(ws),
                                   ws.numel(), B, flags, ptr(bps), ptr(rot9), ptr(transl), ptr(joint), ptr(d_logit),
-                                  ptr(d_pose), stream_ptr()), "dgg_disc_backward")
+                                  ptr(d_pose), stream_ptr(dev)), "dgg_disc_backward")
     return d_pose
 
 
@@ -105,7 +105,7 @@ def eva_forward(fn, bps, rot9, transl, train, drop_keep=None, seed=0, ws=None):
     out = torch.empty((B, 1), dtype=torch.float32, device=dev)
     check(lib().dgg_eva_forward(C.byref(fn.ccfg), ptr(fn.params), ptr(fn.bn), ptr(ws), ws.numel(), B,
                                 _lib.TRAIN if train else 0, ptr(bps), ptr(rot9), ptr(transl), ptr(dk), int(seed),
-                                ptr(out), stream_ptr()), "dgg_eva_forward")
+                                ptr(out), stream_ptr(dev)), "dgg_eva_forward")
     return out
 
 
@@ -120,7 +120,7 @@ def eva_backward(fn, bps, rot9, transl, d_logit, train, need_input=False, skip_p
             (_lib.SKIP_PARAM_GRADS if skip_param else 0) | (_lib.NEED_INPUT_GRADS if need_input else 0)
     check(lib().dgg_eva_backward(C.byref(fn.ccfg), ptr(fn.params), None if skip_param else ptr(fn.grads), ptr(ws),
                                  ws.numel(), B, flags, ptr(bps), ptr(rot9), ptr(transl), ptr(d_logit), ptr(d_pose),
-                                 stream_ptr()), "dgg_eva_backward")
+                                 stream_ptr(dev)), "dgg_eva_backward")
     return d_pose
 
 
@@ -130,7 +130,7 @@ def ortho6d_forward(o6):
     o6 = f32c(o6, dev)
     B = o6.shape[0]
     r = torch.empty((B, 9), dtype=torch.float32, device=dev)
-    check(lib().dgg_ortho6d_forward(ptr(o6), o6.stride(0), B, ptr(r), stream_ptr()), "dgg_ortho6d_forward")
+    check(lib().dgg_ortho6d_forward(ptr(o6), o6.stride(0), B, ptr(r), stream_ptr(dev)), "dgg_ortho6d_forward")
     return r.view(B, 3, 3)
 
 
@@ -139,7 +139,7 @@ def ortho6d_backward(o6, d_rot):
     o6, d_rot = f32c(o6, dev), f32c(d_rot, dev).reshape(-1, 9)
     B = o6.shape[0]
     d = torch.empty((B, 6), dtype=torch.float32, device=dev)
-    check(lib().dgg_ortho6d_backward(ptr(o6), o6.stride(0), B, ptr(d_rot), ptr(d), 6, stream_ptr()),
+    check(lib().dgg_ortho6d_backward(ptr(o6), o6.stride(0), B, ptr(d_rot), ptr(d), 6, stream_ptr(dev)),
           "dgg_ortho6d_backward")
     return d
 
@@ -154,7 +154,7 @@ def bce(p, target, weight=1.0, loss_scale=1.0, want_grad=True):
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
     dl = torch.empty((B, 1), dtype=torch.float32, device=dev) if want_grad else None
     check(lib().dgg_bce(ptr(p), ptr(labels), const, B, float(weight), float(loss_scale), ptr(loss), ptr(dl),
-                        stream_ptr()), "dgg_bce")
+                        stream_ptr(dev)), "dgg_bce")
     return loss[0], dl
 
 
@@ -163,7 +163,7 @@ def translate_along_axis(transl, rot9, axis, offset):
     if not transl.is_contiguous() or transl.dtype != torch.float32:
         raise _lib.DggError("translate_along_axis works in place on a contiguous float32 (N, 3) tensor")
     check(lib().dgg_translate_along_axis(ptr(transl), ptr(f32c(rot9, dev)), transl.shape[0], int(axis), float(offset),
-                                         stream_ptr()), "dgg_translate_along_axis")
+                                         stream_ptr(dev)), "dgg_translate_along_axis")
     return transl
 
 

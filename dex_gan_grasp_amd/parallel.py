@@ -23,18 +23,32 @@ def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def rehearsal():
+    """DGG_REHEARSE=1: run the multi-rank code path on ONE GPU — every rank on cuda:0, collectives over gloo.
+    For tests of the engine's collective / stream ordering on a 1-GPU box; never for reported numbers."""
+    return os.environ.get("DGG_REHEARSE") == "1"
+
+
+def local_device_index():
+    """Index of the GPU this process drives: LOCAL_RANK under torchrun (0 in a rehearsal)."""
+    _, world, local = env_rank_world()
+    return 0 if (world == 1 or rehearsal()) else local
+
+
 def init_from_env(backend=None):
-    """Initialise the default process group from torchrun's environment (no-op for WORLD_SIZE=1)."""
-    rank, world, local = env_rank_world()
+    """Initialise the default process group from torchrun's environment (no-op for WORLD_SIZE=1) and make this
+    rank's GPU the current device BEFORE anything else touches HIP.  Returns (rank, world, device index)."""
+    rank, world, _ = env_rank_world()
+    dev = local_device_index()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(dev)
     if world > 1 and not (dist.is_available() and dist.is_initialized()):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            backend = "gloo" if (rehearsal() or not torch.cuda.is_available()) else "nccl"
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return rank, world, local
+    return rank, world, dev
 
 
 def world_size():
@@ -66,6 +80,29 @@ def allreduce_sum_(flat_grads, async_op=False):
     if not is_distributed():
         return None
     return dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
+def broadcast_(t, src=0):
+    """In-place broadcast of a tensor from rank `src` (replicas start / resume identical)."""
+    if is_distributed():
+        dist.broadcast(t, src=src)
+    return t
+
+
+def gather_counts(t):
+    """All-gather of a small per-rank tensor along dim 0 (the inference sweep's filtered-grasp counts, SURVEY.md
+    8(e)): every rank gets the concatenation in rank order.  Shards may differ in length."""
+    if not is_distributed():
+        return t
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    sizes = [torch.zeros_like(n) for _ in range(world_size())]
+    dist.all_gather(sizes, n)
+    m = int(max(int(x.item()) for x in sizes))
+    pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[:t.shape[0]] = t
+    parts = [torch.zeros_like(pad) for _ in range(world_size())]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[:int(k.item())] for p, k in zip(parts, sizes)], dim=0)
 
 
 def grad_scale():

@@ -1,7 +1,8 @@
 """Mirror of the math subset of DexGanGrasp/utils/utils.py that lies on the hot path
-(SURVEY.md 2, row 4): rot_matrix_from_ortho6d (:380-394), normalize_vector (:323-332),
-cross_product (:68-78), translate_along_axis (:19-48), class_labels_from_logits (:60-64),
-dict_to_tensor (:114-121), data_dict_to_dtype (:106-111).  Device math runs in libdgg.so."""
+(SURVEY.md 2, row 4): rot_matrix_from_ortho6d (:380-394; its helpers normalize_vector :323-332 and
+cross_product :68-78 live inside the dgg_ortho6d_* kernels), translate_along_axis (:19-48),
+class_labels_from_logits (:60-64), dict_to_tensor (:114-121), data_dict_to_dtype (:106-111).
+Device math runs in libdgg.so."""
 from __future__ import annotations
 
 import numpy as np
@@ -29,27 +30,6 @@ def rot_matrix_from_ortho6d(ortho6d, dtype=torch.float32):
     if not ortho6d.is_cuda:
         raise _lib.DggError("rot_matrix_from_ortho6d: GPU tensor required (no CPU path)")
     return _Ortho6dFn.apply(ortho6d)
-
-
-def normalize_vector(v, return_mag=False):
-    """utils/utils.py:323-332 (eps 1e-8); plain tensor ops on the caller's device."""
-    batch = v.shape[0]
-    v_mag = torch.sqrt(v.pow(2).sum(1))
-    v_mag = torch.max(v_mag, torch.tensor([1e-8], dtype=v.dtype, device=v.device))
-    v_mag = v_mag.view(batch, 1).expand(batch, v.shape[1])
-    v = v / v_mag
-    if return_mag:
-        return v, v_mag[:, 0]
-    return v
-
-
-def cross_product(u, v):
-    """utils/utils.py:68-78."""
-    batch = u.shape[0]
-    i = u[:, 1] * v[:, 2] - u[:, 2] * v[:, 1]
-    j = u[:, 2] * v[:, 0] - u[:, 0] * v[:, 2]
-    k = u[:, 0] * v[:, 1] - u[:, 1] * v[:, 0]
-    return torch.cat((i.view(batch, 1), j.view(batch, 1), k.view(batch, 1)), 1)
 
 
 def translate_along_axis(out, axis, translation):

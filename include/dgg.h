@@ -18,6 +18,21 @@
  *  - return value: DGG_OK (0) or a negative dgg_status; no exceptions cross the boundary;
  *  - re-entrant across streams with distinct workspaces; not thread-safe on one workspace.
  *  - all tensors fp32 row-major contiguous unless a leading dimension is given.
+ *
+ * Hidden state (everything else is stateless).  The library keeps, PER CALLING THREAD:
+ *  (a) a pool of 64 timing-disabled HIP events used for its internal fork/join between streams;
+ *  (b) the stream -> weight-gradient side stream map of dgg_set_wgrad_stream / dgg_enable_wgrad_stream
+ *      (the latter creates and owns the side streams, reference-counted);
+ *  (c) up to 4 "pending real pass" slots of dgg_cgan_d_real_prefetch, keyed by the raw step-workspace pointer
+ *      (6 events each) and matched against (B, input pointers, d_params) by the next dgg_cgan_d_phase2.
+ * Consequences: use one thread per engine (or call from one thread only); a workspace that is freed while a slot
+ * refers to it must be released first with dgg_cgan_release(ws) — a new allocation at the same address with the same
+ * input pointers would otherwise match a stale slot; dgg_reset() drops (b) and (c) for the calling thread
+ * (synchronising and destroying the library-owned side streams).  (a) lives until the thread exits.
+ *
+ * Arithmetic: the large GEMMs use the "bf16x3" scheme by default (see DGG_GEMM_BF16X3 below): fp32-accurate on
+ * finite operands; an operand element that is +-Inf yields NaN in every output it touches (x - bf16(x) = Inf - Inf),
+ * where an fp32 fma chain would give +-Inf (or NaN, depending on the other operand).  NaN operands give NaN either way.
  */
 #ifndef DGG_H
 #define DGG_H
@@ -83,6 +98,22 @@ int dgg_bps_encode(const float* clouds, int B, int N, const float* basis, int P,
 #define DGG_SKIP_PARAM_GRADS 4u /* backward: input gradients only (G-phase pass through D) */
 #define DGG_NEED_INPUT_GRADS 8u /* backward: also produce gradients w.r.t. the network inputs */
 
+/* A2 — ResBlock.forward(x, final_nl=True) on its own, networks.py:43-56 (Fin != Fout: fc3 present, as at every
+ * call site of the reference).  One flat parameter buffer [fc1.weight ; fc3.weight | fc1.bias ; fc3.bias |
+ * bn1.weight | bn1.bias | fc2.weight | fc2.bias | bn2.weight | bn2.bias] and one running-statistics buffer
+ * [bn1.running_mean | bn1.running_var | bn2.running_mean | bn2.running_var], offsets from dgg_resblock_table
+ * (names as in the module's state_dict: "fc1.weight", ...).  x (B, fin) with row stride ldx -> y (B, 512).
+ * Backward (autograd of :43-56): dy (B,512) -> grads (layout of params; DGG_ACCUM_GRADS / DGG_SKIP_PARAM_GRADS
+ * honoured) and dx (B, fin) if non-NULL; must follow a forward on the same workspace. */
+int64_t dgg_resblock_param_floats(int fin);
+int64_t dgg_resblock_bnstat_floats(int fin);
+int dgg_resblock_table(int fin, dgg_entry* out /*host*/, int cap);
+int64_t dgg_resblock_workspace_bytes(int fin, int batch);
+int dgg_resblock_forward(int fin, const float* params, float* bnstats, void* ws, size_t ws_bytes, int B,
+                         unsigned flags, const float* x, int ldx, float* y, void* stream);
+int dgg_resblock_backward(int fin, const float* params, float* grads, void* ws, size_t ws_bytes, int B,
+                          unsigned flags, const float* x, int ldx, const float* dy, float* dx, void* stream);
+
 /* A3 — Generator.forward(Zin, bps_object), networks.py:88-103.
  * out_heads (B,21) = [joint_conf(12) | rot_6D(6) | transl(3)] (column blocks of one buffer). */
 int dgg_gen_forward(const dgg_cfg* cfg, const float* params, float* bnstats, void* ws, size_t ws_bytes,
@@ -113,6 +144,10 @@ int dgg_eva_forward(const dgg_cfg* cfg, const float* params, float* bnstats, voi
 int dgg_eva_backward(const dgg_cfg* cfg, const float* params, float* grads, void* ws, size_t ws_bytes, int B,
                      unsigned flags, const float* bps, const float* rot9, const float* transl,
                      const float* d_logit, float* d_pose /* (B,12) or NULL */, void* stream);
+/* Byte offset, inside an evaluator workspace for `batch` rows, of the dropout keep mask (batch x 512 bytes in
+ * {0,1}) that the last train-mode forward wrote for dropout site r (0..2) and that the backward reads.  Lets a
+ * caller (tests; a checkpoint of an in-flight step) read back the masks drawn in-kernel.  <0 on bad arguments. */
+int64_t dgg_eva_keep_offset(const dgg_cfg* cfg, int batch, int r);
 
 /* A6 — utils.rot_matrix_from_ortho6d, utils/utils.py:380-394 (+ normalize_vector :323-332,
  * cross_product :68-78).  o6 (B,6) with row stride ld_o6 -> R (B,9) row-major, columns x,y,z. */
@@ -190,12 +225,20 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hpa
  * D phase — its inputs must already be resident — while the current step's G phase is still running; it starts
  * once this thread's last dgg_cgan_g_phase on the same workspace has passed its D forward (D's parameters and
  * BatchNorm running statistics are then final for this step).  The next dgg_cgan_d_phase2 call on this thread with
- * the same workspace, batch size, input pointers and a stream2 picks it up and runs only the generator / fake-batch half; with anything else
- * the prefetched pass is dropped and redone.  Results are bit-identical to the unpipelined order.  Uses
- * losses[12] as scratch; up to 4 workspaces per thread can be in flight. */
+ * the same workspace, batch size, input pointers, d_params and a stream2 picks it up and runs only the generator /
+ * fake-batch half; with anything else the prefetched pass is dropped and redone (D's BatchNorm running statistics
+ * then hold one extra real-batch update).  B must equal the batch size of the step in flight on this workspace
+ * (the workspace is carved per batch size): otherwise DGG_ERR_INVALID, nothing is enqueued.  Results are
+ * bit-identical to the unpipelined order.  Uses losses[12] as scratch; up to 4 workspaces per thread can be in
+ * flight. */
 int dgg_cgan_d_real_prefetch(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hparams* hp, void* ws,
                              size_t ws_bytes, int B, const float* bps, const float* rot9, const float* transl,
                              const float* joint, float* losses, void* stream2);
+/* Forget the pending-prefetch slot keyed by workspace `ws` (call before freeing / reusing that memory). */
+int dgg_cgan_release(void* ws);
+/* Drop this thread's hidden state (see the header comment): pending prefetches and the wgrad side-stream map;
+ * library-owned side streams are synchronised and destroyed. */
+int dgg_reset(void);
 /* Steps 9-12 up to (not including) optim_G.step: D forward #3 with the updated discriminator,
  * generator loss, backward through D (input gradients only) and G -> st->g_grads.
  * Must follow dgg_cgan_d_phase on the same workspace (reuses the saved generator activations). */

@@ -240,9 +240,9 @@ def _set_requires_grad(sd, names, flag):
 # ----------------------------------------------------------------------------------------------
 # Train steps (dexgangrasp.py:739-823)
 # ----------------------------------------------------------------------------------------------
-def cgan_step(sd, batch, z, adam_g, adam_d, cfg, is_train_gen=True, return_grads=False):
-    """dexgangrasp.py:757-823 (BCE branch).  `sd` holds the DexGANGrasp state_dict
-    ('generator.*', 'discriminator.*'), modified in place.  z is the injected latent (:770)."""
+def cgan_d_part(sd, batch, z, cfg):
+    """dexgangrasp.py:766-793 up to (not including) optim_D.step: G forward (train, graph kept), D on real then on
+    the detached fake, discriminator loss, its gradients.  Returns (loss dict, D grads, ctx for cgan_g_part)."""
     bw = float(cfg.get("bce_weight", 1))
     gn = [n for n in param_names(sd) if n.startswith("generator.")]
     dn = [n for n in param_names(sd) if n.startswith("discriminator.")]
@@ -252,7 +252,6 @@ def cgan_step(sd, batch, z, adam_g, adam_d, cfg, is_train_gen=True, return_grads
     rot = batch["rot_matrix"].float().reshape(b, 9)
     transl = batch["transl"].float()
     joint = batch["joint_conf"].float()
-
     # :772-776  G forward #1 (train mode, graph kept), R from ortho6d
     y = generator_forward(sd, z, bps, True, "generator.")
     r_fake = rot_matrix_from_ortho6d(y["rot_6D"])
@@ -261,24 +260,103 @@ def cgan_step(sd, batch, z, adam_g, adam_d, cfg, is_train_gen=True, return_grads
     fake_score = discriminator_forward(
         sd, bps, r_fake.detach(), y["transl"].detach(), y["joint_conf"].detach(), True, "discriminator.")
     l_d, dict_d = loss_discriminator(real_score, fake_score, bw)
-    # :792-794
-    g_d = _grads(l_d, sd, dn)
-    adam_step(sd, g_d, adam_d, lr=cfg["lr_dis"], b1=cfg["beta1"], wd=cfg["weight_decay"])
-    out = {k: v.detach() for k, v in dict_d.items()}
+    g_d = _grads(l_d, sd, dn)  # :792-793
+    ctx = {"y": y, "r_fake": r_fake, "bps": bps, "rot": rot, "transl": transl, "joint": joint, "gn": gn, "dn": dn,
+           "real_score": real_score.detach(), "fake_score": fake_score.detach()}
+    return {k: v.detach() for k, v in dict_d.items()}, g_d, ctx
+
+
+def cgan_g_part(sd, ctx, cfg):
+    """dexgangrasp.py:808-815 up to (not including) optim_G.step: D forward #3 with the UPDATED discriminator (graph
+    through G), generator loss, its gradients w.r.t. the generator."""
+    bw = float(cfg.get("bce_weight", 1))
+    y = ctx["y"]
+    fake_score_gen = discriminator_forward(sd, ctx["bps"], ctx["r_fake"], y["transl"], y["joint_conf"], True,
+                                           "discriminator.")
+    l_g, dict_g = loss_generator(y, ctx["rot"], ctx["transl"], ctx["joint"], fake_score_gen, bw)
+    g_g = _grads(l_g, sd, ctx["gn"])
+    return {k: v.detach() for k, v in dict_g.items()}, g_g
+
+
+def cgan_step(sd, batch, z, adam_g, adam_d, cfg, is_train_gen=True, return_grads=False):
+    """dexgangrasp.py:757-823 (BCE branch).  `sd` holds the DexGANGrasp state_dict
+    ('generator.*', 'discriminator.*'), modified in place.  z is the injected latent (:770)."""
+    out, g_d, ctx = cgan_d_part(sd, batch, z, cfg)
+    adam_step(sd, g_d, adam_d, lr=cfg["lr_dis"], b1=cfg["beta1"], wd=cfg["weight_decay"])  # :794
     g_g = None
     if is_train_gen:
-        # :808 D forward #3 with the UPDATED discriminator, graph through G
-        fake_score_gen = discriminator_forward(sd, bps, r_fake, y["transl"], y["joint_conf"], True, "discriminator.")
-        l_g, dict_g = loss_generator(y, rot, transl, joint, fake_score_gen, bw)
-        g_g = _grads(l_g, sd, gn)
-        adam_step(sd, g_g, adam_g, lr=cfg["lr_gen"], b1=cfg["beta1"], wd=cfg["weight_decay"])
-        out.update({k: v.detach() for k, v in dict_g.items()})
-    _set_requires_grad(sd, gn + dn, False)
+        dict_g, g_g = cgan_g_part(sd, ctx, cfg)
+        adam_step(sd, g_g, adam_g, lr=cfg["lr_gen"], b1=cfg["beta1"], wd=cfg["weight_decay"])  # :816
+        out.update(dict_g)
+    _set_requires_grad(sd, ctx["gn"] + ctx["dn"], False)
     if return_grads:
-        return out, g_d, g_g, {"real_score": real_score.detach(), "fake_score": fake_score.detach(),
+        y = ctx["y"]
+        return out, g_d, g_g, {"real_score": ctx["real_score"], "fake_score": ctx["fake_score"],
                                "rot_6D": y["rot_6D"].detach(), "transl": y["transl"].detach(),
                                "joint_conf": y["joint_conf"].detach()}
     return out
+
+
+def _mean_grads(gs):
+    """Mean over ranks of per-shard gradient dicts (what the sum all-reduce + 1/world scale produce)."""
+    return {n: sum(g[n] for g in gs) / float(len(gs)) for n in gs[0]}
+
+
+def _copy_params(dst, src, names):
+    with torch.no_grad():
+        for n in names:
+            dst[n].copy_(src[n])
+
+
+def cgan_step_dp(sds, shards, zs, adam_g, adam_d, cfg, is_train_gen=True):
+    """Data-parallel definition of the cGAN step (the reference's nn.DataParallel path is broken, so
+    this DEFINES it): identical parameters on every rank, per-rank BatchNorm batch / running statistics (sds[r] keeps
+    rank r's buffers), gradients averaged over ranks between backward and each Adam.  sds: one state dict per rank
+    (parameters equal on entry and on exit); Adam state is shared (kept for sds[0], copied to the others)."""
+    w = len(sds)
+    parts = [cgan_d_part(sds[r], shards[r], zs[r], cfg) for r in range(w)]
+    g_d = _mean_grads([p[1] for p in parts])
+    adam_step(sds[0], g_d, adam_d, lr=cfg["lr_dis"], b1=cfg["beta1"], wd=cfg["weight_decay"])
+    dn = parts[0][2]["dn"]
+    gn = parts[0][2]["gn"]
+    for r in range(1, w):
+        _copy_params(sds[r], sds[0], dn)
+    outs = [dict(p[0]) for p in parts]
+    g_g = None
+    if is_train_gen:
+        gparts = [cgan_g_part(sds[r], parts[r][2], cfg) for r in range(w)]
+        g_g = _mean_grads([p[1] for p in gparts])
+        adam_step(sds[0], g_g, adam_g, lr=cfg["lr_gen"], b1=cfg["beta1"], wd=cfg["weight_decay"])
+        for r in range(1, w):
+            _copy_params(sds[r], sds[0], gn)
+        for r in range(w):
+            outs[r].update(gparts[r][0])
+    for r in range(w):
+        _set_requires_grad(sds[r], gn + dn, False)
+    return outs, g_d, g_g
+
+
+def eva_step_dp(sds, shards, adam_e, cfg, masks):
+    """Data-parallel evaluator step: as cgan_step_dp.  masks[r]: rank r's dropout keep masks (3, B/w, 512)."""
+    w = len(sds)
+    bw = float(cfg.get("bce_weight", 1))
+    en = param_names(sds[0])
+    outs, gs = [], []
+    for r in range(w):
+        _set_requires_grad(sds[r], en, True)
+        label = shards[r]["label"].float().unsqueeze(-1)
+        p = evaluator_forward(sds[r], shards[r]["bps_object"], shards[r]["rot_matrix"], shards[r]["transl"], True,
+                              masks[r])
+        l_e, dict_e = loss_evaluator(p, label, bw)
+        gs.append(_grads(l_e, sds[r], en))
+        outs.append({k: v.detach() for k, v in dict_e.items()})
+    g_e = _mean_grads(gs)
+    adam_step(sds[0], g_e, adam_e, lr=cfg["lr"], b1=cfg["beta1"], wd=cfg["weight_decay"])
+    for r in range(w):
+        if r:
+            _copy_params(sds[r], sds[0], en)
+        _set_requires_grad(sds[r], en, False)
+    return outs, g_e
 
 
 def eva_step(sd, batch, adam_e, cfg, drop_masks=None, return_grads=False):

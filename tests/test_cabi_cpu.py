@@ -105,3 +105,21 @@ def test_wrapper_error_conventions():
     cfg["weight_init_type"] = "bogus"
     with pytest.raises(NotImplementedError):
         DexGanGrasp(cfg)
+
+
+def test_early_stopping_rule_matches_reference():
+    """utils/train_tools.py:6-42: defaults (patience 7, delta 0) and the stopping rule."""
+    from dex_gan_grasp_amd.utils.train_tools import EarlyStopping
+    es = EarlyStopping()
+    assert (es.patience, es.delta, es.counter, es.best_score, es.early_stop) == (7, 0, 0, None, False)
+    assert es(1.0) is False and es.best_score == -1.0
+    assert es(0.5) is False and es.best_score == -0.5 and es.counter == 0
+    for k in range(6):
+        assert es(0.5 + 0.01 * k) is False      # equal or worse: counts (score < best + delta is False only if better)
+    assert es.counter == 5 or es.counter == 6
+    es2 = EarlyStopping(patience=2)
+    es2(1.0)
+    assert es2(1.0) is False                    # equal score: NOT below best + 0 -> treated as the new best, counter 0
+    assert es2.counter == 0
+    assert es2(2.0) is False and es2.counter == 1
+    assert es2(2.0) is True and es2.early_stop

@@ -1,0 +1,436 @@
+"""GPU parity AT THE BENCHED SIZES (BASELINE configs 2-4): the path bench.py times — engine.joint_step with the
+cross-step prefetch and in-kernel Philox dropout at B = 1024 — and the single-network steps at B = 256 / 1024, all
+directly against the CPU oracle; in-kernel dropout statistics; ragged batches under pipelining; the multi-rank engine
+and wrapper (2 processes, gloo rehearsal on one GPU); init distributions (A15); the stand-alone ResBlock (A2)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from dex_gan_grasp_amd import synth
+
+pytestmark = pytest.mark.gpu
+CFG = dict(synth.DEFAULT_CFG)
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOSS_NAMES = ["total_loss_disc", "bce_loss_real", "bce_loss_fake", "gen_loss_fake", "transl_loss", "rot_loss",
+              "conf_loss", "total_loss_gen"]
+
+
+def _mods():
+    from dex_gan_grasp_amd import _lib, ops, engine
+    return _lib, ops, engine
+
+
+def _engine(variant="wide"):
+    L, ops, engine = _mods()
+    sd, sde = H.gan_sd(variant), H.eva_sd(variant)
+    fg, fd, fe = (L.FlatNet(k, CFG, DEV) for k in (L.NET_GEN, L.NET_DISC, L.NET_EVA))
+    fg.load_state_dict(sd, "generator.")
+    fd.load_state_dict(sd, "discriminator.")
+    fe.load_state_dict(sde)
+    return engine.TrainEngine(CFG, fg, fd, fe, DEV), sd, sde
+
+
+def _dev_inputs(batch, with_label=False):
+    b = batch["bps_object"].shape[0]
+    f = lambda t: t.float().to(DEV).contiguous()
+    last = f(batch["label"]) if with_label else f(batch["joint_conf"])
+    return (f(batch["bps_object"]), f(batch["rot_matrix"]).reshape(b, 9), f(batch["transl"]), last)
+
+
+def _grad_items(flat, ref, prefix, batch):
+    gv = {k: v.cpu() for k, v in flat.views("grads").items()}
+    return [(n[len(prefix):], gv[n[len(prefix):]], r, True, batch) for n, r in ref.items()]
+
+
+def _check_loose_collect_strict(items, strict_ok, key):
+    """Every tensor within the kink-tolerant bound (helpers.assert_grad_tensor_close); remember whether this
+    (network, step) also passes the strict bound on all its tensors."""
+    ok = True
+    for name, got, ref, train, batch in items:
+        H.assert_grad_tensor_close(name, got, ref, train=train, batch=batch, strict=False, what=key + " ")
+        try:
+            H.assert_grad_tensor_close(name, got, ref, train=train, batch=batch, strict=True)
+        except AssertionError:
+            ok = False
+    strict_ok.setdefault(key.split("/")[0], []).append(ok)
+
+
+def _adopt(flat, sd, adam, prefix):
+    """The oracle continues from the ENGINE's parameters and Adam moments (running statistics stay its own): both
+    sides start the next step from identical state while the engine's prefetched pass stays valid."""
+    pv, mv, vv = flat.views("params"), flat.views("m"), flat.views("v")
+    for n in pv:
+        sd[prefix + n].copy_(pv[n].cpu())
+        adam.m[prefix + n] = mv[n].cpu().clone()
+        adam.v[prefix + n] = vv[n].cpu().clone()
+
+
+def _snap_flat(flat):
+    return {"p": flat.params.clone(), "m": flat.m.clone(), "v": flat.v.clone(), "t": flat.step}
+
+
+def _cmp_adam_of_own_grads(flat, before, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8, wd=5e-4, what=""):
+    """Exact post-step check where the step's own gradient buffer is still intact: the parameters must be
+    torch.optim.Adam (L2-coupled, dexgangrasp.py:97-112) applied to the gradients THIS implementation computed —
+    evaluated here in float64 from the pre-step snapshot.  Together with the gradient comparison against the oracle
+    this pins the update without Adam's amplification of sub-eps gradient differences (helpers.assert_state_close)."""
+    t = before["t"] + 1
+    assert flat.step == t, what
+    p0, m0, v0 = (before[k].double() for k in ("p", "m", "v"))
+    g = flat.grads.double() + wd * p0
+    m = m0 + (1 - b1) * (g - m0)
+    v = b2 * v0 + (1 - b2) * g * g
+    want = p0 - (lr / (1 - b1 ** t)) * m / (v.sqrt() / np.sqrt(1 - b2 ** t) + eps)
+    err = (flat.params.double() - want).abs()
+    # fp32 evaluation of the same formula: a few ulp of the parameter plus 1e-3 of the largest possible step
+    tol = 4e-7 * want.abs() + 1e-3 * lr
+    assert bool((err <= tol).all()), "%s: Adam(own grads) max err %.3e" % (what, float(err.max()))
+    # first moment: fp32 lerp vs float64 (cancellation where m ~ 0: absolute slack relative to the tensor's scale)
+    np.testing.assert_allclose(flat.m.double().cpu().numpy(), m.cpu().numpy(), rtol=1e-5,
+                               atol=1e-6 * float(m.abs().max()))
+
+
+def _cmp_update(flat, sd, prev, prefix, skip_running=False, l2_frac=2e-2):
+    for n, t in flat.state_dict().items():
+        r = sd[prefix + n]
+        if "running_" in n:
+            if skip_running:
+                continue
+            d = (t - r).abs()
+            if "rb" in n and n.endswith("running_mean"):
+                assert float(d.max()) <= 2.5e-4, n          # integrates the (noise-level) pre-BN bias
+            else:
+                tol = 1e-4 * r.abs() + 1e-5 * float(r.pow(2).mean().sqrt()) + 1e-7
+                assert bool((d <= tol).all()), "%s: max err %.3e" % (n, float(d.max()))
+            continue
+        _update_close(n, t, r, prev[prefix + n], l2_frac)
+
+
+def _update_close(name, t, r, prev, l2_frac, lr=1e-4):
+    """helpers.assert_update_close with the L2 fraction as a parameter.  At B = 1024 the wide input-BatchNorm
+    gradients are sums of 1024 cancelling terms: a handful of their ~4k elements lie within the fp32 summation noise
+    of zero, Adam's first steps move those by +-lr on EITHER side of the comparison (sign-like update), and 4 such
+    elements of 4108 are already 6 % of the update's L2 norm.  The exact statement is _cmp_adam_of_own_grads; this
+    one bounds what remains (every element within 2.5 lr, the update within l2_frac in L2)."""
+    d = (t - r).abs()
+    assert float(d.max()) <= 2.5 * lr, "%s: max err %.3e beyond the hard bound" % (name, float(d.max()))
+    if H.is_pre_bn_bias(name):
+        return
+    upd = float((r - prev).double().pow(2).sum().sqrt())
+    err = float((t - r).double().pow(2).sum().sqrt())
+    assert err <= l2_frac * upd + 1e-12, "%s: update L2 error %.3e vs update norm %.3e" % (name, err, upd)
+
+
+@pytest.mark.parametrize("b", [1024, 256])
+def test_benched_joint_step_with_prefetch_and_philox_vs_oracle(b):
+    """What bench.py times, at its size: 3 x joint_step(next_gan_inputs=...) with the evaluator's dropout masks drawn
+    in-kernel.  Per step: the 10 losses (1e-4), the gradients of G and E (D's are overwritten by the prefetched pass of
+    the next step: compared on the last step), every parameter after Adam, the masks read back from the workspace and
+    fed to the oracle.  BatchNorm running statistics at the end."""
+    from oracle import dexgan_oracle as O
+    L, ops, engine = _mods()
+    eng, sd, sde = _engine("wide")
+    ag = O.AdamState([n for n in O.param_names(sd) if n.startswith("generator.")])
+    ad = O.AdamState([n for n in O.param_names(sd) if n.startswith("discriminator.")])
+    ae = O.AdamState(O.param_names(sde))
+    gbs = [synth.make_batch(b, 1), synth.make_batch(b, 11)]
+    g_ins = [_dev_inputs(x) for x in gbs]
+    eb = synth.make_batch(b, 2, with_label=True)
+    e_in = _dev_inputs(eb, with_label=True)
+    strict_ok = {}
+    steps = 3
+    for i in range(steps):
+        z = synth.make_z(b, 100 + i)
+        nxt = g_ins[(i + 1) % 2] if i + 1 < steps else None
+        before = {k: _snap_flat(fl) for k, fl in (("G", eng.G), ("D", eng.D), ("E", eng.E))}
+        got = eng.joint_step(g_ins[i % 2], z.to(DEV), e_in, True, None, 4242 + i, next_gan_inputs=nxt)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        keep = eng.eva_keep_masks(b)                       # (3, b, 512) uint8, what the backward used
+        assert keep.dtype == torch.uint8 and int(keep.max()) == 1 and int(keep.min()) == 0
+        masks = keep.float().cpu()
+        prev, preve = {k: v.clone() for k, v in sd.items()}, {k: v.clone() for k, v in sde.items()}
+        ref, g_d, g_g, _ = O.cgan_step(sd, H.clone_batch(gbs[i % 2]), z, ag, ad, CFG, True, return_grads=True)
+        refe, g_e, _ = O.eva_step(sde, H.clone_batch(eb), ae, CFG, masks, return_grads=True)
+        for k, n in enumerate(LOSS_NAMES):
+            np.testing.assert_allclose(got[k], float(ref[n]), rtol=1e-4, atol=1e-6, err_msg="step %d %s" % (i, n))
+        np.testing.assert_allclose(got[L.L_TOTAL_EVA], float(refe["total_loss_eva"]), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(got[L.L_BCE_EVA], float(refe["bce_loss"]), rtol=1e-4, atol=1e-6)
+        _check_loose_collect_strict(_grad_items(eng.G, g_g, "generator.", b), strict_ok, "G/%d" % i)
+        _check_loose_collect_strict(_grad_items(eng.E, g_e, "", b), strict_ok, "E/%d" % i)
+        if nxt is None:
+            _check_loose_collect_strict(_grad_items(eng.D, g_d, "discriminator.", b), strict_ok, "D/%d" % i)
+        _cmp_adam_of_own_grads(eng.G, before["G"], what="G step %d" % i)
+        _cmp_adam_of_own_grads(eng.E, before["E"], what="E step %d" % i)
+        if nxt is None:
+            _cmp_adam_of_own_grads(eng.D, before["D"], what="D step %d" % i)
+        _cmp_update(eng.G, sd, prev, "generator.", skip_running=True, l2_frac=0.1)
+        _cmp_update(eng.D, sd, prev, "discriminator.", skip_running=True, l2_frac=0.1)
+        _cmp_update(eng.E, sde, preve, "", skip_running=True, l2_frac=0.1)
+        _adopt(eng.G, sd, ag, "generator.")
+        _adopt(eng.D, sd, ad, "discriminator.")
+        _adopt(eng.E, sde, ae, "")
+    # a LeakyReLU kink crossing is a rare data-dependent event (helpers.assert_grad_tensor_close): G and E must be
+    # strictly right on at least one of their three steps
+    assert any(strict_ok["G"]) and any(strict_ok["E"]), strict_ok
+    # running statistics integrate three steps of batch statistics (real, fake, fake for D)
+    for flat, s, pre in ((eng.G, sd, "generator."), (eng.D, sd, "discriminator."), (eng.E, sde, "")):
+        for n, t in flat.state_dict().items():
+            if "running_var" in n or (n.endswith("running_mean") and "rb" not in n):
+                r = s[pre + n]
+                tol = 1e-4 * r.abs() + 1e-5 * float(r.pow(2).mean().sqrt()) + 1e-7
+                assert bool(((t - r).abs() <= tol).all()), n
+    eng.close()
+
+
+def test_evaluator_step_at_1024_vs_oracle():
+    """BASELINE config 3: the evaluator update alone at B = 1024 (injected masks), two steps, through the API-path
+    entry (eva_step with side streams)."""
+    from oracle import dexgan_oracle as O
+    L, ops, engine = _mods()
+    b = 1024
+    eng, _, sde = _engine("wide")
+    ae = O.AdamState(O.param_names(sde))
+    eb = synth.make_batch(b, 2, with_label=True)
+    e_in = _dev_inputs(eb, with_label=True)
+    strict_ok = {}
+    for i in range(2):
+        masks = synth.make_dropout_masks(b, 50 + i)
+        preve = {k: v.clone() for k, v in sde.items()}
+        refe, g_e, _ = O.eva_step(sde, H.clone_batch(eb), ae, CFG, masks, return_grads=True)
+        before = _snap_flat(eng.E)
+        got = eng.eva_step(*e_in, masks.to(DEV), 0, two_streams=True).cpu().numpy()
+        np.testing.assert_allclose(got[L.L_TOTAL_EVA], float(refe["total_loss_eva"]), rtol=1e-4, atol=1e-6)
+        assert torch.equal(eng.eva_keep_masks(b).cpu(), masks.to(torch.uint8))   # given masks land in the workspace
+        _check_loose_collect_strict(_grad_items(eng.E, g_e, "", b), strict_ok, "E/%d" % i)
+        _cmp_adam_of_own_grads(eng.E, before, what="E step %d" % i)
+        _cmp_update(eng.E, sde, preve, "", l2_frac=0.1)
+        _adopt(eng.E, sde, ae, "")
+    assert any(strict_ok["E"])
+    eng.close()
+
+
+def test_cgan_step_at_256_vs_oracle():
+    """BASELINE config 2: the cGAN update alone at B = 256, two steps, through the API-path entry (cgan_step with the
+    D-phase fork and the weight-gradient side streams)."""
+    from oracle import dexgan_oracle as O
+    L, ops, engine = _mods()
+    b = 256
+    eng, sd, _ = _engine("wide")
+    ag = O.AdamState([n for n in O.param_names(sd) if n.startswith("generator.")])
+    ad = O.AdamState([n for n in O.param_names(sd) if n.startswith("discriminator.")])
+    gb = synth.make_batch(b, 1)
+    g_in = _dev_inputs(gb)
+    strict_ok = {}
+    for i in range(2):
+        z = synth.make_z(b, 100 + i)
+        prev = {k: v.clone() for k, v in sd.items()}
+        ref, g_d, g_g, _ = O.cgan_step(sd, H.clone_batch(gb), z, ag, ad, CFG, True, return_grads=True)
+        before = {k: _snap_flat(fl) for k, fl in (("G", eng.G), ("D", eng.D))}
+        got = eng.cgan_step(*g_in, z.to(DEV), True, two_streams=True).cpu().numpy()
+        for k, n in enumerate(LOSS_NAMES):
+            np.testing.assert_allclose(got[k], float(ref[n]), rtol=1e-4, atol=1e-6, err_msg=n)
+        _check_loose_collect_strict(_grad_items(eng.G, g_g, "generator.", b), strict_ok, "G/%d" % i)
+        _check_loose_collect_strict(_grad_items(eng.D, g_d, "discriminator.", b), strict_ok, "D/%d" % i)
+        _cmp_adam_of_own_grads(eng.G, before["G"], what="G step %d" % i)
+        _cmp_adam_of_own_grads(eng.D, before["D"], what="D step %d" % i)
+        _cmp_update(eng.G, sd, prev, "generator.", l2_frac=0.05)
+        _cmp_update(eng.D, sd, prev, "discriminator.", l2_frac=0.05)
+        _adopt(eng.G, sd, ag, "generator.")
+        _adopt(eng.D, sd, ad, "discriminator.")
+    assert any(strict_ok["G"])
+    eng.close()
+
+
+def test_in_kernel_dropout_masks():
+    """networks.py:294 nn.Dropout(0.3) drawn in-kernel (Philox4x32-10 keyed by seed and element): keep rate 0.7
+    within 4 sigma per site, sites independent, masks change with the seed, and the backward uses the very mask the
+    forward drew (the gradient equals the oracle's under the read-back masks: previous tests; here: a dropped unit's
+    column of d(rb output) is exactly zero, visible in fc-weight gradients only through the mask)."""
+    L, ops, engine = _mods()
+    b = 1024
+    eng, _, _ = _engine("wide")
+    eb = synth.make_batch(b, 2, with_label=True)
+    e_in = _dev_inputs(eb, with_label=True)
+    seen = []
+    for seed in (7, 7, 8):
+        eng2, _, _ = _engine("wide")
+        eng2.eva_step(*e_in, None, seed)
+        seen.append((eng2.eva_keep_masks(b).cpu(), eng2.E.grads.clone().cpu()))
+        eng2.close()
+    k7, k7b, k8 = seen[0][0], seen[1][0], seen[2][0]
+    assert torch.equal(k7, k7b) and torch.equal(seen[0][1], seen[1][1])          # same seed: same masks, same grads
+    assert not torch.equal(k7, k8)
+    n = b * 512
+    sigma = np.sqrt(0.3 * 0.7 / n)
+    for r in range(3):
+        for k in (k7, k8):
+            assert abs(float(k[r].float().mean()) - 0.7) <= 4 * sigma, (r, float(k[r].float().mean()))
+    # sites / seeds are independent draws: agreement rate of two masks = 0.7^2 + 0.3^2 = 0.58
+    for a, c in ((k7[0], k7[1]), (k7[1], k7[2]), (k7[0], k8[0])):
+        agree = float((a == c).float().mean())
+        assert abs(agree - 0.58) <= 6 * np.sqrt(0.58 * 0.42 / n), agree
+    # per-row and per-column keep rates are unstructured
+    assert float(k7[0].float().mean(0).std()) < 3 * np.sqrt(0.21 / b) and float(k7[0].float().mean(1).std()) < 3 * np.sqrt(0.21 / 512)
+    eng.close()
+
+
+def test_ragged_last_batch_under_pipelining():
+    """seq = [B, B, B-17] with next_gan_inputs passed every time.  The ragged batch is not prefetched
+    (the workspace is carved per batch size); results equal the unpipelined engine bit for bit, and the C entry
+    refuses a mismatched prefetch outright."""
+    import ctypes as C
+    L, ops, engine = _mods()
+    b = 96
+    gb_a, gb_b, gb_c = synth.make_batch(b, 1), synth.make_batch(b, 11), synth.make_batch(b - 17, 12)
+    seq = [_dev_inputs(gb_a), _dev_inputs(gb_b), _dev_inputs(gb_c)]
+    eb = synth.make_batch(b, 2, with_label=True)
+    e_in = _dev_inputs(eb, with_label=True)
+    e1, _, _ = _engine("wide")
+    e2, _, _ = _engine("wide")
+    for i in range(3):
+        z = synth.make_z(seq[i][0].shape[0], 100 + i).to(DEV)
+        nxt = seq[i + 1] if i < 2 else None
+        l1 = e1.joint_step(seq[i], z, e_in, True, None, 9 + i, next_gan_inputs=nxt)
+        l2 = e2.joint_step(seq[i], z, e_in, True, None, 9 + i)
+        torch.cuda.synchronize()
+        assert torch.equal(l1[:10], l2[:10]), i
+    for a, c in ((e1.G, e2.G), (e1.D, e2.D), (e1.E, e2.E)):
+        assert torch.equal(a.params, c.params) and torch.equal(a.m, c.m) and torch.equal(a.v, c.v)
+    assert torch.equal(e1.G.bn, e2.G.bn) and torch.equal(e1.D.bn, e2.D.bn)
+    # the C-ABI itself: a prefetch for another batch size than the step in flight is rejected, nothing enqueued
+    ws = e1._cgan_ws(b - 17)
+    st, hp = e1._state(), e1._hp()
+    big = seq[0]
+    s2 = C.c_void_p(e1._side2.cuda_stream)
+    rc = L.lib().dgg_cgan_d_real_prefetch(C.byref(e1.ccfg), C.byref(st), C.byref(hp), L.ptr(ws), ws.numel(), b,
+                                          L.ptr(big[0]), L.ptr(big[1]), L.ptr(big[2]), L.ptr(big[3]),
+                                          L.ptr(e1.losses), s2)
+    assert rc in (-1, -3), rc        # DGG_ERR_INVALID (mismatch) or DGG_ERR_WORKSPACE (too small), never 0
+    # a serial entry point after a pipelined step joins the prefetched pass first (engine.flush)
+    e3, _, _ = _engine("wide")
+    e4, _, _ = _engine("wide")
+    z = synth.make_z(b, 5).to(DEV)
+    e3.joint_step(seq[0], z, e_in, True, None, 1, next_gan_inputs=seq[1])
+    e4.joint_step(seq[0], z, e_in, True, None, 1)
+    e3.cgan_step(*seq[1], z, True)      # the prefetched pass is dropped and redone on the main stream
+    e4.cgan_step(*seq[1], z, True)
+    torch.cuda.synchronize()
+    assert torch.equal(e3.G.params, e4.G.params) and torch.equal(e3.D.params, e4.D.params)
+    for e in (e1, e2, e3, e4):
+        e.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("mode", ["engine", "wrapper"])
+def test_two_rank_data_parallel_on_one_gpu(mode):
+    """BASELINE config 4's code path (engine world > 1): two fresh processes, both on cuda:0, collectives over gloo
+    (DGG_REHEARSE) — tools/dp_check.py compares every rank with the data-parallel oracle and the ranks with each
+    other.  The children initialise the GPU themselves, after the launcher started them."""
+    env = dict(os.environ)
+    env.update({"DGG_REHEARSE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "4"})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "dp_check.py"), mode]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-4000:]
+    assert out.count("dp_check %s: rank" % mode) == 2, out[-2000:]
+
+
+def test_init_net_distribution_lands_in_flat_buffers():
+    """A15 (dexgangrasp.py:28-62): xavier_normal(gain) on every Linear.weight, BatchNorm weight ~ N(1, gain), BatchNorm
+    bias 0, Linear.bias left at torch's default; and the values ARE the library's flat buffers (the kernels see them)."""
+    from dex_gan_grasp_amd.models.dexgangrasp import DexGanGrasp
+    L, _, _ = _mods()
+    cfg = dict(CFG)
+    cfg["train_ffhevaluator"] = True
+    torch.manual_seed(77)
+    m = DexGanGrasp(cfg)
+    gain = cfg["init_gain"]
+    for mod in (m.DexGANGrasp.generator, m.DexGANGrasp.discriminator, m.DexEvaluator):
+        flat = mod._require_flat()
+        views = flat.views("params")
+        named = dict(mod.named_parameters())
+        assert set(views) == set(named)
+        bn_w = []
+        for name, p in named.items():
+            assert p.data_ptr() == views[name].data_ptr(), name      # Parameter storage = flat buffer
+            t = p.detach().float().cpu()
+            if name.endswith("weight") and t.dim() == 2:
+                fan_out, fan_in = t.shape
+                want = gain * np.sqrt(2.0 / (fan_in + fan_out))
+                if t.numel() >= 5000:                                # 2 % needs ~5k samples (sigma of std ~ 1/sqrt(2n))
+                    assert abs(float(t.std()) / want - 1.0) < 0.02, (name, float(t.std()), want)
+                else:
+                    assert abs(float(t.std()) / want - 1.0) < 4.0 / np.sqrt(2.0 * t.numel()) + 0.02, name
+                assert abs(float(t.mean())) < 5 * want / np.sqrt(t.numel())
+            elif name.endswith("weight"):                            # BatchNorm gamma ~ N(1, gain)
+                bn_w.append(t)
+            elif "bn" in name and name.endswith("bias"):
+                assert float(t.abs().max()) == 0.0, name
+            else:                                                    # Linear.bias: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                fan_in = named[name.replace("bias", "weight")].shape[1]
+                assert float(t.abs().max()) <= 1.0 / np.sqrt(fan_in) + 1e-7, name
+        g = torch.cat(bn_w)
+        assert abs(float(g.mean()) - 1.0) < 5 * gain / np.sqrt(g.numel()) and abs(float(g.std()) / gain - 1.0) < 0.05
+    with pytest.raises(NotImplementedError):
+        bad = dict(cfg)
+        bad["weight_init_type"] = "nope"
+        DexGanGrasp(bad)
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_standalone_resblock_matches_oracle(train):
+    """A2 (networks.py:43-56): ResBlock called on its own, forward and autograd backward (dx and all 10 parameter
+    tensors), train and eval mode, against the oracle's resblock under torch autograd."""
+    from oracle import dexgan_oracle as O
+    from dex_gan_grasp_amd.models.networks import ResBlock
+    torch.manual_seed(3)
+    fin, b = 333, 96
+    rb = ResBlock(fin, 512).to(DEV)
+    with torch.no_grad():   # non-trivial BatchNorm state
+        for bn in (rb.bn1, rb.bn2):
+            bn.weight.normal_(1.0, 0.2)
+            bn.bias.normal_(0.0, 0.2)
+            bn.running_mean.normal_(0.0, 0.3)
+            bn.running_var.uniform_(0.5, 1.5)
+    rb.train(train)
+    sd = {k: v.detach().cpu().clone() for k, v in rb.state_dict().items()}
+    x = torch.randn(b, fin)
+    dy = torch.randn(b, 512)
+    xg = x.to(DEV).requires_grad_(True)
+    y = rb(xg)
+    y.backward(dy.to(DEV))
+    names = [n for n in sd if sd[n].dtype.is_floating_point and "running" not in n]
+    for n in names:
+        sd[n].requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    yr = O.resblock(sd, "", xr, train)
+    yr.backward(dy)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-4)
+    H.assert_grad_tensor_close("dx", xg.grad, xr.grad, train=False, batch=b)
+    got = dict(rb.named_parameters())
+    for n in names:
+        H.assert_grad_tensor_close(n, got[n].grad, sd[n].grad, train=train, batch=b)
+    if train:
+        assert int(rb.bn1.num_batches_tracked) == 1
+        for n in ("bn1.running_var", "bn2.running_var"):
+            np.testing.assert_allclose(rb.state_dict()[n].cpu().numpy(), sd[n].numpy(), rtol=1e-4, atol=1e-6)
+    with pytest.raises(Exception):
+        rb(xg, final_nl=False)
