@@ -278,6 +278,30 @@ def sub_results(cfg, dev, eng):
     dt = wall(api, 30)
     out["api_path_b1024"] = {"ms_per_step": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1),
                              "workload": "DexGanGrasp.update_dexgangrasp + update_dexevaluator (wrapper), batch 1024"}
+    # config 4 front end (one rank's share of the global batch 4096 = 512 / GPU): synthetic clouds -> BPS encode ->
+    # batch dict -> gen+eval step; the encode is reported as its own stage (it is not part of the reference's step)
+    from dex_gan_grasp_amd.data.synthetic_data_set import SyntheticGraspBatches
+    b = 512
+    g = torch.Generator().manual_seed(0)
+    basis = (torch.rand((4096, 3), generator=g) * 0.2 - 0.1).to(dev)
+    ds = SyntheticGraspBatches(cfg, b, 4, basis, n_points=2048, device=dev, with_label=True, device_tensors=True)
+    clouds = ds.clouds(0)
+    enc_ms = _time_stream(lambda: ds.encode(clouds), 10)
+    bt = ds.batch(0)
+    g_in = (bt["bps_object"], bt["rot_matrix"].reshape(b, 9).contiguous(), bt["transl"], bt["joint_conf"])
+    e_in = (bt["bps_object"], bt["rot_matrix"].reshape(b, 9).contiguous(), bt["transl"], bt["label"].float())
+    z = synth.make_z(b, 3).to(dev)
+    k2 = [0]
+
+    def both():
+        k2[0] += 1
+        bps = ds.encode(clouds)
+        eng.joint_step((bps,) + g_in[1:], z, (bps,) + e_in[1:], True, None, 500 + k2[0])
+    dt = wall(both, 30)
+    out["config4_front_end_b512"] = {"encode_ms": round(enc_ms, 4), "encode_clouds_per_s": round(b / enc_ms * 1e3, 1),
+                                     "ms_per_step_with_encode": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1),
+                                     "workload": "512 clouds x 2048 points -> dgg_bps_encode -> gen+eval step, batch 512 "
+                                                 "(one rank's share of global batch 4096)"}
     # config 5 (one rank's share): 1250 objects x 200 grasps, encode (N = 2048) + generate + evaluate + 3 thresholds
     n_obj, n_g, n_pts = 1250, 200, 2048
     with contextlib.redirect_stdout(io.StringIO()):

@@ -338,6 +338,28 @@ class DexGanGrasp(object):
             out.append(f)
         return out
 
+    def sweep_objects_sharded(self, bps_objects, n_samples, thresholds=(0.5, 0.75, 0.90), z_offset=0.025, z=None,
+                              chunk_objects=256):
+        """Config 5 across ranks ("replicas only, no collective; gather of filtered grasp counts at the
+        end"; the per-object loop of dexgangrasp_offline.py:147-162 split by object).  Every rank calls this with the
+        SAME list of objects; rank r sweeps the contiguous shard [r*ceil(O/W), ...) with its replica, then the
+        per-threshold counts are all-gathered so every rank returns `count` (T, O) for ALL objects.  The grasps
+        themselves stay on the rank that generated them: returns (local_result, (lo, hi), count_all)."""
+        bps_objects = torch.as_tensor(bps_objects, dtype=self.dtype)
+        n_obj = bps_objects.shape[0]
+        w, r = parallel.world_size(), parallel.rank()
+        per = (n_obj + w - 1) // w
+        lo, hi = min(n_obj, r * per), min(n_obj, (r + 1) * per)
+        zc = None if z is None else z[lo * n_samples:hi * n_samples]
+        if hi > lo:
+            local = self.sweep_objects(bps_objects[lo:hi], n_samples, thresholds, z_offset, zc, chunk_objects)
+            cnt = local['count']
+        else:
+            local = None
+            cnt = torch.zeros((len(thresholds), 0), dtype=torch.int64, device=self.device)
+        gathered = parallel.gather_counts(cnt.t().contiguous())
+        return local, (lo, hi), gathered.t().contiguous()
+
     def sweep_objects(self, bps_objects, n_samples, thresholds=(0.5, 0.75, 0.90), z_offset=0.025, z=None,
                       chunk_objects=256):
         """Config 5 (BASELINE.json; dexgangrasp_offline.py:27-92 run over many objects) as ONE generator pass and ONE

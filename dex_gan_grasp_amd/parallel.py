@@ -91,18 +91,22 @@ def broadcast_(t, src=0):
 
 def gather_counts(t):
     """All-gather of a small per-rank tensor along dim 0 (the inference sweep's filtered-grasp counts, SURVEY.md
-    8(e)): every rank gets the concatenation in rank order.  Shards may differ in length."""
+    8(e)): every rank gets the concatenation in rank order.  Shards may differ in length.  The exchange runs where
+    the backend can (RCCL: device tensors; gloo: host tensors); the result comes back on t's device."""
     if not is_distributed():
         return t
-    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    home = t.device
+    where = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = t.to(where)
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=where)
     sizes = [torch.zeros_like(n) for _ in range(world_size())]
     dist.all_gather(sizes, n)
     m = int(max(int(x.item()) for x in sizes))
-    pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=where)
     pad[:t.shape[0]] = t
     parts = [torch.zeros_like(pad) for _ in range(world_size())]
     dist.all_gather(parts, pad)
-    return torch.cat([p[:int(k.item())] for p, k in zip(parts, sizes)], dim=0)
+    return torch.cat([p[:int(k.item())] for p, k in zip(parts, sizes)], dim=0).to(home)
 
 
 def grad_scale():

@@ -340,7 +340,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("mode", ["engine", "wrapper"])
+@pytest.mark.parametrize("mode", ["engine", "wrapper", "sweep"])
 def test_two_rank_data_parallel_on_one_gpu(mode):
     """BASELINE config 4's code path (engine world > 1): two fresh processes, both on cuda:0, collectives over gloo
     (DGG_REHEARSE) — tools/dp_check.py compares every rank with the data-parallel oracle and the ranks with each
@@ -438,3 +438,104 @@ def test_standalone_resblock_matches_oracle(train):
             np.testing.assert_allclose(rb.state_dict()[n].cpu().numpy(), sd[n].numpy(), rtol=1e-4, atol=1e-6)
     with pytest.raises(Exception):
         rb(xg, final_nl=False)
+
+
+def test_synthetic_front_end_encode_to_update():
+    """Config 4 / N4 front end (dexgenerator_data_set.py:124-186 schema; dexgangrasp_real_robot.py:133-141 call
+    pattern): clouds -> dgg_bps_encode -> batch dict -> update_dexgangrasp / update_dexevaluator.  The encoded block
+    equals the CPU oracle's brute force bit for bit; the dict has the keys, shapes and dtypes of data/eval_batch.pth;
+    the wrapper's step on it equals the engine's step on the same tensors."""
+    from oracle import bps_oracle
+    from dex_gan_grasp_amd.data.synthetic_data_set import SyntheticGraspBatches
+    from dex_gan_grasp_amd.models.dexgangrasp import DexGanGrasp
+    L, ops, engine = _mods()
+    basis = H.load("bps_real_objects.npz")["basis"]
+    b = 48
+    ds = SyntheticGraspBatches(CFG, b, 3, basis, n_points=700, seed=5, with_label=True)
+    batch = ds.batch(1)
+    ref = H.eval_rows()
+    for k in ("rot_matrix", "transl", "joint_conf", "bps_object"):
+        assert batch[k].dtype == ref[k].dtype and tuple(batch[k].shape[1:]) == tuple(ref[k].shape[1:]), k
+    assert batch["bps_object"].is_cuda and batch["label"].dtype == torch.int64 and len(batch["obj_name"]) == b
+    clouds = ds.clouds(1).cpu().numpy()
+    got = batch["bps_object"].cpu().numpy()
+    for i in (0, 17, b - 1):
+        od, _ = bps_oracle.encode_f32(clouds[i], basis)
+        assert np.array_equal(got[i], od), i
+    assert float(got.min()) < 0.1                                   # bps_encoder.py:50
+    again = ds.batch(1)
+    assert torch.equal(again["bps_object"], batch["bps_object"]) and torch.equal(again["transl"], batch["transl"])
+    assert not torch.equal(ds.batch(2)["bps_object"], batch["bps_object"])
+    # the dict drops into the wrapper unchanged
+    cfg = dict(CFG)
+    cfg["train_ffhevaluator"] = True
+    m = DexGanGrasp(cfg)
+    m.DexGANGrasp.load_state_dict(H.gan_sd("wide"))
+    m.DexEvaluator.load_state_dict(H.eva_sd("wide"))
+    eng, _, _ = _engine("wide")
+    z = synth.make_z(b, 3)
+    m._z_override = z
+    losses = m.update_dexgangrasp(dict(batch))
+    f = lambda t: t.float().to(DEV).contiguous()
+    want = eng.cgan_step(batch["bps_object"], f(batch["rot_matrix"]).reshape(b, 9), f(batch["transl"]),
+                         f(batch["joint_conf"]), z.to(DEV), True)
+    assert float(losses["total_loss_gen"]) == float(want[L.L_TOTAL_GEN])
+    assert float(losses["total_loss_disc"]) == float(want[L.L_TOTAL_DISC])
+    masks = synth.make_dropout_masks(b, 9)
+    m._drop_keep = masks
+    le = m.update_dexevaluator(dict(batch))
+    we = eng.eva_step(batch["bps_object"], f(batch["rot_matrix"]).reshape(b, 9), f(batch["transl"]),
+                      f(batch["label"]), masks.to(DEV))
+    assert float(le["total_loss_eva"]) == float(we[L.L_TOTAL_EVA])
+    assert torch.equal(m.DexEvaluator._require_flat().params, eng.E.params)
+    eng.close()
+
+
+def test_config5_sweep_at_rank_share_size():
+    """BASELINE config 5 at one rank's share (1250 objects x 200 grasps): sweep_objects (one generator + one evaluator
+    pass per chunk of objects) against the reference's per-object call sequence generate_grasps -> filter x3
+    (dexgangrasp_offline.py:27-92,147-162; dexgangrasp.py:393-442) on a sample of the objects, with "wide" weights and
+    thresholds that keep a non-empty, non-total subset; and the sharded form's bookkeeping on one rank."""
+    from dex_gan_grasp_amd.models.dexgangrasp import DexGanGrasp
+    cfg = dict(CFG)
+    cfg["is_train"] = False
+    m = DexGanGrasp(cfg)
+    m.DexGANGrasp.load_state_dict(H.gan_sd("wide"))
+    m.DexEvaluator.load_state_dict(H.eva_sd("wide"))
+    n_obj, n = 1250, 200
+    g = torch.Generator().manual_seed(3)
+    rows = (torch.rand((n_obj, 4096), generator=g) * 0.2).numpy().astype(np.float32)
+    z = torch.randn((n_obj * n, 5), generator=g).to(DEV)
+    probe = m.sweep_objects(rows[:8], n, thresholds=(0.5,), z=z[:8 * n])
+    sc = probe["score"].flatten().cpu().numpy()
+    thresholds = tuple(float(np.quantile(sc, q)) for q in (0.3, 0.6, 0.9))   # keep ~70 % / 40 % / 10 %
+    out = m.sweep_objects(rows, n, thresholds=thresholds, z=z)
+    assert out["score"].shape == (n_obj, n) and out["count"].shape == (3, n_obj)
+    tot = out["count"].sum(dim=1).cpu().numpy()
+    assert 0 < tot[2] < tot[1] < tot[0] < n_obj * n, tot
+    for o in (0, 1, 617, n_obj - 1):          # the reference's per-object sequence on a sample of objects
+        orig = torch.randn
+        try:
+            torch.randn = lambda *a, **k: z[o * n:(o + 1) * n].to(k.get("device", "cpu"))
+            gr = m.generate_grasps(rows[o], n, return_arr=True)
+        finally:
+            torch.randn = orig
+        np.testing.assert_allclose(out["transl"][o].cpu().numpy(), gr["transl"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(out["joint_conf"][o].cpu().numpy(), gr["joint_conf"], rtol=0, atol=2e-5)
+        score = out["score"][o].cpu().numpy()
+        for t, thr in enumerate(thresholds):
+            near = int(((score > thr - 1e-5) & (score < thr + 1e-5)).sum())
+            try:
+                f = m.filter_grasps(rows[o], {k: v.copy() for k, v in gr.items()}, thresh=thr)
+                ref_cnt = f["transl"].shape[0]
+            except ValueError:
+                ref_cnt = 0
+            cnt = int(out["count"][t, o])
+            assert abs(cnt - ref_cnt) <= near, (o, thr, cnt, ref_cnt)
+            if cnt and near == 0:   # same SET of grasps (scores 1e-7 apart may swap places in the two orderings)
+                sel = out["order"][o, :cnt].cpu().numpy()
+                a, c = out["transl"][o].cpu().numpy()[sel], f["transl"]
+                a, c = a[np.lexsort(a.T[::-1])], c[np.lexsort(c.T[::-1])]
+                np.testing.assert_allclose(a, c, rtol=0, atol=2e-5)
+    local, (lo, hi), count_all = m.sweep_objects_sharded(rows[:300], n, thresholds=thresholds, z=z[:300 * n])
+    assert (lo, hi) == (0, 300) and torch.equal(count_all.cpu(), out["count"][:, :300].cpu())

@@ -73,3 +73,28 @@ def test_single_process_is_a_noop():
     assert parallel.allreduce_sum_(t) is None and torch.equal(t, torch.ones(4))
     with pytest.raises(ValueError):
         parallel.shard_rows(torch.zeros(5, 2), 0, 2)
+
+
+def _gather_worker(rank, world, port, out_dir):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank),
+                       "WORLD_SIZE": str(world), "LOCAL_RANK": str(rank)})
+    parallel.init_from_env(backend="gloo")
+    t = torch.arange((rank + 2) * 3, dtype=torch.int64).view(rank + 2, 3) + 100 * rank     # ragged shards
+    g = parallel.gather_counts(t)
+    torch.save(g, os.path.join(out_dir, "g%d.pt" % rank))
+    b = torch.full((5,), float(rank))
+    parallel.broadcast_(b, src=0)
+    assert float(b.sum()) == 0.0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_of_ragged_counts(tmp_path):
+    """The collective of the object-sharded inference sweep: per-rank count blocks of different
+    lengths arrive concatenated in rank order on every rank."""
+    port = _free_port()
+    mp.spawn(_gather_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(str(tmp_path), "g0.pt"))
+    b = torch.load(os.path.join(str(tmp_path), "g1.pt"))
+    want = torch.cat([torch.arange(6).view(2, 3), torch.arange(9).view(3, 3) + 100])
+    assert torch.equal(a, want) and torch.equal(b, want)

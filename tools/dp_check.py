@@ -151,9 +151,36 @@ def check_wrapper(per_rank=32, steps=2):
     print("dp_check wrapper: rank %d ok" % rank, flush=True)
 
 
+def check_sweep(n_obj=37, n=64):
+    """Config 5 sharded by object: every rank sweeps its contiguous share with its own replica; the gathered counts
+    equal a single-rank sweep of all objects (same latents)."""
+    import helpers as H
+    from dex_gan_grasp_amd.models.dexgangrasp import DexGanGrasp
+    rank, world, _ = parallel.env_rank_world()
+    cfg = dict(synth.DEFAULT_CFG)
+    cfg["is_train"] = False
+    m = DexGanGrasp(cfg)
+    m.DexGANGrasp.load_state_dict(H.gan_sd("wide"))
+    m.DexEvaluator.load_state_dict(H.eva_sd("wide"))
+    g = torch.Generator().manual_seed(3)
+    rows = torch.rand((n_obj, 4096), generator=g) * 0.2
+    z = torch.randn((n_obj * n, 5), generator=g).to(m.device)
+    full = m.sweep_objects(rows, n, thresholds=(0.3, 0.5, 0.7), z=z)
+    local, (lo, hi), count_all = m.sweep_objects_sharded(rows, n, thresholds=(0.3, 0.5, 0.7), z=z)
+    per = (n_obj + world - 1) // world
+    assert (lo, hi) == (rank * per, min(n_obj, (rank + 1) * per))
+    assert tuple(count_all.shape) == (3, n_obj)
+    near = sum(int(((full["score"] > t - 1e-5) & (full["score"] < t + 1e-5)).sum()) for t in (0.3, 0.5, 0.7))
+    assert int((count_all.cpu() - full["count"].cpu()).abs().sum()) <= near
+    # another batch size picks another split-K plan: same scores up to the summation order
+    assert float((local["score"] - full["score"][lo:hi]).abs().max()) <= 2e-6
+    assert int(count_all.sum()) > 0
+    print("dp_check sweep: rank %d ok" % rank, flush=True)
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "engine"
-    {"engine": check_engine, "wrapper": check_wrapper}[mode]()
+    {"engine": check_engine, "wrapper": check_wrapper, "sweep": check_sweep}[mode]()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
