@@ -92,6 +92,9 @@ SIGNATURES = {
     "dgg_gen_loss": (_I, [_CFG, C.POINTER(HParams), _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "dgg_translate_along_axis": (_I, [_VP, _VP, _I, _I, _F, _VP]),
     "dgg_gemm_occupancy": (_I, [_I, _I, _I]),
+    "dgg_objects_workspace_bytes": (_I64, [_I, _CFG, _I, _I]),
+    "dgg_gen_forward_objects": (_I, [_CFG, _VP, _VP, _VP, _SZ, _I, _I, _VP, _VP, _VP, _VP]),
+    "dgg_eva_forward_objects": (_I, [_CFG, _VP, _VP, _VP, _SZ, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "dgg_cgan_release": (_I, [_VP]),
     "dgg_reset": (_I, []),
     "dgg_eva_keep_offset": (_I64, [_CFG, _I, _I]),

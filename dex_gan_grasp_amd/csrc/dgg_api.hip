@@ -443,6 +443,8 @@ struct Ctx {
     hipStream_t sw;   // side stream for weight-gradient GEMMs (NULL: same stream)
 };
 
+static int rb_tail(Ctx& c, int r, int drop_mode, const float* keep_in, uint64_t seed, uint64_t seed_off);
+
 static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, const float* keep_in, uint64_t seed,
                       uint64_t seed_off) {
     const NetL& L = *c.L;
@@ -507,6 +509,16 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
     else
         DGG_TRY(reduce_bias_launch(c.W.slabs, nslab, slab, L.n13, c.P + R.b13, A.a13, L.n13, B, B, 1, L.n13, 0, L.hid,
                                    L.hid, L.n13, c.W.part, c.st));
+    return rb_tail(c, r, drop_mode, keep_in, seed, seed_off);
+}
+
+// ResBlock forward from the pre-activations a13 = [a1 | lrelu(a3)] on: bn1 + LeakyReLU, fc2, bn2 + residual + LeakyReLU
+// [+ dropout] (networks.py:46-56).
+static int rb_tail(Ctx& c, int r, int drop_mode, const float* keep_in, uint64_t seed, uint64_t seed_off) {
+    const NetL& L = *c.L;
+    const RbL& R = L.rb[r];
+    RbW& A = c.W.rb[r];
+    const int B = c.B;
     // 3. h = lrelu(bn1(a1)); the statistics are finalized inside the kernel (mean1 / rstd1 kept for the backward)
     {
         BnFused fz{c.W.part, c.train ? 1 : 0, c.bn ? c.bn + R.rm1 : nullptr, c.bn ? c.bn + R.rv1 : nullptr, A.mean1,
@@ -853,6 +865,141 @@ static ColSrcs srcs_pose(const dgg_cfg* cfg, const float* bps, const float* rot9
 }
 
 // ------------------------------------------------------------------------------------------------
+// Inference over many objects, factorised per object (BASELINE config 5).  generate_grasps / filter_grasps
+// tile ONE BPS row over the n samples of an object (dexgangrasp.py:495-514, :406-411): in eval mode (running
+// statistics: rows do not interact) the BPS part of every fused fc1||fc3 product, bn(bps) W13[:, bps]^T + b13, is one row
+// per OBJECT.  It is computed once per object (M = objects instead of objects x n: 200x fewer MACs at n = 200) and
+// every sample adds only its own few columns (generator: Z, 5; evaluator: rot9 | transl, 12) and, from the second
+// block on, the previous block's 512 outputs.  The (objects x n) x 4.1k input block is never materialised.
+// ------------------------------------------------------------------------------------------------
+struct ObjW {
+    float *Xobj, *imean, *irstd, *aff_scale, *aff_shift, *cobj[3], *oslabs;
+    NetW S;  // sample-level buffers in NetW form (rb[r] share a13 / h / a2; y alternates)
+    int osplits;
+    size_t bytes;
+};
+
+static void carve_objects(const NetL& L, int O, int n, void* base, ObjW& W) {
+    Bump b{reinterpret_cast<char*>(base), 0};
+    const size_t Oz = (size_t)O, Bz = (size_t)O * (size_t)n;
+    const int kb = (int)align4(L.in_bps);
+    W.Xobj = b.take<float>(Oz * kb);
+    W.imean = b.take<float>(2 * (size_t)L.in_bps);
+    W.irstd = b.take<float>(2 * (size_t)L.in_bps);
+    W.aff_scale = b.take<float>((size_t)L.in_bps);
+    W.aff_shift = b.take<float>((size_t)L.in_bps);
+    for (int r = 0; r < 3; ++r) W.cobj[r] = r < L.nrb ? b.take<float>(Oz * L.n13) : nullptr;
+    {
+        int widths[1] = {L.in_bps}, sp[1];
+        plan13(O, L.n13, widths, 1, sp);
+        W.osplits = sp[0];
+    }
+    W.oslabs = b.take<float>((size_t)(W.osplits + 1) * Oz * L.n13);
+    memset(&W.S, 0, sizeof(W.S));
+    float* a13 = b.take<float>(Bz * L.n13);
+    float* h = b.take<float>(Bz * L.hid);
+    float* a2 = b.take<float>(Bz * L.nn);
+    float* y[2] = {b.take<float>(Bz * L.nn), b.take<float>(Bz * L.nn)};
+    float* m1 = b.take<float>(2 * (size_t)L.hid);
+    float* r1 = b.take<float>(2 * (size_t)L.hid);
+    float* m2 = b.take<float>(2 * (size_t)L.nn);
+    float* r2 = b.take<float>(2 * (size_t)L.nn);
+    for (int r = 0; r < L.nrb; ++r) {
+        RbW& R = W.S.rb[r];
+        R.a13 = a13; R.h = h; R.a2 = a2; R.y = y[r & 1]; R.keep = nullptr;
+        R.mean1 = m1; R.rstd1 = r1; R.mean2 = m2; R.rstd2 = r2;
+    }
+    // split-K slabs of the sample-level GEMMs: the previous block's product (B x 768) / fc2 (B x 512), few splits at
+    // these row counts; heads scratch
+    int wd[1] = {L.nn}, sp[1];
+    plan13((int)Bz, L.n13, wd, 1, sp);
+    int64_t need = (int64_t)(sp[0] + 1) * (int64_t)Bz * L.n13;
+    const int64_t need2 = (int64_t)(gemm_pick_splits(GEMM_NT, (int)Bz, L.nn, L.hid, 0) + 1) * (int64_t)Bz * L.nn;
+    if (need2 > need) need = need2;
+    const int64_t needh = (int64_t)8 * (int64_t)Bz * (L.nh > 1 ? L.nh : 1);
+    if (needh > need) need = needh;
+    W.S.slab_floats = need;
+    W.S.slabs = b.take<float>((size_t)need);
+    const size_t nrb = (Bz + kRowBlock - 1) / kRowBlock + 2;
+    W.S.part = b.take<float>(nrb * 2 * (size_t)L.n13);
+    W.bytes = (b.off + 255) & ~(size_t)255;
+}
+
+// small: the per-sample raw columns (generator: Z; evaluator: rot9 | transl), `out`: heads (O*n, nh).
+static int objects_forward(const NetL& L, const float* params, float* bn, void* ws, size_t ws_bytes, int O, int n,
+                           const float* bps_obj, const ColSrcs& small, float* out, hipStream_t st) {
+    if (!params || !bn || !ws || !bps_obj || !out || O < 1 || n < 1) return DGG_ERR_INVALID;
+    if ((int64_t)O * n > (int64_t)1 << 24) return DGG_ERR_INVALID;
+    ObjW W;
+    carve_objects(L, O, n, ws, W);
+    if (W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
+    const int B = O * n;
+    const int kb = (int)align4(L.in_bps);
+    const bool small_first = L.nprefix > 0;              // generator: X0 = [Z | bps]; evaluator: X0 = [bps | pose]
+    const int bps_off = small_first ? L.nprefix : 0;     // first BPS column inside the X0 segment
+    const int small_off = small_first ? 0 : L.in_bps;
+    if (small.total != (small_first ? L.nprefix : L.k_in - L.in_bps)) return DGG_ERR_INVALID;
+    // 1. x_hat of the objects' BPS rows (running statistics) + the affine vectors the GEMM folds in
+    {
+        ColSrcs sb;
+        memset(&sb, 0, sizeof(sb));
+        sb.nsrc = 1; sb.s[0].p = bps_obj; sb.s[0].ld = L.in_bps; sb.s[0].n = L.in_bps; sb.total = L.in_bps;
+        BnFused fz{W.S.part, 0, bn + L.irm, bn + L.irv, W.imean, W.irstd};
+        DGG_TRY(ibn_apply_launch(sb, O, O, W.imean, W.irstd, nullptr, nullptr, nullptr, 0, W.Xobj, kb, params + L.ibnw,
+                                 params + L.ibnb, W.aff_scale, W.aff_shift, st, &fz));
+    }
+    auto wcol_x0 = [&](int r) { return r == 0 ? 0 : (L.x1_first ? L.nn : 0); };
+    // 2. per object and ResBlock: cobj = bn(bps) W13[:, bps]^T + b13
+    for (int r = 0; r < L.nrb; ++r) {
+        const RbL& R = L.rb[r];
+        GemmBatch g;
+        memset(&g, 0, sizeof(g));
+        g.nprob = 1;
+        prob_init(g.p[0], W.Xobj, kb, params + R.w13 + wcol_x0(r) + bps_off, R.fin, W.oslabs, L.n13, O, L.n13, L.in_bps);
+        prob_split(g.p[0], W.osplits, (long long)O * L.n13);
+        g.p[0].a_scale = W.aff_scale;
+        g.p[0].a_shift = W.aff_shift;
+        DGG_TRY(gemm_launch(GEMM_NT, g, st));
+        DGG_TRY(reduce_bias_launch(W.oslabs, g.p[0].splits, (long long)O * L.n13, L.n13, params + R.b13, W.cobj[r], L.n13,
+                                   O, O, 1, L.n13, 0, 0, 0, 0, nullptr, st));
+    }
+    // 3. per sample
+    Ctx c;
+    c.share = nullptr;
+    c.L = &L; c.P = params; c.G = nullptr; c.bn = bn; c.W = W.S; c.B = B; c.train = false; c.st = st; c.sw = nullptr;
+    const float* sg = small_first ? nullptr : params + L.ibnw + L.in_bps;
+    const float* sbeta = small_first ? nullptr : params + L.ibnb + L.in_bps;
+    const float* srm = small_first ? nullptr : bn + L.irm + L.in_bps;
+    const float* srv = small_first ? nullptr : bn + L.irv + L.in_bps;
+    for (int r = 0; r < L.nrb; ++r) {
+        const RbL& R = L.rb[r];
+        int nslab = 0;
+        const long long slab = (long long)B * L.n13;
+        if (r > 0) {  // the previous block's 512 outputs: X1 W13[:, x1]^T
+            int wd[1] = {L.nn}, sp[1];
+            plan13(B, L.n13, wd, 1, sp);
+            GemmBatch g;
+            memset(&g, 0, sizeof(g));
+            g.nprob = 1;
+            prob_init(g.p[0], c.W.rb[r - 1].y, L.nn, params + R.w13 + (L.x1_first ? 0 : L.k0), R.fin, c.W.slabs, L.n13, B,
+                      L.n13, L.nn);
+            prob_split(g.p[0], sp[0], slab);
+            if ((int64_t)g.p[0].splits * slab > c.W.slab_floats) return DGG_ERR_WORKSPACE;
+            DGG_TRY(gemm_launch(GEMM_NT, g, st));
+            nslab = g.p[0].splits;
+        }
+        DGG_TRY(expand_rows_launch(W.cobj[r], L.n13, n, c.W.slabs, nslab, slab, L.n13, small, sg, sbeta, srm, srv,
+                                   params + R.w13 + wcol_x0(r) + small_off, R.fin, c.W.rb[r].a13, L.n13, B, L.n13, L.hid,
+                                   L.n13, st));
+        DGG_TRY(rb_tail(c, r, 0, nullptr, 0, 0));
+    }
+    const int sig = L.net != DGG_NET_GEN;
+    DGG_TRY(heads_fwd_launch(c.W.rb[L.nrb - 1].y, L.nn, B, L.nn, params + L.wh, params + L.bh, L.nh, sig, out, L.nh,
+                             c.W.slabs, st));
+    return DGG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Training phases (dexgangrasp.py:739-823)
 // ------------------------------------------------------------------------------------------------
 struct StepW {
@@ -1012,6 +1159,41 @@ int dgg_eva_backward(const dgg_cfg* cfg, const float* params, float* grads, void
     return net_backward(L, params, grads, ws, ws_bytes, B, flags, srcs_pose(cfg, bps, rot9, transl, nullptr), d_logit,
                         nullptr, want ? cfg->in_bps : 0, want ? L.k_in : 0, want ? d_pose : nullptr,
                         (hipStream_t)stream);
+}
+
+int64_t dgg_objects_workspace_bytes(int net, const dgg_cfg* cfg, int n_obj, int n_per_obj) {
+    NetL L;
+    if (n_obj < 1 || n_per_obj < 1 || build_layout(net, cfg, L) || net == DGG_NET_DISC) return DGG_ERR_INVALID;
+    ObjW W;
+    carve_objects(L, n_obj, n_per_obj, nullptr, W);
+    return (int64_t)W.bytes;
+}
+
+int dgg_gen_forward_objects(const dgg_cfg* cfg, const float* params, float* bnstats, void* ws, size_t ws_bytes,
+                            int n_obj, int n_per_obj, const float* z, const float* bps_obj, float* out_heads,
+                            void* stream) {
+    NetL L;
+    DGG_TRY(build_layout(DGG_NET_GEN, cfg, L));
+    if (!z) return DGG_ERR_INVALID;
+    ColSrcs sm;
+    memset(&sm, 0, sizeof(sm));
+    sm.nsrc = 1; sm.s[0].p = z; sm.s[0].ld = cfg->latent_d; sm.s[0].n = cfg->latent_d; sm.total = cfg->latent_d;
+    return objects_forward(L, params, bnstats, ws, ws_bytes, n_obj, n_per_obj, bps_obj, sm, out_heads, (hipStream_t)stream);
+}
+
+int dgg_eva_forward_objects(const dgg_cfg* cfg, const float* params, float* bnstats, void* ws, size_t ws_bytes,
+                            int n_obj, int n_per_obj, const float* bps_obj, const float* rot9, const float* transl,
+                            float* out_p, void* stream) {
+    NetL L;
+    DGG_TRY(build_layout(DGG_NET_EVA, cfg, L));
+    if (!rot9 || !transl) return DGG_ERR_INVALID;
+    ColSrcs sm;
+    memset(&sm, 0, sizeof(sm));
+    sm.nsrc = 2;
+    sm.s[0].p = rot9; sm.s[0].ld = 9; sm.s[0].n = 9;
+    sm.s[1].p = transl; sm.s[1].ld = 3; sm.s[1].n = 3;
+    sm.total = 12;
+    return objects_forward(L, params, bnstats, ws, ws_bytes, n_obj, n_per_obj, bps_obj, sm, out_p, (hipStream_t)stream);
 }
 
 int dgg_ortho6d_forward(const float* o6, int ld_o6, int B, float* rot9, void* stream) {

@@ -105,6 +105,12 @@ int reduce_bias_launch(const float* slabs, int nslab, long long slab_stride, int
                        float* out, int ld_out, int B, int rows_per_group, int groups, int N, int stat_lo,
                        int stat_hi, int act_lo, int act_hi, float* part, hipStream_t st, int accumulate = 0,
                        const float* slabs2 = nullptr, int nslab2 = 0);
+// Per-object factorised first layer (eval mode): out[m][c] = cobj[m / n_per][c] + sum_s slabs[s][m][c]
+//   + sum_j bn_eval(small)(m, j) * wsm[c * ldw + j]; LeakyReLU on [act_lo, act_hi).  small.total <= 16.
+int expand_rows_launch(const float* cobj, int ldc, int n_per, const float* slabs, int nslab, long long slab_stride,
+                       int ld_slab, const ColSrcs& small, const float* gamma, const float* beta, const float* rm,
+                       const float* rv, const float* wsm, int ldw, float* out, int ld_out, int B, int N, int act_lo,
+                       int act_hi, hipStream_t st);
 // h[m][c] = lrelu((a[m][c]-mean)*rstd*gamma+beta)
 int bn_act_launch(const float* a, int lda, int B, int rows_per_group, int N, const float* mean, const float* rstd,
                   const float* gamma, const float* beta, float* h, int ldh, hipStream_t st,

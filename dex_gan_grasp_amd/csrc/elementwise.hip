@@ -1032,6 +1032,71 @@ int reduce_bias_launch(const float* slabs, int nslab, long long slab_stride, int
     return check_launch("reduce_bias");
 }
 
+// Per-object factorisation of an eval-mode first layer: all n_per samples of an object share
+// its BPS row, so x_hat_bps W13[:, bps]^T + b13 is ONE row per object (cobj).  A sample's pre-activation is
+//   out[m][c] = cobj[m / n_per][c] + sum_s slabs[s][m][c] + sum_j small(m, j) * wsm[c * ldw + j]
+// with the few per-sample input columns `small` (generator: Z; evaluator: eval-BatchNorm'd rot9 | transl), LeakyReLU on
+// columns [act_lo, act_hi).  grid: (ceil(N/64), ceil(B/RB)).
+struct SmallIn {
+    ColSrcs srcs;                           // raw per-sample columns (virtual concat), srcs.total <= 16
+    const float *gamma, *beta, *rm, *rv;    // eval BatchNorm of those columns (NULL gamma: identity)
+};
+__global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restrict__ cobj, int ldc, int n_per,
+                                                          const float* __restrict__ slabs, int nslab,
+                                                          long long slab_stride, int ld_slab, SmallIn sm,
+                                                          const float* __restrict__ wsm, int ldw,
+                                                          float* __restrict__ out, int ld_out, int B, int N, int act_lo,
+                                                          int act_hi) {
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    if (c >= N) return;
+    const int ns = sm.srcs.total;
+    float w[16], sc[16], shf[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        w[j] = j < ns ? wsm[(size_t)c * ldw + j] : 0.f;
+        sc[j] = 1.f;
+        shf[j] = 0.f;
+        if (j < ns && sm.gamma) {
+            sc[j] = sm.gamma[j] * (1.0f / sqrtf(sm.rv[j] + kBnEps));
+            shf[j] = sm.beta[j] - sm.rm[j] * sc[j];
+        }
+    }
+    const bool act = c >= act_lo && c < act_hi;
+    const int r0 = blockIdx.y * RB + sub * RS;
+    const int n = min(RS, B - r0);
+    for (int r = 0; r < n; ++r) {
+        const int row = r0 + r;
+        float v = cobj[(size_t)(row / n_per) * ldc + c];
+        for (int s2 = 0; s2 < nslab; ++s2) v += slabs[(size_t)s2 * slab_stride + (size_t)row * ld_slab + c];
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j < ns) {
+                int ld;
+                const float* p = src_col(sm.srcs, j, ld);
+                t = fmaf(fmaf(p[(size_t)row * ld], sc[j], shf[j]), w[j], t);
+            }
+        }
+        v += t;
+        out[(size_t)row * ld_out + c] = act ? lrelu(v) : v;
+    }
+}
+
+int expand_rows_launch(const float* cobj, int ldc, int n_per, const float* slabs, int nslab, long long slab_stride,
+                       int ld_slab, const ColSrcs& small, const float* gamma, const float* beta, const float* rm,
+                       const float* rv, const float* wsm, int ldw, float* out, int ld_out, int B, int N, int act_lo,
+                       int act_hi, hipStream_t st) {
+    if (small.total > 16 || n_per < 1) return DGG_ERR_UNSUPPORTED;
+    SmallIn sm;
+    sm.srcs = small;
+    sm.gamma = gamma; sm.beta = beta; sm.rm = rm; sm.rv = rv;
+    dim3 grid(cdiv(N, 64), cdiv(B, RB));
+    hipLaunchKernelGGL(expand_rows_kernel, grid, dim3(256), 0, st, cobj, ldc, n_per, slabs, nslab, slab_stride, ld_slab, sm,
+                       wsm, ldw, out, ld_out, B, N, act_lo, act_hi);
+    return check_launch("expand_rows");
+}
+
 int bn_act_launch(const float* a, int lda, int B, int rpg, int N, const float* mean, const float* rstd,
                   const float* gamma, const float* beta, float* h, int ldh, hipStream_t st, const BnFused* fz) {
     BnFin fin;

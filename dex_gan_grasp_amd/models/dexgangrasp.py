@@ -361,12 +361,15 @@ class DexGanGrasp(object):
         return local, (lo, hi), gathered.t().contiguous()
 
     def sweep_objects(self, bps_objects, n_samples, thresholds=(0.5, 0.75, 0.90), z_offset=0.025, z=None,
-                      chunk_objects=256):
+                      chunk_objects=256, dense=False):
         """Config 5 (BASELINE.json; dexgangrasp_offline.py:27-92 run over many objects) as ONE generator pass and ONE
         evaluator pass for all objects: the reference loops per object (generate_grasps -> filter_grasps x3), i.e.
         2 + 3 network passes of 200 rows each per object — launch-bound on any GPU.  Both networks are in eval mode
         here (running BatchNorm statistics), so rows of different objects do not interact and stacking them changes
-        nothing.  bps_objects (O, 4096); z: optional latents (O * n_samples, latentD) instead of torch.randn.
+        nothing.  The passes are FACTORISED per object (dgg_gen_forward_objects / dgg_eva_forward_objects): the BPS
+        row is identical for an object's n samples, so its share of every first-layer product is computed once per
+        object and the (objects x n) x 4096 tiled input is never built (dense=True keeps the tiled form, for tests).
+        bps_objects (O, 4096); z: optional latents (O * n_samples, latentD) instead of torch.randn.
         Returns device tensors: 'transl' (O,n,3), 'rot_matrix' (O,n,3,3), 'joint_conf' (O,n,nj), 'z' (O,n,latentD),
         'score' (O,n), 'order' (O,n: indices by descending score) and 'count' (T,O): grasps with score > threshold —
         object o's filter_grasps(thresholds[t]) result is rows order[o, :count[t, o]].  Objects are processed
@@ -377,25 +380,36 @@ class DexGanGrasp(object):
             for lo in range(0, bps_objects.shape[0], chunk_objects):
                 hi = min(lo + chunk_objects, bps_objects.shape[0])
                 zc = None if z is None else z[lo * n_samples:hi * n_samples]
-                parts.append(self.sweep_objects(bps_objects[lo:hi], n_samples, thresholds, z_offset, zc, chunk_objects))
+                parts.append(self.sweep_objects(bps_objects[lo:hi], n_samples, thresholds, z_offset, zc, chunk_objects,
+                                                dense))
             return {k: torch.cat([p[k] for p in parts], dim=1 if k == 'count' else 0) for k in parts[0]}
         gen, eva = self.DexGANGrasp, self.DexEvaluator
         gen.eval()
         eva.eval()
         n_obj = bps_objects.shape[0]
-        bps_rows = bps_objects.repeat_interleave(n_samples, dim=0)
+        nj = self.cfg["n_hand_joints"]
         with torch.no_grad():
             if z is None:
                 z = torch.randn((n_obj * n_samples, gen.latentD), dtype=self.dtype, device=self.device)
-            res = gen.generator(z.to(self.device, self.dtype), bps_rows)
+            z = z.to(self.device, self.dtype).contiguous()
+            if dense:
+                bps_rows = bps_objects.repeat_interleave(n_samples, dim=0)
+                res = gen.generator(z, bps_rows)
+            else:
+                heads = ops.gen_forward_objects(gen.generator._require_flat(), z, bps_objects, n_samples)
+                res = {"rot_6D": heads[:, nj:nj + 6], "transl": heads[:, nj + 6:nj + 9], "joint_conf": heads[:, :nj], "z": z}
             rot = utils.rot_matrix_from_ortho6d(res.pop('rot_6D'))
             res['rot_matrix'] = rot
             res = utils.translate_along_axis(res, 0, z_offset)
-            score = eva({'bps_object': bps_rows, 'rot_matrix': res['rot_matrix'], 'transl': res['transl']})
+            if dense:
+                score = eva({'bps_object': bps_rows, 'rot_matrix': res['rot_matrix'], 'transl': res['transl']})
+            else:
+                score = ops.eva_forward_objects(eva._require_flat(), bps_objects, res['rot_matrix'].reshape(-1, 9),
+                                                res['transl'], n_samples)
             score = score.view(n_obj, n_samples)
             sorted_score, order = score.sort(dim=1, descending=True)
             count = torch.stack([(sorted_score > t).sum(dim=1) for t in thresholds])
-        out = {k: v.view(n_obj, n_samples, *v.shape[1:]) for k, v in res.items()}
+        out = {k: v.reshape(n_obj, n_samples, *v.shape[1:]) for k, v in res.items()}
         out.update(score=score, order=order, count=count)
         return out
 

@@ -124,6 +124,49 @@ def eva_backward(fn, bps, rot9, transl, d_logit, train, need_input=False, skip_p
     return d_pose
 
 
+# ------------------------------------------------------------------------------------------ config 5
+def _objects_ws(fn, n_obj, n_per):
+    key = ("objects", n_obj, n_per)
+    ws = fn._ws.get(key)
+    if ws is None:
+        nb = int(lib().dgg_objects_workspace_bytes(fn.net, C.byref(fn.ccfg), n_obj, n_per))
+        if nb < 0:
+            raise _lib.DggError("dgg_objects_workspace_bytes: %d" % nb)
+        ws = _lib.new_workspace(nb + 4096, fn.device)
+        fn._ws[key] = ws
+    return ws
+
+
+def gen_forward_objects(fn, z, bps_obj, n_per):
+    """Eval-mode generator over O objects x n_per samples, factorised per object (dgg_gen_forward_objects).
+    z (O*n_per, latent), bps_obj (O, 4096) -> heads (O*n_per, nj+9)."""
+    dev = fn.device
+    z, bps_obj = f32c(z, dev), f32c(bps_obj, dev)
+    n_obj = bps_obj.shape[0]
+    if z.shape[0] != n_obj * n_per:
+        raise _lib.DggError("gen_forward_objects: z has %d rows, expected %d" % (z.shape[0], n_obj * n_per))
+    ws = _objects_ws(fn, n_obj, n_per)
+    out = torch.empty((n_obj * n_per, fn.ccfg.n_hand_joints + 9), dtype=torch.float32, device=dev)
+    check(lib().dgg_gen_forward_objects(C.byref(fn.ccfg), ptr(fn.params), ptr(fn.bn), ptr(ws), ws.numel(), n_obj, n_per,
+                                        ptr(z), ptr(bps_obj), ptr(out), stream_ptr(dev)), "dgg_gen_forward_objects")
+    return out
+
+
+def eva_forward_objects(fn, bps_obj, rot9, transl, n_per):
+    """Eval-mode evaluator over O objects x n_per samples, factorised per object -> p (O*n_per, 1)."""
+    dev = fn.device
+    bps_obj, rot9, transl = f32c(bps_obj, dev), f32c(rot9, dev).reshape(-1, 9), f32c(transl, dev)
+    n_obj = bps_obj.shape[0]
+    if rot9.shape[0] != n_obj * n_per or transl.shape[0] != n_obj * n_per:
+        raise _lib.DggError("eva_forward_objects: per-sample inputs need %d rows" % (n_obj * n_per))
+    ws = _objects_ws(fn, n_obj, n_per)
+    out = torch.empty((n_obj * n_per, 1), dtype=torch.float32, device=dev)
+    check(lib().dgg_eva_forward_objects(C.byref(fn.ccfg), ptr(fn.params), ptr(fn.bn), ptr(ws), ws.numel(), n_obj, n_per,
+                                        ptr(bps_obj), ptr(rot9), ptr(transl), ptr(out), stream_ptr(dev)),
+          "dgg_eva_forward_objects")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ small ops
 def ortho6d_forward(o6):
     dev = _dev(o6)

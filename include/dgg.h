@@ -149,6 +149,21 @@ int dgg_eva_backward(const dgg_cfg* cfg, const float* params, float* grads, void
  * caller (tests; a checkpoint of an in-flight step) read back the masks drawn in-kernel.  <0 on bad arguments. */
 int64_t dgg_eva_keep_offset(const dgg_cfg* cfg, int batch, int r);
 
+/* Config 5 (dexgangrasp_offline.py:147-162 over many objects) — eval-mode forward of O objects x n samples each,
+ * factorised per object: DexGanGrasp.generate_grasps / filter_grasps tile ONE BPS row over an object's n samples
+ * (dexgangrasp.py:495-514, :406-411), so the BPS part of every fused fc1||fc3 product is computed once per object
+ * (M = O rows instead of O*n) and each sample adds only its own columns.  Same results as dgg_gen_forward /
+ * dgg_eva_forward (flags = 0) on the tiled rows, up to the summation order.  bps_obj (O, 4096); per-sample inputs
+ * have O*n rows, sample s of object o at row o*n + s: z (O*n, latent); rot9 (O*n, 9), transl (O*n, 3).
+ * Outputs: out_heads (O*n, nj+9) as dgg_gen_forward; out_p (O*n, 1).  Workspace: dgg_objects_workspace_bytes. */
+int64_t dgg_objects_workspace_bytes(int net, const dgg_cfg* cfg, int n_obj, int n_per_obj);
+int dgg_gen_forward_objects(const dgg_cfg* cfg, const float* params, float* bnstats, void* ws, size_t ws_bytes,
+                            int n_obj, int n_per_obj, const float* z, const float* bps_obj, float* out_heads,
+                            void* stream);
+int dgg_eva_forward_objects(const dgg_cfg* cfg, const float* params, float* bnstats, void* ws, size_t ws_bytes,
+                            int n_obj, int n_per_obj, const float* bps_obj, const float* rot9, const float* transl,
+                            float* out_p, void* stream);
+
 /* A6 — utils.rot_matrix_from_ortho6d, utils/utils.py:380-394 (+ normalize_vector :323-332,
  * cross_product :68-78).  o6 (B,6) with row stride ld_o6 -> R (B,9) row-major, columns x,y,z. */
 int dgg_ortho6d_forward(const float* o6, int ld_o6, int B, float* rot9, void* stream);

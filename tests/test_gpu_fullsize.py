@@ -537,5 +537,11 @@ def test_config5_sweep_at_rank_share_size():
                 a, c = out["transl"][o].cpu().numpy()[sel], f["transl"]
                 a, c = a[np.lexsort(a.T[::-1])], c[np.lexsort(c.T[::-1])]
                 np.testing.assert_allclose(a, c, rtol=0, atol=2e-5)
+    # the factorised passes against the tiled (dense) ones on a slice: same grasps and scores up to the summation order
+    dn = m.sweep_objects(rows[:40], n, thresholds=thresholds, z=z[:40 * n], dense=True)
+    for k in ("transl", "rot_matrix", "joint_conf", "score"):
+        np.testing.assert_allclose(out[k][:40].cpu().numpy(), dn[k].cpu().numpy(), rtol=0, atol=3e-5, err_msg=k)
     local, (lo, hi), count_all = m.sweep_objects_sharded(rows[:300], n, thresholds=thresholds, z=z[:300 * n])
-    assert (lo, hi) == (0, 300) and torch.equal(count_all.cpu(), out["count"][:, :300].cpu())
+    assert (lo, hi) == (0, 300)
+    near = sum(int(((out["score"][:300] > t - 1e-5) & (out["score"][:300] < t + 1e-5)).sum()) for t in thresholds)
+    assert int((count_all.cpu() - out["count"][:, :300].cpu()).abs().sum()) <= near     # another chunking, another split-K
