@@ -297,6 +297,87 @@ def cgan_step(sd, batch, z, adam_g, adam_d, cfg, is_train_gen=True, return_grads
     return out
 
 
+# ----------------------------------------------------------------------------------------------
+# WGAN-GP variant (dexgangrasp.py:149-211, 234-270; cfg["is_wgan"])
+# ----------------------------------------------------------------------------------------------
+def gradient_penalty(sd, bps, real_rot, real_transl, real_joint, fake_rot, fake_transl, fake_joint, alphas,
+                     prefix="discriminator."):
+    """dexgangrasp.py:149-197.  alphas = (a_rot (B,1,1), a_transl (B,1), a_joint (B,1)): the three torch.randn draws of
+    calculate_interp, injected (NORMAL, not uniform, weights — as the reference draws them).  Interpolates keep the
+    dtype torch's promotion gives them (float64 when the batch's tensors are float64), like the reference's."""
+    a_r, a_t, a_j = alphas
+    rot_i = (a_r * real_rot + (1 - a_r) * fake_rot).requires_grad_(True)
+    tr_i = (a_t * real_transl + (1 - a_t) * fake_transl).requires_grad_(True)
+    jt_i = (a_j * real_joint + (1 - a_j) * fake_joint).requires_grad_(True)
+    score = discriminator_forward(sd, bps, rot_i, tr_i, jt_i, True, prefix)   # networks.py:132-159: casts to f32
+    pens = []
+    for x in (rot_i, tr_i, jt_i):
+        g = torch.autograd.grad(outputs=score, inputs=x, grad_outputs=torch.ones_like(score), create_graph=True,
+                                retain_graph=True, only_inputs=True)[0]
+        g = g.view(g.size(0), -1)
+        pens.append(torch.mean((g.norm(2, dim=1) - 1) ** 2))
+    return torch.mean(torch.stack(pens))
+
+
+def wgan_d_part(sd, batch, z, alphas, cfg, penalty_gain=10):
+    """dexgangrasp.py:766-793 with the Wasserstein discriminator loss (:199-211): -mean(real) + mean(fake) +
+    penalty_gain * GP.  Four discriminator forwards per step update its BatchNorm statistics (real, fake, interp,
+    and the generator phase's)."""
+    gn = [n for n in param_names(sd) if n.startswith("generator.")]
+    dn = [n for n in param_names(sd) if n.startswith("discriminator.")]
+    _set_requires_grad(sd, gn + dn, True)
+    b = batch["bps_object"].shape[0]
+    bps = batch["bps_object"].float()
+    rot, transl, joint = batch["rot_matrix"], batch["transl"], batch["joint_conf"]
+    y = generator_forward(sd, z, bps, True, "generator.")
+    r_fake = rot_matrix_from_ortho6d(y["rot_6D"])
+    real_score = discriminator_forward(sd, bps, rot, transl, joint, True, "discriminator.")
+    fake_score = discriminator_forward(
+        sd, bps, r_fake.detach(), y["transl"].detach(), y["joint_conf"].detach(), True, "discriminator.")
+    l_real, l_fake = torch.mean(real_score), torch.mean(fake_score)
+    gp = gradient_penalty(sd, bps, rot.reshape(b, 3, 3) if rot.dim() == 2 else rot, transl, joint, r_fake.detach(),
+                          y["transl"].detach(), y["joint_conf"].detach(), alphas)
+    tot = -l_real + l_fake + gp * penalty_gain
+    g_d = _grads(tot, sd, dn)
+    ctx = {"y": y, "r_fake": r_fake, "bps": bps, "rot": rot.float().reshape(b, 9), "transl": transl.float(),
+           "joint": joint.float(), "gn": gn, "dn": dn}
+    out = {"total_loss_disc": tot.detach(), "bce_loss_real": l_real.detach(), "bce_loss_fake": l_fake.detach(),
+           "gradient_penalty": gp.detach()}
+    return out, g_d, ctx
+
+
+def wgan_g_part(sd, ctx, cfg):
+    """dexgangrasp.py:808-815 with the Wasserstein generator loss (:234-270): gen_loss_fake = -mean(fake_score)."""
+    y = ctx["y"]
+    fake_score_gen = discriminator_forward(sd, ctx["bps"], ctx["r_fake"], y["transl"], y["joint_conf"], True,
+                                           "discriminator.")
+    pred_r = rot_matrix_from_ortho6d(y["rot_6D"]).reshape(-1, 9)
+    l_rot = F.mse_loss(pred_r, ctx["rot"])
+    l_tr = F.mse_loss(y["transl"], ctx["transl"])
+    l_cf = F.mse_loss(y["joint_conf"].float(), ctx["joint"])
+    l_f = -torch.mean(fake_score_gen)
+    d = {"gen_loss_fake": l_f, "transl_loss": 100.0 * l_tr, "rot_loss": 1.0 * l_rot, "conf_loss": 10.0 * l_cf}
+    tot = l_f + (d["transl_loss"] + d["rot_loss"] + d["conf_loss"])
+    d["total_loss_gen"] = tot
+    g_g = _grads(tot, sd, ctx["gn"])
+    return {k: v.detach() for k, v in d.items()}, g_g
+
+
+def wgan_step(sd, batch, z, alphas, adam_g, adam_d, cfg, is_train_gen=True, return_grads=False):
+    """dexgangrasp.py:757-823 with cfg["is_wgan"] = True."""
+    out, g_d, ctx = wgan_d_part(sd, batch, z, alphas, cfg)
+    adam_step(sd, g_d, adam_d, lr=cfg["lr_dis"], b1=cfg["beta1"], wd=cfg["weight_decay"])
+    g_g = None
+    if is_train_gen:
+        dict_g, g_g = wgan_g_part(sd, ctx, cfg)
+        adam_step(sd, g_g, adam_g, lr=cfg["lr_gen"], b1=cfg["beta1"], wd=cfg["weight_decay"])
+        out.update(dict_g)
+    _set_requires_grad(sd, ctx["gn"] + ctx["dn"], False)
+    if return_grads:
+        return out, g_d, g_g
+    return out
+
+
 def _mean_grads(gs):
     """Mean over ranks of per-shard gradient dicts (what the sum all-reduce + 1/world scale produce)."""
     return {n: sum(g[n] for g in gs) / float(len(gs)) for n in gs[0]}

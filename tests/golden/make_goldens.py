@@ -225,6 +225,54 @@ def gen_step_goldens(cfg, eval_rows):
     print("step goldens:", len(out), "arrays")
 
 
+def wgan_draws(b, seed):
+    """The random draws of one is_wgan update, in the reference's order: Z (dexgangrasp.py:770), then the three
+    interpolation weights of calculate_interp (:149-158: rot (B,1,1), transl (B,1), joint_conf (B,1); all randn)."""
+    torch.manual_seed(seed)
+    return torch.randn((b, 5)), (torch.randn((b, 1, 1)), torch.randn((b, 1)), torch.randn((b, 1)))
+
+
+def gen_wgan_goldens(cfg, eval_rows):
+    """N3: two update_dexgangrasp steps with cfg["is_wgan"] = True (WGAN-GP, dexgangrasp.py:149-211, 234-270)."""
+    out = {}
+    wcfg = dict(cfg)
+    wcfg["is_wgan"] = True
+    for variant, bname in [("wide", "real16"), ("wide", "syn64"), ("init", "syn64")]:
+        batch = batches(eval_rows)[bname]
+        b = batch["bps_object"].shape[0]
+        m = build_reference(wcfg, variant)
+        key = "%s/%s/" % (variant, bname)
+        cap = {}
+
+        def wrap(opt, tag, module, prefix):
+            orig = opt.step
+
+            def step(*a, **k):
+                cap[tag] = {prefix + n: p.grad.detach().clone() for n, p in module.named_parameters()}
+                return orig(*a, **k)
+            opt.step = step
+        wrap(m.optim_dexgangrasp_discriminator, "d", m.DexGANGrasp.discriminator, "discriminator.")
+        wrap(m.optim_dexgangrasp_generator, "g", m.DexGANGrasp.generator, "generator.")
+        for step in range(2):
+            z, (a_r, a_t, a_j) = wgan_draws(b, 500 + step)
+            torch.manual_seed(500 + step)
+            losses = m.update_dexgangrasp(clone_batch(batch), is_train_gen=True)
+            sk = key + "wgan%d/" % step
+            out[sk + "z"] = z.numpy()
+            out[sk + "alpha_rot"] = a_r.numpy()
+            out[sk + "alpha_transl"] = a_t.numpy()
+            out[sk + "alpha_joint"] = a_j.numpy()
+            for k, v in losses.items():
+                out[sk + "loss/" + k] = np.float64(v.item())
+            for tag in ["d", "g"]:
+                for n, g in cap[tag].items():
+                    out[sk + "grad_%s/" % tag + n] = summarize(g)
+            for n, t in m.DexGANGrasp.state_dict().items():
+                out[sk + "state/" + n] = summarize(t)
+    np.savez_compressed(os.path.join(HERE, "wgan_goldens.npz"), **out)
+    print("wgan goldens:", len(out), "arrays")
+
+
 def gen_inference_goldens(cfg):
     out = {}
     bps = np.load(os.path.join(REF, "data/real_objects/bps/red_mug.npy"))
@@ -305,8 +353,13 @@ def main():
     cfg["save_dir"] = "/tmp/dgg_ref_ckpt"
     cfg["eval_dir"] = "/tmp/dgg_ref_ckpt"
     cfg["train_ffhevaluator"] = True
+    if len(sys.argv) > 1 and sys.argv[1] == "wgan":     # only the N3 fixture (the others are unchanged)
+        d = np.load(os.path.join(HERE, "eval_batch_rows16.npz"))
+        gen_wgan_goldens(cfg, {k: torch.from_numpy(d[k].copy()) for k in d.files})
+        return
     gen_bps_fixture()
     rows = gen_eval_rows()
+    gen_wgan_goldens(cfg, rows)
     gen_forward_goldens(cfg, rows)
     gen_step_goldens(cfg, rows)
     gen_inference_goldens(cfg)

@@ -187,3 +187,38 @@ def test_magd_mirror_vs_reference():
     np.testing.assert_allclose([t, r, j, c], g["result"], rtol=1e-6)
     t2, r2, j2, c2 = metrics.magd_for_grasp_distribution({k: torch.from_numpy(v) for k, v in pred.items()}, gt)
     assert (t2, c2) == (t, c)
+
+
+# ------------------------------------------------------------------ N3: WGAN-GP
+@pytest.mark.parametrize("variant,bname", [("wide", "real16"), ("wide", "syn64"), ("init", "syn64")])
+def test_wgan_gp_steps_vs_reference(variant, bname):
+    """dexgangrasp.py:149-211, 234-270 (cfg["is_wgan"]): two update_dexgangrasp steps of the reference, with its Z and
+    its three interpolation weights injected — losses, every gradient before each optimiser step, post-step state."""
+    g = H.load("wgan_goldens.npz")
+    key = "%s/%s/" % (variant, bname)
+    batch = H.batches()[bname]
+    sd = H.gan_sd(variant)
+    ag = O.AdamState([n for n in O.param_names(sd) if n.startswith("generator.")])
+    ad = O.AdamState([n for n in O.param_names(sd) if n.startswith("discriminator.")])
+    for step in range(2):
+        sk = key + "wgan%d/" % step
+        z = torch.from_numpy(g[sk + "z"])
+        alphas = tuple(torch.from_numpy(g[sk + "alpha_" + n]) for n in ("rot", "transl", "joint"))
+        losses, g_d, g_g = O.wgan_step(sd, H.clone_batch(batch), z, alphas, ag, ad, CFG, True, return_grads=True)
+        for k in ("total_loss_disc", "bce_loss_real", "bce_loss_fake", "gen_loss_fake", "transl_loss", "rot_loss",
+                  "conf_loss", "total_loss_gen"):
+            np.testing.assert_allclose(float(losses[k]), float(g[sk + "loss/" + k]), rtol=2e-5, atol=1e-7, err_msg=k)
+        # second step: starts from post-Adam parameters that two fp32 evaluations only share to ~1e-3 of lr where the
+        # gradient is eps-sized (helpers.assert_state_close) — the absolute slack follows that
+        atol = 2e-4 if step == 0 else 2e-3
+        for n, t in g_d.items():
+            sib = H.rms_of_summary(g[sk + "grad_d/" + H.sibling_bn_bias(n)])
+            H.assert_grad_close(n, t, g[sk + "grad_d/" + n], sib, 2e-3, atol)
+        for n, t in g_g.items():
+            sib = H.rms_of_summary(g[sk + "grad_g/" + H.sibling_bn_bias(n)])
+            H.assert_grad_close(n, t, g[sk + "grad_g/" + n], sib, 2e-3, atol)
+        for n, t in sd.items():
+            H.assert_state_close(n, t, g[sk + "state/" + n], step)
+    # the discriminator runs FOUR train-mode forwards per step here (real, fake, interpolates, generator phase)
+    assert int(sd["discriminator.disc_bn1.num_batches_tracked"]) == 8
+    assert int(sd["generator.gen_bn1.num_batches_tracked"]) == 2
