@@ -19,6 +19,7 @@ NET_GEN, NET_DISC, NET_EVA = 0, 1, 2
 TRAIN, ACCUM_GRADS, SKIP_PARAM_GRADS, NEED_INPUT_GRADS = 1, 2, 4, 8
 # loss slots (include/dgg.h)
 L_TOTAL_DISC, L_BCE_REAL, L_BCE_FAKE, L_GEN_FAKE, L_TRANSL, L_ROT, L_CONF, L_TOTAL_GEN, L_TOTAL_EVA, L_BCE_EVA = range(10)
+L_GRAD_PENALTY = 10
 
 
 class DggError(RuntimeError):
@@ -95,6 +96,11 @@ SIGNATURES = {
     "dgg_objects_workspace_bytes": (_I64, [_I, _CFG, _I, _I]),
     "dgg_gen_forward_objects": (_I, [_CFG, _VP, _VP, _VP, _SZ, _I, _I, _VP, _VP, _VP, _VP]),
     "dgg_eva_forward_objects": (_I, [_CFG, _VP, _VP, _VP, _SZ, _I, _I, _VP, _VP, _VP, _VP, _VP]),
+    "dgg_wgan_workspace_bytes": (_I64, [_CFG, _I]),
+    "dgg_wgan_d_phase": (_I, [_CFG, C.POINTER(GanState), C.POINTER(HParams), _VP, _SZ, _I, _VP, _VP, _VP, _VP, _VP, _VP,
+                              _D, _VP, _VP]),
+    "dgg_wgan_g_phase": (_I, [_CFG, C.POINTER(GanState), C.POINTER(HParams), _VP, _SZ, _I, _VP, _VP, _VP, _VP, _VP, _VP,
+                              _VP]),
     "dgg_cgan_release": (_I, [_VP]),
     "dgg_reset": (_I, []),
     "dgg_eva_keep_offset": (_I64, [_CFG, _I, _I]),

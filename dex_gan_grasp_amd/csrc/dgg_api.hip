@@ -1642,6 +1642,234 @@ int dgg_resblock_backward(int fin, const float* params, float* grads, void* ws, 
     return rb_backward(c, 0, &seg, 1, dy, false, (flags & DGG_ACCUM_GRADS) != 0, skip, ibn_tiles);
 }
 
+// ---- N3: WGAN-GP (dexgangrasp.py:149-211, 234-270) ----------------------------------------------
+// second_order.hip explains the method: (1) forward + input-gradient backward on the interpolates -> g, v = gain dGP/dg;
+// (2) tangent forward of v; (3) one reverse sweep of F = sum_b sigmoid'(l_b) ldot_b through the primal + tangent graph.
+namespace dgg {
+struct GpW {
+    void* ws_di;
+    float *xi_rot, *xi_tr, *xi_jt, *p_i, *dl_i, *g, *v, *xhd0, *tu0, *tu0bar, *c1, *c2, *cs;
+    float *ta13[2], *th[2], *ta2[2], *ty[2];
+    float *A13bar, *A13dbar, *a2bar, *a2dbar, *hbar, *hdbar, *pbar, *pdbar, *ybar, *ydbar;
+    size_t bytes;
+};
+
+static int carve_wgan(const dgg_cfg* cfg, int B, void* base, StepW& S, GpW& W) {
+    DGG_TRY(carve_step(cfg, B, base, S));
+    NetL Ld;
+    DGG_TRY(build_layout(DGG_NET_DISC, cfg, Ld));
+    if (Ld.nrb != 2) return DGG_ERR_UNSUPPORTED;
+    Bump b{reinterpret_cast<char*>(base), S.bytes};
+    const size_t Bz = (size_t)B;
+    const int nj = cfg->n_hand_joints, np = 12 + nj;
+    W.ws_di = b.take<char>(S.d_bytes);
+    W.xi_rot = b.take<float>(Bz * 9);
+    W.xi_tr = b.take<float>(Bz * 3);
+    W.xi_jt = b.take<float>(Bz * nj);
+    W.p_i = b.take<float>(Bz);
+    W.dl_i = b.take<float>(Bz);
+    W.g = b.take<float>(Bz * np);
+    W.v = b.take<float>(Bz * np);
+    W.xhd0 = b.take<float>(Bz * np);
+    W.tu0 = b.take<float>(Bz * np);
+    W.tu0bar = b.take<float>(Bz * np);
+    W.c1 = b.take<float>(Bz);
+    W.c2 = b.take<float>(Bz);
+    W.cs = b.take<float>((size_t)Ld.n13);
+    for (int r = 0; r < 2; ++r) {
+        W.ta13[r] = b.take<float>(Bz * Ld.n13);
+        W.th[r] = b.take<float>(Bz * Ld.hid);
+        W.ta2[r] = b.take<float>(Bz * Ld.nn);
+        W.ty[r] = b.take<float>(Bz * Ld.nn);
+    }
+    W.A13bar = b.take<float>(Bz * Ld.n13);
+    W.A13dbar = b.take<float>(Bz * Ld.n13);
+    W.a2bar = b.take<float>(Bz * Ld.nn);
+    W.a2dbar = b.take<float>(Bz * Ld.nn);
+    W.hbar = b.take<float>(Bz * Ld.hid);
+    W.hdbar = b.take<float>(Bz * Ld.hid);
+    W.pbar = b.take<float>(Bz * Ld.nn);
+    W.pdbar = b.take<float>(Bz * Ld.nn);
+    W.ybar = b.take<float>(Bz * Ld.nn);
+    W.ydbar = b.take<float>(Bz * Ld.nn);
+    W.bytes = (b.off + 255) & ~(size_t)255;
+    return DGG_OK;
+}
+
+static int gemm1(int mode, const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K,
+                 int accumulate, hipStream_t st) {
+    GemmBatch g;
+    memset(&g, 0, sizeof(g));
+    g.nprob = 1;
+    prob_init(g.p[0], A, lda, Bm, ldb, C, ldc, M, N, K);
+    g.p[0].accumulate = accumulate;
+    return gemm_launch(mode, g, st);
+}
+
+// The gradient-penalty term: adds gain * dGP/dtheta to d_grads, writes GP to losses[DGG_L_GRAD_PENALTY].
+static int gradient_penalty(const dgg_cfg* cfg, const dgg_gan_state* s, const StepW& S, GpW& Q, int B, const float* bps,
+                            const float* rot9, const float* transl, const float* joint, const float* alphas, float gain,
+                            float* losses, hipStream_t st) {
+    NetL L;
+    DGG_TRY(build_layout(DGG_NET_DISC, cfg, L));
+    const int nj = cfg->n_hand_joints, np = 12 + nj, ib = cfg->in_bps;
+    const float* P = s->d_params;
+    float* G = s->d_grads;
+    // (1) interpolates (:149-158), D forward in train mode (its running statistics advance: the step's third D pass),
+    //     g = d sum(score) / d(rot, transl, joint)  (:160-172)
+    DGG_TRY(gp_interp_launch(alphas, rot9, transl, joint, S.rfake, S.f_transl, S.f_joint, B, nj, Q.xi_rot, Q.xi_tr,
+                             Q.xi_jt, st));
+    DGG_TRY(dgg_disc_forward(cfg, P, s->d_bn, Q.ws_di, S.d_bytes, B, DGG_TRAIN, bps, Q.xi_rot, Q.xi_tr, Q.xi_jt, Q.p_i,
+                             st));
+    DGG_TRY(sig_grad_launch(Q.p_i, B, Q.dl_i, st));
+    DGG_TRY(dgg_disc_backward(cfg, P, nullptr, Q.ws_di, S.d_bytes, B,
+                              DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_NEED_INPUT_GRADS, bps, Q.xi_rot, Q.xi_tr, Q.xi_jt,
+                              Q.dl_i, Q.g, st));
+    DGG_TRY(gp_value_launch(Q.g, B, nj, gain, losses + DGG_L_GRAD_PENALTY, Q.v, st));
+    // (2) tangent forward of v next to the stored activations of that forward
+    NetW W;
+    carve(L, B, Q.ws_di, W);
+    DGG_TRY(bn_jvp_launch(W.X0 + ib, L.ldx0, Q.v, np, nullptr, W.irstd + ib, P + L.ibnw + ib, nullptr, 0, nullptr, 0, B, np,
+                          Q.tu0, np, Q.xhd0, np, 1, st));
+    for (int r = 0; r < 2; ++r) {
+        const RbL& R = L.rb[r];
+        RbW& A = W.rb[r];
+        DGG_TRY(gemm1(GEMM_NT, Q.tu0, np, P + R.w13 + ib, R.fin, Q.ta13[r], L.n13, B, L.n13, np, 0, st));
+        if (r > 0)
+            DGG_TRY(gemm1(GEMM_NT, Q.ty[r - 1], L.nn, P + R.w13 + L.k0, R.fin, Q.ta13[r], L.n13, B, L.n13, L.nn, 1, st));
+        DGG_TRY(mask_inplace_launch(Q.ta13[r] + L.hid, L.n13, A.a13 + L.hid, L.n13, B, L.nn, st));
+        DGG_TRY(bn_jvp_launch(A.a13, L.n13, Q.ta13[r], L.n13, A.mean1, A.rstd1, P + R.bn1w, nullptr, 0, A.h, L.hid, B, L.hid,
+                              Q.th[r], L.hid, nullptr, 0, 0, st));
+        DGG_TRY(gemm1(GEMM_NT, Q.th[r], L.hid, P + R.w2, L.hid, Q.ta2[r], L.nn, B, L.nn, L.hid, 0, st));
+        DGG_TRY(bn_jvp_launch(A.a2, L.nn, Q.ta2[r], L.nn, A.mean2, A.rstd2, P + R.bn2w, Q.ta13[r] + L.hid, L.n13, A.y, L.nn, B,
+                              L.nn, Q.ty[r], L.nn, nullptr, 0, 0, st));
+    }
+    DGG_TRY(head2_launch(Q.ty[1], L.nn, P + L.wh, Q.p_i, B, L.nn, Q.c1, Q.c2, st));
+    // (3) reverse sweep of F: primal adjoints (bar) and tangent adjoints (dbar) side by side; everything accumulates
+    DGG_TRY(head2_grads_launch(W.rb[1].y, L.nn, Q.ty[1], L.nn, Q.c1, Q.c2, B, L.nn, G + L.wh, G + L.bh, st));
+    int ibn_tiles[2] = {0, 0};
+    for (int r = 1; r >= 0; --r) {
+        const RbL& R = L.rb[r];
+        RbW& A = W.rb[r];
+        const bool last = r == 1;
+        DGG_TRY(out2_bwd_launch(last ? nullptr : Q.ybar, last ? nullptr : Q.ydbar, L.nn, last ? Q.c1 : nullptr,
+                                last ? Q.c2 : nullptr, P + L.wh, A.y, L.nn, A.a13 + L.hid, L.n13, B, L.nn, Q.pbar, Q.pdbar,
+                                L.nn, Q.A13bar + L.hid, Q.A13dbar + L.hid, L.n13, st));
+        DGG_TRY(bn_second_bwd_launch(A.a2, L.nn, Q.ta2[r], L.nn, A.mean2, A.rstd2, P + R.bn2w, Q.pbar, Q.pdbar, L.nn, nullptr,
+                                     0, B, L.nn, Q.a2bar, Q.a2dbar, L.nn, G + R.bn2w, G + R.bn2b, st));
+        // fc2: a2 = h W2^T + b2, a2dot = hdot W2^T  (b2 feeds a train-mode BatchNorm: its gradient is exactly zero)
+        DGG_TRY(gemm1(GEMM_NN, Q.a2bar, L.nn, P + R.w2, L.hid, Q.hbar, L.hid, B, L.hid, L.nn, 0, st));
+        DGG_TRY(gemm1(GEMM_NN, Q.a2dbar, L.nn, P + R.w2, L.hid, Q.hdbar, L.hid, B, L.hid, L.nn, 0, st));
+        DGG_TRY(gemm1(GEMM_TN, Q.a2bar, L.nn, A.h, L.hid, G + R.w2, L.hid, L.nn, L.hid, B, 1, st));
+        DGG_TRY(gemm1(GEMM_TN, Q.a2dbar, L.nn, Q.th[r], L.hid, G + R.w2, L.hid, L.nn, L.hid, B, 1, st));
+        DGG_TRY(bn_second_bwd_launch(A.a13, L.n13, Q.ta13[r], L.n13, A.mean1, A.rstd1, P + R.bn1w, Q.hbar, Q.hdbar, L.hid, A.h,
+                                     L.hid, B, L.hid, Q.A13bar, Q.A13dbar, L.n13, G + R.bn1w, G + R.bn1b, st));
+        // fc3.bias (the fc1.bias part is exactly zero) and the column sums the BatchNorm-aware wgrad epilogue needs
+        DGG_TRY(colsum_prod_launch(Q.A13bar + L.hid, L.n13, nullptr, 0, B, L.nn, Q.cs + L.hid, 0, st));
+        DGG_TRY(colsum_prod_launch(Q.A13bar + L.hid, L.n13, nullptr, 0, B, L.nn, G + R.b13 + L.hid, 1, st));
+        {  // [fc1;fc3] weights, primal stream: the x_hat segment through the epilogue that also yields d gamma0 / d beta0
+            GemmBatch g;
+            memset(&g, 0, sizeof(g));
+            g.nprob = r > 0 ? 2 : 1;
+            prob_init(g.p[0], Q.A13bar, L.n13, W.X0, L.ldx0, G + R.w13, R.fin, L.n13, L.k0, B);
+            g.p[0].accumulate = 1;
+            g.p[0].ep_gamma = W.aff_scale;
+            g.p[0].ep_beta = W.aff_shift;
+            g.p[0].ep_cs0 = nullptr;
+            g.p[0].ep_cs1 = Q.cs + L.hid;
+            g.p[0].ep_split = L.hid;
+            g.p[0].ep_w = P + R.w13;
+            g.p[0].ep_ldw = R.fin;
+            g.p[0].ep_part = W.ibn_part + (size_t)r * 12 * 2 * L.k0;
+            if (r > 0) {
+                prob_init(g.p[1], Q.A13bar, L.n13, W.rb[r - 1].y, L.nn, G + R.w13 + L.k0, R.fin, L.n13, L.nn, B);
+                g.p[1].accumulate = 1;
+            }
+            int bm, bn;
+            gemm_tile_shape(GEMM_TN, g.p[0].M, g.p[0].N, bm, bn, g.p[0].K);
+            ibn_tiles[r] = (L.n13 + bm - 1) / bm;
+            if (ibn_tiles[r] > 12) return DGG_ERR_INVALID;
+            DGG_TRY(gemm_launch(GEMM_TN, g, st));
+        }
+        // tangent stream: only the pose columns of x_hat (and the previous block) carry a tangent
+        DGG_TRY(gemm1(GEMM_TN, Q.A13dbar, L.n13, Q.tu0, np, G + R.w13 + ib, R.fin, L.n13, np, B, 1, st));
+        if (r > 0) {
+            DGG_TRY(gemm1(GEMM_TN, Q.A13dbar, L.n13, Q.ty[r - 1], L.nn, G + R.w13 + L.k0, R.fin, L.n13, L.nn, B, 1, st));
+            DGG_TRY(gemm1(GEMM_NN, Q.A13bar, L.n13, P + R.w13 + L.k0, R.fin, Q.ybar, L.nn, B, L.nn, L.n13, 0, st));
+            DGG_TRY(gemm1(GEMM_NN, Q.A13dbar, L.n13, P + R.w13 + L.k0, R.fin, Q.ydbar, L.nn, B, L.nn, L.n13, 0, st));
+        }
+        DGG_TRY(gemm1(GEMM_NN, Q.A13dbar, L.n13, P + R.w13 + ib, R.fin, Q.tu0bar, np, B, np, L.n13, last ? 0 : 1, st));
+    }
+    // input BatchNorm: d gamma0 / d beta0 from the primal epilogue partials, d gamma0 (pose columns) from the tangent
+    for (int r = 0; r < 2; ++r)
+        DGG_TRY(colsum_finalize_launch(W.ibn_part + (size_t)r * 12 * 2 * L.k0, 1, ibn_tiles[r], 2, L.k_in, nullptr, G + L.ibnw,
+                                       G + L.ibnb, nullptr, 1, st, L.k0, L.nprefix));
+    DGG_TRY(colsum_prod_launch(Q.tu0bar, np, Q.xhd0, np, B, np, G + L.ibnw + ib, 1, st));
+    return DGG_OK;
+}
+}  // namespace dgg
+
+int64_t dgg_wgan_workspace_bytes(const dgg_cfg* cfg, int batch) {
+    if (batch < 2) return DGG_ERR_INVALID;
+    StepW S;
+    GpW Q;
+    if (carve_wgan(cfg, batch, nullptr, S, Q)) return DGG_ERR_INVALID;
+    return (int64_t)Q.bytes;
+}
+
+int dgg_wgan_d_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, void* ws, size_t ws_bytes, int B,
+                     const float* bps, const float* rot9, const float* transl, const float* joint, const float* z,
+                     const float* alphas, double penalty_gain, float* losses, void* stream) {
+    if (!s || !hp || !ws || !bps || !rot9 || !transl || !joint || !z || !alphas || !losses || B < 2) return DGG_ERR_INVALID;
+    StepW S;
+    GpW Q;
+    DGG_TRY(carve_wgan(cfg, B, ws, S, Q));
+    if (Q.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
+    const int nj = cfg->n_hand_joints, nh = nj + 9;
+    hipStream_t st = (hipStream_t)stream;
+    // :772-776 generator forward (train, activations kept for the G phase), R = ortho6d(rot_6D)
+    DGG_TRY(dgg_gen_forward(cfg, s->g_params, s->g_bn, S.ws_g, S.g_bytes, B, DGG_TRAIN, z, bps, S.heads, stream));
+    DGG_TRY(ortho6d_fwd_launch(S.heads + nj, nh, B, S.rfake, st));
+    DGG_TRY(copy_cols_launch(S.heads + nj + 6, nh, S.f_transl, 3, B, 3, st));
+    DGG_TRY(copy_cols_launch(S.heads, nh, S.f_joint, nj, B, nj, st));
+    // :788-789 D(real), D(fake.detach()); :199-205 -mean(real) + mean(fake)
+    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint, S.p_real,
+                             stream));
+    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN, bps, S.rfake, S.f_transl, S.f_joint,
+                             S.p_fake, stream));
+    DGG_TRY(wass_launch(S.p_real, B, -1.f, losses + DGG_L_BCE_REAL, S.dl_real, st));
+    DGG_TRY(wass_launch(S.p_fake, B, 1.f, losses + DGG_L_BCE_FAKE, S.dl_fake, st));
+    DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint,
+                              S.dl_real, nullptr, stream));
+    DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_df, S.d_bytes, B, DGG_TRAIN | DGG_ACCUM_GRADS, bps, S.rfake,
+                              S.f_transl, S.f_joint, S.dl_fake, nullptr, stream));
+    // :174-197 gradient penalty and its parameter gradient
+    DGG_TRY(gradient_penalty(cfg, s, S, Q, B, bps, rot9, transl, joint, alphas, (float)penalty_gain, losses, st));
+    return wgan_combine_launch(losses, (float)penalty_gain, DGG_L_GRAD_PENALTY, st);
+}
+
+int dgg_wgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, void* ws, size_t ws_bytes, int B,
+                     const float* bps, const float* rot9, const float* transl, const float* joint, const float* z,
+                     float* losses, void* stream) {
+    if (!s || !hp || !ws || !bps || !rot9 || !transl || !joint || !z || !losses || B < 2) return DGG_ERR_INVALID;
+    StepW S;
+    GpW Q;
+    DGG_TRY(carve_wgan(cfg, B, ws, S, Q));
+    if (Q.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    // :808 D forward with the updated discriminator; :258 gen_loss_fake = -mean(fake_score)
+    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN, bps, S.rfake, S.f_transl, S.f_joint,
+                             S.p_gen, stream));
+    DGG_TRY(wass_launch(S.p_gen, B, -1.f, nullptr, S.dl_gen, st));
+    DGG_TRY(dgg_disc_backward(cfg, s->d_params, nullptr, S.ws_df, S.d_bytes, B,
+                              DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_NEED_INPUT_GRADS, bps, S.rfake, S.f_transl, S.f_joint,
+                              S.dl_gen, S.d_pose, stream));
+    DGG_TRY(gen_loss_launch(cfg, hp, B, S.heads, rot9, transl, joint, S.p_gen, S.d_pose, losses, S.d_heads, st,
+                            B >= 4 * ((B + 63) / 64) ? S.dl_gen : nullptr, 1));
+    return dgg_gen_backward(cfg, s->g_params, s->g_grads, S.ws_g, S.g_bytes, B, DGG_TRAIN, z, bps, S.d_heads, nullptr, nullptr,
+                            stream);
+}
+
 int dgg_gemm_occupancy(int mode, int bm, int bn) {
     return gemm_algo() == 1 && bm == 128 && bn == 128 ? gemm_x3_occupancy(mode) : gemm_occupancy(mode, bm, bn);
 }

@@ -171,8 +171,34 @@ int ortho6d_fwd_launch(const float* o6, int ld, int B, float* rot9, hipStream_t 
 int ortho6d_bwd_launch(const float* o6, int ld, int B, const float* d_rot9, float* d_o6, int ldd, hipStream_t st);
 int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const float* heads, const float* gt_rot9,
                     const float* gt_transl, const float* gt_joint, const float* fake_score, const float* d_pose,
-                    float* losses, float* d_heads, hipStream_t st, float* scratch = nullptr /* >= 4*ceil(B/64) floats */);
+                    float* losses, float* d_heads, hipStream_t st, float* scratch = nullptr /* >= 4*ceil(B/64) floats */,
+                    int wass = 0 /* 1: gen_loss_fake = -mean(fake_score) (dexgangrasp.py:258) instead of BCE(., 1) */);
 int disc_loss_combine_launch(float* losses, hipStream_t st, int real_slot = DGG_L_BCE_REAL);
+
+// ---------------------------------------------------------------- WGAN-GP second-order pass (second_order.hip)
+int gp_interp_launch(const float* alphas, const float* r_rot, const float* r_tr, const float* r_jt, const float* f_rot,
+                     const float* f_tr, const float* f_jt, int B, int nj, float* o_rot, float* o_tr, float* o_jt,
+                     hipStream_t st);
+int wass_launch(const float* p, int B, float sign, float* loss_out, float* d_logit, hipStream_t st);
+int sig_grad_launch(const float* p, int B, float* d_logit, hipStream_t st);
+int gp_value_launch(const float* g, int B, int nj, float gain, float* gp_out, float* v, hipStream_t st);
+int wgan_combine_launch(float* losses, float gain, int gp_slot, hipStream_t st);
+int bn_jvp_launch(const float* a, int lda, const float* adot, int ldad, const float* mean, const float* rstd,
+                  const float* gamma, const float* addend, int ldadd, const float* mask_ref, int ldm, int B, int N,
+                  float* out, int ldo, float* xhd_out, int ldx, int a_is_xhat, hipStream_t st);
+int mask_inplace_launch(float* x, int ldx, const float* ref, int ldr, int B, int N, hipStream_t st);
+int head2_launch(const float* ydot, int ld, const float* w, const float* p, int B, int K, float* c1, float* c2,
+                 hipStream_t st);
+int head2_grads_launch(const float* y, int ldy, const float* ydot, int ldyd, const float* c1, const float* c2, int B,
+                       int K, float* gw, float* gb, hipStream_t st);
+int out2_bwd_launch(const float* ybar, const float* ydbar, int ldyb, const float* c1, const float* c2, const float* w,
+                    const float* y, int ldy, const float* s3, int lds, int B, int N, float* pbar, float* pdbar, int ldp,
+                    float* a3bar, float* a3dbar, int lda3, hipStream_t st);
+int bn_second_bwd_launch(const float* a, int lda, const float* adot, int ldad, const float* mean, const float* rstd,
+                         const float* gamma, const float* zbar, const float* zdbar, int ldz, const float* mask_ref, int ldm,
+                         int B, int N, float* abar, float* adbar, int ldo, float* g_gamma, float* g_beta, hipStream_t st);
+int colsum_prod_launch(const float* x, int ldx, const float* y, int ldy, int B, int N, float* dst, int accumulate,
+                       hipStream_t st);
 int adam_launch(float* params, const float* grads, float* m, float* v, int64_t n, int step, double lr, double b1,
                 double b2, double eps, double wd, double grad_scale, hipStream_t st);
 int translate_axis_launch(float* transl, const float* rot9, int B, int axis, float offset, hipStream_t st);

@@ -883,7 +883,7 @@ __global__ __launch_bounds__(1024) void gen_loss_kernel(int nj, float bce_w, flo
 #pragma unroll
             for (int e = 0; e < 6; ++e) d_heads[(size_t)i * nh + nj + e] = go[e];
         }
-        if (fake_score) l_f += -fmaxf(logf(fake_score[i]), -100.f);
+        if (fake_score) l_f += bce_w < 0.f ? -fake_score[i] : -fmaxf(logf(fake_score[i]), -100.f);  // bce_w < 0: Wasserstein
     }
     const float t_tr = block_sum_1024(l_tr, sh);
     const float t_rot = block_sum_1024(l_rot, sh);
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(1024) void gen_loss_kernel(int nj, float bce_w, flo
         return;
     }
     if (threadIdx.x == 0) {
-        const float lf = bce_w * (t_f / (float)B);
+        const float lf = (bce_w < 0.f ? 1.f : bce_w) * (t_f / (float)B);
         const float ltr = c_tr * (t_tr / (3.f * (float)B));
         const float lrot = c_rot * (t_rot / (9.f * (float)B));
         const float lcf = c_cf * (t_cf / ((float)nj * (float)B));
@@ -914,7 +914,7 @@ __global__ void gen_loss_final_kernel(int nj, float bce_w, float c_tr, float c_r
     float t[4] = {0.f, 0.f, 0.f, 0.f};
     for (int b = 0; b < nblk; ++b)
         for (int q = 0; q < 4; ++q) t[q] += partial[4 * b + q];
-    const float lf = bce_w * (t[3] / (float)B);
+    const float lf = (bce_w < 0.f ? 1.f : bce_w) * (t[3] / (float)B);
     const float ltr = c_tr * (t[0] / (3.f * (float)B));
     const float lrot = c_rot * (t[1] / (9.f * (float)B));
     const float lcf = c_cf * (t[2] / ((float)nj * (float)B));
@@ -1281,8 +1281,9 @@ int ortho6d_bwd_launch(const float* o6, int ld, int B, const float* d_rot9, floa
 
 int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const float* heads, const float* gt_rot9,
                     const float* gt_transl, const float* gt_joint, const float* fake_score, const float* d_pose,
-                    float* losses, float* d_heads, hipStream_t st, float* scratch) {
-    const float bw = (float)hp->bce_weight, ct = (float)hp->transl_coef, cr = (float)hp->rot_coef,
+                    float* losses, float* d_heads, hipStream_t st, float* scratch, int wass) {
+    // the kernels read a negative BCE weight as "Wasserstein term -mean(fake_score) with weight 1"
+    const float bw = wass ? -1.f : (float)hp->bce_weight, ct = (float)hp->transl_coef, cr = (float)hp->rot_coef,
                 cc = (float)hp->conf_coef;
     const int nblk = cdiv(B, 64);
     if (!scratch || nblk < 2) {

@@ -1,0 +1,385 @@
+// Kernels of the WGAN-GP gradient penalty (DexGanGrasp/models/dexgangrasp.py:149-197, cfg["is_wgan"]).
+//
+// The penalty GP(theta) = mean over the three pose parts of mean_b (|dS/dx_part|_b - 1)^2, S = sum_b D(x_b), is a
+// function of the discriminator's INPUT gradient g; its parameter gradient needs a second derivative of the
+// network.  With v = dGP/dg held fixed,  dGP/dtheta = d/dtheta (v . g) = d/dtheta [ d/deps S(x + eps v) ]:
+// (1) an ordinary forward + input-gradient backward gives g and v; (2) a TANGENT forward pass (JVP) propagates v through
+// the network next to the stored primal activations and yields F = sum_b sigmoid'(l_b) ldot_b; (3) one reverse sweep of
+// F through the primal + tangent graph gives every parameter gradient.  Linear layers need nothing new (tangents and
+// both adjoint streams go through the GEMM kernels); this file holds what is specific: the tangent of a train-mode
+// BatchNorm1d (batch statistics couple the samples), its second-order backward, the LeakyReLU masks (second derivative
+// zero), the sigmoid head and the penalty itself.
+//
+// Layout: these are narrow launches (the discriminator has 2 ResBlocks, widths 256 / 512, batch <= a few thousand): a
+// 256-thread workgroup owns 16 columns x ALL rows (16 row-lanes), makes its sweeps over the rows and reduces across the
+// row-lanes through LDS in a fixed order — deterministic, no atomics, no partial buffers.  WGAN-GP is off in the
+// shipped configuration (config_dexgangrasp.yaml:55); these kernels are written for clarity, not for the roofline.
+#include "dgg_internal.h"
+
+namespace dgg {
+
+constexpr int SC = 16;  // columns per workgroup
+constexpr int SR = 16;  // row-lanes per workgroup
+
+__device__ __forceinline__ float lrelu_d(float post) { return post > 0.f ? 1.f : kLrelu; }
+
+// sums over the 16 row-lanes of a column, NQ quantities at once; every thread of the column gets the totals
+template <int NQ>
+__device__ __forceinline__ void col_reduce(float (&q)[NQ], float (*sh)[SR][SC]) {
+    const int cl = threadIdx.x & (SC - 1), rl = threadIdx.x / SC;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) sh[i][rl][cl] = q[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < SR; ++r) t += sh[i][r][cl];
+        q[i] = t;
+    }
+}
+
+// x_i = alpha * real + (1 - alpha) * fake for the 12 + nj pose columns; alphas (B,3) = [rot | transl | joint]
+__global__ void gp_interp_kernel(const float* __restrict__ alphas, const float* __restrict__ r_rot,
+                                 const float* __restrict__ r_tr, const float* __restrict__ r_jt,
+                                 const float* __restrict__ f_rot, const float* __restrict__ f_tr,
+                                 const float* __restrict__ f_jt, int B, int nj, float* __restrict__ o_rot,
+                                 float* __restrict__ o_tr, float* __restrict__ o_jt) {
+    const int np = 12 + nj;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * np) return;
+    const int b = i / np, j = i - b * np;
+    if (j < 9) {
+        const float a = alphas[b * 3 + 0];
+        o_rot[b * 9 + j] = a * r_rot[b * 9 + j] + (1.f - a) * f_rot[b * 9 + j];
+    } else if (j < 12) {
+        const float a = alphas[b * 3 + 1];
+        o_tr[b * 3 + j - 9] = a * r_tr[b * 3 + j - 9] + (1.f - a) * f_tr[b * 3 + j - 9];
+    } else {
+        const float a = alphas[b * 3 + 2];
+        o_jt[b * nj + j - 12] = a * r_jt[b * nj + j - 12] + (1.f - a) * f_jt[b * nj + j - 12];
+    }
+}
+
+// Wasserstein terms (dexgangrasp.py:199-211, :258): loss_out = mean(p); d_logit = sign * p (1 - p) / B
+__global__ __launch_bounds__(256) void wass_kernel(const float* __restrict__ p, int B, float sign, float* __restrict__ loss_out,
+                                                   float* __restrict__ d_logit) {
+    __shared__ float sh[256];
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float v = p[b];
+        s += v;
+        if (d_logit) d_logit[b] = sign * v * (1.f - v) / (float)B;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && loss_out) loss_out[0] = sh[0] / (float)B;
+}
+
+// d_logit = p (1 - p): upstream gradient 1 on every sigmoid output (grad_outputs = ones, dexgangrasp.py:160)
+__global__ void sig_grad_kernel(const float* __restrict__ p, int B, float* __restrict__ d_logit) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) d_logit[b] = p[b] * (1.f - p[b]);
+}
+
+// GP value and v = gain * dGP/dg from the input gradient g (B, 12 + nj): parts rot (9), transl (3), joint (nj)
+__global__ __launch_bounds__(256) void gp_value_kernel(const float* __restrict__ g, int B, int nj, float gain,
+                                                       float* __restrict__ gp_out, float* __restrict__ v) {
+    __shared__ float sh[256];
+    const int np = 12 + nj;
+    const int lo[3] = {0, 9, 12}, hi[3] = {9, 12, 12 + nj};
+    float pen = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* gr = g + (size_t)b * np;
+        for (int part = 0; part < 3; ++part) {
+            float s = 0.f;
+            for (int j = lo[part]; j < hi[part]; ++j) s = fmaf(gr[j], gr[j], s);
+            const float n = sqrtf(s);
+            pen += (n - 1.f) * (n - 1.f);
+            // d/dg of mean_parts mean_b (n - 1)^2 = 2 (n - 1) g / n / (3 B)
+            const float k = n > 0.f ? gain * 2.f * (n - 1.f) / (n * 3.f * (float)B) : 0.f;
+            for (int j = lo[part]; j < hi[part]; ++j) v[(size_t)b * np + j] = k * gr[j];
+        }
+    }
+    sh[threadIdx.x] = pen;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) gp_out[0] = sh[0] / (3.f * (float)B);
+}
+
+__global__ void wgan_combine_kernel(float* losses, float gain, int gp_slot) {
+    losses[DGG_L_TOTAL_DISC] = -losses[DGG_L_BCE_REAL] + losses[DGG_L_BCE_FAKE] + gain * losses[gp_slot];
+}
+
+// Tangent of a train-mode BatchNorm1d (+ optional addend, + optional LeakyReLU mask):
+//   x_hat = (a - mean) rstd;  x_hat_dot = rstd (adot - mean(adot) - x_hat mean(x_hat adot))
+//   out = lrelu'(mask_ref) * (gamma x_hat_dot + addend)          (mask_ref / addend may be NULL; gamma NULL = 1)
+// xhd_out (optional): x_hat_dot itself.  grid: ceil(N / 16)
+__global__ __launch_bounds__(256) void bn_jvp_kernel(const float* __restrict__ a, int lda, const float* __restrict__ adot,
+                                                     int ldad, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     const float* __restrict__ addend, int ldadd,
+                                                     const float* __restrict__ mask_ref, int ldm, int B, int N,
+                                                     float* __restrict__ out, int ldo, float* __restrict__ xhd_out,
+                                                     int ldx, int a_is_xhat) {
+    __shared__ float sh[2][SR][SC];
+    const int cl = threadIdx.x & (SC - 1), rl = threadIdx.x / SC;
+    const int c0 = blockIdx.x * SC + cl;
+    const bool ok = c0 < N;
+    const int c = ok ? c0 : N - 1;
+    const float mu = a_is_xhat ? 0.f : mean[c], rs = rstd[c];
+    float q[2] = {0.f, 0.f};
+    for (int b = rl; b < B; b += SR) {
+        const float xh = a_is_xhat ? a[(size_t)b * lda + c] : (a[(size_t)b * lda + c] - mu) * rs;
+        const float ad = adot[(size_t)b * ldad + c];
+        q[0] += ad;
+        q[1] = fmaf(xh, ad, q[1]);
+    }
+    col_reduce<2>(q, sh);
+    const float mad = q[0] / (float)B, m = q[1] / (float)B;
+    const float ga = gamma ? gamma[c] : 1.f;
+    if (!ok) return;
+    for (int b = rl; b < B; b += SR) {
+        const float xh = a_is_xhat ? a[(size_t)b * lda + c] : (a[(size_t)b * lda + c] - mu) * rs;
+        const float xhd = rs * (adot[(size_t)b * ldad + c] - mad - xh * m);
+        if (xhd_out) xhd_out[(size_t)b * ldx + c] = xhd;
+        float t = ga * xhd;
+        if (addend) t += addend[(size_t)b * ldadd + c];
+        if (mask_ref) t *= lrelu_d(mask_ref[(size_t)b * ldm + c]);
+        out[(size_t)b * ldo + c] = t;
+    }
+}
+
+// x *= lrelu'(ref), in place (the fc3 branch: s3_dot = lrelu'(a3) a3_dot; ref stores lrelu(a3), same sign)
+__global__ void mask_inplace_kernel(float* __restrict__ x, int ldx, const float* __restrict__ ref, int ldr, int B, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * N) return;
+    const int b = i / N, c = i - b * N;
+    x[(size_t)b * ldx + c] *= lrelu_d(ref[(size_t)b * ldr + c]);
+}
+
+// Sigmoid head, second order.  l = y.w + b, s = sigmoid(l), ldot = ydot.w, F = sum_b s (1 - s) ldot:
+//   c1 = dF/dldot = s (1 - s);  c2 = dF/dl = s (1 - s)(1 - 2 s) ldot.      One wave per row.
+__global__ __launch_bounds__(256) void head2_kernel(const float* __restrict__ ydot, int ld, const float* __restrict__ w,
+                                                    const float* __restrict__ p, int B, int K, float* __restrict__ c1,
+                                                    float* __restrict__ c2) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc = fmaf(ydot[(size_t)row * ld + k], w[k], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) {
+        const float s = p[row];
+        const float d = s * (1.f - s);
+        c1[row] = d;
+        c2[row] = d * (1.f - 2.f * s) * acc;
+    }
+}
+
+// head parameter gradients: gw[c] += sum_b c2_b y[b][c] + c1_b ydot[b][c];  gb += sum_b c2_b.   grid: ceil(K / 16)
+__global__ __launch_bounds__(256) void head2_grads_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ ydot,
+                                                          int ldyd, const float* __restrict__ c1,
+                                                          const float* __restrict__ c2, int B, int K,
+                                                          float* __restrict__ gw, float* __restrict__ gb) {
+    __shared__ float sh[2][SR][SC];
+    const int cl = threadIdx.x & (SC - 1), rl = threadIdx.x / SC;
+    const int c0 = blockIdx.x * SC + cl;
+    const bool ok = c0 < K;
+    const int c = ok ? c0 : K - 1;
+    float q[2] = {0.f, 0.f};
+    for (int b = rl; b < B; b += SR) {
+        q[0] = fmaf(c2[b], y[(size_t)b * ldy + c], q[0]);
+        q[0] = fmaf(c1[b], ydot[(size_t)b * ldyd + c], q[0]);
+        q[1] += c2[b];
+    }
+    col_reduce<2>(q, sh);
+    if (ok && rl == 0) {
+        gw[c] += q[0];
+        if (c0 == 0) gb[0] += q[1];
+    }
+}
+
+// Output stage of a ResBlock, reverse: y = lrelu(p), p = s3 + z2, s3 = lrelu(a3).
+//   pbar = lrelu'(y) ybar;  a3bar = lrelu'(s3) pbar   (and the same for the tangent adjoints).
+// Head mode (c1 != NULL): ybar = c2_b w_c, ydotbar = c1_b w_c formed on the fly.
+__global__ void out2_bwd_kernel(const float* __restrict__ ybar, const float* __restrict__ ydbar, int ldyb,
+                                const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ w,
+                                const float* __restrict__ y, int ldy, const float* __restrict__ s3, int lds, int B, int N,
+                                float* __restrict__ pbar, float* __restrict__ pdbar, int ldp, float* __restrict__ a3bar,
+                                float* __restrict__ a3dbar, int lda3) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * N) return;
+    const int b = i / N, c = i - b * N;
+    const float my = lrelu_d(y[(size_t)b * ldy + c]), m3 = lrelu_d(s3[(size_t)b * lds + c]);
+    const float yb = c1 ? c2[b] * w[c] : ybar[(size_t)b * ldyb + c];
+    const float ydb = c1 ? c1[b] * w[c] : ydbar[(size_t)b * ldyb + c];
+    const float pb = my * yb, pdb = my * ydb;
+    pbar[(size_t)b * ldp + c] = pb;
+    pdbar[(size_t)b * ldp + c] = pdb;
+    a3bar[(size_t)b * lda3 + c] = m3 * pb;
+    a3dbar[(size_t)b * lda3 + c] = m3 * pdb;
+}
+
+// Second-order backward of a train-mode BatchNorm1d.  Forward (primal) z = gamma x_hat + beta, tangent
+// zdot = gamma x_hat_dot with x_hat_dot = rstd (adot_c - x_hat m), adot_c = adot - mean(adot), m = mean(x_hat adot).
+// Given the adjoints zbar, zdbar of both outputs (already masked by lrelu'(mask_ref) when the BatchNorm feeds a
+// LeakyReLU — folded in here), with w = gamma zdbar:
+//   adotbar = rstd (w - mean(w) - x_hat mean(w x_hat))
+//   xhbar   = -rstd (w m + adot_c mean(w x_hat)),   X = gamma zbar + xhbar
+//   abar    = rstd (X - mean(X) - x_hat mean(X x_hat)) - rstd x_hat mean(w x_hat_dot)      [rstd's own dependence on a]
+//   gamma_bar += sum zbar x_hat + sum zdbar x_hat_dot;   beta_bar += sum zbar
+// grid: ceil(N / 16); three sweeps over the rows.
+__global__ __launch_bounds__(256) void bn_second_bwd_kernel(
+    const float* __restrict__ a, int lda, const float* __restrict__ adot, int ldad, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ zbar,
+    const float* __restrict__ zdbar, int ldz, const float* __restrict__ mask_ref, int ldm, int B, int N,
+    float* __restrict__ abar, float* __restrict__ adbar, int ldo, float* __restrict__ g_gamma, float* __restrict__ g_beta) {
+    __shared__ float sh[6][SR][SC];
+    const int cl = threadIdx.x & (SC - 1), rl = threadIdx.x / SC;
+    const int c0 = blockIdx.x * SC + cl;
+    const bool ok = c0 < N;
+    const int c = ok ? c0 : N - 1;
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c];
+    const float invB = 1.f / (float)B;
+    auto mk = [&](int b) { return mask_ref ? lrelu_d(mask_ref[(size_t)b * ldm + c]) : 1.f; };
+    // sweep 1
+    float q[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // sum adot, sum xh adot, sum w, sum w xh, sum zbar, sum zbar xh
+    for (int b = rl; b < B; b += SR) {
+        const float xh = (a[(size_t)b * lda + c] - mu) * rs;
+        const float ad = adot[(size_t)b * ldad + c];
+        const float m_ = mk(b);
+        const float zb = m_ * zbar[(size_t)b * ldz + c], w = ga * m_ * zdbar[(size_t)b * ldz + c];
+        q[0] += ad;
+        q[1] = fmaf(xh, ad, q[1]);
+        q[2] += w;
+        q[3] = fmaf(w, xh, q[3]);
+        q[4] += zb;
+        q[5] = fmaf(zb, xh, q[5]);
+    }
+    col_reduce<6>(q, sh);
+    const float mad = q[0] * invB, m = q[1] * invB, mw = q[2] * invB, mwx = q[3] * invB;
+    const float s_zb = q[4], s_zbx = q[5];
+    // sweep 2
+    float r2[4] = {0.f, 0.f, 0.f, 0.f};  // sum w xhd, sum X, sum X xh, sum zdbar xhd
+    for (int b = rl; b < B; b += SR) {
+        const float xh = (a[(size_t)b * lda + c] - mu) * rs;
+        const float adc = adot[(size_t)b * ldad + c] - mad;
+        const float m_ = mk(b);
+        const float zb = m_ * zbar[(size_t)b * ldz + c], zdb = m_ * zdbar[(size_t)b * ldz + c];
+        const float w = ga * zdb;
+        const float xhd = rs * (adc - xh * m);
+        const float X = ga * zb - rs * (w * m + adc * mwx);
+        r2[0] = fmaf(w, xhd, r2[0]);
+        r2[1] += X;
+        r2[2] = fmaf(X, xh, r2[2]);
+        r2[3] = fmaf(zdb, xhd, r2[3]);
+    }
+    col_reduce<4>(r2, reinterpret_cast<float(*)[SR][SC]>(sh));
+    const float s_wxd = r2[0], mX = r2[1] * invB, mXx = r2[2] * invB;
+    if (!ok) return;
+    // sweep 3
+    for (int b = rl; b < B; b += SR) {
+        const float xh = (a[(size_t)b * lda + c] - mu) * rs;
+        const float adc = adot[(size_t)b * ldad + c] - mad;
+        const float m_ = mk(b);
+        const float zb = m_ * zbar[(size_t)b * ldz + c], w = ga * m_ * zdbar[(size_t)b * ldz + c];
+        const float X = ga * zb - rs * (w * m + adc * mwx);
+        abar[(size_t)b * ldo + c] = rs * (X - mX - xh * mXx) - rs * xh * (s_wxd * invB);
+        adbar[(size_t)b * ldo + c] = rs * (w - mw - xh * mwx);
+    }
+    if (rl == 0) {
+        g_gamma[c] += s_zbx + r2[3];
+        g_beta[c] += s_zb;
+    }
+}
+
+// dst[c] (+)= sum_b x[b][c] * (y ? y[b][c] : 1).   grid: ceil(N / 16)
+__global__ __launch_bounds__(256) void colsum_prod_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y,
+                                                          int ldy, int B, int N, float* __restrict__ dst, int accumulate) {
+    __shared__ float sh[1][SR][SC];
+    const int cl = threadIdx.x & (SC - 1), rl = threadIdx.x / SC;
+    const int c0 = blockIdx.x * SC + cl;
+    const bool ok = c0 < N;
+    const int c = ok ? c0 : N - 1;
+    float q[1] = {0.f};
+    for (int b = rl; b < B; b += SR) q[0] = fmaf(x[(size_t)b * ldx + c], y ? y[(size_t)b * ldy + c] : 1.f, q[0]);
+    col_reduce<1>(q, sh);
+    if (ok && rl == 0) dst[c] = (accumulate ? dst[c] : 0.f) + q[0];
+}
+
+static inline int cdiv2(int a, int b) { return (a + b - 1) / b; }
+
+int gp_interp_launch(const float* alphas, const float* r_rot, const float* r_tr, const float* r_jt, const float* f_rot,
+                     const float* f_tr, const float* f_jt, int B, int nj, float* o_rot, float* o_tr, float* o_jt,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(gp_interp_kernel, dim3(cdiv2(B * (12 + nj), 256)), dim3(256), 0, st, alphas, r_rot, r_tr, r_jt,
+                       f_rot, f_tr, f_jt, B, nj, o_rot, o_tr, o_jt);
+    return check_launch("gp_interp");
+}
+int wass_launch(const float* p, int B, float sign, float* loss_out, float* d_logit, hipStream_t st) {
+    hipLaunchKernelGGL(wass_kernel, dim3(1), dim3(256), 0, st, p, B, sign, loss_out, d_logit);
+    return check_launch("wass");
+}
+int sig_grad_launch(const float* p, int B, float* d_logit, hipStream_t st) {
+    hipLaunchKernelGGL(sig_grad_kernel, dim3(cdiv2(B, 256)), dim3(256), 0, st, p, B, d_logit);
+    return check_launch("sig_grad");
+}
+int gp_value_launch(const float* g, int B, int nj, float gain, float* gp_out, float* v, hipStream_t st) {
+    hipLaunchKernelGGL(gp_value_kernel, dim3(1), dim3(256), 0, st, g, B, nj, gain, gp_out, v);
+    return check_launch("gp_value");
+}
+int wgan_combine_launch(float* losses, float gain, int gp_slot, hipStream_t st) {
+    hipLaunchKernelGGL(wgan_combine_kernel, dim3(1), dim3(1), 0, st, losses, gain, gp_slot);
+    return check_launch("wgan_combine");
+}
+int bn_jvp_launch(const float* a, int lda, const float* adot, int ldad, const float* mean, const float* rstd,
+                  const float* gamma, const float* addend, int ldadd, const float* mask_ref, int ldm, int B, int N,
+                  float* out, int ldo, float* xhd_out, int ldx, int a_is_xhat, hipStream_t st) {
+    hipLaunchKernelGGL(bn_jvp_kernel, dim3(cdiv2(N, SC)), dim3(256), 0, st, a, lda, adot, ldad, mean, rstd, gamma, addend,
+                       ldadd, mask_ref, ldm, B, N, out, ldo, xhd_out, ldx, a_is_xhat);
+    return check_launch("bn_jvp");
+}
+int mask_inplace_launch(float* x, int ldx, const float* ref, int ldr, int B, int N, hipStream_t st) {
+    hipLaunchKernelGGL(mask_inplace_kernel, dim3(cdiv2(B * N, 256)), dim3(256), 0, st, x, ldx, ref, ldr, B, N);
+    return check_launch("mask_inplace");
+}
+int head2_launch(const float* ydot, int ld, const float* w, const float* p, int B, int K, float* c1, float* c2,
+                 hipStream_t st) {
+    hipLaunchKernelGGL(head2_kernel, dim3(cdiv2(B, 4)), dim3(256), 0, st, ydot, ld, w, p, B, K, c1, c2);
+    return check_launch("head2");
+}
+int head2_grads_launch(const float* y, int ldy, const float* ydot, int ldyd, const float* c1, const float* c2, int B,
+                       int K, float* gw, float* gb, hipStream_t st) {
+    hipLaunchKernelGGL(head2_grads_kernel, dim3(cdiv2(K, SC)), dim3(256), 0, st, y, ldy, ydot, ldyd, c1, c2, B, K, gw, gb);
+    return check_launch("head2_grads");
+}
+int out2_bwd_launch(const float* ybar, const float* ydbar, int ldyb, const float* c1, const float* c2, const float* w,
+                    const float* y, int ldy, const float* s3, int lds, int B, int N, float* pbar, float* pdbar, int ldp,
+                    float* a3bar, float* a3dbar, int lda3, hipStream_t st) {
+    hipLaunchKernelGGL(out2_bwd_kernel, dim3(cdiv2(B * N, 256)), dim3(256), 0, st, ybar, ydbar, ldyb, c1, c2, w, y, ldy, s3,
+                       lds, B, N, pbar, pdbar, ldp, a3bar, a3dbar, lda3);
+    return check_launch("out2_bwd");
+}
+int bn_second_bwd_launch(const float* a, int lda, const float* adot, int ldad, const float* mean, const float* rstd,
+                         const float* gamma, const float* zbar, const float* zdbar, int ldz, const float* mask_ref, int ldm,
+                         int B, int N, float* abar, float* adbar, int ldo, float* g_gamma, float* g_beta, hipStream_t st) {
+    hipLaunchKernelGGL(bn_second_bwd_kernel, dim3(cdiv2(N, SC)), dim3(256), 0, st, a, lda, adot, ldad, mean, rstd, gamma,
+                       zbar, zdbar, ldz, mask_ref, ldm, B, N, abar, adbar, ldo, g_gamma, g_beta);
+    return check_launch("bn_second_bwd");
+}
+int colsum_prod_launch(const float* x, int ldx, const float* y, int ldy, int B, int N, float* dst, int accumulate,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(colsum_prod_kernel, dim3(cdiv2(N, SC)), dim3(256), 0, st, x, ldx, y, ldy, B, N, dst, accumulate);
+    return check_launch("colsum_prod");
+}
+
+}  // namespace dgg

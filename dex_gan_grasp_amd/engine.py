@@ -105,6 +105,44 @@ class TrainEngine:
             self.G.adam_step(hp.lr_gen, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
         return self.losses.clone()
 
+    # ---- N3: WGAN-GP variant of the cGAN step (cfg["is_wgan"], dexgangrasp.py:149-211, 234-270)
+    def _wgan_ws(self, B):
+        key = ("wgan", B)
+        ws = self._ws.get(key)
+        if ws is None:
+            n = int(lib().dgg_wgan_workspace_bytes(C.byref(self.ccfg), B))
+            if n < 0:
+                raise _lib.DggError("dgg_wgan_workspace_bytes: %d" % n)
+            ws = _lib.new_workspace(n, self.device)
+            self._ws[key] = ws
+        return ws
+
+    def wgan_step(self, bps, rot9, transl, joint, z, alphas, is_train_gen=True, lr_gen=None, lr_dis=None,
+                  penalty_gain=10.0):
+        """One update_dexgangrasp step with the Wasserstein losses and the gradient penalty.  alphas (B,3): the
+        interpolation weights [rot | transl | joint_conf] of calculate_interp (:149-158).  Returns the loss vector
+        (slot L_GRAD_PENALTY holds the penalty)."""
+        dev = self.device
+        self.flush()
+        bps, rot9, transl, joint, z = (f32c(t, dev) for t in (bps, rot9.reshape(-1, 9), transl, joint, z))
+        alphas = f32c(alphas, dev).reshape(-1, 3)
+        B = bps.shape[0]
+        ws = self._wgan_ws(B)
+        hp = self._hp(lr_gen, lr_dis)
+        st = self._state()
+        cfg_p = C.byref(self.ccfg)
+        args = (ptr(bps), ptr(rot9), ptr(transl), ptr(joint), ptr(z))
+        check(lib().dgg_wgan_d_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(alphas),
+                                     float(penalty_gain), ptr(self.losses), stream_ptr(dev)), "dgg_wgan_d_phase")
+        parallel.allreduce_sum_(self.D.grads)
+        self.D.adam_step(hp.lr_dis, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
+        if is_train_gen:
+            check(lib().dgg_wgan_g_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args,
+                                         ptr(self.losses), stream_ptr(dev)), "dgg_wgan_g_phase")
+            parallel.allreduce_sum_(self.G.grads)
+            self.G.adam_step(hp.lr_gen, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
+        return self.losses.clone()
+
     # ---- A11
     def eva_step(self, bps, rot9, transl, label, drop_keep=None, seed=0, lr=None, two_streams=False):
         dev = self.device
@@ -140,8 +178,9 @@ class TrainEngine:
         """Release what the library remembers about this engine: pending-prefetch slots keyed by its workspaces and
         its weight-gradient side streams (one disable per enable).  Must run on the thread that used the engine."""
         try:
-            for ws in self._ws.values():
-                lib().dgg_cgan_release(ptr(ws))
+            for key, ws in self._ws.items():
+                if not isinstance(key, tuple):
+                    lib().dgg_cgan_release(ptr(ws))
             for key in getattr(self, "_wg_mapped", None) or ():
                 lib().dgg_enable_wgrad_stream(C.c_void_p(key), 0)
             self._wg_mapped = set()

@@ -99,9 +99,6 @@ class DexGanGrasp(object):
                 "multi-GPU runs use one process per GPU: launch with torchrun / torch.distributed.run "
                 "(gradients are all-reduced over RCCL); nn.DataParallel is not used")
 
-        if self.is_wgan:
-            raise NotImplementedError("is_wgan=True (WGAN-GP, dexgangrasp.py:149-211,234-270) is not built yet")
-
         if cfg["model"] in ("ffhnet", "dexgangrasp"):
             self.DexGANGrasp, self.DexEvaluator = build_network(cfg, self.device, is_train=self.is_train)
         else:
@@ -145,6 +142,7 @@ class DexGanGrasp(object):
         self._engine = None
         self._z_override = None      # tests: inject the latent instead of torch.randn (:770)
         self._drop_keep = None       # tests: explicit evaluator dropout masks
+        self._alpha_override = None  # tests: inject the WGAN-GP interpolation weights (B,3) instead of torch.randn (:151-153)
 
     # ------------------------------------------------------------------ engine plumbing
     def _sync_replicas(self, with_optim=False):
@@ -590,12 +588,21 @@ class DexGanGrasp(object):
         rot9 = _lib.f32c(real_data["rot_matrix"], dev).reshape(n_samples, 9)
         transl = _lib.f32c(real_data["transl"], dev)
         joint = _lib.f32c(real_data["joint_conf"], dev)
-        out = self._eng().cgan_step(bps, rot9, transl, joint, Zgen, is_train_gen,
-                                    self.optim_dexgangrasp_generator.param_groups[0]['lr'],
-                                    self.optim_dexgangrasp_discriminator.param_groups[0]['lr'],
-                                    two_streams=_API_STREAMS)
+        lr_g = self.optim_dexgangrasp_generator.param_groups[0]['lr']
+        lr_d = self.optim_dexgangrasp_discriminator.param_groups[0]['lr']
+        if self.is_wgan:
+            # :149-158 calculate_interp draws three torch.randn weights per sample: rot (B,1,1), transl (B,1), joint (B,1)
+            if self._alpha_override is not None:
+                alphas = self._alpha_override.to(dev, self.dtype).reshape(n_samples, 3)
+            else:
+                alphas = torch.cat([torch.randn((n_samples, 1, 1), device=dev).view(n_samples, 1),
+                                    torch.randn((n_samples, 1), device=dev), torch.randn((n_samples, 1), device=dev)], 1)
+            out = self._eng().wgan_step(bps, rot9, transl, joint, Zgen, alphas, is_train_gen, lr_g, lr_d)
+        else:
+            out = self._eng().cgan_step(bps, rot9, transl, joint, Zgen, is_train_gen, lr_g, lr_d, two_streams=_API_STREAMS)
         self._bump(gan.generator, 1)
-        self._bump(gan.discriminator, 3 if is_train_gen else 2)
+        # D forwards per step: real, fake [, interpolates (WGAN-GP)] [, generator phase]
+        self._bump(gan.discriminator, 2 + (1 if self.is_wgan else 0) + (1 if is_train_gen else 0))
         loss_dict = {'total_loss_disc': out[_lib.L_TOTAL_DISC], 'bce_loss_real': out[_lib.L_BCE_REAL],
                      'bce_loss_fake': out[_lib.L_BCE_FAKE]}
         if is_train_gen:

@@ -210,7 +210,8 @@ int64_t dgg_cgan_workspace_bytes(const dgg_cfg* cfg, int batch);
 enum {
     DGG_L_TOTAL_DISC = 0, DGG_L_BCE_REAL = 1, DGG_L_BCE_FAKE = 2, DGG_L_GEN_FAKE = 3,
     DGG_L_TRANSL = 4, DGG_L_ROT = 5, DGG_L_CONF = 6, DGG_L_TOTAL_GEN = 7,
-    DGG_L_TOTAL_EVA = 8, DGG_L_BCE_EVA = 9
+    DGG_L_TOTAL_EVA = 8, DGG_L_BCE_EVA = 9,
+    DGG_L_GRAD_PENALTY = 10 /* WGAN-GP: the gradient penalty (before the gain) */
 };
 
 /* Optional concurrency hint (per calling thread): while set, every *_backward / phase call enqueued on `stream`
@@ -260,6 +261,22 @@ int dgg_reset(void);
 int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hparams* hp, void* ws,
                      size_t ws_bytes, int B, const float* bps, const float* rot9, const float* transl,
                      const float* joint, const float* z, float* losses, void* stream);
+/* N3 — the WGAN-GP variant of the two phases (cfg["is_wgan"]; dexgangrasp.py:149-211, 234-270).
+ * D phase: total_loss_disc = -mean(real_score) + mean(fake_score) + penalty_gain * GP (slots DGG_L_BCE_REAL /
+ * DGG_L_BCE_FAKE hold the two means, DGG_L_GRAD_PENALTY the penalty), gradients -> st->d_grads.  The penalty is
+ * evaluated on interpolates alpha * real + (1 - alpha) * fake with the per-sample weights alphas (B,3) =
+ * [rot | transl | joint_conf] — the reference draws them with torch.randn (:151-153), the caller supplies them; its
+ * parameter gradient needs a second derivative of the discriminator (tangent forward + one reverse sweep,
+ * csrc/second_order.hip).  The discriminator's BatchNorm running statistics advance three times here (real, fake,
+ * interpolates) and once more in the G phase.  G phase: gen_loss_fake = -mean(fake_score) (:258).
+ * Workspace: dgg_wgan_workspace_bytes (a superset of the cGAN step's).  Single stream; B >= 2. */
+int64_t dgg_wgan_workspace_bytes(const dgg_cfg* cfg, int batch);
+int dgg_wgan_d_phase(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hparams* hp, void* ws, size_t ws_bytes, int B,
+                     const float* bps, const float* rot9, const float* transl, const float* joint, const float* z,
+                     const float* alphas, double penalty_gain, float* losses, void* stream);
+int dgg_wgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hparams* hp, void* ws, size_t ws_bytes, int B,
+                     const float* bps, const float* rot9, const float* transl, const float* joint, const float* z,
+                     float* losses, void* stream);
 /* Convenience single-GPU step: d_phase, Adam(D), [g_phase, Adam(G)] (is_train_gen). */
 int dgg_cgan_step(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hparams* hp, void* ws, size_t ws_bytes,
                   int B, const float* bps, const float* rot9, const float* transl, const float* joint,

@@ -545,3 +545,87 @@ def test_config5_sweep_at_rank_share_size():
     assert (lo, hi) == (0, 300)
     near = sum(int(((out["score"][:300] > t - 1e-5) & (out["score"][:300] < t + 1e-5)).sum()) for t in thresholds)
     assert int((count_all.cpu() - out["count"][:, :300].cpu()).abs().sum()) <= near     # another chunking, another split-K
+
+
+# ------------------------------------------------------------------ N3: WGAN-GP
+def _alphas(b, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn((b, 1, 1), generator=g), torch.randn((b, 1), generator=g), torch.randn((b, 1), generator=g)
+
+
+@pytest.mark.parametrize("b", [64, 300])
+def test_wgan_gp_phases_vs_oracle(b):
+    """dexgangrasp.py:149-211, 234-270: the Wasserstein D phase with gradient penalty (second derivative of the
+    discriminator) and the G phase, gradients before each Adam against torch's double backward on the oracle."""
+    import ctypes as C
+    from oracle import dexgan_oracle as O
+    L, ops, engine = _mods()
+
+    def run(seed):
+        eng, sd, _ = _engine("wide")
+        batch = synth.make_batch(b, seed)
+        z = synth.make_z(b, 100 + seed)
+        al = _alphas(b, 200 + seed)
+        ref, g_d, ctx = O.wgan_d_part(sd, H.clone_batch(batch), z, al, CFG)
+        f = lambda t: t.float().to(DEV).contiguous()
+        ins = (f(batch["bps_object"]), f(batch["rot_matrix"]).reshape(b, 9), f(batch["transl"]), f(batch["joint_conf"]))
+        ald = torch.cat([al[0].view(b, 1), al[1], al[2]], 1).to(DEV).contiguous()
+        ws = eng._wgan_ws(b)
+        st, hp = eng._state(), eng._hp()
+        zd = z.to(DEV)
+        args = tuple(L.ptr(t) for t in ins) + (L.ptr(zd),)
+        L.check(L.lib().dgg_wgan_d_phase(C.byref(eng.ccfg), C.byref(st), C.byref(hp), L.ptr(ws), ws.numel(), b, *args,
+                                         L.ptr(ald), 10.0, L.ptr(eng.losses), L.stream_ptr()))
+        got = eng.losses.cpu().numpy()
+        np.testing.assert_allclose(got[L.L_BCE_REAL], float(ref["bce_loss_real"]), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(got[L.L_BCE_FAKE], float(ref["bce_loss_fake"]), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(got[L.L_GRAD_PENALTY], float(ref["gradient_penalty"]), rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(got[L.L_TOTAL_DISC], float(ref["total_loss_disc"]), rtol=2e-4, atol=1e-5)
+        items = _grad_items(eng.D, g_d, "discriminator.", b)
+        # G phase on the oracle's post-Adam discriminator
+        ad = O.AdamState([n for n in O.param_names(sd) if n.startswith("discriminator.")])
+        O.adam_step(sd, g_d, ad, lr=CFG["lr_dis"], b1=CFG["beta1"], wd=CFG["weight_decay"])
+        eng.D.load_state_dict(sd, "discriminator.")      # identical D on both sides for the G phase
+        refg, g_g = O.wgan_g_part(sd, ctx, CFG)
+        L.check(L.lib().dgg_wgan_g_phase(C.byref(eng.ccfg), C.byref(st), C.byref(hp), L.ptr(ws), ws.numel(), b, *args,
+                                         L.ptr(eng.losses), L.stream_ptr()))
+        got = eng.losses.cpu().numpy()
+        for k, n in ((L.L_GEN_FAKE, "gen_loss_fake"), (L.L_TRANSL, "transl_loss"), (L.L_ROT, "rot_loss"),
+                     (L.L_CONF, "conf_loss"), (L.L_TOTAL_GEN, "total_loss_gen")):
+            np.testing.assert_allclose(got[k], float(refg[n]), rtol=1e-4, atol=1e-6, err_msg=n)
+        items += _grad_items(eng.G, g_g, "generator.", b)
+        eng.close()
+        return items
+    H.check_grads_over_seeds(run, [1, 2, 3])
+
+
+@pytest.mark.parametrize("variant,bname", [("wide", "real16"), ("wide", "syn64")])
+def test_wrapper_wgan_steps_vs_reference_goldens(variant, bname):
+    """The drop-in wrapper with cfg["is_wgan"] = True against the reference's own two update_dexgangrasp steps."""
+    from dex_gan_grasp_amd.models.dexgangrasp import DexGanGrasp
+    g = H.load("wgan_goldens.npz")
+    key = "%s/%s/" % (variant, bname)
+    cfg = dict(CFG)
+    cfg["is_wgan"] = True
+    m = DexGanGrasp(cfg)
+    m.DexGANGrasp.load_state_dict(H.gan_sd(variant))
+    batch = H.batches()[bname]
+    b = batch["bps_object"].shape[0]
+    for step in range(2):
+        sk = key + "wgan%d/" % step
+        m._z_override = torch.from_numpy(g[sk + "z"])
+        m._alpha_override = torch.cat([torch.from_numpy(g[sk + "alpha_rot"]).view(b, 1),
+                                       torch.from_numpy(g[sk + "alpha_transl"]), torch.from_numpy(g[sk + "alpha_joint"])], 1)
+        losses = m.update_dexgangrasp(H.clone_batch(batch), is_train_gen=True)
+        for k, v in losses.items():
+            np.testing.assert_allclose(v.item(), float(g[sk + "loss/" + k]), rtol=2e-4, atol=1e-5, err_msg=k)
+        for n, t in m.DexGANGrasp.state_dict().items():
+            H.assert_state_close(n, t.cpu(), g[sk + "state/" + n], step)
+    sd = m.DexGANGrasp.state_dict()
+    assert int(sd["discriminator.disc_bn1.num_batches_tracked"]) == 8
+    # the interpolation weights are drawn like the reference's when nothing is injected
+    m._z_override = None
+    m._alpha_override = None
+    out = m.update_dexgangrasp(H.clone_batch(batch), is_train_gen=False)
+    assert set(out.keys()) >= {"total_loss_disc", "bce_loss_real", "bce_loss_fake", "total_loss_gen"}
+    assert all(torch.isfinite(v).item() for v in out.values())
