@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 output of tools/collect_profiles.sh (gpurun_out/prof_<tag>/) into the committed summaries under
+profiles/: the bench step's kernel statistics and, per micro-benchmarked kernel, one JSON with the kernel-trace average
+duration and the PMC counters of the separate --pmc passes (FETCH_SIZE doubled per the gfx950 correction of
+MI355X_MICROARCH.md for 16-byte-per-lane streaming reads; WRITE_SIZE exact)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+
+
+def rows(path):
+    with open(path) as f:
+        return list(csv.DictReader(f))
+
+
+def counters(dirname, kernel_substr):
+    out = {}
+    for f in glob.glob(os.path.join(src, dirname, "*counter_collection.csv")):
+        for r in rows(f):
+            if kernel_substr in r["Kernel_Name"]:
+                out.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in out.items()}, {k: len(v) for k, v in out.items()}
+
+
+def avg_duration_ns(dirname, kernel_substr):
+    for f in glob.glob(os.path.join(src, dirname, "*kernel_stats.csv")):
+        for r in rows(f):
+            if kernel_substr in r["Name"]:
+                return float(r["AverageNs"]), int(r["Calls"])
+    return None, 0
+
+
+bench_stats = glob.glob(os.path.join(src, "bench", "*kernel_stats.csv"))
+if bench_stats:
+    shutil.copy(bench_stats[0], os.path.join(dst, "%s_bench_kernel_stats.csv" % tag))
+    for line in open(os.path.join(src, "bench.log")):
+        if line.startswith("{"):
+            open(os.path.join(dst, "%s_bench.json" % tag), "w").write(line)
+
+specs = [
+    ("gemm_nt", "gemm_x3_kernel<true, true", "gemm_x3", {"M": 1024, "N": 768, "K": 4120, "splits": 4},
+     "python3 tools/microbench.py gemm --k 4120 --splits 4 --iters 10", 2.0 * 1024 * 768 * 4120,
+     4 * (1024 * 4120 + 768 * 4120 + 4 * 1024 * 768)),
+    ("gemm_tn", "gemm_x3_kernel<false, false", "gemm_x3_tn", {"M": 768, "N": 4120, "K": 1024, "splits": 0},
+     "python3 tools/microbench.py gemm --mode 2 --m 768 --n 4120 --k 1024 --splits 0 --iters 10", 2.0 * 768 * 4120 * 1024,
+     4 * (1024 * 768 + 1024 * 4120 + 768 * 4120)),
+    ("bps", "bps_batched_kernel", "bps_encode", {"B": 1024, "N": 2048, "P": 4096},
+     "python3 tools/microbench.py bps --iters 5", 1024 * 2048 * 4096 * 8.0, 1024 * (2048 * 12 + 4096 * 8) + 4096 * 12),
+]
+for name, ksub, outname, shape, cmd, flops, alg_bytes in specs:
+    c = {}
+    n = {}
+    for d in glob.glob(os.path.join(src, name + "_pmc_*")):
+        if os.path.isdir(d):
+            cc, nn = counters(os.path.basename(d), ksub)
+            c.update(cc)
+            n.update(nn)
+    dur, calls = avg_duration_ns(name + "_trace", ksub)
+    if dur is None:
+        continue
+    fetch = c.get("FETCH_SIZE", 0.0) * 1024 * 2      # KB, x2 per the gfx950 correction
+    write = c.get("WRITE_SIZE", 0.0) * 1024
+    out = {"round": int(tag[1:]), "kernel": ksub, "shape": shape,
+           "command": "rocprofv3 --pmc <counters> -- " + cmd + " (one pass per counter group; kernel-trace in its own run)",
+           "avg_duration_ns_kernel_trace": dur, "launches_in_trace": calls,
+           "FETCH_SIZE_KB_raw": c.get("FETCH_SIZE"), "WRITE_SIZE_KB_raw": c.get("WRITE_SIZE"),
+           "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane loads -> doubled; WRITE_SIZE exact",
+           "fetch_bytes": fetch, "write_bytes": write, "traffic_bytes": fetch + write, "algorithmic_bytes": alg_bytes,
+           "counters_avg_per_launch": c, "launches_per_counter": n}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+        clk = c["GRBM_GUI_ACTIVE"] / 8.0 / (dur * 1e-9) / 1e9
+        out["derived"] = {"shader_clock_ghz_from_GRBM_GUI_ACTIVE": round(clk, 3),
+                          "mfma_pipe_busy_frac": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0) / (256 * 4), 4),
+                          "tflops_algorithmic": round(flops / (dur * 1e-9) / 1e12, 2)}
+    json.dump(out, open(os.path.join(dst, "%s_%s_pmc.json" % (tag, outname)), "w"), indent=1)
+    print(outname, json.dumps(out.get("derived")), "traffic MB %.1f alg MB %.1f dur us %.1f" % ((fetch + write) / 1e6, alg_bytes / 1e6, dur / 1e3))
