@@ -101,6 +101,9 @@ SIGNATURES = {
                               _D, _VP, _VP]),
     "dgg_wgan_g_phase": (_I, [_CFG, C.POINTER(GanState), C.POINTER(HParams), _VP, _SZ, _I, _VP, _VP, _VP, _VP, _VP, _VP,
                               _VP]),
+    "dgg_adam_l2_graph": (_I, [_VP, _VP, _VP, _VP, _I64, _VP, _VP, _D, _D, _D, _D, _D, _D, _VP]),
+    "dgg_eva_phase_graph": (_I, [_CFG, _VP, _VP, _VP, C.POINTER(HParams), _VP, _SZ, _I, _VP, _VP, _VP, _VP, _VP, _VP,
+                                 _VP]),
     "dgg_cgan_release": (_I, [_VP]),
     "dgg_reset": (_I, []),
     "dgg_eva_keep_offset": (_I64, [_CFG, _I, _I]),
@@ -197,6 +200,8 @@ class FlatNet:
         self.v = z(self.n_params) if with_optim else None
         self.step = 0
         self._ws = {}
+        self._step_dev = None   # graph mode: the step number in device memory (int64) + 2 floats of scratch
+        self._dyn = None
 
     def _shape_view(self, buf, e):
         name, off, rows, cols, kind = e
@@ -237,7 +242,19 @@ class FlatNet:
             self._ws[batch] = ws
         return ws
 
+    def adam_step_graph(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-4, grad_scale=1.0):
+        """dgg_adam_l2_graph: the step number lives on the device (capturable).  The host counter is NOT advanced here:
+        the caller adds the number of replays (TrainEngine.GraphStep)."""
+        if self._step_dev is None:
+            self._step_dev = torch.tensor([self.step], dtype=torch.int64, device=self.device)
+            self._dyn = torch.zeros(2, dtype=torch.float32, device=self.device)
+        check(lib().dgg_adam_l2_graph(ptr(self.params), ptr(self.grads), ptr(self.m), ptr(self.v), self.n_params,
+                                      ptr(self._step_dev), ptr(self._dyn), lr, beta1, beta2, eps, weight_decay,
+                                      grad_scale, stream_ptr(self.device)), "dgg_adam_l2_graph")
+
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-4, grad_scale=1.0):
         self.step += 1
+        if self._step_dev is not None:      # keep the device-resident counter of the graph path in step
+            self._step_dev.fill_(self.step)
         check(lib().dgg_adam_l2(ptr(self.params), ptr(self.grads), ptr(self.m), ptr(self.v), self.n_params, self.step,
                                 lr, beta1, beta2, eps, weight_decay, grad_scale, stream_ptr(self.device)), "dgg_adam_l2")

@@ -725,7 +725,8 @@ static int net_forward(const NetL& L, const float* params, float* bn, void* ws, 
         Seg segs[2];
         int nseg;
         make_segs(L, c.W, r, segs, nseg);
-        const int mode = drop ? (drop_keep ? 1 : 2) : 0;
+        // 1: masks given, 2: Philox with the seed passed by value, 3: Philox, `seed` is a device pointer to the seed
+        const int mode = drop ? (drop_keep ? 1 : ((flags & DGG_SEED_ON_DEVICE) ? 3 : 2)) : 0;
         const float* keep = (drop && drop_keep) ? drop_keep + (size_t)r * B * L.nn : nullptr;
         DGG_TRY(rb_forward(c, r, segs, nseg, mode, keep, seed, (uint64_t)r * (uint64_t)B * L.nn));
     }
@@ -1868,6 +1869,36 @@ int dgg_wgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
                             B >= 4 * ((B + 63) / 64) ? S.dl_gen : nullptr, 1));
     return dgg_gen_backward(cfg, s->g_params, s->g_grads, S.ws_g, S.g_bytes, B, DGG_TRAIN, z, bps, S.d_heads, nullptr, nullptr,
                             stream);
+}
+
+// ---- HIP-graph-friendly forms: everything that changes from step to step lives in device memory ---------------
+int dgg_adam_l2_graph(float* params, const float* grads, float* m, float* v, int64_t n, int64_t* step_dev, float* dyn2,
+                      double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
+                      void* stream) {
+    if (!params || !grads || !m || !v || !step_dev || !dyn2) return DGG_ERR_INVALID;
+    return adam_graph_launch(params, grads, m, v, n, step_dev, dyn2, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                             (hipStream_t)stream);
+}
+
+int dgg_eva_phase_graph(const dgg_cfg* cfg, const float* e_params, float* e_grads, float* e_bn, const dgg_hparams* hp,
+                        void* ws, size_t ws_bytes, int B, const float* bps, const float* rot9, const float* transl,
+                        const float* label, uint64_t* seed_dev, float* losses, void* stream) {
+    if (!hp || !ws || !label || !losses || !seed_dev) return DGG_ERR_INVALID;
+    NetL L;
+    DGG_TRY(build_layout(DGG_NET_EVA, cfg, L));
+    NetW W;
+    carve(L, B, nullptr, W);
+    const size_t extra = ((size_t)B * 2 * sizeof(float) + 255) & ~(size_t)255;
+    if (W.bytes + extra > ws_bytes) return DGG_ERR_WORKSPACE;
+    float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + W.bytes);
+    float* dl = p + B;
+    hipStream_t st = (hipStream_t)stream;
+    DGG_TRY(dgg_eva_forward(cfg, e_params, e_bn, ws, W.bytes, B, DGG_TRAIN | DGG_SEED_ON_DEVICE, bps, rot9, transl, nullptr,
+                            (uint64_t)(uintptr_t)seed_dev, p, stream));
+    DGG_TRY(bce_launch(p, label, 0.f, B, (float)hp->bce_weight, 1.0f, losses + DGG_L_TOTAL_EVA, dl, st));
+    DGG_TRY(copy_cols_launch(losses + DGG_L_TOTAL_EVA, 1, losses + DGG_L_BCE_EVA, 1, 1, 1, st));
+    DGG_TRY(dgg_eva_backward(cfg, e_params, e_grads, ws, W.bytes, B, DGG_TRAIN, bps, rot9, transl, dl, nullptr, stream));
+    return seed_bump_launch(seed_dev, st);  // the next replay draws other masks
 }
 
 int dgg_gemm_occupancy(int mode, int bm, int bn) {

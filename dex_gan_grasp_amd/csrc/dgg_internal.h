@@ -201,6 +201,9 @@ int colsum_prod_launch(const float* x, int ldx, const float* y, int ldy, int B, 
                        hipStream_t st);
 int adam_launch(float* params, const float* grads, float* m, float* v, int64_t n, int step, double lr, double b1,
                 double b2, double eps, double wd, double grad_scale, hipStream_t st);
+int adam_graph_launch(float* params, const float* grads, float* m, float* v, int64_t n, int64_t* step_dev, float* dyn,
+                      double lr, double b1, double b2, double eps, double wd, double grad_scale, hipStream_t st);
+int seed_bump_launch(uint64_t* seed_dev, hipStream_t st);
 int translate_axis_launch(float* transl, const float* rot9, int B, int axis, float offset, hipStream_t st);
 int copy_cols_launch(const float* src, int lds, float* dst, int ldd, int B, int n, hipStream_t st);
 

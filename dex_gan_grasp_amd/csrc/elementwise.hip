@@ -413,7 +413,9 @@ __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ 
         float v = lrelu(s[(size_t)row * lds + c] + fmaf(a2[(size_t)row * lda2 + c], sc, shf));
         if (drop_mode) {
             const size_t e = (size_t)row * N + c;
-            const float k = drop_mode == 1 ? keep_in[e] : philox_keep(seed, seed_off + e);
+            // drop_mode 3: `seed` carries a device pointer to the seed (graph replay: the seed lives in device memory)
+            const uint64_t sd = drop_mode == 3 ? *reinterpret_cast<const uint64_t*>(seed) : seed;
+            const float k = drop_mode == 1 ? keep_in[e] : philox_keep(sd, seed_off + e);
             keep_out[e] = (uint8_t)(k != 0.f);
             v = v * k * inv_keep;
         }
@@ -931,10 +933,24 @@ __global__ void disc_loss_combine_kernel(float* losses, int real_slot) {
     losses[DGG_L_TOTAL_DISC] = (r + losses[DGG_L_BCE_FAKE]) / 2.f;
 }
 
+// Graph replay: the optimiser's step number lives in device memory.  step[0] += 1; dyn = {lr / (1 - b1^t), sqrt(1 - b2^t)}
+// formed in double, as adam_launch does on the host.  seed (optional): the dropout seed, advanced alongside.
+__global__ void adam_prep_kernel(int64_t* __restrict__ step, float* __restrict__ dyn, double lr, double b1, double b2) {
+    const int64_t t = step[0] + 1;
+    step[0] = t;
+    dyn[0] = (float)(lr / (1.0 - pow(b1, (double)t)));
+    dyn[1] = (float)sqrt(1.0 - pow(b2, (double)t));
+}
+__global__ void seed_bump_kernel(uint64_t* __restrict__ seed) { seed[0] += 0x9E3779B97F4A7C15ull; }
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    float step_size, float bc2_sqrt, float omb1, float b2, float omb2,
-                                                   float eps, float wd, float gscale) {
+                                                   float eps, float wd, float gscale, const float* __restrict__ dyn) {
+    if (dyn) {  // device-resident step-dependent scalars (dgg_adam_l2_graph)
+        step_size = dyn[0];
+        bc2_sqrt = dyn[1];
+    }
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -1316,8 +1332,26 @@ int adam_launch(float* params, const float* grads, float* m, float* v, int64_t n
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, m, v, n, step_size,
                        bc2_sqrt, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)wd,
-                       (float)grad_scale);
+                       (float)grad_scale, (const float*)nullptr);
     return check_launch("adam");
+}
+
+int adam_graph_launch(float* params, const float* grads, float* m, float* v, int64_t n, int64_t* step_dev, float* dyn,
+                      double lr, double b1, double b2, double eps, double wd, double grad_scale, hipStream_t st) {
+    if (n <= 0) return DGG_ERR_INVALID;
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, st, step_dev, dyn, lr, b1, b2);
+    int64_t blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, m, v, n, 0.f, 1.f,
+                       (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)wd, (float)grad_scale,
+                       (const float*)dyn);
+    return check_launch("adam_graph");
+}
+
+int seed_bump_launch(uint64_t* seed_dev, hipStream_t st) {
+    hipLaunchKernelGGL(seed_bump_kernel, dim3(1), dim3(1), 0, st, seed_dev);
+    return check_launch("seed_bump");
 }
 
 int translate_axis_launch(float* transl, const float* rot9, int B, int axis, float offset, hipStream_t st) {

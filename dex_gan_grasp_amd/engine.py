@@ -13,6 +13,27 @@ from . import _lib, ops, parallel
 from ._lib import check, lib, ptr, stream_ptr, f32c
 
 
+SEED_STRIDE = 0x9E3779B97F4A7C15   # what dgg_eva_phase_graph adds to the device-resident dropout seed per step
+
+
+class GraphStep:
+    """One gen+eval train step captured into a HIP graph (TrainEngine.capture_joint_step).  The inputs are the very
+    tensors given at capture: refresh their CONTENTS (copy_) between replays, keep them alive.  replay() enqueues the
+    whole step — ~230 kernel launches on 6 streams — as one graph launch on the current stream."""
+
+    def __init__(self, eng, graph, keep, is_train_gen):
+        self.eng, self.graph, self.keep, self.is_train_gen = eng, graph, keep, is_train_gen
+
+    def replay(self):
+        self.graph.replay()
+        e = self.eng
+        e.D.step += 1
+        e.E.step += 1
+        if self.is_train_gen:
+            e.G.step += 1
+        return e.losses
+
+
 class TrainEngine:
     def __init__(self, cfg, flat_g, flat_d, flat_e, device):
         self.cfg = cfg
@@ -68,15 +89,19 @@ class TrainEngine:
             torch.cuda.current_stream(self.device).wait_event(self._side2_busy)
             self._side2_busy = None
 
-    def _streams(self, two_streams):
+    def _streams(self, two_streams, graph_mode=False):
         """(main, s2 as void* or None): the D phase forks its real-batch pass onto _side2, and every compute
-        stream gets a library-owned weight-gradient side stream."""
+        stream gets a library-owned weight-gradient side stream (graph_mode: only the main stream, see
+        capture_joint_step)."""
         main = torch.cuda.current_stream(self.device)
         if not two_streams:
             return main, None
         if self._side2 is None:
             self._side2 = torch.cuda.Stream(device=self.device)
-        self._map_wgrad_streams(main, self._side2)
+        if graph_mode:
+            self._map_wgrad_streams(main)
+        else:
+            self._map_wgrad_streams(main, self._side2)
         return main, C.c_void_p(self._side2.cuda_stream)
 
     # ---- A10
@@ -207,9 +232,45 @@ class TrainEngine:
             check(lib().dgg_enable_wgrad_stream(C.c_void_p(key), 1), "dgg_enable_wgrad_stream")
             self._wg_mapped.add(key)
 
+    def _unmap_wgrad_streams(self, *streams):
+        for s in streams:
+            if s is not None and s.cuda_stream in (getattr(self, "_wg_mapped", None) or ()):
+                check(lib().dgg_enable_wgrad_stream(C.c_void_p(s.cuda_stream), 0), "dgg_enable_wgrad_stream")
+                self._wg_mapped.discard(s.cuda_stream)
+
     # ---- gen + eval step with communication/compute overlap (the unit bench.py times)
+    def capture_joint_step(self, gan_inputs, z, eva_inputs, is_train_gen=True, seed=0, lr_gen=None, lr_dis=None,
+                           lr_eva=None):
+        """Capture joint_step into a HIP graph.  What changes from step to step is kept in device memory — the three
+        Adam step numbers (dgg_adam_l2_graph) and the dropout seed (dgg_eva_phase_graph; the s-th replay draws masks
+        from seed + s * SEED_STRIDE) — so a replay continues training exactly like an eager step (bit-identical,
+        tests/test_gpu_fullsize.py).  One eager step in graph form runs first (it is a real training step: streams,
+        events, workspaces and the device counters come into being outside the capture).  Single GPU only: collectives
+        are not captured.  Returns a GraphStep."""
+        if parallel.is_distributed():
+            raise _lib.DggError("capture_joint_step: data-parallel steps are not captured (RCCL work is enqueued eagerly)")
+        dev = self.device
+        keep = (tuple(gan_inputs), z, tuple(eva_inputs))
+        for t in keep[0] + (z,) + keep[2]:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.losses.device:
+                raise _lib.DggError("capture_joint_step needs resident contiguous float32 tensors (they are used in place)")
+        if getattr(self, "_seed_dev", None) is None:
+            self._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._seed_dev.fill_(int(seed) - (1 << 64) if int(seed) >= (1 << 63) else int(seed))
+        kw = dict(is_train_gen=is_train_gen, lr_gen=lr_gen, lr_dis=lr_dis, lr_eva=lr_eva, graph_mode=True)
+        # ROCm 7.2: a stream forked into a capture must not wait on another captured stream (dgg.h) — the two side
+        # compute streams therefore run without weight-gradient streams of their own while capturing
+        self._unmap_wgrad_streams(self._side, self._side2)
+        self.joint_step(gan_inputs, z, eva_inputs, **kw)           # priming step, eager
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            self.joint_step(gan_inputs, z, eva_inputs, **kw)
+        # the capture itself executed nothing: undo the host-side step counters the captured call advanced
+        return GraphStep(self, g, keep, is_train_gen)
+
     def joint_step(self, gan_inputs, z, eva_inputs, is_train_gen=True, drop_keep=None, seed=0, lr_gen=None,
-                   lr_dis=None, lr_eva=None, two_streams=True, next_gan_inputs=None):
+                   lr_dis=None, lr_eva=None, two_streams=True, next_gan_inputs=None, graph_mode=False):
         """One update_dexgangrasp + one update_dexevaluator.  The two updates touch disjoint networks, batches
         and workspaces, so the evaluator update runs on a SECOND HIP stream concurrently with the cGAN update:
         most launches of either (column kernels, split-K reduces, the K=256 GEMMs) occupy a fraction of the 256
@@ -239,14 +300,19 @@ class TrainEngine:
         cfg_p = C.byref(self.ccfg)
         args = (ptr(bps), ptr(rot9), ptr(transl), ptr(joint), ptr(z))
         G, D, E = self.G, self.D, self.E
-        adam = lambda net, lr: net.adam_step(lr, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
-        main, s2 = self._streams(two_streams)
+        if graph_mode:   # step numbers and dropout seed in device memory; the host counters follow in GraphStep.replay
+            adam = lambda net, lr: net.adam_step_graph(lr, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
+            next_gan_inputs = None
+        else:
+            adam = lambda net, lr: net.adam_step(lr, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
+        main, s2 = self._streams(two_streams, graph_mode)
         if two_streams:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
             side = self._side
             side.wait_stream(main)          # inputs / previous step are ordered before the evaluator update
-            self._map_wgrad_streams(side)
+            if not graph_mode:
+                self._map_wgrad_streams(side)
         else:
             side = main
         check(lib().dgg_cgan_d_phase2(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(self.losses),
@@ -254,9 +320,15 @@ class TrainEngine:
         self._side2_busy = None             # the D phase joins _side2 (a picked-up prefetch included) into main
         w_d = parallel.allreduce_sum_(D.grads, async_op=True)
         with torch.cuda.stream(side):
-            check(lib().dgg_eva_phase(cfg_p, ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(wse),
-                                      wse.numel(), Be, ptr(ebps), ptr(erot9), ptr(etransl), ptr(elabel), ptr(dk),
-                                      int(seed), ptr(self.losses), stream_ptr(dev)), "dgg_eva_phase")
+            if graph_mode:
+                check(lib().dgg_eva_phase_graph(cfg_p, ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(wse),
+                                                wse.numel(), Be, ptr(ebps), ptr(erot9), ptr(etransl), ptr(elabel),
+                                                ptr(self._seed_dev), ptr(self.losses), stream_ptr(dev)),
+                      "dgg_eva_phase_graph")
+            else:
+                check(lib().dgg_eva_phase(cfg_p, ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(wse),
+                                          wse.numel(), Be, ptr(ebps), ptr(erot9), ptr(etransl), ptr(elabel), ptr(dk),
+                                          int(seed), ptr(self.losses), stream_ptr(dev)), "dgg_eva_phase")
             w_e = parallel.allreduce_sum_(E.grads, async_op=True)
         if w_d is not None:
             w_d.wait()
@@ -288,4 +360,11 @@ class TrainEngine:
             adam(G, hp.lr_gen)
         if two_streams:
             main.wait_stream(side)
+        if graph_mode:       # eager priming step: the host counters follow the device's (a captured call runs nothing)
+            if not torch.cuda.is_current_stream_capturing():
+                D.step += 1
+                E.step += 1
+                if is_train_gen:
+                    G.step += 1
+            return self.losses
         return self.losses.clone()

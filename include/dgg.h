@@ -97,6 +97,7 @@ int dgg_bps_encode(const float* clouds, int B, int N, const float* basis, int P,
 #define DGG_ACCUM_GRADS 2u      /* backward: add into grads instead of overwriting */
 #define DGG_SKIP_PARAM_GRADS 4u /* backward: input gradients only (G-phase pass through D) */
 #define DGG_NEED_INPUT_GRADS 8u /* backward: also produce gradients w.r.t. the network inputs */
+#define DGG_SEED_ON_DEVICE 16u  /* dgg_eva_forward: `seed` holds a device pointer (uint64_t*) to the dropout seed */
 
 /* A2 — ResBlock.forward(x, final_nl=True) on its own, networks.py:43-56 (Fin != Fout: fc3 present, as at every
  * call site of the reference).  One flat parameter buffer [fc1.weight ; fc3.weight | fc1.bias ; fc3.bias |
@@ -224,6 +225,10 @@ int dgg_set_wgrad_stream(void* stream, void* wgrad_stream);
  * one disable).  Prefer this form: a caller-provided side stream that is ALSO some compute stream with a side stream
  * of its own (easy to get from a pooled stream allocator) can close a wait cycle between the two. */
 int dgg_enable_wgrad_stream(void* stream, int enable);
+/* Stream capture (hipStreamBeginCapture on `stream`): every call of this library may be captured.  ROCm 7.2 limits
+ * the shape: a stream that was itself forked into the capture must not wait on an event of ANOTHER captured stream
+ * (hip::Stream::EndCapture then recurses without end), so map weight-gradient side streams only to the capturing
+ * stream itself — second compute streams (stream2 below, a caller's evaluator stream) run their dW GEMMs in line. */
 
 /* Steps 1-8 of SURVEY.md 3.1 up to (not including) optim_D.step: G forward (train), ortho6d,
  * D forward on real then on fake.detach(), discriminator loss, D backward (both) -> st->d_grads.
@@ -287,6 +292,19 @@ int dgg_cgan_step(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hparams
 int dgg_eva_phase(const dgg_cfg* cfg, const float* e_params, float* e_grads, float* e_bn, const dgg_hparams* hp,
                   void* ws, size_t ws_bytes, int B, const float* bps, const float* rot9, const float* transl,
                   const float* label, const float* drop_keep, uint64_t seed, float* losses, void* stream);
+
+/* HIP-graph-friendly forms of the two entry points whose arguments change every step (a captured launch replays its
+ * arguments): the optimiser's step number and the dropout seed live in DEVICE memory and are advanced by the calls.
+ * dgg_adam_l2_graph: step_dev[0] += 1, then the update of dgg_adam_l2 with t = step_dev[0] (bias corrections formed in
+ * double on the device; dyn2: 2 floats of scratch).  dgg_eva_phase_graph: dgg_eva_phase with in-kernel masks drawn
+ * from seed_dev[0], which is then advanced.  With these a whole gen+eval step (engine.TrainEngine.joint_step) is
+ * captured once into a HIP graph and replayed. */
+int dgg_adam_l2_graph(float* params, const float* grads, float* m, float* v, int64_t n, int64_t* step_dev, float* dyn2,
+                      double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
+                      void* stream);
+int dgg_eva_phase_graph(const dgg_cfg* cfg, const float* e_params, float* e_grads, float* e_bn, const dgg_hparams* hp,
+                        void* ws, size_t ws_bytes, int B, const float* bps, const float* rot9, const float* transl,
+                        const float* label, uint64_t* seed_dev, float* losses, void* stream);
 
 /* Generator-loss pieces (A8, dexgangrasp.py:272-307 + losses.py:61-76), exposed for the parity
  * tests and for the autograd path: heads (B,21) -> losses[DGG_L_GEN_FAKE..DGG_L_TOTAL_GEN] and

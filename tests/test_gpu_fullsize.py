@@ -629,3 +629,39 @@ def test_wrapper_wgan_steps_vs_reference_goldens(variant, bname):
     out = m.update_dexgangrasp(H.clone_batch(batch), is_train_gen=False)
     assert set(out.keys()) >= {"total_loss_disc", "bce_loss_real", "bce_loss_fake", "total_loss_gen"}
     assert all(torch.isfinite(v).item() for v in out.values())
+
+
+def test_graph_replay_equals_eager_steps():
+    """HIP-graph capture of the gen+eval step (device-resident Adam step numbers and dropout seed): priming step + 3
+    replays are bit-identical to 4 eager joint_steps given the same seeds, inputs refreshed in place between replays."""
+    from dex_gan_grasp_amd.engine import SEED_STRIDE
+    L, ops, engine = _mods()
+    b = 128
+    gbs = [_dev_inputs(synth.make_batch(b, s)) for s in (1, 11)]
+    eb = _dev_inputs(synth.make_batch(b, 2, with_label=True), with_label=True)
+    zs = [synth.make_z(b, 100 + i).to(DEV) for i in range(4)]
+    e1, _, _ = _engine("wide")
+    e2, _, _ = _engine("wide")
+    seed0 = 12345
+    for i in range(4):      # eager reference: the seeds the graph path will use
+        e1.joint_step(gbs[i % 2], zs[i], eb, True, None, (seed0 + i * SEED_STRIDE) % (1 << 64))
+    g_in = tuple(t.clone() for t in gbs[0])
+    z_in = zs[0].clone()
+    gs = e2.capture_joint_step(g_in, z_in, eb, True, seed=seed0)          # runs step 0 eagerly
+    for i in range(1, 4):
+        for dst, src in zip(g_in, gbs[i % 2]):
+            dst.copy_(src)
+        z_in.copy_(zs[i])
+        gs.replay()
+    torch.cuda.synchronize()
+    for a, c in ((e1.G, e2.G), (e1.D, e2.D), (e1.E, e2.E)):
+        assert torch.equal(a.params, c.params) and torch.equal(a.m, c.m) and torch.equal(a.v, c.v) and torch.equal(a.bn, c.bn)
+        assert a.step == c.step == 4
+    assert torch.equal(e1.losses[:10], e2.losses[:10])
+    # eager steps continue correctly after replays (device and host step counters agree)
+    e1.joint_step(gbs[0], zs[0], eb, True, None, 7)
+    e2.joint_step(gbs[0], zs[0], eb, True, None, 7)
+    torch.cuda.synchronize()
+    assert torch.equal(e1.G.params, e2.G.params) and torch.equal(e1.E.params, e2.E.params) and e2.E.step == 5
+    e1.close()
+    e2.close()
