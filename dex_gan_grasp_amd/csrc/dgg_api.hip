@@ -248,7 +248,7 @@ struct NetW {
     float *ibn_part;             // [nrb][12][2][k0] per-tile partials of d gamma / d beta from the wgrad epilogue
     RbW rb[3];
     // scratch (not preserved between calls)
-    float *slabs, *part, *sums, *dpre, *dh, *dX0, *dXa, *dXb;
+    float *slabs, *part, *part2, *sums, *dpre, *dh, *dX0, *dXa, *dXb;
     // per-ResBlock backward operands: the weight-gradient GEMMs may run on a side stream while the main
     // stream already back-propagates the next block, so they are not shared scratch
     float *dY13[3], *da2[3];
@@ -346,6 +346,7 @@ static void carve(const NetL& L, int B, void* base, NetW& W) {
     if (2 * (size_t)L.k_in > part) part = 2 * (size_t)L.k_in;
     if ((size_t)L.nh * (L.nn + 1) > part) part = (size_t)L.nh * (L.nn + 1);
     W.part = b.take<float>(nrb * part);
+    W.part2 = b.take<float>(nrb * 2 * (size_t)L.n13);  // bn_bwd_apply's own partials while it reads W.part (ColFin)
     size_t sums = 2 * 3 * (size_t)L.n13;
     if (2 * 2 * (size_t)L.k_in > sums) sums = 2 * 2 * (size_t)L.k_in;
     W.sums = b.take<float>(sums);
@@ -580,19 +581,22 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     // fc1.bias / fc2.bias feed a train-mode BatchNorm: their gradient is EXACTLY zero (the batch-mean subtraction
     // removes any per-column constant; the reference stores fp32 rounding noise there) — cleared by this launch
     const bool zero_pre_bn = c.train && !skip_param && !accum;
-    DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, nq1, L.nn, c.W.sums, gp(R.bn2b), gp(R.bn2w), gp(R.b13 + L.hid),
-                                   acc, c.st, 0, 0, nullptr, cs13 + L.hid, zero_pre_bn ? G + R.b2 : nullptr, L.nn,
-                                   zero_pre_bn ? G + R.b13 : nullptr, L.hid, nq1 == 5 ? hb->gw : nullptr,
-                                   nq1 == 5 ? hb->gb : nullptr));
-    // 2. bn2 backward -> da2; its column sums are fc2.bias' gradient
-    DGG_TRY(bn_bwd_apply_launch(c.W.dpre, L.nn, A.a2, L.nn, A.mean2, A.rstd2, c.P + R.bn2w, c.W.sums, c.train, B, B,
-                                L.nn, da2, L.nn, c.W.part, c.st));
+    // 2. bn2 backward -> da2; its column sums are fc2.bias' gradient.  The column totals of stage 1's partials
+    //    (d bn2.bias, d bn2.weight, the fc3 half of d fc13.bias [+ the head's gradients]) are formed inside this launch.
+    {
+        ColFin fin = {c.W.part, nq1, {gp(R.bn2b), gp(R.bn2w), gp(R.b13 + L.hid), nq1 == 5 ? hb->gw : nullptr,
+                                      nq1 == 5 ? hb->gb : nullptr},
+                      acc, cs13 + L.hid, zero_pre_bn ? G + R.b2 : nullptr, zero_pre_bn ? G + R.b13 : nullptr, L.nn,
+                      L.hid};
+        DGG_TRY(bn_bwd_apply_launch(c.W.dpre, L.nn, A.a2, L.nn, A.mean2, A.rstd2, c.P + R.bn2w, nullptr, c.train, B, B,
+                                    L.nn, da2, L.nn, c.W.part2, c.st, &fin));
+    }
     // fc2.bias feeds a BatchNorm: in train mode the batch-mean subtraction makes its gradient EXACTLY zero
     // (sum_m da2 = 0 analytically); the reference stores fp32 rounding noise there.  We store the exact
     // value in train mode and the real column sum in eval mode (running statistics).
     if (!skip_param) {
         if (!c.train)
-            DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 1, L.nn, nullptr, G + R.b2, nullptr, nullptr, acc, c.st));
+            DGG_TRY(colsum_finalize_launch(c.W.part2, 1, nrb, 1, L.nn, nullptr, G + R.b2, nullptr, nullptr, acc, c.st));
     }
     // 3. fc2: dh = da2 W2 (B x 256 output: split-K over slabs fills the chip)
     {
@@ -607,13 +611,15 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
         DGG_TRY(act_bwd_launch(c.W.slabs, L.hid, A.h, L.hid, A.a13, L.n13, A.mean1, A.rstd1, B, B, L.hid, c.W.dh, L.hid,
                                c.W.part, c.st, g.p[0].splits, slab));
     }
-    DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 2, L.hid, c.W.sums, gp(R.bn1b), gp(R.bn1w), nullptr, acc, c.st));
-    DGG_TRY(bn_bwd_apply_launch(c.W.dh, L.hid, A.a13, L.n13, A.mean1, A.rstd1, c.P + R.bn1w, c.W.sums, c.train, B, B,
-                                L.hid, dY13, L.n13, c.W.part, c.st));
+    {
+        ColFin fin = {c.W.part, 2, {gp(R.bn1b), gp(R.bn1w), nullptr, nullptr, nullptr}, acc, nullptr, nullptr, nullptr, 0, 0};
+        DGG_TRY(bn_bwd_apply_launch(c.W.dh, L.hid, A.a13, L.n13, A.mean1, A.rstd1, c.P + R.bn1w, nullptr, c.train, B, B,
+                                    L.hid, dY13, L.n13, c.W.part2, c.st, &fin));
+    }
     // fc1.bias: same argument as fc2.bias above; in eval mode the real column sum is also kept in cs13[0:hid]
     // for the BatchNorm-aware wgrad epilogue (train mode: exactly zero -> ep_cs0 = NULL)
     if (!c.train)
-        DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 1, L.hid, nullptr, gp(R.b13), nullptr, nullptr, acc, c.st, 0,
+        DGG_TRY(colsum_finalize_launch(c.W.part2, 1, nrb, 1, L.hid, nullptr, gp(R.b13), nullptr, nullptr, acc, c.st, 0,
                                        0, cs13, nullptr));
     // 5. wgrad of [fc1;fc3]: dW13[:, wcol:] = dY13^T X_seg.  For the [prefix | x_hat] segment the epilogue
     //    turns T = dY13^T x_hat into dW = gamma T + beta cs and emits the partials of d gamma / d beta of the

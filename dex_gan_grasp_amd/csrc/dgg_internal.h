@@ -139,9 +139,24 @@ int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const
                        hipStream_t st, const float* hd_dout = nullptr, const float* hd_w = nullptr, int nq = 3);
 // Stage 2/4 (BN backward apply): dx = gamma*rstd*(dz - sum_dz/B - xhat*sum_dzx/B) (train) or
 //          gamma*rstd*dz (eval);  partial sums of dx (-> bias gradient of the preceding Linear).
+// `fin` (one group only): the column sums come straight from the producer's row-block partials fin->part
+// [nrb][nq][N] — every workgroup sums quantities 0, 1 of its own 64 columns (4 waves over disjoint row-block ranges,
+// then in order: same order and bits as colsum_finalize) and the first row of workgroups also stores what
+// colsum_finalize would have: totals of quantity q into d[q] (NULL: skip; d[4] is one scalar), a plain copy of
+// quantity 2 into copy2, and clears zero0 / zero1.  fin->part must not alias `part` (other workgroups still read it).
+struct ColFin {
+    const float* part;
+    int nq;
+    float* d[5];
+    int accumulate;
+    float* copy2;
+    float *zero0, *zero1;
+    int nz0, nz1;
+};
 int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, const float* mean, const float* rstd,
                         const float* gamma, const float* sums /*[groups][2][N]*/, int train, int B,
-                        int rows_per_group, int N, float* dx, int lddx, float* part, hipStream_t st);
+                        int rows_per_group, int N, float* dx, int lddx, float* part, hipStream_t st,
+                        const ColFin* fin = nullptr);
 // Stage 3: dq = dh * lrelu'(h) (in place on dh allowed); partial sums: sum dq, sum dq*xhat1.
 int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const float* a1, int lda1, const float* mean,
                    const float* rstd, int B, int rows_per_group, int N, float* dq, int lddq, float* part,

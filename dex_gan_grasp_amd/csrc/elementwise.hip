@@ -528,8 +528,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ sums, int train, int rpg,
                                                            int nrb, int N, float* __restrict__ dx, int lddx,
-                                                           float* __restrict__ part) {
+                                                           float* __restrict__ part, ColFin fin) {
     __shared__ float sh[SUB][1][64];
+    __shared__ float tq[2][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 64 + lane;
     const bool cok = c0 < N;
@@ -540,8 +541,42 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float mu = mean[g * N + c], rs = rstd[g * N + c];
     const float k = gamma[c] * rs;
     const float inv_n = 1.0f / (float)rpg;
-    const float m0 = train ? sums[(size_t)(g * 2 + 0) * N + c] * inv_n : 0.f;
-    const float m1 = train ? sums[(size_t)(g * 2 + 1) * N + c] * inv_n : 0.f;
+    float m0 = 0.f, m1 = 0.f;
+    if (fin.part) {  // one group: column totals from the row-block partials (see ColFin)
+        const bool writer = blockIdx.y == 0;
+        if (writer && blockIdx.x == 0) {
+            for (int z = threadIdx.x; z < fin.nz0; z += 256) fin.zero0[z] = 0.f;
+            for (int z = threadIdx.x; z < fin.nz1; z += 256) fin.zero1[z] = 0.f;
+        }
+        const int per = (nrb + SUB - 1) / SUB;
+        const int rb_lo = min(nrb, sub * per), rb_hi = min(nrb, rb_lo + per);
+        const int nqq = writer ? fin.nq : (train ? 2 : 0);  // workgroup-uniform
+        for (int q = 0; q < nqq; ++q) {
+            float sg = 0.f;
+            for (int b = rb_lo; b < rb_hi; ++b) sg += fin.part[((size_t)b * fin.nq + q) * N + c];
+            __syncthreads();
+            sh[sub][0][lane] = sg;
+            __syncthreads();
+            if (sub == 0) {
+                const float tot = ((sh[0][0][lane] + sh[1][0][lane]) + sh[2][0][lane]) + sh[3][0][lane];
+                if (q < 2) tq[q][lane] = tot;
+                if (writer && cok) {
+                    float* d = q < 4 ? fin.d[q] : (c == 0 ? fin.d[4] : nullptr);  // q 4: one scalar
+                    if (d) d[c] = fin.accumulate ? d[c] + tot : tot;
+                    if (q == 2 && fin.copy2) fin.copy2[c] = tot;
+                }
+            }
+        }
+        __syncthreads();
+        if (train) {
+            m0 = tq[0][lane] * inv_n;
+            m1 = tq[1][lane] * inv_n;
+        }
+        __syncthreads();  // sh is reused below
+    } else if (train) {
+        m0 = sums[(size_t)(g * 2 + 0) * N + c] * inv_n;
+        m1 = sums[(size_t)(g * 2 + 1) * N + c] * inv_n;
+    }
     float sb = 0.f;
     for (int r = 0; r < n; ++r) {
         const size_t row = (size_t)(g * rpg + r0 + r);
@@ -1232,11 +1267,18 @@ int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const
 
 int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, const float* mean, const float* rstd,
                         const float* gamma, const float* sums, int train, int B, int rpg, int N, float* dx, int lddx,
-                        float* part, hipStream_t st) {
+                        float* part, hipStream_t st, const ColFin* fin) {
     const int groups = B / rpg;
     dim3 grid(cdiv(N, 64), groups * nrb_of(rpg));
+    ColFin f = {};
+    if (fin) {
+        if (groups != 1 || fin->part == part || fin->nq < 2 || fin->nq > 5) return DGG_ERR_INVALID;
+        f = *fin;
+        if (!f.zero0) f.nz0 = 0;
+        if (!f.zero1) f.nz1 = 0;
+    }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, dz, lddz, a, lda, mean, rstd, gamma, sums, train,
-                       rpg, nrb_of(rpg), N, dx, lddx, part);
+                       rpg, nrb_of(rpg), N, dx, lddx, part, f);
     return check_launch("bn_bwd_apply");
 }
 
