@@ -21,6 +21,12 @@ constexpr int RB = kRowBlock;
 constexpr int SUB = 4;          // waves per workgroup, each takes RB/SUB rows of the row block
 constexpr int RS = RB / SUB;    // rows per wave
 
+// These kernels are latency-bound (a workgroup touches 32 rows x 64 columns): every wave loads ALL its RS rows before
+// it uses any — a `for (r < n)` loop with a data-dependent trip count compiles to one load, one s_waitcnt vmcnt(0) per
+// row, i.e. RS serial memory round trips.  Rows past the wave's last one re-read that last row (clamped index: always
+// a valid address) and are masked out of stores and sums, which keep their row order (same bits as the plain loop).
+__device__ __forceinline__ int row_clamp(int r, int n) { return r < n ? r : n - 1; }
+
 __device__ __forceinline__ float lrelu(float x) { return x > 0.f ? x : kLrelu * x; }
 __device__ __forceinline__ float lrelu_grad(float y) { return y > 0.f ? 1.f : kLrelu; }
 
@@ -157,15 +163,25 @@ __device__ __forceinline__ void bn_block_stats(const BnFin& f, int rpg, int grou
     const int rb_lo = min(f.nrb, sub * per), rb_hi = min(f.nrb, rb_lo + per);
     for (int g = 0; g < groups; ++g) {
         float cnt = 0.f, mean = 0.f, m2 = 0.f;
-        for (int rb = rb_lo; rb < rb_hi; ++rb) {
-            const float* p = f.part + (size_t)(g * f.nrb + rb) * 2 * ncols;
-            const float nb = (float)min(RB, rpg - rb * RB);
-            const float mb = p[c], qb = p[ncols + c];
-            const float tot = cnt + nb;
-            const float d = mb - mean;
-            mean += d * (nb / tot);
-            m2 += qb + d * d * (cnt * nb / tot);
-            cnt = tot;
+        for (int rb8 = rb_lo; rb8 < rb_hi; rb8 += 8) {  // 16 loads in flight, merged in row-block order
+            float mb[8], qb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float* p = f.part + (size_t)(g * f.nrb + min(rb8 + j, rb_hi - 1)) * 2 * ncols;
+                mb[j] = p[c];
+                qb[j] = p[ncols + c];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (rb8 + j < rb_hi) {
+                    const float nb = (float)min(RB, rpg - (rb8 + j) * RB);
+                    const float tot = cnt + nb;
+                    const float d = mb[j] - mean;
+                    mean += d * (nb / tot);
+                    m2 += qb[j] + d * d * (cnt * nb / tot);
+                    cnt = tot;
+                }
+            }
         }
         __syncthreads();
         sh[sub][0][lane] = cnt;
@@ -234,21 +250,32 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
         aff_scale[oc] = oc < nprefix ? 1.f : aff_gamma[oc - nprefix];
         aff_shift[oc] = oc < nprefix ? 0.f : aff_beta[oc - nprefix];
     }
+    if (n <= 0) return;
+    float xv[RS];
     if (oc < nprefix) {
-        for (int r = 0; r < n; ++r) X0[(size_t)(r0 + r) * ldx + oc] = prefix[(size_t)(r0 + r) * nprefix + oc];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) xv[r] = prefix[(size_t)(r0 + row_clamp(r, n)) * nprefix + oc];
+#pragma unroll
+        for (int r = 0; r < RS; ++r)
+            if (r < n) X0[(size_t)(r0 + r) * ldx + oc] = xv[r];
         return;
     }
     int ld;
     const float* p = src_col(S, c, ld);
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-    for (int r = 0; r < n; ++r) {
-        const int row = r0 + r;
-        const int g = row / rpg;
-        const float mu = fused ? res[g][0][lane] : mean[g * S.total + c];
-        const float rs = fused ? res[g][1][lane] : rstd[g * S.total + c];
-        const float sc = rs * ga;
-        const float shf = be - mu * sc;
-        X0[(size_t)row * ldx + oc] = fmaf(p[(size_t)row * ld], sc, shf);
+#pragma unroll
+    for (int r = 0; r < RS; ++r) xv[r] = p[(size_t)(r0 + row_clamp(r, n)) * ld];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        if (r < n) {
+            const int row = r0 + r;
+            const int g = row / rpg;
+            const float mu = fused ? res[g][0][lane] : mean[g * S.total + c];
+            const float rs = fused ? res[g][1][lane] : rstd[g * S.total + c];
+            const float sc = rs * ga;
+            const float shf = be - mu * sc;
+            X0[(size_t)row * ldx + oc] = fmaf(xv[r], sc, shf);
+        }
     }
 }
 
@@ -344,15 +371,22 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ a
     if (!cok) return;
     const int r0 = blockIdx.y * RB + sub * RS;
     const int n = min(RS, B - r0);
+    if (n <= 0) return;
     const float ga = gamma[c], be = beta[c];
-    for (int r = 0; r < n; ++r) {
-        const int row = r0 + r;
-        const int g = row / rpg;
-        const float mu = fused ? res[g][0][lane] : mean[g * N + c];
-        const float rs = fused ? res[g][1][lane] : rstd[g * N + c];
-        const float sc = rs * ga;
-        const float shf = be - mu * sc;
-        h[(size_t)row * ldh + c] = lrelu(fmaf(a[(size_t)row * lda + c], sc, shf));
+    float av[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) av[r] = a[(size_t)(r0 + row_clamp(r, n)) * lda + c];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        if (r < n) {
+            const int row = r0 + r;
+            const int g = row / rpg;
+            const float mu = fused ? res[g][0][lane] : mean[g * N + c];
+            const float rs = fused ? res[g][1][lane] : rstd[g * N + c];
+            const float sc = rs * ga;
+            const float shf = be - mu * sc;
+            h[(size_t)row * ldh + c] = lrelu(fmaf(av[r], sc, shf));
+        }
     }
 }
 
@@ -401,25 +435,37 @@ __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ 
     if (!cok) return;
     const int r0 = blockIdx.y * RB + sub * RS;
     const int n = min(RS, B - r0);
+    if (n <= 0) return;
     const float ga = gamma[c], be = beta[c];
     const float inv_keep = 1.0f / (1.0f - kDropP);
-    for (int r = 0; r < n; ++r) {
-        const int row = r0 + r;
-        const int g = row / rpg;
-        const float mu = fused ? res[g][0][lane] : mean[g * N + c];
-        const float rs = fused ? res[g][1][lane] : rstd[g * N + c];
-        const float sc = rs * ga;
-        const float shf = be - mu * sc;
-        float v = lrelu(s[(size_t)row * lds + c] + fmaf(a2[(size_t)row * lda2 + c], sc, shf));
-        if (drop_mode) {
-            const size_t e = (size_t)row * N + c;
-            // drop_mode 3: `seed` carries a device pointer to the seed (graph replay: the seed lives in device memory)
-            const uint64_t sd = drop_mode == 3 ? *reinterpret_cast<const uint64_t*>(seed) : seed;
-            const float k = drop_mode == 1 ? keep_in[e] : philox_keep(sd, seed_off + e);
-            keep_out[e] = (uint8_t)(k != 0.f);
-            v = v * k * inv_keep;
+    // drop_mode 3: `seed` carries a device pointer to the seed (graph replay: the seed lives in device memory)
+    const uint64_t sd = drop_mode == 3 ? *reinterpret_cast<const uint64_t*>(seed) : seed;
+    float sv[RS], av[RS], kv[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        const size_t row = (size_t)(r0 + row_clamp(r, n));
+        sv[r] = s[row * lds + c];
+        av[r] = a2[row * lda2 + c];
+        kv[r] = drop_mode == 1 ? keep_in[row * N + c] : 1.f;
+    }
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        if (r < n) {
+            const int row = r0 + r;
+            const int g = row / rpg;
+            const float mu = fused ? res[g][0][lane] : mean[g * N + c];
+            const float rs = fused ? res[g][1][lane] : rstd[g * N + c];
+            const float sc = rs * ga;
+            const float shf = be - mu * sc;
+            float v = lrelu(sv[r] + fmaf(av[r], sc, shf));
+            if (drop_mode) {
+                const size_t e = (size_t)row * N + c;
+                const float k = drop_mode == 1 ? kv[r] : philox_keep(sd, seed_off + e);
+                keep_out[e] = (uint8_t)(k != 0.f);
+                v = v * k * inv_keep;
+            }
+            y[(size_t)row * ldy + c] = v;
         }
-        y[(size_t)row * ldy + c] = v;
     }
 }
 
@@ -485,27 +531,43 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
     const float inv_keep = 1.0f / (1.0f - kDropP);
     const float wv = hd_dout ? hd_w[c] : 0.f;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
-    for (int r = 0; r < n; ++r) {
-        const size_t row = (size_t)(g * rpg + r0 + r);
-        const float yv = y[row * ldy + c];
-        float d;
-        if (hd_dout) {
-            const float ds = hd_dout[row];
-            d = ds * wv;
-            s3 = fmaf(ds, yv, s3);
-            s4 += ds;
-        } else {
-            d = dy[row * lddy + c];
+    if (n > 0) {
+        float yv_[RS], dv_[RS], av_[RS], sv_[RS];
+        uint8_t kp_[RS];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const size_t row = (size_t)(g * rpg + r0 + row_clamp(r, n));
+            yv_[r] = y[row * ldy + c];
+            dv_[r] = hd_dout ? hd_dout[row] : dy[row * lddy + c];
+            kp_[r] = keep ? keep[row * N + c] : (uint8_t)1;
+            av_[r] = a2[row * lda2 + c];
+            sv_[r] = s[row * lds + c];
         }
-        if (keep) d = keep[row * N + c] ? d * inv_keep : 0.f;
-        d *= lrelu_grad(yv);
-        if (cok) dpre[row * N + c] = d;
-        const float xh = (a2[row * lda2 + c] - mu) * rs;
-        const float d3 = d * lrelu_grad(s[row * lds + c]);
-        if (cok) da3[row * ldda3 + c] = d3;
-        s0 += d;
-        s1 = fmaf(d, xh, s1);
-        s2 += d3;
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            if (r < n) {
+                const size_t row = (size_t)(g * rpg + r0 + r);
+                const float yv = yv_[r];
+                float d;
+                if (hd_dout) {
+                    const float ds = dv_[r];
+                    d = ds * wv;
+                    s3 = fmaf(ds, yv, s3);
+                    s4 += ds;
+                } else {
+                    d = dv_[r];
+                }
+                if (keep) d = kp_[r] ? d * inv_keep : 0.f;
+                d *= lrelu_grad(yv);
+                if (cok) dpre[row * N + c] = d;
+                const float xh = (av_[r] - mu) * rs;
+                const float d3 = d * lrelu_grad(sv_[r]);
+                if (cok) da3[row * ldda3 + c] = d3;
+                s0 += d;
+                s1 = fmaf(d, xh, s1);
+                s2 += d3;
+            }
+        }
     }
     sh[sub][0][lane] = s0;
     sh[sub][1][lane] = s1;
@@ -553,7 +615,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const int nqq = writer ? fin.nq : (train ? 2 : 0);  // workgroup-uniform
         for (int q = 0; q < nqq; ++q) {
             float sg = 0.f;
-            for (int b = rb_lo; b < rb_hi; ++b) sg += fin.part[((size_t)b * fin.nq + q) * N + c];
+            for (int b8 = rb_lo; b8 < rb_hi; b8 += 8) {
+                float t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = fin.part[((size_t)min(b8 + j, rb_hi - 1) * fin.nq + q) * N + c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (b8 + j < rb_hi) sg += t[j];
+            }
             __syncthreads();
             sh[sub][0][lane] = sg;
             __syncthreads();
@@ -578,13 +647,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         m1 = sums[(size_t)(g * 2 + 1) * N + c] * inv_n;
     }
     float sb = 0.f;
-    for (int r = 0; r < n; ++r) {
-        const size_t row = (size_t)(g * rpg + r0 + r);
-        const float d = dz[row * lddz + c];
-        const float xh = (a[row * lda + c] - mu) * rs;
-        const float v = k * (d - m0 - xh * m1);
-        if (cok) dx[row * lddx + c] = v;
-        sb += v;
+    if (n > 0) {
+        float dv_[RS], av_[RS];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const size_t row = (size_t)(g * rpg + r0 + row_clamp(r, n));
+            dv_[r] = dz[row * lddz + c];
+            av_[r] = a[row * lda + c];
+        }
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            if (r < n) {
+                const size_t row = (size_t)(g * rpg + r0 + r);
+                const float xh = (av_[r] - mu) * rs;
+                const float v = k * (dv_[r] - m0 - xh * m1);
+                if (cok) dx[row * lddx + c] = v;
+                sb += v;
+            }
+        }
     }
     sh[sub][0][lane] = sb;
     __syncthreads();
@@ -611,15 +691,34 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     const int n = min(RS, max(0, rpg - r0));
     const float mu = mean[g * N + c], rs = rstd[g * N + c];
     float s0 = 0.f, s1 = 0.f;
-    for (int r = 0; r < n; ++r) {
-        const size_t row = (size_t)(g * rpg + r0 + r);
-        float dv = dh[row * lddh + c];
-        for (int q = 1; q < nslab; ++q) dv += dh[(size_t)q * slab_stride + row * lddh + c];
-        const float d = dv * lrelu_grad(h[row * ldh + c]);
-        if (cok) dq[row * lddq + c] = d;
-        const float xh = (a1[row * lda1 + c] - mu) * rs;
-        s0 += d;
-        s1 = fmaf(d, xh, s1);
+    if (n > 0) {
+        float dv_[RS], hv_[RS], av_[RS];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const size_t row = (size_t)(g * rpg + r0 + row_clamp(r, n));
+            dv_[r] = dh[row * lddh + c];
+            hv_[r] = h[row * ldh + c];
+            av_[r] = a1[row * lda1 + c];
+        }
+        for (int q = 1; q < nslab; ++q) {  // slab (= k) order; RS loads in flight per slab
+            float t[RS];
+#pragma unroll
+            for (int r = 0; r < RS; ++r)
+                t[r] = dh[(size_t)q * slab_stride + (size_t)(g * rpg + r0 + row_clamp(r, n)) * lddh + c];
+#pragma unroll
+            for (int r = 0; r < RS; ++r) dv_[r] += t[r];
+        }
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            if (r < n) {
+                const size_t row = (size_t)(g * rpg + r0 + r);
+                const float d = dv_[r] * lrelu_grad(hv_[r]);
+                if (cok) dq[row * lddq + c] = d;
+                const float xh = (av_[r] - mu) * rs;
+                s0 += d;
+                s1 = fmaf(d, xh, s1);
+            }
+        }
     }
     sh[sub][0][lane] = s0;
     sh[sub][1][lane] = s1;
@@ -656,7 +755,15 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     float tot = 0.f;
     for (int g = 0; g < groups; ++g) {
         float sg = 0.f;
-        for (int rb = rb_lo; rb < rb_hi; ++rb) sg += part[((size_t)(g * nrb + rb) * nq + q) * ld + c_lo + c];
+        for (int b8 = rb_lo; b8 < rb_hi; b8 += 8) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                t[j] = part[((size_t)(g * nrb + min(b8 + j, rb_hi - 1)) * nq + q) * ld + c_lo + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (b8 + j < rb_hi) sg += t[j];
+        }
         __syncthreads();
         sh[sub][lane] = sg;
         __syncthreads();
