@@ -275,6 +275,7 @@ struct Seg {
     bool is_x0;      // the [prefix | x_hat] operand: BN affine folded into the GEMMs
     float* dp;       // backward: gradient destination for columns [d_lo, d_hi) of this segment
     int dld, d_lo, d_hi, d_accum;
+    bool d_split;    // the consumer of dp is the previous block's res_out_bwd, which can sum split-K slabs
 };
 
 static const int kSlabCap = 24;  // upper bound on split-K slabs of one GEMM
@@ -442,6 +443,10 @@ struct Ctx {
     bool train;
     hipStream_t st;
     hipStream_t sw;   // side stream for weight-gradient GEMMs (NULL: same stream)
+    // set by a block's dgrad when it left its output gradient as split-K slabs in W.slabs (consumed, and summed, by
+    // the next rb_backward's first stage instead of the `dy` it is given)
+    int dy_nslab = 0;
+    long long dy_stride = 0;
 };
 
 static int rb_tail(Ctx& c, int r, int drop_mode, const float* keep_in, uint64_t seed, uint64_t seed_off);
@@ -575,9 +580,12 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     float* cs13 = c.W.cs13[r];
     // 1. through the output LeakyReLU / dropout; split into the bn2 branch (dpre) and the fc3 branch (da3)
     const int nq1 = (hb && !skip_param) ? 5 : 3;
-    DGG_TRY(res_out_bwd_launch(hb ? nullptr : dy, L.nn, A.y, L.nn, had_dropout ? A.keep : nullptr, A.a13 + L.hid, L.n13,
-                               A.a2, L.nn, A.mean2, A.rstd2, B, B, L.nn, c.W.dpre, dY13 + L.hid, L.n13, c.W.part, c.st,
-                               hb ? hb->d_score : nullptr, hb ? hb->w : nullptr, nq1));
+    const bool dy_slabs = !hb && c.dy_nslab > 1;
+    DGG_TRY(res_out_bwd_launch(hb ? nullptr : (dy_slabs ? c.W.slabs : dy), L.nn, A.y, L.nn,
+                               had_dropout ? A.keep : nullptr, A.a13 + L.hid, L.n13, A.a2, L.nn, A.mean2, A.rstd2, B, B,
+                               L.nn, c.W.dpre, dY13 + L.hid, L.n13, c.W.part, c.st, hb ? hb->d_score : nullptr,
+                               hb ? hb->w : nullptr, nq1, dy_slabs ? c.dy_nslab : 0, c.dy_stride));
+    c.dy_nslab = 0;
     // fc1.bias / fc2.bias feed a train-mode BatchNorm: their gradient is EXACTLY zero (the batch-mean subtraction
     // removes any per-column constant; the reference stores fp32 rounding noise there) — cleared by this launch
     const bool zero_pre_bn = c.train && !skip_param && !accum;
@@ -683,6 +691,16 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
             prob_init(g.p[np], dY13, L.n13, c.P + R.w13 + segs[i].wcol + segs[i].d_lo, R.fin,
                       segs[i].dp + segs[i].d_lo, segs[i].dld, B, segs[i].d_hi - segs[i].d_lo, L.n13);
             g.p[np].accumulate = segs[i].d_accum;
+            // B x 512 output, K = 768: 64 x 64 tiles alone fill half the chip with 24 k-tiles each — three K
+            // splits, left as slabs that the previous block's first backward stage sums
+            const int ks = 3;
+            if (segs[i].d_split && !segs[i].d_accum && segs[i].d_lo == 0 && segs[i].dld == segs[i].d_hi &&
+                (int64_t)ks * B * segs[i].dld <= c.W.slab_floats && L.n13 >= ks * 4 * 32) {
+                g.p[np].C = c.W.slabs;
+                prob_split(g.p[np], ks, (long long)B * segs[i].dld);
+                c.dy_nslab = g.p[np].splits;
+                c.dy_stride = (long long)B * segs[i].dld;
+            }
             ++np;
         }
         if (np == 2 && g.p[1].N > g.p[0].N) { GemmProb t = g.p[0]; g.p[0] = g.p[1]; g.p[1] = t; }
@@ -810,6 +828,7 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
                 }
             } else {
                 segs[i].dp = other; segs[i].dld = L.nn; segs[i].d_lo = 0; segs[i].d_hi = L.nn; segs[i].d_accum = 0;
+                segs[i].d_split = true;
             }
         }
         DGG_TRY(rb_backward(c, r, segs, nseg, dy, drop, accum, skip, ibn_tiles,

@@ -136,7 +136,8 @@ int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B,
 int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const uint8_t* keep, const float* s,
                        int lds, const float* a2, int lda2, const float* mean, const float* rstd, int B,
                        int rows_per_group, int N, float* dpre, float* da3, int ldda3, float* part,
-                       hipStream_t st, const float* hd_dout = nullptr, const float* hd_w = nullptr, int nq = 3);
+                       hipStream_t st, const float* hd_dout = nullptr, const float* hd_w = nullptr, int nq = 3,
+                       int nslab = 0, long long slab_stride = 0);  // nslab > 1: dy = split-K slabs, summed in order
 // Stage 2/4 (BN backward apply): dx = gamma*rstd*(dz - sum_dz/B - xhat*sum_dzx/B) (train) or
 //          gamma*rstd*dz (eval);  partial sums of dx (-> bias gradient of the preceding Linear).
 // `fin` (one group only): the column sums come straight from the producer's row-block partials fin->part

@@ -518,7 +518,9 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
                                                           float* __restrict__ dpre, float* __restrict__ da3,
                                                           int ldda3, float* __restrict__ part,
                                                           const float* __restrict__ hd_dout,
-                                                          const float* __restrict__ hd_w, int nq) {
+                                                          const float* __restrict__ hd_w, int nq, int nslab,
+                                                          long long slab_stride) {
+    // nslab > 1: `dy` is a stack of split-K slabs of the next block's dgrad GEMM, summed here in slab (= k) order
     __shared__ float sh[SUB][5][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 64 + lane;
@@ -542,6 +544,14 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
             kp_[r] = keep ? keep[row * N + c] : (uint8_t)1;
             av_[r] = a2[row * lda2 + c];
             sv_[r] = s[row * lds + c];
+        }
+        for (int q = 1; q < nslab; ++q) {
+            float t[RS];
+#pragma unroll
+            for (int r = 0; r < RS; ++r)
+                t[r] = dy[(size_t)q * slab_stride + (size_t)(g * rpg + r0 + row_clamp(r, n)) * lddy + c];
+#pragma unroll
+            for (int r = 0; r < RS; ++r) dv_[r] += t[r];
         }
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
@@ -1363,12 +1373,13 @@ int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B,
 int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const uint8_t* keep, const float* s,
                        int lds, const float* a2, int lda2, const float* mean, const float* rstd, int B, int rpg, int N,
                        float* dpre, float* da3, int ldda3, float* part, hipStream_t st, const float* hd_dout,
-                       const float* hd_w, int nq) {
+                       const float* hd_w, int nq, int nslab, long long slab_stride) {
     if (!dy && !hd_dout) return DGG_ERR_INVALID;
+    if (hd_dout) nslab = 0;
     const int groups = B / rpg;
     dim3 grid(cdiv(N, 64), groups * nrb_of(rpg));
     hipLaunchKernelGGL(res_out_bwd_kernel, grid, dim3(256), 0, st, dy, lddy, y, ldy, keep, s, lds, a2, lda2, mean,
-                       rstd, rpg, nrb_of(rpg), N, dpre, da3, ldda3, part, hd_dout, hd_w, nq);
+                       rstd, rpg, nrb_of(rpg), N, dpre, da3, ldda3, part, hd_dout, hd_w, nq, nslab, slab_stride);
     return check_launch("res_out_bwd");
 }
 

@@ -146,11 +146,14 @@ def test_benched_joint_step_with_prefetch_and_philox_vs_oracle(b):
     ae = O.AdamState(O.param_names(sde))
     gbs = [synth.make_batch(b, 1), synth.make_batch(b, 11)]
     g_ins = [_dev_inputs(x) for x in gbs]
-    eb = synth.make_batch(b, 2, with_label=True)
-    e_in = _dev_inputs(eb, with_label=True)
+    # a fresh evaluator batch per step, as in training: a pre-activation that sits on the LeakyReLU kink in one batch
+    # (seed 2 has one in rb1) would otherwise fail the strict criterion on every step
+    ebs = [synth.make_batch(b, 2 + 10 * i, with_label=True) for i in range(3)]
     strict_ok = {}
     steps = 3
     for i in range(steps):
+        eb = ebs[i]
+        e_in = _dev_inputs(eb, with_label=True)
         z = synth.make_z(b, 100 + i)
         nxt = g_ins[(i + 1) % 2] if i + 1 < steps else None
         before = {k: _snap_flat(fl) for k, fl in (("G", eng.G), ("D", eng.D), ("E", eng.E))}
