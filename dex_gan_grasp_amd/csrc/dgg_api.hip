@@ -276,7 +276,17 @@ struct Seg {
     float* dp;       // backward: gradient destination for columns [d_lo, d_hi) of this segment
     int dld, d_lo, d_hi, d_accum;
     bool d_split;    // the consumer of dp is the previous block's res_out_bwd, which can sum split-K slabs
+    float* d_slabs;  // != NULL: leave columns [d_lo, d_hi) as d_ks split-K slabs here (pitch kPoseLd, B * kPoseLd apart)
+    int d_ks;
 };
+static const int kPoseLd = 64;  // row pitch of the input-gradient slabs (a narrow column range of X0: the pose columns)
+static const int kPoseKs = 6;
+
+static int splits_used(int K, int ks) {  // what prob_split makes of a request for ks splits
+    const int ksteps = (K + 31) / 32;
+    const int per = (ksteps + ks - 1) / ks;
+    return (K + per * 32 - 1) / (per * 32);
+}
 
 static const int kSlabCap = 24;  // upper bound on split-K slabs of one GEMM
 
@@ -688,6 +698,13 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
         int np = 0;
         for (int i = 0; i < nseg; ++i) {
             if (!segs[i].dp || segs[i].d_hi <= segs[i].d_lo) continue;
+            if (segs[i].d_slabs) {  // a few columns, 16 row tiles: K splits, summed by the input BatchNorm's backward
+                prob_init(g.p[np], dY13, L.n13, c.P + R.w13 + segs[i].wcol + segs[i].d_lo, R.fin, segs[i].d_slabs,
+                          kPoseLd, B, segs[i].d_hi - segs[i].d_lo, L.n13);
+                prob_split(g.p[np], segs[i].d_ks, (long long)B * kPoseLd);
+                ++np;
+                continue;
+            }
             prob_init(g.p[np], dY13, L.n13, c.P + R.w13 + segs[i].wcol + segs[i].d_lo, R.fin,
                       segs[i].dp + segs[i].d_lo, segs[i].dld, B, segs[i].d_hi - segs[i].d_lo, L.n13);
             g.p[np].accumulate = segs[i].d_accum;
@@ -805,6 +822,12 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
         if (L.nprefix + d_in_lo < x_lo) x_lo = L.nprefix + d_in_lo;
         if (L.nprefix + d_in_hi > x_hi) x_hi = L.nprefix + d_in_hi;
     }
+    // input gradients of a narrow column range only (the pose columns of D in the G phase): every block leaves its
+    // contribution as split-K slabs inside the (otherwise unused) dX0 buffer — block after block, so that the
+    // input BatchNorm's backward sums them in a fixed order — instead of 16 workgroups walking K = 768 three times
+    const int pose_used = splits_used(L.n13, kPoseKs);
+    const bool pose_slabs = want_in && !(d_prefix && L.nprefix > 0) && x_hi - x_lo <= kPoseLd && x_lo == L.nprefix + d_in_lo &&
+                            L.n13 >= kPoseKs * 4 * 32 && (int64_t)L.nrb * pose_used * kPoseLd <= L.ldx0;
     int ibn_tiles[3] = {0, 0, 0};
     const bool drop = (L.net == DGG_NET_EVA) && c.train;
     // heads
@@ -825,6 +848,10 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
                 if (x_hi > x_lo) {
                     segs[i].dp = c.W.dX0; segs[i].dld = L.ldx0; segs[i].d_lo = x_lo; segs[i].d_hi = x_hi;
                     segs[i].d_accum = (r != L.nrb - 1) ? 1 : 0;
+                    if (pose_slabs) {
+                        segs[i].d_slabs = c.W.dX0 + (size_t)(L.nrb - 1 - r) * pose_used * B * kPoseLd;
+                        segs[i].d_ks = kPoseKs;
+                    }
                 }
             } else {
                 segs[i].dp = other; segs[i].dld = L.nn; segs[i].d_lo = 0; segs[i].d_hi = L.nn; segs[i].d_accum = 0;
@@ -851,14 +878,21 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     }
     if (want_in) {  // input gradients for the requested columns through the (train: batch-statistics) BN backward
         ColSrcs sub = sub_srcs(srcs, d_in_lo, d_in_hi);
+        const float* dsrc = c.W.dX0;
+        int dld = L.ldx0, dcol = L.nprefix + d_in_lo, nslab = 0;
+        long long dstride = 0;
+        if (pose_slabs) { dld = kPoseLd; dcol = 0; nslab = L.nrb * pose_used; dstride = (long long)B * kPoseLd; }
         if (c.train) {
-            DGG_TRY(ibn_bwd_stats_launch(sub, c.W.dX0, L.ldx0, L.nprefix + d_in_lo, c.W.imean + d_in_lo,
-                                         c.W.irstd + d_in_lo, B, 1, c.W.part, st));
-            DGG_TRY(colsum_finalize_launch(c.W.part, 1, nrb, 2, sub.total, c.W.sums, nullptr, nullptr, nullptr, 0, st));
+            // the statistics pass also leaves the slab sum, compact, in dXa (free: the block chain is done)
+            float* dsum = nslab > 1 ? c.W.dXa : nullptr;
+            DGG_TRY(ibn_bwd_stats_launch(sub, dsrc, dld, dcol, c.W.imean + d_in_lo, c.W.irstd + d_in_lo, B, 1, c.W.part, st,
+                                         nslab, dstride, dsum));
+            if (dsum) { dsrc = dsum; dld = sub.total; dcol = 0; nslab = 0; }
         }
-        DGG_TRY(ibn_bwd_apply_launch(sub, c.W.dX0, L.ldx0, L.nprefix + d_in_lo, c.W.imean + d_in_lo,
-                                     c.W.irstd + d_in_lo, params + L.ibnw + d_in_lo, c.W.sums, c.train, B, B, 0,
-                                     sub.total, d_in, sub.total, st));
+        // the column sums of the statistics pass are formed inside the apply kernel (no finalize launch)
+        DGG_TRY(ibn_bwd_apply_launch(sub, dsrc, dld, dcol, c.W.imean + d_in_lo, c.W.irstd + d_in_lo,
+                                     params + L.ibnw + d_in_lo, nullptr, c.train, B, B, 0, sub.total, d_in, sub.total, st,
+                                     c.train ? c.W.part : nullptr, nslab, dstride));
     }
     if (d_prefix && L.nprefix > 0) DGG_TRY(copy_cols_launch(c.W.dX0, L.ldx0, d_prefix, L.nprefix, B, L.nprefix, st));
     return DGG_OK;

@@ -174,11 +174,13 @@ int colsum_finalize_launch(const float* part, int groups, int nrb, int nq, int n
                            float* zero1 = nullptr, int nz1 = 0, float* dst3 = nullptr, float* dst4 = nullptr);
 // Input BN backward: partial sums of dX0 and dX0*xhat over the concat sources.
 int ibn_bwd_stats_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col_off, const float* mean,
-                         const float* rstd, int rows_per_group, int groups, float* part, hipStream_t st);
+                         const float* rstd, int rows_per_group, int groups, float* part, hipStream_t st, int nslab = 0,
+                         long long slab_stride = 0, float* dsum = nullptr);
 // Input gradient for a column range [c_lo, c_hi) of the concat: dx written to dst (B, c_hi-c_lo).
 int ibn_bwd_apply_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col_off, const float* mean,
                          const float* rstd, const float* gamma, const float* sums, int train, int B,
-                         int rows_per_group, int c_lo, int c_hi, float* dst, int ldd, hipStream_t st);
+                         int rows_per_group, int c_lo, int c_hi, float* dst, int ldd, hipStream_t st,
+                         const float* fin_part = nullptr, int nslab = 0, long long slab_stride = 0);
 
 // losses -------------------------------------------------------------------------------------
 int bce_launch(const float* p, const float* labels, float target_const, int B, float weight, float loss_scale,

@@ -792,10 +792,13 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 }
 
 // grid: (ceil(ncols/256), groups*nrb)
+// nslab > 1: dX0 is a stack of split-K slabs (slab_stride apart) summed here in slab order; dsum (optional): the summed
+// gradient, compact (pitch S.total), for ibn_bwd_apply
 __global__ __launch_bounds__(256) void ibn_bwd_stats_kernel(ColSrcs S, const float* __restrict__ dX0, int ldx,
                                                             int col_off, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int rpg, int nrb,
-                                                            float* __restrict__ part) {
+                                                            float* __restrict__ part, int nslab,
+                                                            long long slab_stride, float* __restrict__ dsum) {
     __shared__ float sh[SUB][2][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 64 + lane;
@@ -808,12 +811,32 @@ __global__ __launch_bounds__(256) void ibn_bwd_stats_kernel(ColSrcs S, const flo
     const float* p = src_col(S, c, ld);
     const float mu = mean[g * S.total + c], rs = rstd[g * S.total + c];
     float s0 = 0.f, s1 = 0.f;
-    for (int r = 0; r < n; ++r) {
-        const size_t row = (size_t)(g * rpg + r0 + r);
-        const float d = dX0[row * ldx + col_off + c];
-        const float xh = (p[row * ld] - mu) * rs;
-        s0 += d;
-        s1 = fmaf(d, xh, s1);
+    if (n > 0) {
+        float dv_[RS], xv_[RS];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const size_t row = (size_t)(g * rpg + r0 + row_clamp(r, n));
+            dv_[r] = dX0[row * ldx + col_off + c];
+            xv_[r] = p[row * ld];
+        }
+        for (int q = 1; q < nslab; ++q) {
+            float t[RS];
+#pragma unroll
+            for (int r = 0; r < RS; ++r)
+                t[r] = dX0[(size_t)q * slab_stride + (size_t)(g * rpg + r0 + row_clamp(r, n)) * ldx + col_off + c];
+#pragma unroll
+            for (int r = 0; r < RS; ++r) dv_[r] += t[r];
+        }
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            if (r < n) {
+                const size_t row = (size_t)(g * rpg + r0 + r);
+                if (dsum && cok) dsum[row * S.total + c] = dv_[r];
+                const float xh = (xv_[r] - mu) * rs;
+                s0 += dv_[r];
+                s1 = fmaf(dv_[r], xh, s1);
+            }
+        }
     }
     sh[sub][0][lane] = s0;
     sh[sub][1][lane] = s1;
@@ -831,31 +854,77 @@ __global__ __launch_bounds__(256) void ibn_bwd_apply_kernel(ColSrcs S, const flo
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ sums, int train, int B, int rpg,
-                                                            int c_lo, int c_hi, float* __restrict__ dst, int ldd) {
+                                                            int c_lo, int c_hi, float* __restrict__ dst, int ldd,
+                                                            const float* __restrict__ fin_part, int fin_nrb, int nslab,
+                                                            long long slab_stride) {
+    // fin_part (train, one group): the column sums come from ibn_bwd_stats' row-block partials [nrb][2][S.total],
+    // summed by every workgroup for its own columns in colsum_finalize's order.  nslab > 1: dX0 = split-K slabs.
+    __shared__ float sh[SUB][64];
+    __shared__ float tq[2][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const int c = c_lo + blockIdx.x * 64 + lane;
-    if (c >= c_hi) return;
+    const int c0 = c_lo + blockIdx.x * 64 + lane;
+    const bool cok = c0 < c_hi;
+    const int c = cok ? c0 : c_hi - 1;
+    const float inv_n = 1.0f / (float)rpg;
+    if (fin_part && train) {
+        const int per = (fin_nrb + SUB - 1) / SUB;
+        const int rb_lo = min(fin_nrb, sub * per), rb_hi = min(fin_nrb, rb_lo + per);
+        for (int q = 0; q < 2; ++q) {
+            float sg = 0.f;
+            for (int b8 = rb_lo; b8 < rb_hi; b8 += 8) {
+                float t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = fin_part[((size_t)min(b8 + j, rb_hi - 1) * 2 + q) * S.total + c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (b8 + j < rb_hi) sg += t[j];
+            }
+            __syncthreads();
+            sh[sub][lane] = sg;
+            __syncthreads();
+            if (sub == 0) tq[q][lane] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+        }
+        __syncthreads();
+    }
+    if (!cok) return;
     const int r0 = blockIdx.y * RB + sub * RS;
     const int n = min(RS, B - r0);
+    if (n <= 0) return;
     int ld;
     const float* p = src_col(S, c, ld);
     const float ga = gamma[c];
-    const float inv_n = 1.0f / (float)rpg;
-    for (int r = 0; r < n; ++r) {
-        const int row = r0 + r;
-        const int g = row / rpg;
-        const float mu = mean[g * S.total + c], rs = rstd[g * S.total + c];
-        const float d = dX0[(size_t)row * ldx + col_off + c];
-        float v;
-        if (train) {
-            const float m0 = sums[(size_t)(g * 2 + 0) * S.total + c] * inv_n;
-            const float m1 = sums[(size_t)(g * 2 + 1) * S.total + c] * inv_n;
-            const float xh = (p[(size_t)row * ld] - mu) * rs;
-            v = ga * rs * (d - m0 - xh * m1);
-        } else {
-            v = ga * rs * d;
+    float dv_[RS], xv_[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        const size_t row = (size_t)(r0 + row_clamp(r, n));
+        dv_[r] = dX0[row * ldx + col_off + c];
+        xv_[r] = p[row * ld];
+    }
+    for (int q = 1; q < nslab; ++q) {
+        float t[RS];
+#pragma unroll
+        for (int r = 0; r < RS; ++r)
+            t[r] = dX0[(size_t)q * slab_stride + (size_t)(r0 + row_clamp(r, n)) * ldx + col_off + c];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) dv_[r] += t[r];
+    }
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        if (r < n) {
+            const int row = r0 + r;
+            const int g = row / rpg;
+            const float mu = mean[g * S.total + c], rs = rstd[g * S.total + c];
+            float v;
+            if (train) {
+                const float m0 = (fin_part ? tq[0][lane] : sums[(size_t)(g * 2 + 0) * S.total + c]) * inv_n;
+                const float m1 = (fin_part ? tq[1][lane] : sums[(size_t)(g * 2 + 1) * S.total + c]) * inv_n;
+                const float xh = (xv_[r] - mu) * rs;
+                v = ga * rs * (dv_[r] - m0 - xh * m1);
+            } else {
+                v = ga * rs * dv_[r];
+            }
+            dst[(size_t)row * ldd + (c - c_lo)] = v;
         }
-        dst[(size_t)row * ldd + (c - c_lo)] = v;
     }
 }
 
@@ -1421,20 +1490,23 @@ int colsum_finalize_launch(const float* part, int groups, int nrb, int nq, int n
 }
 
 int ibn_bwd_stats_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col_off, const float* mean,
-                         const float* rstd, int rpg, int groups, float* part, hipStream_t st) {
+                         const float* rstd, int rpg, int groups, float* part, hipStream_t st, int nslab,
+                         long long slab_stride, float* dsum) {
     dim3 grid(cdiv(srcs.total, 64), groups * nrb_of(rpg));
     hipLaunchKernelGGL(ibn_bwd_stats_kernel, grid, dim3(256), 0, st, srcs, dX0, ldx, col_off, mean, rstd, rpg,
-                       nrb_of(rpg), part);
+                       nrb_of(rpg), part, nslab, slab_stride, dsum);
     return check_launch("ibn_bwd_stats");
 }
 
 int ibn_bwd_apply_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col_off, const float* mean,
                          const float* rstd, const float* gamma, const float* sums, int train, int B, int rpg, int c_lo,
-                         int c_hi, float* dst, int ldd, hipStream_t st) {
+                         int c_hi, float* dst, int ldd, hipStream_t st, const float* fin_part, int nslab,
+                         long long slab_stride) {
     if (c_hi <= c_lo) return DGG_OK;
+    if (fin_part && B != rpg) return DGG_ERR_INVALID;
     dim3 grid(cdiv(c_hi - c_lo, 64), cdiv(B, RB));
     hipLaunchKernelGGL(ibn_bwd_apply_kernel, grid, dim3(256), 0, st, srcs, dX0, ldx, col_off, mean, rstd, gamma, sums,
-                       train, B, rpg, c_lo, c_hi, dst, ldd);
+                       train, B, rpg, c_lo, c_hi, dst, ldd, fin_part, nrb_of(rpg), nslab, slab_stride);
     return check_launch("ibn_bwd_apply");
 }
 
