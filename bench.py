@@ -418,7 +418,7 @@ def main():
                                       if PIPELINE else "none"),
                        "gemm_arithmetic": ("fp32 operands split exactly into 3 bf16 pieces, 6 partial products on the "
                                            "bf16 MFMA, fp32 accumulate (fp32-accurate)"
-                                           if int(_lib.lib().dgg_get_gemm_algo()) == 1 else "f32 MFMA")},
+                                           if int(_lib.lib().dgg_get_gemm_algo()) >= 1 else "f32 MFMA")},
         }
         # dominant kernel of the step: the weight gradient of a ResBlock's fused fc1||fc3 layer,
         # dW13[768, 4120] = dY13[1024, 768]^T X0[1024, 4120] (TN); the forward of the same layer (NT, split-K 4) next

@@ -32,6 +32,8 @@ int check_launch(const char* what) {
         if (rc__ != DGG_OK) return rc__; \
     } while (0)
 
+static inline int64_t round64(int64_t x) { return (x + 63) / 64 * 64; }
+
 // ------------------------------------------------------------------------------------------------
 // Layout of the flat parameter / BN-statistics buffers.
 //   fc1.weight and fc3.weight of a ResBlock are stored back to back so that they form ONE
@@ -254,8 +256,25 @@ struct NetW {
     float *dY13[3], *da2[3];
     float *slabs_w;              // split-K slabs of the fc2 weight gradient
     int64_t slab_floats;
+    // bf16 planes of the large GEMMs' operands (gemm_p3.hip); carved for train-sized batches only (p3)
+    bool p3;
+    int ldk0, ldB;               // pitches: round64(k0), round64(B)
+    __bf16 *X0p, *X0t;           // [3][B][ldk0]: gamma x_hat + beta (forward);  [3][k0][ldB]: x_hat transposed (wgrad)
+    __bf16 *Wp0[3], *Wp1[3];     // per block: W13[:, X0 columns] [3][n13][ldk0];  W13[:, previous-block columns] [3][n13][nn]
+    __bf16 *Yp[3], *Yt[3];       // block output y as the next block's operand: [3][B][nn], [3][nn][ldB]
+    __bf16 *dYt[3];              // dY13 transposed: [3][n13][ldB]
     size_t bytes;
 };
+static const int kP3MaxB = 8192;   // larger batches (inference sweeps) never train: no planes carved for them
+// diagnostics: DGG_P3_FWD=0 / DGG_P3_WGRAD=0 keep the forward / the weight gradient on the in-register-split kernel
+static bool p3_use_fwd() {
+    static const bool v = [] { const char* e = getenv("DGG_P3_FWD"); return !(e && e[0] == '0'); }();
+    return v;
+}
+static bool p3_use_wgrad() {
+    static const bool v = [] { const char* e = getenv("DGG_P3_WGRAD"); return !(e && e[0] == '0'); }();
+    return v;
+}
 
 struct Bump {
     char* base;
@@ -304,7 +323,7 @@ static void plan13(int B, int n13, const int* widths, int nseg, int* splits) {
         return t < 0 ? 0 : t;
     }();
     // bf16x3 kernel: one workgroup per CU; measured best at 144-192 (other streams keep CUs)
-    const int target = env_target > 0 ? env_target : (gemm_algo() == 1 ? 192 : 512);
+    const int target = env_target > 0 ? env_target : (gemm_algo() >= 1 ? 192 : 512);
     int s_total = target / (tiles > 0 ? tiles : 1);
     if (s_total < 1) s_total = 1;
     if (s_total > 16) s_total = 16;
@@ -371,6 +390,20 @@ static void carve(const NetL& L, int B, void* base, NetW& W) {
     W.dX0 = b.take<float>(Bz * L.ldx0);
     W.dXa = b.take<float>(Bz * L.nn);
     W.dXb = b.take<float>(Bz * L.nn);
+    W.p3 = B <= kP3MaxB;
+    W.ldk0 = (int)round64(L.k0);
+    W.ldB = (int)round64(B);
+    if (W.p3) {
+        W.X0p = b.take<__bf16>(3 * Bz * W.ldk0);
+        W.X0t = b.take<__bf16>(3 * (size_t)L.k0 * W.ldB);
+        for (int r = 0; r < L.nrb; ++r) {
+            W.Wp0[r] = b.take<__bf16>(3 * (size_t)L.n13 * W.ldk0);
+            W.Wp1[r] = r > 0 ? b.take<__bf16>(3 * (size_t)L.n13 * L.nn) : nullptr;
+            W.Yp[r] = r + 1 < L.nrb ? b.take<__bf16>(3 * Bz * L.nn) : nullptr;
+            W.Yt[r] = r + 1 < L.nrb ? b.take<__bf16>(3 * (size_t)L.nn * W.ldB) : nullptr;
+            W.dYt[r] = b.take<__bf16>(3 * (size_t)L.n13 * W.ldB);
+        }
+    }
     W.bytes = (b.off + 255) & ~(size_t)255;
 }
 
@@ -457,6 +490,9 @@ struct Ctx {
     // the next rb_backward's first stage instead of the `dy` it is given)
     int dy_nslab = 0;
     long long dy_stride = 0;
+    bool p3 = false;      // this pass runs its large GEMMs on pre-split planes (train pass, planes carved, algorithm 2)
+    bool p3_fwd = false;  // ... including the forward (a D fake pass that consumes shared BPS products has no large one)
+    bool p3_t = false;    // forward: a weight-gradient pass follows — emit the transposed planes of X0 and of the block outputs
 };
 
 static int rb_tail(Ctx& c, int r, int drop_mode, const float* keep_in, uint64_t seed, uint64_t seed_off);
@@ -512,7 +548,41 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
     }
     gb.nprob = nq;
     if ((int64_t)nslab * slab > c.W.slab_floats) return DGG_ERR_WORKSPACE;
-    DGG_TRY(gemm_launch(GEMM_NT, gb, c.st));
+    int widest = 0;
+    for (int i = 0; i < np; ++i)
+        if (!(pc[i].shared && sh->mode == 2) && pc[i].width > widest) widest = pc[i].width;
+    if (c.p3_fwd && widest >= 1024) {
+        // the launch's operands as bf16 planes: [gamma x_hat + beta] / block r-1's output against the matching columns of
+        // W13 (net_forward / rb_tail produced them); K rounds up to 32 inside the planes' zero padding
+        int q = 0;
+        for (int i = 0; i < np; ++i) {
+            if (pc[i].shared && sh->mode == 2) continue;
+            GemmProb& g = gb.p[q++];
+            if (pc[i].x0) {
+                g.A = reinterpret_cast<const float*>(c.W.X0p + pc[i].x0_off);
+                g.lda = c.W.ldk0;
+                g.a_plane = (long long)B * c.W.ldk0;
+                g.B = reinterpret_cast<const float*>(c.W.Wp0[r] + pc[i].x0_off);
+                g.ldb = c.W.ldk0;
+                g.b_plane = (long long)L.n13 * c.W.ldk0;
+            } else {
+                g.A = reinterpret_cast<const float*>(c.W.Yp[r - 1]);
+                g.lda = L.nn;
+                g.a_plane = (long long)B * L.nn;
+                g.B = reinterpret_cast<const float*>(c.W.Wp1[r]);
+                g.ldb = L.nn;
+                g.b_plane = (long long)L.n13 * L.nn;
+            }
+            g.a_scale = g.a_shift = nullptr;
+            g.K = (pc[i].width + 31) / 32 * 32;
+            const int want = g.splits;
+            prob_split(g, want, slab);
+            if (g.splits != want) return DGG_ERR_INVALID;  // same K tiling as planned: the slab count is already booked
+        }
+        DGG_TRY(gemm_p3_launch(gb, false, c.st));
+    } else {
+        DGG_TRY(gemm_launch(GEMM_NT, gb, c.st));
+    }
     const bool shared_here = sh && np > nseg;
     if (shared_here && sh->events) {
         if (sh->mode == 1 && hipEventRecord(sh->ready[r], c.st) != hipSuccess) return DGG_ERR_LAUNCH;
@@ -558,8 +628,13 @@ static int rb_tail(Ctx& c, int r, int drop_mode, const float* keep_in, uint64_t 
     {
         BnFused fz{c.W.part, c.train ? 1 : 0, c.bn ? c.bn + R.rm2 : nullptr, c.bn ? c.bn + R.rv2 : nullptr, A.mean2,
                    A.rstd2};
+        // y is the next block's second operand: its planes for that block's forward and (transposed) weight gradient
+        const bool more = (c.p3_fwd || c.p3_t) && r + 1 < L.nrb;
+        PlaneOut pl = {(more && c.p3_fwd) ? c.W.Yp[r] : nullptr, L.nn, 0, (long long)B * L.nn,
+                       (more && c.p3_t) ? c.W.Yt[r] : nullptr, c.W.ldB, 0, (long long)L.nn * c.W.ldB};
         DGG_TRY(res_out_launch(A.a13 + L.hid, L.n13, A.a2, L.nn, B, B, L.nn, A.mean2, A.rstd2, c.P + R.bn2w,
-                               c.P + R.bn2b, drop_mode, keep_in, seed, seed_off, A.keep, A.y, L.nn, c.st, &fz));
+                               c.P + R.bn2b, drop_mode, keep_in, seed, seed_off, A.keep, A.y, L.nn, c.st, &fz,
+                               more ? &pl : nullptr));
     }
     return DGG_OK;
 }
@@ -590,11 +665,16 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     float* cs13 = c.W.cs13[r];
     // 1. through the output LeakyReLU / dropout; split into the bn2 branch (dpre) and the fc3 branch (da3)
     const int nq1 = (hb && !skip_param) ? 5 : 3;
+    // planes GEMM: dY13 goes out transposed as well ([n13][B]: rows 0 .. hid-1 from stage 4, the rest from stage 1)
+    const bool use_p3 = c.p3 && !skip_param && L.net != kNetResBlock;
+    const PlaneOut plt1 = {nullptr, 0, 0, 0, use_p3 ? c.W.dYt[r] : nullptr, c.W.ldB, 0, (long long)L.n13 * c.W.ldB};
+    const PlaneOut plt3 = {nullptr, 0, 0, 0, use_p3 ? c.W.dYt[r] : nullptr, c.W.ldB, L.hid, (long long)L.n13 * c.W.ldB};
     const bool dy_slabs = !hb && c.dy_nslab > 1;
     DGG_TRY(res_out_bwd_launch(hb ? nullptr : (dy_slabs ? c.W.slabs : dy), L.nn, A.y, L.nn,
                                had_dropout ? A.keep : nullptr, A.a13 + L.hid, L.n13, A.a2, L.nn, A.mean2, A.rstd2, B, B,
                                L.nn, c.W.dpre, dY13 + L.hid, L.n13, c.W.part, c.st, hb ? hb->d_score : nullptr,
-                               hb ? hb->w : nullptr, nq1, dy_slabs ? c.dy_nslab : 0, c.dy_stride));
+                               hb ? hb->w : nullptr, nq1, dy_slabs ? c.dy_nslab : 0, c.dy_stride,
+                               use_p3 ? &plt3 : nullptr));
     c.dy_nslab = 0;
     // fc1.bias / fc2.bias feed a train-mode BatchNorm: their gradient is EXACTLY zero (the batch-mean subtraction
     // removes any per-column constant; the reference stores fp32 rounding noise there) — cleared by this launch
@@ -632,7 +712,7 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     {
         ColFin fin = {c.W.part, 2, {gp(R.bn1b), gp(R.bn1w), nullptr, nullptr, nullptr}, acc, nullptr, nullptr, nullptr, 0, 0};
         DGG_TRY(bn_bwd_apply_launch(c.W.dh, L.hid, A.a13, L.n13, A.mean1, A.rstd1, c.P + R.bn1w, nullptr, c.train, B, B,
-                                    L.hid, dY13, L.n13, c.W.part2, c.st, &fin));
+                                    L.hid, dY13, L.n13, c.W.part2, c.st, &fin, use_p3 ? &plt1 : nullptr));
     }
     // fc1.bias: same argument as fc2.bias above; in eval mode the real column sum is also kept in cs13[0:hid]
     // for the BatchNorm-aware wgrad epilogue (train mode: exactly zero -> ep_cs0 = NULL)
@@ -685,11 +765,29 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
         }
         // the widest segment decides the tile shape
         if (nseg == 2 && g.p[1].N > g.p[0].N) { GemmProb t = g.p[0]; g.p[0] = g.p[1]; g.p[1] = t; }
-        int bm, bn;
-        gemm_tile_shape(GEMM_TN, g.p[0].M, g.p[0].N, bm, bn, g.p[0].K);
-        ibn_tiles[r] = (L.n13 + bm - 1) / bm;
-        if (ibn_tiles[r] > 12 || (ix0 < 0 && L.net != kNetResBlock)) return DGG_ERR_INVALID;
-        DGG_TRY(gemm_launch(GEMM_TN, g, sw));
+        if (use_p3) {
+            // dW13[n][k] = sum_b dY13[b][n] X[b][k] over the transposed planes dY13^T [n13][B], X^T [width][B]
+            for (int i = 0; i < nseg; ++i) {
+                GemmProb& q = g.p[i];
+                const bool x0 = q.ep_gamma != nullptr;  // set above for the [prefix | x_hat] segment only
+                q.A = reinterpret_cast<const float*>(c.W.dYt[r]);
+                q.lda = c.W.ldB;
+                q.a_plane = (long long)L.n13 * c.W.ldB;
+                q.B = reinterpret_cast<const float*>(x0 ? c.W.X0t : c.W.Yt[r - 1]);
+                q.ldb = c.W.ldB;
+                q.b_plane = (long long)(x0 ? L.k0 : L.nn) * c.W.ldB;
+                q.K = (B + 31) / 32 * 32;
+            }
+            ibn_tiles[r] = (L.n13 + 127) / 128;
+            if (ibn_tiles[r] > 12 || ix0 < 0) return DGG_ERR_INVALID;
+            DGG_TRY(gemm_p3_launch(g, true, sw));
+        } else {
+            int bm, bn;
+            gemm_tile_shape(GEMM_TN, g.p[0].M, g.p[0].N, bm, bn, g.p[0].K);
+            ibn_tiles[r] = (L.n13 + bm - 1) / bm;
+            if (ibn_tiles[r] > 12 || (ix0 < 0 && L.net != kNetResBlock)) return DGG_ERR_INVALID;
+            DGG_TRY(gemm_launch(GEMM_TN, g, sw));
+        }
     }
     // 6. dgrad: dX_seg[:, lo:hi] (+)= dY13 W13[:, wcol+lo : wcol+hi]
     {
@@ -756,10 +854,35 @@ static int net_forward(const NetL& L, const float* params, float* bn, void* ws, 
     if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
     if (!bn) return DGG_ERR_INVALID;
     if (c.train) DGG_TRY(ibn_stats_launch(srcs, B, 1, c.W.part, st));
+    // Train pass on the planes GEMM (gemm_p3.hip): the operands are split where they are produced — the input
+    // BatchNorm emits [gamma x_hat + beta] row-major for the forward and x_hat transposed for the weight gradient,
+    // every block's output and dY13 follow in rb_tail / rb_backward — and W13's column pieces in one launch here
+    c.p3 = c.train && c.W.p3 && gemm_algo() == 2;
+    c.p3_fwd = c.p3 && p3_use_fwd() && !(share && share->mode == 2);
+    c.p3_t = c.p3 && p3_use_wgrad() && !(flags & DGG_SKIP_PARAM_GRADS);
     {
         BnFused fz{c.W.part, c.train ? 1 : 0, bn + L.irm, bn + L.irv, c.W.imean, c.W.irstd};
+        PlaneOut pl = {c.p3_fwd ? c.W.X0p : nullptr, c.W.ldk0, 0, (long long)B * c.W.ldk0,
+                       c.p3_t ? c.W.X0t : nullptr, c.W.ldB, 0, (long long)L.k0 * c.W.ldB};
         DGG_TRY(ibn_apply_launch(srcs, B, B, c.W.imean, c.W.irstd, nullptr, nullptr, prefix, L.nprefix, c.W.X0, L.ldx0,
-                                 params + L.ibnw, params + L.ibnb, c.W.aff_scale, c.W.aff_shift, st, &fz));
+                                 params + L.ibnw, params + L.ibnb, c.W.aff_scale, c.W.aff_shift, st, &fz,
+                                 (c.p3_fwd || c.p3_t) ? &pl : nullptr));
+    }
+    if (c.p3_fwd) {
+        PlanesJobs jobs;
+        jobs.n = 0;
+        for (int r = 0; r < L.nrb; ++r) {
+            Seg segs[2];
+            int nseg;
+            make_segs(L, c.W, r, segs, nseg);
+            for (int i = 0; i < nseg; ++i) {
+                const bool x0 = segs[i].is_x0;
+                DGG_TRY(planes_add(jobs, params + L.rb[r].w13 + segs[i].wcol, L.rb[r].fin, L.n13, segs[i].width, nullptr,
+                                   nullptr, x0 ? c.W.Wp0[r] : c.W.Wp1[r], x0 ? c.W.ldk0 : L.nn,
+                                   (long long)L.n13 * (x0 ? c.W.ldk0 : L.nn), nullptr, 0, 0));
+            }
+        }
+        DGG_TRY(planes_run(jobs, st));
     }
     const bool drop = (L.net == DGG_NET_EVA) && c.train;
     for (int r = 0; r < L.nrb; ++r) {
@@ -813,6 +936,7 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     if (c.sw == st) c.sw = nullptr;
     carve(L, B, ws, c.W);
     if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
+    c.p3 = c.train && c.W.p3 && gemm_algo() == 2 && p3_use_wgrad() && !skip;  // the forward left X0^T / y^T planes
     const bool want_in = d_in && d_in_hi > d_in_lo;
     // columns of X0 whose gradient is needed: only those for which the caller wants INPUT gradients —
     // the input BatchNorm's parameter gradients come out of the wgrad epilogue
@@ -1535,8 +1659,9 @@ int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
     // fake transl / joint copies written by the D phase are still valid (same generator output)
     float* g_transl = S.f_transl;
     float* g_joint = S.f_joint;
-    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN, bps, S.rfake, g_transl,
-                             g_joint, S.p_gen, stream));
+    // (no weight gradient follows this pass: DGG_SKIP_PARAM_GRADS spares the forward the operands only a wgrad reads)
+    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN | DGG_SKIP_PARAM_GRADS, bps,
+                             S.rfake, g_transl, g_joint, S.p_gen, stream));
     // D-free mark: from here on nothing in this step writes D's parameters or running statistics
     if (PendingReal* Pp = pending_slot(ws, true)) {
         if (hipEventRecord(Pp->ev[5], st) != hipSuccess) return DGG_ERR_LAUNCH;
@@ -1965,7 +2090,7 @@ int dgg_gemm_occupancy(int mode, int bm, int bn) {
 }
 
 int dgg_set_gemm_algo(int algo) {
-    if (algo != DGG_GEMM_F32 && algo != DGG_GEMM_BF16X3) return DGG_ERR_INVALID;
+    if (algo != DGG_GEMM_F32 && algo != DGG_GEMM_BF16X3 && algo != DGG_GEMM_PLANES) return DGG_ERR_INVALID;
     gemm_set_algo(algo);
     return DGG_OK;
 }
@@ -1990,6 +2115,45 @@ int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const f
     prob_init(g.p[0], A, lda, Bm, ldb, C, ldc, M, N, K);
     g.p[0].accumulate = accumulate;
     return gemm_launch(mode, g, st);
+}
+
+size_t dgg_gemm_planes_workspace_bytes(int M, int N, int K) {
+    return (size_t)(3 * (round64(M) + round64(N)) * round64(K) * 2 + 256);
+}
+
+int dgg_gemm_planes(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb,
+                    float* C, int ldc, int splits, float* slabs, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    if (!A || !Bm || (!C && splits < 1) || M < 1 || N < 1 || K < 1 || !ws) return DGG_ERR_INVALID;
+    if (ws_bytes < dgg_gemm_planes_workspace_bytes(M, N, K) || ((uintptr_t)ws & 15)) return DGG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int ldk = (int)round64(K);
+    __bf16* pa = (__bf16*)ws;
+    __bf16* pb = pa + 3 * round64(M) * ldk;
+    const long long apl = (long long)round64(M) * ldk, bpl = (long long)round64(N) * ldk;
+    // k-major operand ([K][rows] in memory): the transposing branch of the producer
+    if (a_kmajor) DGG_TRY(planes_launch(A, lda, K, M, nullptr, nullptr, nullptr, 0, 0, pa, ldk, apl, st));
+    else DGG_TRY(planes_launch(A, lda, M, K, nullptr, nullptr, pa, ldk, apl, nullptr, 0, 0, st));
+    if (b_kmajor) DGG_TRY(planes_launch(Bm, ldb, K, N, nullptr, nullptr, nullptr, 0, 0, pb, ldk, bpl, st));
+    else DGG_TRY(planes_launch(Bm, ldb, N, K, nullptr, nullptr, pb, ldk, bpl, nullptr, 0, 0, st));
+    GemmBatch g;
+    memset(&g, 0, sizeof(g));
+    g.nprob = 1;
+    const int Kp = (K + 31) / 32 * 32;
+    if (splits >= 1) {
+        if (!slabs || accumulate) return DGG_ERR_INVALID;
+        prob_init(g.p[0], (const float*)pa, ldk, (const float*)pb, ldk, slabs, N, M, N, Kp);
+        prob_split(g.p[0], splits, (long long)M * N);
+    } else {
+        prob_init(g.p[0], (const float*)pa, ldk, (const float*)pb, ldk, C, ldc, M, N, Kp);
+        g.p[0].accumulate = accumulate;
+    }
+    g.p[0].a_plane = apl;
+    g.p[0].b_plane = bpl;
+    DGG_TRY(gemm_p3_launch(g, false, st));
+    if (splits >= 1 && C)
+        return reduce_bias_launch(slabs, g.p[0].splits, (long long)M * N, N, nullptr, C, ldc, M, M, 1, N, 0, 0, 0, 0, nullptr,
+                                  st);
+    return DGG_OK;
 }
 
 }  // extern "C"

@@ -48,6 +48,9 @@ struct GemmProb {
     const float* ep_w;     // weights, indexed like C (row n, column k), pitch ep_ldw
     int ep_ldw;
     float* ep_part;        // [tiles_m][2][N]
+    // gemm_p3 only: the operands are bf16 planes (A / B point at plane 0, lda / ldb and these plane distances count
+    // bf16 elements); 0 = fp32 operand
+    long long a_plane, b_plane;
 };
 struct GemmBatch {
     GemmProb p[4];
@@ -64,6 +67,43 @@ int gemm_occupancy(int mode, int bm, int bn);
 int gemm_algo();
 void gemm_set_algo(int a);
 void gemm_x3_dispatch(int mode, const GemmBatch& batch, hipStream_t st);  // gemm_x3.hip, 128 x 128 tiles
+// gemm_p3.hip: C = A B^T on pre-split bf16 planes (forward, and the wgrad over transposed planes with wgrad = true)
+int gemm_p3_launch(GemmBatch& batch, bool wgrad, hipStream_t st);
+// Plane outputs of the column kernels (ibn_apply, res_out, bn_bwd_apply, res_out_bwd; one batch group only): what the
+// kernel writes as fp32 also goes out split into bf16 planes, so that the large GEMMs run without a split of their own.
+//   row-major  [3][rows][ld]: element (row, col0 + c);  columns up to `ld` are zero-filled where a kernel says so
+//   transposed [3][cols][ldT]: element (col0 + c, row); rows B .. ldT-1 zero-filled (the K padding of the wgrad)
+struct PlaneOut {
+    __bf16* p;      // NULL: none
+    int ld, col0;
+    long long plane;
+    __bf16* pT;     // NULL: none
+    int ldT, colT0;
+    long long planeT;
+};
+// fp32 [R][C] -> planes [3][R][ldp] (affine per column optional) and / or transposed planes [3][C][ldpT]
+static const int kPlanesJobs = 6;
+struct PlanesJob {
+    const float* src;
+    int ld, R, C;
+    const float *scale, *shift;
+    __bf16* dst;
+    int ldp;
+    long long dplane;
+    __bf16* dstT;
+    int ldpT;
+    long long tplane;
+    int gx, gy;
+};
+struct PlanesJobs {
+    PlanesJob j[kPlanesJobs];
+    int n;
+};
+int planes_add(PlanesJobs& jobs, const float* src, int ld, int R, int C, const float* scale, const float* shift, void* dst,
+               int ldp, long long dplane, void* dstT, int ldpT, long long tplane);
+int planes_run(const PlanesJobs& jobs, hipStream_t st);
+int planes_launch(const float* src, int ld, int R, int C, const float* scale, const float* shift, void* dst, int ldp,
+                  long long dplane, void* dstT, int ldpT, long long tplane, hipStream_t st);
 int gemm_x3_occupancy(int mode);
 
 // ---------------------------------------------------------------- BPS encode (bps_encode.hip)
@@ -97,7 +137,9 @@ struct BnFused {
 int ibn_apply_launch(const ColSrcs& srcs, int B, int rows_per_group, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, const float* prefix, int nprefix, float* X0, int ldx,
                      const float* aff_gamma, const float* aff_beta, float* aff_scale, float* aff_shift,
-                     hipStream_t st, const BnFused* fused = nullptr);
+                     hipStream_t st, const BnFused* fused = nullptr, const PlaneOut* planes = nullptr);
+// planes (ibn_apply): row-major = aff_gamma * x_hat + aff_beta (prefix columns as they are), zero-filled up to its
+// pitch; transposed = x_hat
 
 // out[m][c] = sum_s slabs[s][m][c] (+ sum_s slabs2[s][m][c], same stride / pitch) + bias[c];  columns [stat_lo, stat_hi) get partial statistics,
 // columns [act_lo, act_hi) get LeakyReLU applied before the store.
@@ -120,7 +162,7 @@ int bn_act_launch(const float* a, int lda, int B, int rows_per_group, int N, con
 int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, int rows_per_group, int N,
                    const float* mean, const float* rstd, const float* gamma, const float* beta, int drop_mode,
                    const float* keep_in, uint64_t seed, uint64_t seed_off, uint8_t* keep_out, float* y, int ldy,
-                   hipStream_t st, const BnFused* fused = nullptr);
+                   hipStream_t st, const BnFused* fused = nullptr, const PlaneOut* planes = nullptr);
 // heads: out[m][j] = sum_k y[m][k] Wh[j][k] + bh[j]; sigmoid optionally.
 int heads_fwd_launch(const float* y, int ldy, int B, int K, const float* wh, const float* bh, int nh, int sigmoid,
                      float* out, int ldo, float* scratch, hipStream_t st);
@@ -137,7 +179,8 @@ int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const
                        int lds, const float* a2, int lda2, const float* mean, const float* rstd, int B,
                        int rows_per_group, int N, float* dpre, float* da3, int ldda3, float* part,
                        hipStream_t st, const float* hd_dout = nullptr, const float* hd_w = nullptr, int nq = 3,
-                       int nslab = 0, long long slab_stride = 0);  // nslab > 1: dy = split-K slabs, summed in order
+                       int nslab = 0, long long slab_stride = 0,  // nslab > 1: dy = split-K slabs, summed in order
+                       const PlaneOut* planes = nullptr);          // transposed da3 only
 // Stage 2/4 (BN backward apply): dx = gamma*rstd*(dz - sum_dz/B - xhat*sum_dzx/B) (train) or
 //          gamma*rstd*dz (eval);  partial sums of dx (-> bias gradient of the preceding Linear).
 // `fin` (one group only): the column sums come straight from the producer's row-block partials fin->part
@@ -157,7 +200,7 @@ struct ColFin {
 int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, const float* mean, const float* rstd,
                         const float* gamma, const float* sums /*[groups][2][N]*/, int train, int B,
                         int rows_per_group, int N, float* dx, int lddx, float* part, hipStream_t st,
-                        const ColFin* fin = nullptr);
+                        const ColFin* fin = nullptr, const PlaneOut* planes = nullptr);  // planes: transposed dx only
 // Stage 3: dq = dh * lrelu'(h) (in place on dh allowed); partial sums: sum dq, sum dq*xhat1.
 int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const float* a1, int lda1, const float* mean,
                    const float* rstd, int B, int rows_per_group, int N, float* dq, int lddq, float* part,

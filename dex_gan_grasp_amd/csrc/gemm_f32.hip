@@ -267,7 +267,7 @@ void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn, int K) {
     }
     // the bf16x3 kernel (128 x 128 only, one workgroup per CU) is worth a partly filled chip: 198 tiles of the
     // 768 x 4101 weight gradient at 128 x 128 beat 780 tiles of 64 x 64 on the f32 pipe by 1.5x
-    const long enough = gemm_algo() == 1 ? 128 : 200;
+    const long enough = gemm_algo() >= 1 ? 128 : 200;
     if (t128 < enough) {
         bm = (M >= 1024) ? 128 : 64;
         bn = 64;
@@ -284,7 +284,7 @@ int gemm_pick_splits(int mode, int M, int N, int K, int other_blocks) {
     static int target = -1;
     if (target < 0) {
         const char* e = getenv("DGG_SPLITK_TARGET");
-        target = e ? atoi(e) : (gemm_algo() == 1 ? 192 : 512);  // bf16x3: one workgroup per CU, a quarter of the chip left to the other streams
+        target = e ? atoi(e) : (gemm_algo() >= 1 ? 192 : 512);  // bf16x3: one workgroup per CU, a quarter of the chip left to the other streams
     }
     int s = (target - other_blocks) / (tiles > 0 ? tiles : 1);
     if (s < 1) s = 1;
@@ -327,17 +327,19 @@ static void launch_shape(int bm, int bn, const GemmBatch& b, hipStream_t st) {
         hipLaunchKernelGGL((gemm_f32_kernel<64, 64, A_KC, B_KC>), grid, block, 0, st, b);
 }
 
-// Which kernel family executes the GEMMs: 1 = bf16x3 split on the bf16 matrix pipe (gemm_x3.hip, default),
-// 0 = native f32 MFMA (this file).  Process-wide; DGG_GEMM_ALGO=f32 selects 0 at start-up.
+// Which kernel family executes the large GEMMs: 1 = bf16x3 with the split done in the GEMM's registers (gemm_x3.hip,
+// default), 2 = bf16x3 on operands pre-split into bf16 planes by their producers (gemm_p3.hip; train passes; falls back
+// to 1 wherever no planes exist) — 20 % faster as a kernel, but no faster as a step —, 0 = native f32 MFMA
+// (this file).  Process-wide; DGG_GEMM_ALGO=f32 / planes select 0 / 2 at start-up.
 static int g_algo = -1;
 int gemm_algo() {
     if (g_algo < 0) {
         const char* e = getenv("DGG_GEMM_ALGO");
-        g_algo = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;
+        g_algo = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : (e && (e[0] == 'p' || e[0] == '2')) ? 2 : 1;
     }
     return g_algo;
 }
-void gemm_set_algo(int a) { g_algo = a ? 1 : 0; }
+void gemm_set_algo(int a) { g_algo = a < 0 ? 0 : a > 2 ? 2 : a; }
 
 // All problems of one grouped launch must use the same tile shape: the launcher derives it from
 // problem 0 and re-plans the others with it.
@@ -359,7 +361,7 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
     }
     batch.total_blocks = blocks;
     if (mode != GEMM_NT && mode != GEMM_NN && mode != GEMM_TN) return DGG_ERR_INVALID;
-    if (gemm_algo() == 1 && bm == 128 && bn == 128) {
+    if (gemm_algo() >= 1 && bm == 128 && bn == 128) {
         gemm_x3_dispatch(mode, batch, st);
         return check_launch("gemm_x3");
     }

@@ -89,19 +89,21 @@ class TrainEngine:
             torch.cuda.current_stream(self.device).wait_event(self._side2_busy)
             self._side2_busy = None
 
-    def _streams(self, two_streams, graph_mode=False):
-        """(main, s2 as void* or None): the D phase forks its real-batch pass onto _side2, and every compute
-        stream gets a library-owned weight-gradient side stream (graph_mode: only the main stream, see
-        capture_joint_step)."""
+    def _streams(self, two_streams, wgrad=True):
+        """(main, s2 as void* or None): the D phase forks its real-batch pass onto _side2; wgrad: every compute stream
+        also gets a library-owned weight-gradient side stream (cgan_step / eva_step on their own: up to 4 streams,
+        one per hardware queue of the default HIP runtime configuration).  joint_step runs WITHOUT them: its three
+        compute streams already keep the chip busy, and six streams on four hardware queues serialise in pairs —
+        measured 1.92 ms per step against 2.00 ms with the weight-gradient streams (tools/phase_times.py)."""
         main = torch.cuda.current_stream(self.device)
         if not two_streams:
             return main, None
         if self._side2 is None:
             self._side2 = torch.cuda.Stream(device=self.device)
-        if graph_mode:
-            self._map_wgrad_streams(main)
-        else:
+        if wgrad:
             self._map_wgrad_streams(main, self._side2)
+        else:
+            self._unmap_wgrad_streams(main, self._side, self._side2)
         return main, C.c_void_p(self._side2.cuda_stream)
 
     # ---- A10
@@ -221,8 +223,11 @@ class TrainEngine:
         created and owned by the library — streams from torch's pool are shared between users, and one that served
         as a side stream here and as a compute stream (with its own side stream) elsewhere could close a wait
         cycle."""
-        if os.environ.get("DGG_WGRAD_STREAMS", "1") == "0":
+        mode = os.environ.get("DGG_WGRAD_STREAMS", "1")
+        if mode == "0":
             return
+        if mode == "main":   # diagnostics: only the stream the step is called on gets one
+            streams = [s for s in streams if s is not self._side and s is not self._side2]
         if getattr(self, "_wg_mapped", None) is None:
             self._wg_mapped = set()
         for s in streams:
@@ -233,8 +238,10 @@ class TrainEngine:
             self._wg_mapped.add(key)
 
     def _unmap_wgrad_streams(self, *streams):
+        if not getattr(self, "_wg_mapped", None):
+            return
         for s in streams:
-            if s is not None and s.cuda_stream in (getattr(self, "_wg_mapped", None) or ()):
+            if s is not None and s.cuda_stream in self._wg_mapped:
                 check(lib().dgg_enable_wgrad_stream(C.c_void_p(s.cuda_stream), 0), "dgg_enable_wgrad_stream")
                 self._wg_mapped.discard(s.cuda_stream)
 
@@ -258,9 +265,8 @@ class TrainEngine:
             self._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self._seed_dev.fill_(int(seed) - (1 << 64) if int(seed) >= (1 << 63) else int(seed))
         kw = dict(is_train_gen=is_train_gen, lr_gen=lr_gen, lr_dis=lr_dis, lr_eva=lr_eva, graph_mode=True)
-        # ROCm 7.2: a stream forked into a capture must not wait on another captured stream (dgg.h) — the two side
-        # compute streams therefore run without weight-gradient streams of their own while capturing
-        self._unmap_wgrad_streams(self._side, self._side2)
+        # (joint_step maps no weight-gradient streams: every stream of the capture is a direct child of the capturing
+        # stream — ROCm 7.2 crashes on a captured stream that waits on another forked one, see dgg.h)
         self.joint_step(gan_inputs, z, eva_inputs, **kw)           # priming step, eager
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
@@ -268,6 +274,15 @@ class TrainEngine:
             self.joint_step(gan_inputs, z, eva_inputs, **kw)
         # the capture itself executed nothing: undo the host-side step counters the captured call advanced
         return GraphStep(self, g, keep, is_train_gen)
+
+    def _mark(self, name, stream=None):
+        """Diagnostics (tools/phase_times.py): with self.trace = [] every joint_step leaves timed events at its phase
+        boundaries on the stream that runs the phase."""
+        tr = getattr(self, "trace", None)
+        if tr is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream if stream is not None else torch.cuda.current_stream(self.device))
+            tr.append((name, ev))
 
     def joint_step(self, gan_inputs, z, eva_inputs, is_train_gen=True, drop_keep=None, seed=0, lr_gen=None,
                    lr_dis=None, lr_eva=None, two_streams=True, next_gan_inputs=None, graph_mode=False):
@@ -305,18 +320,21 @@ class TrainEngine:
             next_gan_inputs = None
         else:
             adam = lambda net, lr: net.adam_step(lr, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
-        main, s2 = self._streams(two_streams, graph_mode)
+        wg = os.environ.get("DGG_JOINT_WGRAD_STREAMS", "0") == "1" and not graph_mode
+        main, s2 = self._streams(two_streams, wgrad=wg)
         if two_streams:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
             side = self._side
             side.wait_stream(main)          # inputs / previous step are ordered before the evaluator update
-            if not graph_mode:
+            if wg:
                 self._map_wgrad_streams(side)
         else:
             side = main
+        self._mark("step_begin")
         check(lib().dgg_cgan_d_phase2(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(self.losses),
                                       stream_ptr(dev), s2), "dgg_cgan_d_phase2")
+        self._mark("d_phase_end")
         self._side2_busy = None             # the D phase joins _side2 (a picked-up prefetch included) into main
         w_d = parallel.allreduce_sum_(D.grads, async_op=True)
         with torch.cuda.stream(side):
@@ -330,14 +348,23 @@ class TrainEngine:
                                           wse.numel(), Be, ptr(ebps), ptr(erot9), ptr(etransl), ptr(elabel), ptr(dk),
                                           int(seed), ptr(self.losses), stream_ptr(dev)), "dgg_eva_phase")
             w_e = parallel.allreduce_sum_(E.grads, async_op=True)
+            self._mark("e_phase_end", side)
+            # the evaluator's optimiser step follows on its own stream at once (it blocks nothing else there; enqueued
+            # after the G phase it would reach the GPU only when the host gets that far — behind the generator's)
+            if w_e is not None:
+                w_e.wait()
+            adam(E, hp.lr_eva)
+            self._mark("adam_e_end", side)
         if w_d is not None:
             w_d.wait()
         adam(D, hp.lr_dis)
+        self._mark("adam_d_end")
         w_g = None
         if is_train_gen:
             check(lib().dgg_cgan_g_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args,
                                          ptr(self.losses), stream_ptr(dev)), "dgg_cgan_g_phase")
             w_g = parallel.allreduce_sum_(G.grads, async_op=True)
+            self._mark("g_phase_end")
             # a ragged next batch (last of an epoch) is simply not prefetched: the workspace is carved per batch size
             if two_streams and next_gan_inputs is not None and next_gan_inputs[0].shape[0] == B:
                 nb, nr, nt, nj_ = next_gan_inputs
@@ -350,14 +377,11 @@ class TrainEngine:
                                                      ptr(nb), ptr(nr), ptr(nt), ptr(nj_), ptr(self.losses), s2),
                       "dgg_cgan_d_real_prefetch")
                 self._side2_busy = self._side2.record_event()
-        with torch.cuda.stream(side):
-            if w_e is not None:
-                w_e.wait()
-            adam(E, hp.lr_eva)
         if is_train_gen:
             if w_g is not None:
                 w_g.wait()
             adam(G, hp.lr_gen)
+            self._mark("adam_g_end")
         if two_streams:
             main.wait_stream(side)
         if graph_mode:       # eager priming step: the host counters follow the device's (a captured call runs nothing)

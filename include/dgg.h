@@ -95,7 +95,9 @@ int dgg_bps_encode(const float* clouds, int B, int N, const float* basis, int P,
 /* Flags */
 #define DGG_TRAIN 1u            /* BatchNorm batch statistics + running-stat update, dropout on */
 #define DGG_ACCUM_GRADS 2u      /* backward: add into grads instead of overwriting */
-#define DGG_SKIP_PARAM_GRADS 4u /* backward: input gradients only (G-phase pass through D) */
+#define DGG_SKIP_PARAM_GRADS 4u /* backward: input gradients only (G-phase pass through D).  Optional on the FORWARD
+                                 * of such a pass: it then skips preparing the operands only a weight-gradient pass
+                                 * reads — a backward WITHOUT this flag must not follow a forward WITH it */
 #define DGG_NEED_INPUT_GRADS 8u /* backward: also produce gradients w.r.t. the network inputs */
 #define DGG_SEED_ON_DEVICE 16u  /* dgg_eva_forward: `seed` holds a device pointer (uint64_t*) to the dropout seed */
 
@@ -321,18 +323,30 @@ int dgg_translate_along_axis(float* transl, const float* rot9, int B, int axis, 
  * mode 0: C[M,N] = A[M,K] * B[N,K]^T;  1: C[M,N] = A[M,K] * B[K,N];  2: C[M,N] = A[K,M]^T * B[K,N].
  * splits >= 1 (split-K through `slabs`, S*M*N floats; reduced into C, or left as slabs when C is
  * NULL); accumulate: C += . */
-/* GEMM arithmetic (process-wide; default DGG_GEMM_BF16X3, or DGG_GEMM_ALGO=f32 in the environment):
+/* GEMM arithmetic (process-wide; default DGG_GEMM_BF16X3; DGG_GEMM_ALGO=f32 / planes in the environment select the others):
  *   DGG_GEMM_F32    : v_mfma_f32_32x32x2_f32, a k-ordered fp32 fma chain (157 TFLOP/s peak on MI355X);
  *   DGG_GEMM_BF16X3 : each fp32 operand split exactly into three bf16 pieces, the six leading partial products
  *                     accumulated in fp32 on v_mfma_f32_32x32x16_bf16 — error below the fp32 accumulation's own
- *                     rounding, 6/16 of the f32-MFMA cost. */
-enum { DGG_GEMM_F32 = 0, DGG_GEMM_BF16X3 = 1 };
+ *                     rounding, 6/16 of the f32-MFMA cost;
+ *   DGG_GEMM_PLANES : the same bf16x3 arithmetic, with the split hoisted out of the GEMM: the kernels that produce the
+ *                     operands of the large products of a TRAIN pass (input BatchNorm, block outputs, dY, and one pass
+ *                     over W13 per forward) also emit their three bf16 planes, and the product runs without vector ALU
+ *                     work in its k loop (csrc/gemm_p3.hip).  Everything else runs as under DGG_GEMM_BF16X3.  The
+ *                     kernel is 20 % faster than the in-register split, the train step is not: optional. */
+enum { DGG_GEMM_F32 = 0, DGG_GEMM_BF16X3 = 1, DGG_GEMM_PLANES = 2 };
 int dgg_set_gemm_algo(int algo);
 int dgg_get_gemm_algo(void);
 /* Diagnostic: workgroups of the GEMM variant (mode, tile) resident per CU according to the HIP occupancy API. */
 int dgg_gemm_occupancy(int mode, int bm, int bn);
 int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C,
                  int ldc, int splits, float* slabs, int accumulate, void* stream);
+/* Diagnostic / test entry of the pre-split GEMM the train step uses for its large products (csrc/gemm_p3.hip):
+ * C[M,N] = sum_k A(m,k) B(n,k) with both fp32 operands first split into their three bf16 planes in `ws`
+ * (dgg_gemm_planes_workspace_bytes).  a_kmajor / b_kmajor != 0: the operand lies [K][rows] in memory (the weight
+ * gradient's operands) and goes through the producer's transposing branch.  splits / slabs / accumulate as above. */
+size_t dgg_gemm_planes_workspace_bytes(int M, int N, int K);
+int dgg_gemm_planes(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb,
+                    float* C, int ldc, int splits, float* slabs, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -91,7 +91,8 @@ def test_gemm_bf16x3_variants(mode, shape, align):
     M, N, K = shape
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K + mode)
     lib = _lib.lib()
-    assert lib.dgg_get_gemm_algo() == 1, "bf16x3 must be the default GEMM arithmetic"
+    default_algo = lib.dgg_get_gemm_algo()
+    assert default_algo == 1, "bf16x3 must be the default GEMM arithmetic"
     try:
         for kind in ["int", "real", "wide"]:
             if kind == "int":
@@ -126,7 +127,7 @@ def test_gemm_bf16x3_variants(mode, shape, align):
                 assert errs[(1, 0)] <= 1.5 * errs[(0, 0)] + 2e-8, errs
             print("gemm error / sum|a||b|  mode %d %s %s: bf16x3 %.2e  f32 %.2e" % (mode, align, kind, errs[(1, 0)], errs[(0, 0)]))
     finally:
-        lib.dgg_set_gemm_algo(1)
+        lib.dgg_set_gemm_algo(default_algo)
 
 
 # ------------------------------------------------------------------ A1: BPS encode
@@ -474,3 +475,71 @@ def test_other_hand_configs():
     p = ops.disc_forward(fd, bps, rot, tr, jt, True)
     pr = O.discriminator_forward(sdd, bps, rot, tr, jt, True)
     np.testing.assert_allclose(p.cpu().numpy(), pr.numpy(), rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ pre-split planes GEMM (DGG_GEMM_PLANES)
+@pytest.mark.parametrize("shape", [(128, 128, 32, 0, 0, 0), (256, 384, 4120, 0, 0, 0), (1024, 768, 4120, 0, 0, 4),
+                                   (300, 200, 77, 0, 0, 0), (768, 4120, 1024, 1, 1, 0), (130, 515, 300, 1, 1, 0),
+                                   (1024, 768, 517, 0, 0, 2)])
+def test_gemm_planes_vs_fp64(shape):
+    """gemm_p3_kernel behind dgg_gemm_planes: both producer branches (row-major and transposing), K tails inside the
+    zero padding, M / N tails, split-K; integers exact, N(0,1) data at fp32-accumulation error."""
+    _, _lib = _ops()
+    lib = _lib.lib()
+    M, N, K, akm, bkm, splits = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    for kind in ("int", "real"):
+        if kind == "int":
+            A = torch.randint(-3, 4, (K, M) if akm else (M, K), generator=g).float().to(DEV)
+            B = torch.randint(-3, 4, (K, N) if bkm else (N, K), generator=g).float().to(DEV)
+        else:
+            A = torch.randn((K, M) if akm else (M, K), generator=g).to(DEV)
+            B = torch.randn((K, N) if bkm else (N, K), generator=g).to(DEV)
+        Cm = torch.empty((M, N), device=DEV)
+        nws = int(lib.dgg_gemm_planes_workspace_bytes(M, N, K))
+        ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+        slabs = torch.empty((max(splits, 1) * M * N,), device=DEV)
+        _lib.check(lib.dgg_gemm_planes(akm, bkm, M, N, K, _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(Cm), N,
+                                       splits, _lib.ptr(slabs) if splits else None, 0, _lib.ptr(ws), nws,
+                                       _lib.stream_ptr()), "dgg_gemm_planes")
+        a64 = A.double().t() if akm else A.double()
+        b64 = B.double() if bkm else B.double().t()
+        ref = a64 @ b64
+        if kind == "int":
+            assert torch.equal(Cm.double(), ref)
+        else:
+            scale = a64.abs() @ b64.abs()
+            assert float(((Cm.double() - ref).abs() / scale).max()) <= 4e-7
+
+
+def test_train_step_on_planes_matches_in_register_split():
+    """DGG_GEMM_PLANES (operands split by their producers: ibn_apply, res_out, bn_bwd_apply, res_out_bwd, one pass over
+    W13) against the default in-register split on the same joint steps: same arithmetic up to the summation order of the
+    k tiles — losses to 1e-5, every parameter after 2 Adam steps within the Adam-of-own-gradients bound."""
+    import test_gpu_fullsize as F
+    _, _lib = _ops()
+    lib = _lib.lib()
+    b = 256
+    gb = F._dev_inputs(synth.make_batch(b, 1))
+    eb = F._dev_inputs(synth.make_batch(b, 2, with_label=True), with_label=True)
+    out = {}
+    try:
+        for algo in (1, 2):
+            assert lib.dgg_set_gemm_algo(algo) == 0
+            eng, _, _ = F._engine("wide")
+            losses = []
+            for i in range(2):
+                z = synth.make_z(b, 100 + i).to(DEV)
+                losses.append(eng.joint_step(gb, z, eb, True, None, 77 + i).cpu())
+            torch.cuda.synchronize()
+            out[algo] = (losses, [x.grads.clone() for x in (eng.G, eng.D, eng.E)], [x.params.clone() for x in (eng.G, eng.D, eng.E)])
+            eng.close()
+    finally:
+        lib.dgg_set_gemm_algo(1)
+    for l1, l2 in zip(out[1][0], out[2][0]):
+        np.testing.assert_allclose(l2[:10].numpy(), l1[:10].numpy(), rtol=2e-5, atol=1e-7)
+    for g1, g2 in zip(out[1][1], out[2][1]):
+        rel = float((g1 - g2).double().norm() / g1.double().norm())
+        assert rel < 2e-4, rel      # step-2 gradients of parameters that differ by Adam-amplified rounding noise
+    for p1, p2 in zip(out[1][2], out[2][2]):
+        assert float((p1 - p2).abs().max()) <= 2.5 * 1e-4 * 2   # hard Adam bound: 2 steps of at most ~lr each

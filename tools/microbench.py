@@ -57,7 +57,7 @@ def main():
                                                  _lib.stream_ptr()))
         ms = time_it(fn, a.iters)
         fl = 2.0 * M * N * K
-        print(json.dumps({"kernel": ("gemm_x3_kernel<NT>" if lib.dgg_get_gemm_algo() == 1 else "gemm_f32_kernel<128,128,NT>"), "mode": a.mode, "M": M, "N": N, "K": K, "splits": S, "ms": ms,
+        print(json.dumps({"kernel": ("gemm_x3_kernel<NT>" if lib.dgg_get_gemm_algo() >= 1 else "gemm_f32_kernel<128,128,NT>"), "mode": a.mode, "M": M, "N": N, "K": K, "splits": S, "ms": ms,
                           "tflops": fl / ms / 1e9, "algorithmic_bytes": 4 * (M * K + N * K + S * M * N)}))
     else:
         B, Np = (1024, 2048) if a.what == "bps" else (1, 73000)
