@@ -114,6 +114,7 @@ SIGNATURES = {
     "dgg_resblock_forward": (_I, [_I, _VP, _VP, _VP, _SZ, _I, _U, _VP, _I, _VP, _VP]),
     "dgg_resblock_backward": (_I, [_I, _VP, _VP, _VP, _SZ, _I, _U, _VP, _I, _VP, _VP, _VP]),
     "dgg_gemm_f32": (_I, [_I, _I, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _VP, _I, _VP]),
+    "dgg_set_grad_events": (_I, [_VP, _VP, _I, _I]),
     "dgg_gemm_planes_workspace_bytes": (_SZ, [_I, _I, _I]),
     "dgg_gemm_planes": (_I, [_I, _I, _I, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _VP, _I, _VP, _SZ, _VP]),
 }
@@ -232,6 +233,14 @@ class FlatNet:
         for name, v in list(self.views("params").items()) + list(self.views("bn").items()):
             out[prefix + name] = v.detach().clone().cpu()
         return out
+
+    def grad_buckets(self):
+        """[(lo, hi)] float ranges of the flat gradient buffer in the order a backward completes them
+        (dgg_set_grad_events): [last block + heads], .., [block 1], [input BatchNorm + block 0]."""
+        starts = sorted(e[1] for e in self.entries if e[4] == 0 and e[0].endswith("fc1.weight"))
+        bounds = [(starts[r], starts[r + 1] if r + 1 < len(starts) else self.n_params) for r in range(len(starts))]
+        bounds[0] = (0, bounds[0][1])
+        return [bounds[r] for r in range(len(starts) - 1, -1, -1)]
 
     def workspace(self, batch):
         """Cached byte workspace for a batch size (caller-owned memory of the C-ABI)."""

@@ -445,6 +445,20 @@ static hipEvent_t next_event() {
     return pool[cur];
 }
 
+// Gradient-ready events (dgg_set_grad_events): per thread, keyed by the gradient buffer a backward writes
+struct GradEvents {
+    const float* grads;
+    hipEvent_t ev[3];
+    int n, accum_only;
+};
+static thread_local GradEvents g_grad_events[4] = {};
+static const GradEvents* grad_events_for(const float* grads) {
+    if (!grads) return nullptr;
+    for (int i = 0; i < 4; ++i)
+        if (g_grad_events[i].grads == grads) return &g_grad_events[i];
+    return nullptr;
+}
+
 static const int kAuxCap = 64;
 struct AuxMap {
     hipStream_t key[kAuxCap], aux[kAuxCap];
@@ -954,6 +968,8 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
                             L.n13 >= kPoseKs * 4 * 32 && (int64_t)L.nrb * pose_used * kPoseLd <= L.ldx0;
     int ibn_tiles[3] = {0, 0, 0};
     const bool drop = (L.net == DGG_NET_EVA) && c.train;
+    const GradEvents* ge = skip ? nullptr : grad_events_for(grads);
+    if (ge && (ge->n != L.nrb || (ge->accum_only && !accum))) ge = nullptr;
     // heads
     float* dy = c.W.dXa;
     float* other = c.W.dXb;
@@ -984,6 +1000,9 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
         }
         DGG_TRY(rb_backward(c, r, segs, nseg, dy, drop, accum, skip, ibn_tiles,
                             (fold_head && r == L.nrb - 1) ? &hb : nullptr));
+        // block r's parameter gradients (and, for the last block, the heads') are complete on the stream that ran its
+        // weight-gradient GEMMs: a data-parallel caller starts that bucket's all-reduce behind this event
+        if (ge && r >= 1 && hipEventRecord(ge->ev[r], c.sw ? c.sw : st) != hipSuccess) return DGG_ERR_LAUNCH;
         float* t = dy; dy = other; other = t;
     }
     // input BatchNorm backward: parameter gradients = sum over ResBlocks and row tiles of the epilogue partials
@@ -1000,6 +1019,8 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
                                            L.nprefix));
         }
     }
+    // everything else — block 0 and the input BatchNorm — is complete here
+    if (ge && hipEventRecord(ge->ev[0], st) != hipSuccess) return DGG_ERR_LAUNCH;
     if (want_in) {  // input gradients for the requested columns through the (train: batch-statistics) BN backward
         ColSrcs sub = sub_srcs(srcs, d_in_lo, d_in_hi);
         const float* dsrc = c.W.dX0;
@@ -1735,6 +1756,7 @@ int dgg_cgan_release(void* ws) {
 }
 
 int dgg_reset(void) {
+    memset(g_grad_events, 0, sizeof(g_grad_events));
     for (int i = 0; i < kPendingSlots; ++i) {
         g_pending[i].ws = nullptr;
         g_pending[i].valid = false;
@@ -2115,6 +2137,32 @@ int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const f
     prob_init(g.p[0], A, lda, Bm, ldb, C, ldc, M, N, K);
     g.p[0].accumulate = accumulate;
     return gemm_launch(mode, g, st);
+}
+
+int dgg_set_grad_events(const float* grads, void* const* events, int n, int accum_only) {
+    if (!grads) {  // clear the calling thread's registrations
+        memset(g_grad_events, 0, sizeof(g_grad_events));
+        return DGG_OK;
+    }
+    int slot = -1;
+    for (int i = 0; i < 4; ++i)
+        if (g_grad_events[i].grads == grads) slot = i;
+    if (!events || n <= 0) {  // unregister
+        if (slot >= 0) memset(&g_grad_events[slot], 0, sizeof(GradEvents));
+        return DGG_OK;
+    }
+    if (n > 3) return DGG_ERR_INVALID;
+    for (int i = 0; i < 4 && slot < 0; ++i)
+        if (!g_grad_events[i].grads) slot = i;
+    if (slot < 0) return DGG_ERR_INVALID;
+    for (int i = 0; i < n; ++i) {
+        if (!events[i]) return DGG_ERR_INVALID;
+        g_grad_events[slot].ev[i] = (hipEvent_t)events[i];
+    }
+    g_grad_events[slot].grads = grads;
+    g_grad_events[slot].n = n;
+    g_grad_events[slot].accum_only = accum_only;
+    return DGG_OK;
 }
 
 size_t dgg_gemm_planes_workspace_bytes(int M, int N, int K) {

@@ -82,6 +82,62 @@ def allreduce_sum_(flat_grads, async_op=False):
     return dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
+class BucketReducer:
+    """All-reduce of one network's flat gradient buffer in the buckets a backward completes them in
+    (FlatNet.grad_buckets / dgg_set_grad_events): the library records an event per bucket inside the backward's launch
+    sequence, a feeder stream waits for it and issues that bucket's collective — so the all-reduce of the later
+    ResBlocks (their W13 is ~half of the network) runs while the earlier blocks are still being back-propagated, and
+    only the last bucket is exposed.  Same sums as one all-reduce of the whole buffer (element-wise, disjoint ranges)."""
+
+    def __init__(self, flat, accum_only=False):
+        from . import _lib
+        self.flat = flat
+        self.accum_only = bool(accum_only)
+        self.bounds = flat.grad_buckets()
+        dev = flat.grads.device
+        self.feeder = torch.cuda.Stream(device=dev)
+        self.events = [torch.cuda.Event() for _ in self.bounds]
+        for ev in self.events:            # materialise the handles
+            ev.record(torch.cuda.current_stream(dev))
+        n = len(self.events)
+        arr = (_lib.C.c_void_p * n)()
+        # bounds are in readiness order [block n-1, .., block 0]; the library indexes events by block
+        for i, ev in enumerate(self.events):
+            arr[n - 1 - i] = ev.cuda_event
+        self._arr = arr
+        self._lib = _lib
+        self.armed = False
+
+    def arm(self):
+        """Register the events with the library (calling thread) — before the phase call whose backward fills them."""
+        L = self._lib
+        L.check(L.lib().dgg_set_grad_events(L.ptr(self.flat.grads), self._arr, len(self.events), int(self.accum_only)),
+                "dgg_set_grad_events")
+        self.armed = True
+
+    def disarm(self):
+        if self.armed:
+            L = self._lib
+            L.lib().dgg_set_grad_events(L.ptr(self.flat.grads), None, 0, 0)
+            self.armed = False
+
+    def reduce_async(self):
+        """After the phase call: enqueue the bucket collectives behind their events.  Returns the work handles; wait()
+        on each (a stream-level dependency for RCCL) before the optimiser step."""
+        works = []
+        for (lo, hi), ev in zip(self.bounds, self.events):
+            self.feeder.wait_event(ev)
+            with torch.cuda.stream(self.feeder):
+                works.append(dist.all_reduce(self.flat.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        return works
+
+
+def wait_all(works):
+    for w in works or ():
+        if w is not None:
+            w.wait()
+
+
 def broadcast_(t, src=0):
     """In-place broadcast of a tensor from rank `src` (replicas start / resume identical)."""
     if is_distributed():

@@ -232,6 +232,17 @@ int dgg_enable_wgrad_stream(void* stream, int enable);
  * (hip::Stream::EndCapture then recurses without end), so map weight-gradient side streams only to the capturing
  * stream itself — second compute streams (stream2 below, a caller's evaluator stream) run their dW GEMMs in line. */
 
+/* Gradient-ready events for data-parallel callers (per calling thread).  While `events` are registered for a gradient
+ * buffer, every backward / phase call that writes parameter gradients into exactly that buffer records, in stream
+ * order, events[r] (hipEvent_t, r = n-1 .. 1) as soon as ResBlock r's gradients — for the last block also the heads' —
+ * are complete, and events[0] when the rest (input BatchNorm, block 0) is: the flat layout puts these ranges back to back
+ * (dgg_table: [input BN | block 0 | block 1 | .. | heads]), so an all-reduce of the later blocks' range can run while the
+ * backward of the earlier blocks is still in flight.  n must equal the network's number of ResBlocks (else nothing is
+ * recorded).  accum_only != 0: only calls with DGG_ACCUM_GRADS record (the discriminator's gradients are final after
+ * the fake-batch pass, which accumulates onto the real-batch pass).  events == NULL or n == 0 unregisters `grads`;
+ * grads == NULL unregisters everything. */
+int dgg_set_grad_events(const float* grads, void* const* events, int n, int accum_only);
+
 /* Steps 1-8 of SURVEY.md 3.1 up to (not including) optim_D.step: G forward (train), ortho6d,
  * D forward on real then on fake.detach(), discriminator loss, D backward (both) -> st->d_grads.
  * Inputs: bps (B,4096), rot9 (B,9), transl (B,3), joint (B,nj) = the real batch; z (B,latent). */

@@ -25,6 +25,11 @@ e_in = (f(eb["bps_object"]), f(eb["rot_matrix"]).reshape(B, 9), f(eb["transl"]),
 z = synth.make_z(B, 3).to(dev)
 PRE = os.environ.get("DGG_PREFETCH", "1") != "0"
 nxt = lambda i: g_ins[(i + 1) % 2] if PRE else None
+PRIO = int(os.environ.get("DGG_MAIN_PRIO", "0"))
+if PRIO != 0:
+    print("stream priority range (least, greatest):", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "n/a")
+    hp = torch.cuda.Stream(device=dev, priority=PRIO)
+    torch.cuda.set_stream(hp)
 for i in range(20):
     eng.joint_step(g_ins[i % 2], z, e_in, True, None, i, next_gan_inputs=nxt(i))
 torch.cuda.synchronize()
