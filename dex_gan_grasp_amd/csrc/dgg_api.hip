@@ -243,6 +243,7 @@ struct RbW {
     float *mean1, *rstd1, *mean2, *rstd2;
 };
 struct NetW {
+    float* ivaru;                // [k_in] unbiased batch variance of the input (kept for DGG_REUSE_INPUT_NORM)
     float *X0, *imean, *irstd;   // X0 holds [prefix | x_hat]: the input BatchNorm's gamma/beta are folded into
                                  // the GEMMs (aff_scale / aff_shift), never applied to the stored operand
     float *aff_scale, *aff_shift;  // [k0]: [1.. | gamma], [0.. | beta]
@@ -343,6 +344,7 @@ static void carve(const NetL& L, int B, void* base, NetW& W) {
     W.X0 = b.take<float>(Bz * L.ldx0);
     W.imean = b.take<float>(2 * (size_t)L.k_in);
     W.irstd = b.take<float>(2 * (size_t)L.k_in);
+    W.ivaru = b.take<float>((size_t)L.k_in);
     W.aff_scale = b.take<float>((size_t)L.k0);
     W.aff_shift = b.take<float>((size_t)L.k0);
     for (int r = 0; r < L.nrb; ++r) W.cs13[r] = b.take<float>((size_t)L.n13);
@@ -867,15 +869,21 @@ static int net_forward(const NetL& L, const float* params, float* bn, void* ws, 
     carve(L, B, ws, c.W);
     if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
     if (!bn) return DGG_ERR_INVALID;
-    if (c.train) DGG_TRY(ibn_stats_launch(srcs, B, 1, c.W.part, st));
+    // (not with the planes GEMM: the fake-batch pass of a D phase has no large forward product and left no X0 planes)
+    const bool reuse_norm = c.train && (flags & DGG_REUSE_INPUT_NORM) != 0 && !(c.W.p3 && gemm_algo() == 2);
+    if (c.train && !reuse_norm) DGG_TRY(ibn_stats_launch(srcs, B, 1, c.W.part, st));
     // Train pass on the planes GEMM (gemm_p3.hip): the operands are split where they are produced — the input
     // BatchNorm emits [gamma x_hat + beta] row-major for the forward and x_hat transposed for the weight gradient,
     // every block's output and dY13 follow in rb_tail / rb_backward — and W13's column pieces in one launch here
     c.p3 = c.train && c.W.p3 && gemm_algo() == 2;
     c.p3_fwd = c.p3 && p3_use_fwd() && !(share && share->mode == 2);
     c.p3_t = c.p3 && p3_use_wgrad() && !(flags & DGG_SKIP_PARAM_GRADS);
-    {
-        BnFused fz{c.W.part, c.train ? 1 : 0, bn + L.irm, bn + L.irv, c.W.imean, c.W.irstd};
+    if (reuse_norm) {
+        // x_hat, its planes, mean and rstd of this workspace are those of the previous train forward over these inputs
+        DGG_TRY(ibn_refresh_launch(c.W.imean, c.W.ivaru, bn + L.irm, bn + L.irv, params + L.ibnw, params + L.ibnb,
+                                   c.W.aff_scale, c.W.aff_shift, L.nprefix, L.k_in, st));
+    } else {
+        BnFused fz{c.W.part, c.train ? 1 : 0, bn + L.irm, bn + L.irv, c.W.imean, c.W.irstd, c.W.ivaru};
         PlaneOut pl = {c.p3_fwd ? c.W.X0p : nullptr, c.W.ldk0, 0, (long long)B * c.W.ldk0,
                        c.p3_t ? c.W.X0t : nullptr, c.W.ldB, 0, (long long)L.k0 * c.W.ldB};
         DGG_TRY(ibn_apply_launch(srcs, B, B, c.W.imean, c.W.irstd, nullptr, nullptr, prefix, L.nprefix, c.W.X0, L.ldx0,
@@ -1681,8 +1689,10 @@ int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
     float* g_transl = S.f_transl;
     float* g_joint = S.f_joint;
     // (no weight gradient follows this pass: DGG_SKIP_PARAM_GRADS spares the forward the operands only a wgrad reads)
-    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN | DGG_SKIP_PARAM_GRADS, bps,
-                             S.rfake, g_transl, g_joint, S.p_gen, stream));
+    // Same inputs as the D phase's fake-batch pass, same workspace: the input normalisation is reused.
+    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B,
+                             DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_REUSE_INPUT_NORM, bps, S.rfake, g_transl, g_joint,
+                             S.p_gen, stream));
     // D-free mark: from here on nothing in this step writes D's parameters or running statistics
     if (PendingReal* Pp = pending_slot(ws, true)) {
         if (hipEventRecord(Pp->ev[5], st) != hipSuccess) return DGG_ERR_LAUNCH;

@@ -131,7 +131,12 @@ struct BnFused {
     const float* part;
     int train;
     float *run_mean, *run_var, *mean_out, *rstd_out;
+    float* varu_out = nullptr;  // optional (group 0): unbiased batch variance, for ibn_refresh_launch
 };
+// Advance the running statistics once more with stored batch statistics and rewrite the affine vectors (a second
+// train-mode forward over the same inputs with updated gamma / beta).
+int ibn_refresh_launch(const float* mean, const float* var_u, float* run_mean, float* run_var, const float* gamma,
+                       const float* beta, float* aff_scale, float* aff_shift, int nprefix, int total, hipStream_t st);
 // X0[m][col_off + c] = (x - mean)*rstd*gamma + beta over the concat; optionally copies `prefix`
 // (B, nprefix) into columns [0, nprefix).
 int ibn_apply_launch(const ColSrcs& srcs, int B, int rows_per_group, const float* mean, const float* rstd,

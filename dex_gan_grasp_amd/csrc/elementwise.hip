@@ -197,6 +197,7 @@ struct BnFin {
     const float* part;   // NULL: statistics were finalized by an earlier launch (mean / rstd arrays are read)
     int nrb, train;
     float *run_mean, *run_var, *mean_out, *rstd_out;
+    float* varu_out;     // optional: the unbiased batch variance (what the running variance integrates), group 0
 };
 __device__ __forceinline__ void bn_block_stats(const BnFin& f, int rpg, int groups, int ncols, int c, bool cok,
                                                bool writer, float (*sh)[3][64], float (*res)[2][64]) {
@@ -268,6 +269,7 @@ __device__ __forceinline__ void bn_block_stats(const BnFin& f, int rpg, int grou
                 f.rstd_out[g * ncols + c] = rstd;
             }
             const float var_u = m2 / (cnt - 1.f);
+            if (writer && cok && g == 0 && f.varu_out) f.varu_out[c] = var_u;
             rm = (1.f - kBnMom) * rm + kBnMom * mean;
             rv = (1.f - kBnMom) * rv + kBnMom * var_u;
         }
@@ -1349,7 +1351,37 @@ static int make_fin(const BnFused* fz, int rpg, BnFin& fin) {
     fin.run_var = fz->run_var;
     fin.mean_out = fz->mean_out;
     fin.rstd_out = fz->rstd_out;
+    fin.varu_out = fz->varu_out;
     return DGG_OK;
+}
+
+// A second train-mode forward over the SAME inputs (the G phase's pass through the updated discriminator,
+// dexgangrasp.py:808 after :789): x_hat, mean and rstd in the workspace are still right — only the running statistics
+// advance once more (same batch statistics) and the affine vectors follow the updated gamma / beta.
+__global__ __launch_bounds__(256) void ibn_refresh_kernel(const float* __restrict__ mean, const float* __restrict__ var_u,
+                                                          float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ aff_scale, float* __restrict__ aff_shift,
+                                                          int nprefix, int total) {
+    const int oc = blockIdx.x * 256 + threadIdx.x;
+    if (oc >= nprefix + total) return;
+    if (oc < nprefix) {
+        aff_scale[oc] = 1.f;
+        aff_shift[oc] = 0.f;
+        return;
+    }
+    const int c = oc - nprefix;
+    run_mean[c] = (1.f - kBnMom) * run_mean[c] + kBnMom * mean[c];
+    run_var[c] = (1.f - kBnMom) * run_var[c] + kBnMom * var_u[c];
+    aff_scale[oc] = gamma[c];
+    aff_shift[oc] = beta[c];
+}
+
+int ibn_refresh_launch(const float* mean, const float* var_u, float* run_mean, float* run_var, const float* gamma,
+                       const float* beta, float* aff_scale, float* aff_shift, int nprefix, int total, hipStream_t st) {
+    hipLaunchKernelGGL(ibn_refresh_kernel, dim3(cdiv(nprefix + total, 256)), dim3(256), 0, st, mean, var_u, run_mean,
+                       run_var, gamma, beta, aff_scale, aff_shift, nprefix, total);
+    return check_launch("ibn_refresh");
 }
 
 int ibn_apply_launch(const ColSrcs& srcs, int B, int rpg, const float* mean, const float* rstd, const float* gamma,

@@ -99,6 +99,9 @@ int dgg_bps_encode(const float* clouds, int B, int N, const float* basis, int P,
                                  * of such a pass: it then skips preparing the operands only a weight-gradient pass
                                  * reads — a backward WITHOUT this flag must not follow a forward WITH it */
 #define DGG_NEED_INPUT_GRADS 8u /* backward: also produce gradients w.r.t. the network inputs */
+#define DGG_REUSE_INPUT_NORM 32u /* forward (train): the workspace still holds the normalised input of the previous TRAIN
+                                  * forward over the very same inputs (dgg_cgan_g_phase after dgg_cgan_d_phase2): only
+                                  * the running statistics advance and the affine follows the current gamma / beta */
 #define DGG_SEED_ON_DEVICE 16u  /* dgg_eva_forward: `seed` holds a device pointer (uint64_t*) to the dropout seed */
 
 /* A2 — ResBlock.forward(x, final_nl=True) on its own, networks.py:43-56 (Fin != Fout: fc3 present, as at every
