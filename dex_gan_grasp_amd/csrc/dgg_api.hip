@@ -268,6 +268,10 @@ struct NetW {
 };
 static const int kP3MaxB = 8192;   // larger batches (inference sweeps) never train: no planes carved for them
 // diagnostics: DGG_P3_FWD=0 / DGG_P3_WGRAD=0 keep the forward / the weight gradient on the in-register-split kernel
+static bool fuse_fc2() {  // diagnostics: DGG_FUSE_FC2=0 keeps bn_act / fc2 GEMM / reduce as separate launches
+    static const bool v = [] { const char* e = getenv("DGG_FUSE_FC2"); return !(e && e[0] == '0'); }();
+    return v;
+}
 static bool p3_use_fwd() {
     static const bool v = [] { const char* e = getenv("DGG_P3_FWD"); return !(e && e[0] == '0'); }();
     return v;
@@ -621,15 +625,40 @@ static int rb_tail(Ctx& c, int r, int drop_mode, const float* keep_in, uint64_t 
     const RbL& R = L.rb[r];
     RbW& A = c.W.rb[r];
     const int B = c.B;
-    // 3. h = lrelu(bn1(a1)); the statistics are finalized inside the kernel (mean1 / rstd1 kept for the backward)
-    {
-        BnFused fz{c.W.part, c.train ? 1 : 0, c.bn ? c.bn + R.rm1 : nullptr, c.bn ? c.bn + R.rv1 : nullptr, A.mean1,
-                   A.rstd1};
-        DGG_TRY(bn_act_launch(A.a13, L.n13, B, B, L.hid, A.mean1, A.rstd1, c.P + R.bn1w, c.P + R.bn1b, A.h, L.hid, c.st,
-                              &fz));
-    }
-    // 4. a2 = h W2^T + b2 (K = 256)
-    {
+    // 3 + 4. h = lrelu(bn1(a1)) and a2 = h W2^T + b2 (K = 256) in ONE launch: the GEMM finalizes bn1's statistics in its
+    //    prologue (mean1 / rstd1 kept for the backward), normalises and activates its A operand while staging it (writing
+    //    h out for the backward), adds the bias and emits bn2's row-block partials in its epilogue (GemmProb::bn_part).
+    //    DGG_FUSE_FC2=0: the four-launch form (bn_act, GEMM, bias/statistics reduce).
+    const int nrb_b = (B + kRowBlock - 1) / kRowBlock;
+    float* part_bn2 = c.W.part;
+    if (fuse_fc2() && L.hid <= 256) {
+        GemmBatch g2;
+        memset(&g2, 0, sizeof(g2));
+        g2.nprob = 1;
+        GemmProb& q = g2.p[0];
+        prob_init(q, A.a13, L.n13, c.P + R.w2, L.hid, A.a2, L.nn, B, L.nn, L.hid);
+        q.bn_part = c.W.part;
+        q.bn_nrb = nrb_b;
+        q.bn_train = c.train ? 1 : 0;
+        q.bn_rows = B;
+        q.bn_gamma = c.P + R.bn1w;
+        q.bn_beta = c.P + R.bn1b;
+        q.bn_run_mean = c.bn ? c.bn + R.rm1 : nullptr;
+        q.bn_run_var = c.bn ? c.bn + R.rv1 : nullptr;
+        q.bn_mean_out = A.mean1;
+        q.bn_rstd_out = A.rstd1;
+        q.a_out = A.h;
+        q.c_bias = c.P + R.b2;
+        q.c_part = c.W.part2;   // other workgroups are still reading W.part
+        DGG_TRY(gemm_fc2_fused_launch(g2, c.st));
+        part_bn2 = c.W.part2;
+    } else {
+        {
+            BnFused fz{c.W.part, c.train ? 1 : 0, c.bn ? c.bn + R.rm1 : nullptr, c.bn ? c.bn + R.rv1 : nullptr, A.mean1,
+                       A.rstd1};
+            DGG_TRY(bn_act_launch(A.a13, L.n13, B, B, L.hid, A.mean1, A.rstd1, c.P + R.bn1w, c.P + R.bn1b, A.h, L.hid,
+                                  c.st, &fz));
+        }
         GemmBatch g2;
         memset(&g2, 0, sizeof(g2));
         g2.nprob = 1;
@@ -642,7 +671,7 @@ static int rb_tail(Ctx& c, int r, int drop_mode, const float* keep_in, uint64_t 
     }
     // 5. y = lrelu(s + bn2(a2)) [dropout]; bn2's statistics finalized inside
     {
-        BnFused fz{c.W.part, c.train ? 1 : 0, c.bn ? c.bn + R.rm2 : nullptr, c.bn ? c.bn + R.rv2 : nullptr, A.mean2,
+        BnFused fz{part_bn2, c.train ? 1 : 0, c.bn ? c.bn + R.rm2 : nullptr, c.bn ? c.bn + R.rv2 : nullptr, A.mean2,
                    A.rstd2};
         // y is the next block's second operand: its planes for that block's forward and (transposed) weight gradient
         const bool more = (c.p3_fwd || c.p3_t) && r + 1 < L.nrb;
@@ -1135,6 +1164,7 @@ static void carve_objects(const NetL& L, int O, int n, void* base, ObjW& W) {
     W.S.slabs = b.take<float>((size_t)need);
     const size_t nrb = (Bz + kRowBlock - 1) / kRowBlock + 2;
     W.S.part = b.take<float>(nrb * 2 * (size_t)L.n13);
+    W.S.part2 = b.take<float>(nrb * 2 * (size_t)L.n13);  // rb_tail: the fc2 GEMM's bn2 partials (it still reads part)
     W.bytes = (b.off + 255) & ~(size_t)255;
 }
 

@@ -48,6 +48,20 @@ struct GemmProb {
     const float* ep_w;     // weights, indexed like C (row n, column k), pitch ep_ldw
     int ep_ldw;
     float* ep_part;        // [tiles_m][2][N]
+    // gemm_f32 NT with 64 x 64 tiles only ("fc2 forward", bn_part != NULL): the A operand is a PRE-activation whose
+    // train-mode BatchNorm + LeakyReLU is applied while it is staged — every workgroup first merges the row-block
+    // partials bn_part [bn_nrb][2][K] of all K <= 256 columns (same order everywhere), the first one also stores
+    // mean / rstd and advances the running statistics; the activated operand is written to a_out (pitch K) by the first
+    // column of tiles.  Epilogue: C = acc + c_bias[n] and the (mean, M2) partials of every 32-row block of C to c_part
+    // [row block][2][N] (what reduce_bias_kernel emits) — a whole ResBlock stage h = lrelu(bn1(a1)), a2 = h W2^T + b2
+    // in one launch.
+    const float* bn_part;
+    int bn_nrb, bn_train, bn_rows;     // rows per batch (the partials' last block may be short)
+    const float *bn_gamma, *bn_beta;
+    float *bn_run_mean, *bn_run_var, *bn_mean_out, *bn_rstd_out;
+    float* a_out;
+    const float* c_bias;
+    float* c_part;
     // gemm_p3 only: the operands are bf16 planes (A / B point at plane 0, lda / ldb and these plane distances count
     // bf16 elements); 0 = fp32 operand
     long long a_plane, b_plane;
@@ -61,6 +75,8 @@ enum GemmMode { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
 // Fills tiling fields of one problem for the tile shape the launcher will use; returns #blocks.
 int gemm_plan(GemmProb& p, int mode, int splits);
 int gemm_launch(int mode, GemmBatch& batch, hipStream_t st);
+// NT, one problem with GemmProb::bn_part set (see there): 64 x 64 tiles, no split-K, K <= 256
+int gemm_fc2_fused_launch(GemmBatch& batch, hipStream_t st);
 int gemm_pick_splits(int mode, int M, int N, int K, int other_blocks);
 void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn, int K = 1 << 30);
 int gemm_occupancy(int mode, int bm, int bn);

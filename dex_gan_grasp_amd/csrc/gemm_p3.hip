@@ -64,7 +64,10 @@ struct P3Frags {
 
 template <bool WGRAD>
 __global__ __launch_bounds__(256) void gemm_p3_kernel(const GemmBatch batch) {
-    __shared__ __attribute__((aligned(16))) char smem[PS * PSTAGE];
+#ifndef DGG_P3_LDS_PAD
+#define DGG_P3_LDS_PAD 0
+#endif
+    __shared__ __attribute__((aligned(16))) char smem[PS * PSTAGE + DGG_P3_LDS_PAD];
 
     // ---- work assignment: as gemm_f32_kernel (problem select, XCD-contiguous remap, split-K range)
     GemmProb P = batch.p[0];

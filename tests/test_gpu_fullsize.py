@@ -538,8 +538,10 @@ def test_config5_sweep_at_rank_share_size():
             if cnt and near == 0:   # same SET of grasps (scores 1e-7 apart may swap places in the two orderings)
                 sel = out["order"][o, :cnt].cpu().numpy()
                 a, c = out["transl"][o].cpu().numpy()[sel], f["transl"]
-                a, c = a[np.lexsort(a.T[::-1])], c[np.lexsort(c.T[::-1])]
-                np.testing.assert_allclose(a, c, rtol=0, atol=2e-5)
+                # set equality up to 2e-5: every row of one has a partner in the other (sorting the rows instead breaks
+                # when two grasps agree in their first coordinate to within the 1e-6 the two paths differ by)
+                dist = np.abs(a[:, None, :] - c[None, :, :]).max(-1)
+                assert a.shape == c.shape and dist.min(1).max() <= 2e-5 and dist.min(0).max() <= 2e-5, (o, thr)
     # the factorised passes against the tiled (dense) ones on a slice: same grasps and scores up to the summation order
     dn = m.sweep_objects(rows[:40], n, thresholds=thresholds, z=z[:40 * n], dense=True)
     for k in ("transl", "rot_matrix", "joint_conf", "score"):
