@@ -1682,10 +1682,8 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
     }
     // ---- stream A: :772-776 generator forward (train mode, activations kept for the G phase), R = ortho6d(rot_6D)
     DGG_TRY(dgg_gen_forward(cfg, s->g_params, s->g_bn, S.ws_g, S.g_bytes, B, DGG_TRAIN, z, bps, S.heads, stream));
-    DGG_TRY(ortho6d_fwd_launch(S.heads + nj, nh, B, S.rfake, st));
-    // fake transl / joint live inside the heads buffer with pitch nh: pack contiguous copies for D
-    DGG_TRY(copy_cols_launch(S.heads + nj + 6, nh, S.f_transl, 3, B, 3, st));
-    DGG_TRY(copy_cols_launch(S.heads, nh, S.f_joint, nj, B, nj, st));
+    // R = ortho6d(rot_6D); fake transl / joint live inside the heads buffer with pitch nh: contiguous copies for D
+    DGG_TRY(fake_pose_launch(S.heads, nh, nj, B, S.rfake, S.f_transl, S.f_joint, st));
     // :789 D(fake.detach()): its BatchNorm running-statistic updates must follow those of the real pass
     if (fork && hipStreamWaitEvent(st, ev[1], 0) != hipSuccess) return DGG_ERR_LAUNCH;
     share.mode = 2;
@@ -2076,9 +2074,7 @@ int dgg_wgan_d_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
     hipStream_t st = (hipStream_t)stream;
     // :772-776 generator forward (train, activations kept for the G phase), R = ortho6d(rot_6D)
     DGG_TRY(dgg_gen_forward(cfg, s->g_params, s->g_bn, S.ws_g, S.g_bytes, B, DGG_TRAIN, z, bps, S.heads, stream));
-    DGG_TRY(ortho6d_fwd_launch(S.heads + nj, nh, B, S.rfake, st));
-    DGG_TRY(copy_cols_launch(S.heads + nj + 6, nh, S.f_transl, 3, B, 3, st));
-    DGG_TRY(copy_cols_launch(S.heads, nh, S.f_joint, nj, B, nj, st));
+    DGG_TRY(fake_pose_launch(S.heads, nh, nj, B, S.rfake, S.f_transl, S.f_joint, st));
     // :788-789 D(real), D(fake.detach()); :199-205 -mean(real) + mean(fake)
     DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint, S.p_real,
                              stream));

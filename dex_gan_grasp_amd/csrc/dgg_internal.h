@@ -250,6 +250,7 @@ int ibn_bwd_apply_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col
 int bce_launch(const float* p, const float* labels, float target_const, int B, float weight, float loss_scale,
                float* loss_out, float* d_logit, hipStream_t st);
 int ortho6d_fwd_launch(const float* o6, int ld, int B, float* rot9, hipStream_t st);
+int fake_pose_launch(const float* heads, int ld, int nj, int B, float* rot9, float* transl, float* joint, hipStream_t st);
 int ortho6d_bwd_launch(const float* o6, int ld, int B, const float* d_rot9, float* d_o6, int ldd, hipStream_t st);
 int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const float* heads, const float* gt_rot9,
                     const float* gt_transl, const float* gt_joint, const float* fake_score, const float* d_pose,

@@ -1150,6 +1150,24 @@ __global__ __launch_bounds__(256) void ortho6d_fwd_kernel(const float* __restric
     for (int r = 0; r < 3; ++r) { o[3 * r] = R.x[r]; o[3 * r + 1] = R.y[r]; o[3 * r + 2] = R.z[r]; }
 }
 
+// The generator's output row [joint (nj) | rot6 | transl] -> what the discriminator takes: R = ortho6d(rot6) (9), and
+// contiguous copies of transl (3) and joint (nj) — one launch instead of ortho6d + two column copies
+__global__ __launch_bounds__(256) void fake_pose_kernel(const float* __restrict__ heads, int ld, int nj, int B,
+                                                        float* __restrict__ rot9, float* __restrict__ transl,
+                                                        float* __restrict__ joint) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const float* h = heads + (size_t)i * ld;
+    Rot R;
+    ortho6d(h + nj, R);
+    float* o = rot9 + (size_t)i * 9;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { o[3 * r] = R.x[r]; o[3 * r + 1] = R.y[r]; o[3 * r + 2] = R.z[r]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) transl[(size_t)i * 3 + k] = h[nj + 6 + k];
+    for (int k = 0; k < nj; ++k) joint[(size_t)i * nj + k] = h[k];
+}
+
 __global__ __launch_bounds__(256) void ortho6d_bwd_kernel(const float* __restrict__ o6, int ld, int B,
                                                           const float* __restrict__ d_rot9, float* __restrict__ d_o6,
                                                           int ldd) {
@@ -1508,20 +1526,33 @@ int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, in
 
 constexpr int kNhMax = 32;
 
-// column sums of a narrow (B x n <= 32) matrix; one workgroup, fixed summation order
-__global__ __launch_bounds__(256) void narrow_colsum_kernel(const float* __restrict__ x, int ld, int B, int n,
-                                                            float* __restrict__ dst, int accumulate) {
-    __shared__ float sh[8][32];
-    const int j = threadIdx.x & 31, s8 = threadIdx.x >> 5;
+// column sums of a narrow (B x n <= 32) matrix; one workgroup of 1024 threads = 32 row lanes x 32 columns, 8 loads in
+// flight per thread (a row loop with one load per trip costs B / 8 serial memory round trips: 15 us at B = 1024), fixed
+// summation order
+__global__ __launch_bounds__(1024) void narrow_colsum_kernel(const float* __restrict__ x, int ld, int B, int n,
+                                                             float* __restrict__ dst, int accumulate) {
+    __shared__ float sh[32][33];
+    const int j = threadIdx.x & 31, rl = threadIdx.x >> 5;
     float a = 0.f;
-    if (j < n)
-        for (int r = s8; r < B; r += 8) a += x[(size_t)r * ld + j];
-    sh[s8][j] = a;
+    if (j < n) {
+        for (int r0 = rl; r0 < B; r0 += 32 * 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + 32 * u;
+                t[u] = x[(size_t)(r < B ? r : B - 1) * ld + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (r0 + 32 * u < B) a += t[u];
+        }
+    }
+    sh[rl][j] = a;
     __syncthreads();
-    if (s8 == 0 && j < n) {
+    if (rl == 0 && j < n) {
         float t = sh[0][j];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) t += sh[q][j];
+        for (int q = 1; q < 32; ++q) t += sh[q][j];
         dst[j] = accumulate ? dst[j] + t : t;
     }
 }
@@ -1583,7 +1614,7 @@ int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B,
         rc = reduce_bias_launch(scratch, g.p[0].splits, (long long)nh * K, K, nullptr, gwh, K, nh, nh, 1, K, 0, 0, 0, 0,
                                 nullptr, st, accumulate);
         if (rc) return rc;
-        hipLaunchKernelGGL(narrow_colsum_kernel, dim3(1), dim3(256), 0, st, dout, ldd, B, nh, gbh, accumulate);
+        hipLaunchKernelGGL(narrow_colsum_kernel, dim3(1), dim3(1024), 0, st, dout, ldd, B, nh, gbh, accumulate);
         return check_launch("narrow_colsum");
     }
     // nh == 1: folded into the last ResBlock's backward (res_out_bwd head mode), see net_backward
@@ -1681,6 +1712,11 @@ int bce_launch(const float* p, const float* labels, float target_const, int B, f
 int ortho6d_fwd_launch(const float* o6, int ld, int B, float* rot9, hipStream_t st) {
     hipLaunchKernelGGL(ortho6d_fwd_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, o6, ld, B, rot9);
     return check_launch("ortho6d_fwd");
+}
+
+int fake_pose_launch(const float* heads, int ld, int nj, int B, float* rot9, float* transl, float* joint, hipStream_t st) {
+    hipLaunchKernelGGL(fake_pose_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, heads, ld, nj, B, rot9, transl, joint);
+    return check_launch("fake_pose");
 }
 
 int ortho6d_bwd_launch(const float* o6, int ld, int B, const float* d_rot9, float* d_o6, int ldd, hipStream_t st) {

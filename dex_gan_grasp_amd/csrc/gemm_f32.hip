@@ -187,16 +187,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
             float mean = 0.f, rstd;
             if (P.bn_train) {
                 float cnt = 0.f, m2 = 0.f;
-                for (int b8 = 0; b8 < P.bn_nrb; b8 += 8) {
-                    float mb[8], qb[8];
+                for (int b8 = 0; b8 < P.bn_nrb; b8 += 16) {  // 32 loads in flight: one round trip per 16 row blocks
+                    float mb[16], qb[16];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < 16; ++j) {
                         const float* q = P.bn_part + (size_t)min(b8 + j, P.bn_nrb - 1) * 2 * P.K;
                         mb[j] = q[tid];
                         qb[j] = q[P.K + tid];
                     }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < 16; ++j) {
                         if (b8 + j < P.bn_nrb) {
                             const float nb = (float)min(kRowBlock, P.bn_rows - (b8 + j) * kRowBlock);
                             const float tot = cnt + nb;
