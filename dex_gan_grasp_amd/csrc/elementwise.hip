@@ -281,7 +281,12 @@ __device__ __forceinline__ void bn_block_stats(const BnFin& f, int rpg, int grou
     __syncthreads();
 }
 
-// grid: (ceil((nprefix+ncols)/64), ceil(B/RB)).  gamma == NULL: store the un-affined x_hat = (x-mean)*rstd
+#ifndef DGG_IBN_BLOCKS
+#define DGG_IBN_BLOCKS 4
+#endif
+constexpr int kIbnBlocks = DGG_IBN_BLOCKS;  // row blocks of 32 per ibn_apply workgroup
+
+// grid: (ceil((nprefix+ncols)/64), ceil(B/(RB*kIbnBlocks))).  gamma == NULL: store the un-affined x_hat = (x-mean)*rstd
 // (the forward GEMM then folds gamma/beta into its operand staging, see GemmProb::a_scale) and emit the
 // per-column affine vectors aff_scale = [1.. | gamma], aff_shift = [0.. | beta] over prefix + BN columns.
 __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rpg, const float* __restrict__ mean,
@@ -304,62 +309,80 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
     const int groups = B / rpg;
     const bool fused = fin.mean_out != nullptr;
     if (fused) bn_block_stats(fin, rpg, groups, S.total, c, bnc, blockIdx.y == 0, sh, res);
-    const int r0 = blockIdx.y * RB + sub * RS;
-    const int n = min(RS, B - r0);
-    const bool last_block = blockIdx.y == gridDim.y - 1;
-    float xv[RS];
-    if (!ook) {  // columns between the operand's width and the planes' pitch: the forward GEMM's K padding
-        if (PL.p && oc < PL.ld && n > 0) {
-#pragma unroll
-            for (int r = 0; r < RS; ++r) xv[r] = 0.f;
-            planes_store_rows(PL, oc, r0, n, xv);
-        }
-        return;
-    }
-    if (aff_scale && blockIdx.y == 0 && sub == 0) {
+    if (aff_scale && ook && blockIdx.y == 0 && sub == 0) {
         aff_scale[oc] = oc < nprefix ? 1.f : aff_gamma[oc - nprefix];
         aff_shift[oc] = oc < nprefix ? 0.f : aff_beta[oc - nprefix];
     }
-    if (n <= 0) {
-        if (PL.pT) {
+    // A workgroup walks kIbnBlocks row blocks of 32 (the statistics merge above is paid once for all of them); the
+    // loads of all of them are issued before the first use
+    const int nrb_total = (B + RB - 1) / RB;
+    int ld = 0;
+    const float* p = bnc ? src_col(S, c, ld) : nullptr;
+    const float ga = (bnc && gamma) ? gamma[c] : 1.f, be = (bnc && beta) ? beta[c] : 0.f;
+    float xv[kIbnBlocks][RS];
+    if (ook) {
 #pragma unroll
-            for (int r = 0; r < RS; ++r) xv[r] = 0.f;
-            planes_store_cols(PL, oc, r0, 0, xv, last_block);
+        for (int k = 0; k < kIbnBlocks; ++k) {
+            const int r0 = (blockIdx.y * kIbnBlocks + k) * RB + sub * RS;
+            const int n = min(RS, B - r0);
+#pragma unroll
+            for (int r = 0; r < RS; ++r) {
+                const size_t row = (size_t)(n > 0 ? r0 + row_clamp(r, n) : 0);
+                xv[k][r] = bnc ? p[row * ld] : prefix[row * nprefix + oc];
+            }
         }
-        return;
     }
-    if (oc < nprefix) {
 #pragma unroll
-        for (int r = 0; r < RS; ++r) xv[r] = prefix[(size_t)(r0 + row_clamp(r, n)) * nprefix + oc];
+    for (int k = 0; k < kIbnBlocks; ++k) {
+        const int rbk = blockIdx.y * kIbnBlocks + k;
+        if (rbk >= nrb_total) break;
+        const int r0 = rbk * RB + sub * RS;
+        const int n = min(RS, B - r0);
+        const bool last_block = rbk == nrb_total - 1;
+        if (!ook) {  // columns between the operand's width and the planes' pitch: the forward GEMM's K padding
+            if (PL.p && oc < PL.ld && n > 0) {
+                float zv[RS];
 #pragma unroll
-        for (int r = 0; r < RS; ++r)
-            if (r < n) X0[(size_t)(r0 + r) * ldx + oc] = xv[r];
-        if (PL.p) planes_store_rows(PL, oc, r0, n, xv);
-        if (PL.pT) planes_store_cols(PL, oc, r0, n, xv, last_block);
-        return;
-    }
-    int ld;
-    const float* p = src_col(S, c, ld);
-    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+                for (int r = 0; r < RS; ++r) zv[r] = 0.f;
+                planes_store_rows(PL, oc, r0, n, zv);
+            }
+            continue;
+        }
+        if (n <= 0) {
+            if (PL.pT) {
+                float zv[RS];
 #pragma unroll
-    for (int r = 0; r < RS; ++r) xv[r] = p[(size_t)(r0 + row_clamp(r, n)) * ld];
+                for (int r = 0; r < RS; ++r) zv[r] = 0.f;
+                planes_store_cols(PL, oc, r0, 0, zv, last_block);
+            }
+            continue;
+        }
+        if (!bnc) {  // prefix columns pass through
 #pragma unroll
-    for (int r = 0; r < RS; ++r) {
-        const int row = r0 + row_clamp(r, n);
-        const int g = row / rpg;
-        const float mu = fused ? res[g][0][lane] : mean[g * S.total + c];
-        const float rs = fused ? res[g][1][lane] : rstd[g * S.total + c];
-        const float sc = rs * ga;
-        const float shf = be - mu * sc;
-        xv[r] = fmaf(xv[r], sc, shf);
-        if (r < n) X0[(size_t)row * ldx + oc] = xv[r];
-    }
-    if (PL.pT) planes_store_cols(PL, oc, r0, n, xv, last_block);
-    if (PL.p) {  // the forward operand carries the BatchNorm affine the stored x_hat leaves to the GEMM
-        const float ag = aff_gamma[c], ab = aff_beta[c];
+            for (int r = 0; r < RS; ++r)
+                if (r < n) X0[(size_t)(r0 + r) * ldx + oc] = xv[k][r];
+            if (PL.p) planes_store_rows(PL, oc, r0, n, xv[k]);
+            if (PL.pT) planes_store_cols(PL, oc, r0, n, xv[k], last_block);
+            continue;
+        }
 #pragma unroll
-        for (int r = 0; r < RS; ++r) xv[r] = fmaf(xv[r], ag, ab);
-        planes_store_rows(PL, oc, r0, n, xv);
+        for (int r = 0; r < RS; ++r) {
+            const int row = r0 + row_clamp(r, n);
+            const int g = row / rpg;
+            const float mu = fused ? res[g][0][lane] : mean[g * S.total + c];
+            const float rs = fused ? res[g][1][lane] : rstd[g * S.total + c];
+            const float sc = rs * ga;
+            const float shf = be - mu * sc;
+            xv[k][r] = fmaf(xv[k][r], sc, shf);
+            if (r < n) X0[(size_t)row * ldx + oc] = xv[k][r];
+        }
+        if (PL.pT) planes_store_cols(PL, oc, r0, n, xv[k], last_block);
+        if (PL.p) {  // the forward operand carries the BatchNorm affine the stored x_hat leaves to the GEMM
+            const float ag = aff_gamma[c], ab = aff_beta[c];
+#pragma unroll
+            for (int r = 0; r < RS; ++r) xv[k][r] = fmaf(xv[k][r], ag, ab);
+            planes_store_rows(PL, oc, r0, n, xv[k]);
+        }
     }
 }
 
@@ -1415,7 +1438,7 @@ int ibn_apply_launch(const ColSrcs& srcs, int B, int rpg, const float* mean, con
         pl = *planes;
         if (pl.p && pl.ld > width) width = pl.ld;
     }
-    dim3 grid(cdiv(width, 64), cdiv(B, RB));
+    dim3 grid(cdiv(width, 64), cdiv(B, RB * kIbnBlocks));
     hipLaunchKernelGGL(ibn_apply_kernel, grid, dim3(256), 0, st, srcs, B, rpg, mean, rstd, gamma, beta, prefix,
                        nprefix, X0, ldx, aff_gamma, aff_beta, aff_scale, aff_shift, fin, pl);
     return check_launch("ibn_apply");
