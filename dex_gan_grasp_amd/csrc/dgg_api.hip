@@ -255,6 +255,7 @@ struct NetW {
     // per-ResBlock backward operands: the weight-gradient GEMMs may run on a side stream while the main
     // stream already back-propagates the next block, so they are not shared scratch
     float *dY13[3], *da2[3];
+    float* dYs[3];               // dY13 of this pass + dY13 of the discriminator's other pass (Share::bwd_mode 2)
     float *slabs_w;              // split-K slabs of the fc2 weight gradient
     int64_t slab_floats;
     // bf16 planes of the large GEMMs' operands (gemm_p3.hip); carved for train-sized batches only (p3)
@@ -268,6 +269,10 @@ struct NetW {
 };
 static const int kP3MaxB = 8192;   // larger batches (inference sweeps) never train: no planes carved for them
 // diagnostics: DGG_P3_FWD=0 / DGG_P3_WGRAD=0 keep the forward / the weight gradient on the in-register-split kernel
+static bool share_wgrad() {  // diagnostics: DGG_SHARE_WGRAD=0: both passes of D form their own BPS weight gradient
+    static const bool v = [] { const char* e = getenv("DGG_SHARE_WGRAD"); return !(e && e[0] == '0'); }();
+    return v;
+}
 static bool fuse_fc2() {  // diagnostics: DGG_FUSE_FC2=0 keeps bn_act / fc2 GEMM / reduce as separate launches
     static const bool v = [] { const char* e = getenv("DGG_FUSE_FC2"); return !(e && e[0] == '0'); }();
     return v;
@@ -389,6 +394,7 @@ static void carve(const NetL& L, int B, void* base, NetW& W) {
     for (int r = 0; r < L.nrb; ++r) {
         W.dY13[r] = b.take<float>(Bz * L.n13);
         W.da2[r] = b.take<float>(Bz * L.nn);
+        W.dYs[r] = L.net == DGG_NET_DISC ? b.take<float>(Bz * L.n13) : nullptr;
     }
     W.slabs_w = b.take<float>((size_t)8 * L.nn * L.hid);
     W.dpre = b.take<float>(Bz * L.nn);
@@ -492,6 +498,14 @@ struct Share {
     int nslab[3];         // set by the producer
     hipEvent_t ready[3];  // two-stream form: recorded by the producer after its GEMM, awaited by the consumer
     bool events;
+    // Backward: the same x_hat_bps also shares the WEIGHT GRADIENT of the BPS columns —
+    //   dW13[:, bps] = dY_real^T x_hat_bps + dY_fake^T x_hat_bps = (dY_real + dY_fake)^T x_hat_bps
+    // bwd_mode 1 (real pass): only the pose columns' weight gradient is formed, dY13 / cs13 stay in its workspace;
+    // bwd_mode 2 (fake pass, runs after the real pass' backward): its dY13 producers also write dY13 + dY13_other, the
+    // BPS columns take that sum (overwriting: nothing was written there), the pose columns accumulate as before.
+    int bwd_mode;
+    const float* dY13_other[3];
+    const float* cs13_other[3];
 };
 static const int kShareSlabs = 16;  // plan13 never gives one piece more
 
@@ -714,12 +728,18 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     const bool use_p3 = c.p3 && !skip_param && L.net != kNetResBlock;
     const PlaneOut plt1 = {nullptr, 0, 0, 0, use_p3 ? c.W.dYt[r] : nullptr, c.W.ldB, 0, (long long)L.n13 * c.W.ldB};
     const PlaneOut plt3 = {nullptr, 0, 0, 0, use_p3 ? c.W.dYt[r] : nullptr, c.W.ldB, L.hid, (long long)L.n13 * c.W.ldB};
+    // shared BPS weight gradient of the discriminator's two passes (Share::bwd_mode)
+    const Share* sh = c.share;
+    const bool share_ok = sh && sh->bwd_mode && !skip_param && !use_p3 && L.nprefix == 0 && sh->ncols > 0 && sh->ncols < L.k0;
+    const bool share_r = share_ok && sh->bwd_mode == 1, share_f = share_ok && sh->bwd_mode == 2;
+    const SumOut so1 = {share_f ? sh->dY13_other[r] : nullptr, c.W.dYs[r], L.n13};
+    const SumOut so3 = {share_f ? sh->dY13_other[r] + L.hid : nullptr, share_f ? c.W.dYs[r] + L.hid : nullptr, L.n13};
     const bool dy_slabs = !hb && c.dy_nslab > 1;
     DGG_TRY(res_out_bwd_launch(hb ? nullptr : (dy_slabs ? c.W.slabs : dy), L.nn, A.y, L.nn,
                                had_dropout ? A.keep : nullptr, A.a13 + L.hid, L.n13, A.a2, L.nn, A.mean2, A.rstd2, B, B,
                                L.nn, c.W.dpre, dY13 + L.hid, L.n13, c.W.part, c.st, hb ? hb->d_score : nullptr,
                                hb ? hb->w : nullptr, nq1, dy_slabs ? c.dy_nslab : 0, c.dy_stride,
-                               use_p3 ? &plt3 : nullptr));
+                               use_p3 ? &plt3 : nullptr, share_f ? &so3 : nullptr));
     c.dy_nslab = 0;
     // fc1.bias / fc2.bias feed a train-mode BatchNorm: their gradient is EXACTLY zero (the batch-mean subtraction
     // removes any per-column constant; the reference stores fp32 rounding noise there) — cleared by this launch
@@ -757,7 +777,8 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     {
         ColFin fin = {c.W.part, 2, {gp(R.bn1b), gp(R.bn1w), nullptr, nullptr, nullptr}, acc, nullptr, nullptr, nullptr, 0, 0};
         DGG_TRY(bn_bwd_apply_launch(c.W.dh, L.hid, A.a13, L.n13, A.mean1, A.rstd1, c.P + R.bn1w, nullptr, c.train, B, B,
-                                    L.hid, dY13, L.n13, c.W.part2, c.st, &fin, use_p3 ? &plt1 : nullptr));
+                                    L.hid, dY13, L.n13, c.W.part2, c.st, &fin, use_p3 ? &plt1 : nullptr,
+                                    share_f ? &so1 : nullptr));
     }
     // fc1.bias: same argument as fc2.bias above; in eval mode the real column sum is also kept in cs13[0:hid]
     // for the BatchNorm-aware wgrad epilogue (train mode: exactly zero -> ep_cs0 = NULL)
@@ -790,29 +811,46 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     if (!skip_param) {
         GemmBatch g;
         memset(&g, 0, sizeof(g));
-        g.nprob = nseg;
-        int ix0 = -1;
+        int np = 0, ix0 = -1;
+        // one problem per column range [lo, hi) of a segment; A: whose dY13 it takes
+        auto add = [&](const Seg& sg, int lo, int hi, const float* Aop, int accumulate, const float* cs1b) {
+            GemmProb& q = g.p[np++];
+            prob_init(q, Aop, L.n13, sg.p + lo, sg.ld, G + R.w13 + sg.wcol + lo, R.fin, L.n13, hi - lo, B);
+            q.accumulate = accumulate;
+            if (sg.is_x0) {
+                ix0 = np - 1;
+                q.ep_gamma = c.W.aff_scale + lo;
+                q.ep_beta = c.W.aff_shift + lo;
+                q.ep_cs0 = c.train ? nullptr : cs13;
+                q.ep_cs1 = cs13 + L.hid;
+                q.ep_cs1b = cs1b;
+                q.ep_split = L.hid;
+                q.ep_w = c.P + R.w13 + sg.wcol + lo;
+                q.ep_ldw = R.fin;
+                q.ep_part = c.W.ibn_part + (size_t)r * 12 * 2 * L.k0 + lo;
+                q.ep_part_ld = L.k0;
+            }
+        };
         for (int i = 0; i < nseg; ++i) {
-            prob_init(g.p[i], dY13, L.n13, segs[i].p, segs[i].ld, G + R.w13 + segs[i].wcol, R.fin, L.n13,
-                      segs[i].width, B);
-            g.p[i].accumulate = acc;
-            if (segs[i].is_x0) {
-                ix0 = i;
-                g.p[i].ep_gamma = c.W.aff_scale;
-                g.p[i].ep_beta = c.W.aff_shift;
-                g.p[i].ep_cs0 = c.train ? nullptr : cs13;
-                g.p[i].ep_cs1 = cs13 + L.hid;
-                g.p[i].ep_split = L.hid;
-                g.p[i].ep_w = c.P + R.w13 + segs[i].wcol;
-                g.p[i].ep_ldw = R.fin;
-                g.p[i].ep_part = c.W.ibn_part + (size_t)r * 12 * 2 * L.k0;
+            if (segs[i].is_x0 && share_r) {            // real pass: the pose columns only
+                add(segs[i], sh->ncols, segs[i].width, dY13, acc, nullptr);
+            } else if (segs[i].is_x0 && share_f) {     // fake pass: BPS columns on dY_real + dY_fake, pose columns on its own
+                add(segs[i], 0, sh->ncols, c.W.dYs[r], 0, sh->cs13_other[r] + L.hid);
+                add(segs[i], sh->ncols, segs[i].width, dY13, acc, nullptr);
+            } else {
+                add(segs[i], 0, segs[i].width, dY13, acc, nullptr);
             }
         }
-        // the widest segment decides the tile shape
-        if (nseg == 2 && g.p[1].N > g.p[0].N) { GemmProb t = g.p[0]; g.p[0] = g.p[1]; g.p[1] = t; }
+        g.nprob = np;
+        // the widest problem decides the tile shape
+        for (int i = 1; i < np; ++i)
+            if (g.p[i].N > g.p[0].N) {
+                GemmProb t = g.p[0]; g.p[0] = g.p[i]; g.p[i] = t;
+                if (ix0 == i) ix0 = 0; else if (ix0 == 0) ix0 = i;
+            }
         if (use_p3) {
             // dW13[n][k] = sum_b dY13[b][n] X[b][k] over the transposed planes dY13^T [n13][B], X^T [width][B]
-            for (int i = 0; i < nseg; ++i) {
+            for (int i = 0; i < np; ++i) {
                 GemmProb& q = g.p[i];
                 const bool x0 = q.ep_gamma != nullptr;  // set above for the [prefix | x_hat] segment only
                 q.A = reinterpret_cast<const float*>(c.W.dYt[r]);
@@ -975,13 +1013,13 @@ static ColSrcs sub_srcs(const ColSrcs& S, int lo, int hi) {
 // d_prefix (B x nprefix), d_in_lo/hi + d_in (B x (hi-lo)): input-gradient requests on the BN'd concat.
 static int net_backward(const NetL& L, const float* params, float* grads, void* ws, size_t ws_bytes, int B,
                         unsigned flags, const ColSrcs& srcs, const float* d_out, float* d_prefix, int d_in_lo,
-                        int d_in_hi, float* d_in, hipStream_t st) {
+                        int d_in_hi, float* d_in, hipStream_t st, Share* share = nullptr) {
     if (!params || !ws || !d_out || B < 1) return DGG_ERR_INVALID;
     const bool skip = (flags & DGG_SKIP_PARAM_GRADS) != 0;
     const bool accum = (flags & DGG_ACCUM_GRADS) != 0;
     if (!skip && !grads) return DGG_ERR_INVALID;
     Ctx c;
-    c.share = nullptr;
+    c.share = share;
     c.L = &L; c.P = params; c.G = grads; c.bn = nullptr; c.B = B; c.train = (flags & DGG_TRAIN) != 0; c.st = st;
     c.sw = skip ? nullptr : wgrad_stream_of(st);
     if (c.sw == st) c.sw = nullptr;
@@ -1050,10 +1088,16 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
             return DGG_ERR_LAUNCH;
     }
     if (!skip) {
+        // shared BPS weight gradient (Share::bwd_mode, same conditions as in rb_backward): the real pass produced
+        // partials for the pose columns only; the fake pass overwrites the BPS columns and accumulates the rest
+        const bool share_ok = share && share->bwd_mode && !c.p3 && L.nprefix == 0 && share->ncols > 0 && share->ncols < L.k0;
+        const int c_first = (share_ok && share->bwd_mode == 1) ? share->ncols : 0;
         for (int r = 0; r < L.nrb; ++r) {  // part layout per block: [tiles][2][k0]; q0 -> d gamma, q1 -> d beta
-            DGG_TRY(colsum_finalize_launch(c.W.ibn_part + (size_t)r * 12 * 2 * L.k0, 1, ibn_tiles[r], 2, L.k_in, nullptr,
-                                           grads + L.ibnw, grads + L.ibnb, nullptr, (accum || r > 0) ? 1 : 0, st, L.k0,
-                                           L.nprefix));
+            const int noacc = (share_ok && share->bwd_mode == 2 && r == 0) ? share->ncols : 0;
+            DGG_TRY(colsum_finalize_launch(c.W.ibn_part + (size_t)r * 12 * 2 * L.k0, 1, ibn_tiles[r], 2, L.k_in - c_first,
+                                           nullptr, grads + L.ibnw + c_first, grads + L.ibnb + c_first, nullptr,
+                                           (accum || r > 0) ? 1 : 0, st, L.k0, L.nprefix + c_first, nullptr, nullptr,
+                                           nullptr, 0, nullptr, 0, nullptr, nullptr, noacc));
         }
     }
     // everything else — block 0 and the input BatchNorm — is complete here
@@ -1588,8 +1632,10 @@ static int real_pass(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
                         srcs_pose(cfg, bps, rot9, transl, joint), nullptr, nullptr, 0, S.p_real, sb, &share));
     if (fwd_done && hipEventRecord(fwd_done, sb) != hipSuccess) return DGG_ERR_LAUNCH;
     DGG_TRY(bce_launch(S.p_real, nullptr, 1.f, B, (float)hp->bce_weight, 0.5f, loss_slot, S.dl_real, sb));
-    DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint,
-                              S.dl_real, nullptr, sb));
+    // (bwd_mode 1: the weight gradient of the BPS columns is left to the fake pass, which takes dY_real + dY_fake)
+    share.bwd_mode = share_wgrad() ? 1 : 0;
+    DGG_TRY(net_backward(Ld, s->d_params, s->d_grads, S.ws_dr, S.d_bytes, B, DGG_TRAIN, srcs_pose(cfg, bps, rot9, transl, joint),
+                         S.dl_real, nullptr, 0, 0, nullptr, sb, &share));
     if (bwd_done && hipEventRecord(bwd_done, sb) != hipSuccess) return DGG_ERR_LAUNCH;
     return DGG_OK;
 }
@@ -1693,8 +1739,21 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
     // :792-793 the fake pass accumulates onto the real pass' gradients
     if (fork && hipStreamWaitEvent(st, ev[2], 0) != hipSuccess) return DGG_ERR_LAUNCH;
     DGG_TRY(disc_loss_combine_launch(losses, st, real_slot));
-    DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_df, S.d_bytes, B, DGG_TRAIN | DGG_ACCUM_GRADS, bps,
-                              S.rfake, S.f_transl, S.f_joint, S.dl_fake, nullptr, stream));
+    // the real pass (bwd_mode 1) kept dY13 / cs13 of every block in its workspace: the BPS columns' weight gradient is
+    // formed here on dY_real + dY_fake
+    if (share.bwd_mode == 1) {
+        NetW Wr;
+        carve(Ld, B, S.ws_dr, Wr);
+        for (int r = 0; r < Ld.nrb; ++r) {
+            share.dY13_other[r] = Wr.dY13[r];
+            share.cs13_other[r] = Wr.cs13[r];
+        }
+        share.bwd_mode = 2;
+    } else {
+        share.bwd_mode = 0;
+    }
+    DGG_TRY(net_backward(Ld, s->d_params, s->d_grads, S.ws_df, S.d_bytes, B, DGG_TRAIN | DGG_ACCUM_GRADS,
+                         srcs_pose(cfg, bps, S.rfake, S.f_transl, S.f_joint), S.dl_fake, nullptr, 0, 0, nullptr, st, &share));
     return DGG_OK;
 }
 

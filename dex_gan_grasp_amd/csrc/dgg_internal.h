@@ -47,7 +47,9 @@ struct GemmProb {
     int ep_split;
     const float* ep_w;     // weights, indexed like C (row n, column k), pitch ep_ldw
     int ep_ldw;
-    float* ep_part;        // [tiles_m][2][N]
+    float* ep_part;        // [tiles_m][2][ep_part_ld]
+    int ep_part_ld;        // pitch of ep_part rows (0 = N): a column sub-range of a wider matrix keeps the wide layout
+    const float* ep_cs1b;  // optional: a second vector added to ep_cs1 (column sums of ANOTHER pass' dY summed into A)
     // gemm_f32 NT with 64 x 64 tiles only ("fc2 forward", bn_part != NULL): the A operand is a PRE-activation whose
     // train-mode BatchNorm + LeakyReLU is applied while it is staged — every workgroup first merges the row-block
     // partials bn_part [bn_nrb][2][K] of all K <= 256 columns (same order everywhere), the first one also stores
@@ -85,6 +87,13 @@ void gemm_set_algo(int a);
 void gemm_x3_dispatch(int mode, const GemmBatch& batch, hipStream_t st);  // gemm_x3.hip, 128 x 128 tiles
 // gemm_p3.hip: C = A B^T on pre-split bf16 planes (forward, and the wgrad over transposed planes with wgrad = true)
 int gemm_p3_launch(GemmBatch& batch, bool wgrad, hipStream_t st);
+// dx / da3 of THIS pass plus the same tensor of another pass, written next to the plain output (the discriminator's
+// weight gradient over the BPS columns takes dY_real + dY_fake in one product, see Share::bwd_mode)
+struct SumOut {
+    const float* other;   // NULL: none
+    float* sum;
+    int ld;               // pitch of both
+};
 // Plane outputs of the column kernels (ibn_apply, res_out, bn_bwd_apply, res_out_bwd; one batch group only): what the
 // kernel writes as fp32 also goes out split into bf16 planes, so that the large GEMMs run without a split of their own.
 //   row-major  [3][rows][ld]: element (row, col0 + c);  columns up to `ld` are zero-filled where a kernel says so
@@ -201,7 +210,8 @@ int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const
                        int rows_per_group, int N, float* dpre, float* da3, int ldda3, float* part,
                        hipStream_t st, const float* hd_dout = nullptr, const float* hd_w = nullptr, int nq = 3,
                        int nslab = 0, long long slab_stride = 0,  // nslab > 1: dy = split-K slabs, summed in order
-                       const PlaneOut* planes = nullptr);          // transposed da3 only
+                       const PlaneOut* planes = nullptr,           // transposed da3 only
+                       const SumOut* sum = nullptr);
 // Stage 2/4 (BN backward apply): dx = gamma*rstd*(dz - sum_dz/B - xhat*sum_dzx/B) (train) or
 //          gamma*rstd*dz (eval);  partial sums of dx (-> bias gradient of the preceding Linear).
 // `fin` (one group only): the column sums come straight from the producer's row-block partials fin->part
@@ -221,7 +231,8 @@ struct ColFin {
 int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, const float* mean, const float* rstd,
                         const float* gamma, const float* sums /*[groups][2][N]*/, int train, int B,
                         int rows_per_group, int N, float* dx, int lddx, float* part, hipStream_t st,
-                        const ColFin* fin = nullptr, const PlaneOut* planes = nullptr);  // planes: transposed dx only
+                        const ColFin* fin = nullptr, const PlaneOut* planes = nullptr,  // planes: transposed dx only
+                        const SumOut* sum = nullptr);
 // Stage 3: dq = dh * lrelu'(h) (in place on dh allowed); partial sums: sum dq, sum dq*xhat1.
 int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const float* a1, int lda1, const float* mean,
                    const float* rstd, int B, int rows_per_group, int N, float* dq, int lddq, float* part,
@@ -235,7 +246,8 @@ int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const flo
 int colsum_finalize_launch(const float* part, int groups, int nrb, int nq, int ncols, float* sums_out, float* dst0,
                            float* dst1, float* dst2, int accumulate, hipStream_t st, int ld = 0, int c_lo = 0,
                            float* copy0 = nullptr, float* copy2 = nullptr, float* zero0 = nullptr, int nz0 = 0,
-                           float* zero1 = nullptr, int nz1 = 0, float* dst3 = nullptr, float* dst4 = nullptr);
+                           float* zero1 = nullptr, int nz1 = 0, float* dst3 = nullptr, float* dst4 = nullptr,
+                           int noacc_below = 0);  // columns c < noacc_below are overwritten even when accumulating
 // Input BN backward: partial sums of dX0 and dX0*xhat over the concat sources.
 int ibn_bwd_stats_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col_off, const float* mean,
                          const float* rstd, int rows_per_group, int groups, float* part, hipStream_t st, int nslab = 0,

@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
                                                           int ldda3, float* __restrict__ part,
                                                           const float* __restrict__ hd_dout,
                                                           const float* __restrict__ hd_w, int nq, int nslab,
-                                                          long long slab_stride, PlaneOut PL) {
+                                                          long long slab_stride, PlaneOut PL, SumOut SO) {
     // nslab > 1: `dy` is a stack of split-K slabs of the next block's dgrad GEMM, summed here in slab (= k) order
     __shared__ float sh[SUB][5][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
 #pragma unroll
     for (int r = 0; r < RS; ++r) d3v[r] = 0.f;
     if (n > 0) {
-        float yv_[RS], dv_[RS], av_[RS], sv_[RS];
+        float yv_[RS], dv_[RS], av_[RS], sv_[RS], ov_[RS];
         uint8_t kp_[RS];
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
@@ -668,6 +668,7 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
             kp_[r] = keep ? keep[row * N + c] : (uint8_t)1;
             av_[r] = a2[row * lda2 + c];
             sv_[r] = s[row * lds + c];
+            ov_[r] = SO.other ? SO.other[row * SO.ld + c] : 0.f;
         }
         for (int q = 1; q < nslab; ++q) {
             float t[RS];
@@ -698,6 +699,7 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
                 const float d3 = d * lrelu_grad(sv_[r]);
                 d3v[r] = d3;
                 if (cok) da3[row * ldda3 + c] = d3;
+                if (SO.other && cok) SO.sum[row * SO.ld + c] = d3 + ov_[r];
                 s0 += d;
                 s1 = fmaf(d, xh, s1);
                 s2 += d3;
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ sums, int train, int rpg,
                                                            int nrb, int N, float* __restrict__ dx, int lddx,
-                                                           float* __restrict__ part, ColFin fin, PlaneOut PL) {
+                                                           float* __restrict__ part, ColFin fin, PlaneOut PL, SumOut SO) {
     __shared__ float sh[SUB][1][64];
     __shared__ float tq[2][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
@@ -787,12 +789,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < RS; ++r) xo[r] = 0.f;
     if (n > 0) {
-        float dv_[RS], av_[RS];
+        float dv_[RS], av_[RS], ov_[RS];
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
             const size_t row = (size_t)(g * rpg + r0 + row_clamp(r, n));
             dv_[r] = dz[row * lddz + c];
             av_[r] = a[row * lda + c];
+            ov_[r] = SO.other ? SO.other[row * SO.ld + c] : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
@@ -801,6 +804,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 const float xh = (av_[r] - mu) * rs;
                 const float v = k * (dv_[r] - m0 - xh * m1);
                 if (cok) dx[row * lddx + c] = v;
+                if (SO.other && cok) SO.sum[row * SO.ld + c] = v + ov_[r];
                 xo[r] = v;
                 sb += v;
             }
@@ -880,7 +884,8 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
                                                               int accumulate, float* __restrict__ copy0,
                                                               float* __restrict__ copy2, float* __restrict__ zero0,
                                                               int nz0, float* __restrict__ zero1, int nz1,
-                                                              float* __restrict__ d3, float* __restrict__ d4) {
+                                                              float* __restrict__ d3, float* __restrict__ d4,
+                                                              int noacc_below) {
     __shared__ float sh[SUB][64];
     if (blockIdx.x == 0) {  // ranges the caller wants cleared alongside (saves separate memset launches)
         for (int z = threadIdx.x; z < nz0; z += 256) zero0[z] = 0.f;
@@ -916,7 +921,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     }
     if (sub == 0 && ok) {
         float* d = q == 0 ? d0 : q == 1 ? d1 : q == 2 ? d2 : q == 3 ? d3 : (c == 0 ? d4 : nullptr);  // q 4: one scalar
-        if (d) d[c] = accumulate ? d[c] + tot : tot;
+        if (d) d[c] = (accumulate && c >= noacc_below) ? d[c] + tot : tot;
         if (q == 0 && copy0) copy0[c] = tot;
         if (q == 2 && copy2) copy2[c] = tot;
     }
@@ -1647,8 +1652,11 @@ int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B,
 int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const uint8_t* keep, const float* s,
                        int lds, const float* a2, int lda2, const float* mean, const float* rstd, int B, int rpg, int N,
                        float* dpre, float* da3, int ldda3, float* part, hipStream_t st, const float* hd_dout,
-                       const float* hd_w, int nq, int nslab, long long slab_stride, const PlaneOut* planes) {
+                       const float* hd_w, int nq, int nslab, long long slab_stride, const PlaneOut* planes,
+                       const SumOut* sum) {
     if (!dy && !hd_dout) return DGG_ERR_INVALID;
+    SumOut so = {nullptr, nullptr, 0};
+    if (sum && sum->other) so = *sum;
     if (hd_dout) nslab = 0;
     PlaneOut pl = {};
     if (planes) {
@@ -1658,14 +1666,16 @@ int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const
     const int groups = B / rpg;
     dim3 grid(cdiv(N, 64), groups * nrb_of(rpg));
     hipLaunchKernelGGL(res_out_bwd_kernel, grid, dim3(256), 0, st, dy, lddy, y, ldy, keep, s, lds, a2, lda2, mean,
-                       rstd, rpg, nrb_of(rpg), N, dpre, da3, ldda3, part, hd_dout, hd_w, nq, nslab, slab_stride, pl);
+                       rstd, rpg, nrb_of(rpg), N, dpre, da3, ldda3, part, hd_dout, hd_w, nq, nslab, slab_stride, pl, so);
     return check_launch("res_out_bwd");
 }
 
 int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, const float* mean, const float* rstd,
                         const float* gamma, const float* sums, int train, int B, int rpg, int N, float* dx, int lddx,
-                        float* part, hipStream_t st, const ColFin* fin, const PlaneOut* planes) {
+                        float* part, hipStream_t st, const ColFin* fin, const PlaneOut* planes, const SumOut* sum) {
     const int groups = B / rpg;
+    SumOut so = {nullptr, nullptr, 0};
+    if (sum && sum->other) so = *sum;
     PlaneOut pl = {};
     if (planes) {
         if (groups != 1) return DGG_ERR_INVALID;
@@ -1680,7 +1690,7 @@ int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, cons
         if (!f.zero1) f.nz1 = 0;
     }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, dz, lddz, a, lda, mean, rstd, gamma, sums, train,
-                       rpg, nrb_of(rpg), N, dx, lddx, part, f, pl);
+                       rpg, nrb_of(rpg), N, dx, lddx, part, f, pl, so);
     return check_launch("bn_bwd_apply");
 }
 
@@ -1696,11 +1706,12 @@ int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const flo
 
 int colsum_finalize_launch(const float* part, int groups, int nrb, int nq, int ncols, float* sums_out, float* dst0,
                            float* dst1, float* dst2, int accumulate, hipStream_t st, int ld, int c_lo, float* copy0,
-                           float* copy2, float* zero0, int nz0, float* zero1, int nz1, float* dst3, float* dst4) {
+                           float* copy2, float* zero0, int nz0, float* zero1, int nz1, float* dst3, float* dst4,
+                           int noacc_below) {
     if (ld <= 0) ld = ncols;
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(nq * ncols, 64)), dim3(256), 0, st, part, groups, nrb, nq,
                        ncols, ld, c_lo, sums_out, dst0, dst1, dst2, accumulate, copy0, copy2, zero0, zero0 ? nz0 : 0,
-                       zero1, zero1 ? nz1 : 0, dst3, dst4);
+                       zero1, zero1 ? nz1 : 0, dst3, dst4, noacc_below);
     return check_launch("colsum_finalize");
 }
 

@@ -33,7 +33,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProb& P, f32x16 (&acc)[B
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     float v = 0.f;
-                    if (row < M) v = row < P.ep_split ? (P.ep_cs0 ? P.ep_cs0[row] : 0.f) : P.ep_cs1[row - P.ep_split];
+                    if (row < M)
+                        v = row < P.ep_split ? (P.ep_cs0 ? P.ep_cs0[row] : 0.f)
+                                             : P.ep_cs1[row - P.ep_split] + (P.ep_cs1b ? P.ep_cs1b[row - P.ep_split] : 0.f);
                     csn[ta][r] = v;
                 }
 #pragma unroll
@@ -73,7 +75,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProb& P, f32x16 (&acc)[B
                     float t = red[q * BN + cidx];
 #pragma unroll
                     for (int w = 1; w < WM; ++w) t += red[(w * 2 + q) * BN + cidx];  // fixed order: deterministic
-                    P.ep_part[((size_t)tm_i * 2 + q) * N + col] = t;
+                    P.ep_part[((size_t)tm_i * 2 + q) * (P.ep_part_ld ? P.ep_part_ld : N) + col] = t;
                 }
             }
             return;
