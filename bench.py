@@ -34,7 +34,9 @@ MFLOP_PER_GRASP_FULL = 231.38   # cGAN 167.51 + evaluator 63.87 
 # What this implementation executes: no input-gradient GEMM of the BN'd BPS columns (the
 # input-BN parameter gradients come out of the wgrad epilogue), no discriminator dW in the G phase:
 # MACs/sample G 14.6 M + D 36.9 M + E 22.5 M = 74.0 M  ->  148 MFLOP
-MFLOP_PER_GRASP_EXEC = 135.4   # 148.0 minus the BPS-column product that D's fake pass takes from the real pass
+# minus what D's two passes share over the 4096 BPS columns (same x_hat in both): the forward product (2 blocks x
+# 768 x 4096 MAC = 12.6 MFLOP) and the weight gradient, formed once on dY_real + dY_fake (another 12.6 MFLOP)
+MFLOP_PER_GRASP_EXEC = 122.8
 # the next step's batch is resident (as with a prefetching loader): its D real pass is enqueued one step ahead
 PIPELINE = os.environ.get("DGG_PIPELINE", "1") == "1"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
