@@ -12,20 +12,21 @@
 //
 // Structure (round 2).  What bounded the round-1 kernel was the vector-memory path of its producer waves: global ->
 // VGPR -> split -> 3 bf16 planes -> LDS moved 48 KB of LDS stores and 32 KB of register loads per k-tile through waves
-// that issue in order (4200 cycles per k-tile against 1536 cycles of MFMA).  Now:
-//   * waves 4-7, LOADERS: the fp32 operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no
-//     LDS store instructions), 32 pieces of 1 KiB per k-tile, a ring of 4 stages (32.25 KB each) with a counted
-//     vmcnt so that 2 k-tiles stay in flight across the one barrier per k-tile.  A k-contiguous operand tile is
+// that issue in order (4200 cycles per k-tile against 1536 cycles of MFMA).  Now one role per wave, 256 threads =
+// 4 waves (2 x 2 of 64 x 64), one workgroup per CU:
+//   * the fp32 operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no LDS store
+//     instructions), 32 pieces of 1 KiB per k-tile (8 per wave), a ring of 4 stages (32.25 KB each) with a counted
+//     vmcnt so that 2 k-tiles stay in flight across the one raw s_barrier per k-tile.  A k-contiguous operand tile is
 //     [row][32 k] with 128-byte rows fetched as whole 128-byte lines; its 16-byte chunks are XOR-swizzled by
 //     (row >> 1) & 7 on the SOURCE side (the DMA's LDS image is lane-linear) so that the ds_read_b128 fragment
 //     fetches are bank-conflict-free.  A k-strided operand tile is [32 k][128] as it lies in memory.
-//   * waves 0-3, CONSUMERS (one per SIMD, 64 x 64 of the tile each): read fp32 fragments from LDS, apply the folded
-//     input-BatchNorm affine, split them in registers (11 VALU per pair of elements) and feed 24 MFMAs per 16-deep
-//     k-step.  Software-pipelined over k-steps: the split of step s+1 is interleaved with the MFMAs of step s, across
-//     the barrier, so the matrix pipe always has VALU work beside it and never waits for a split.
+//   * every wave reads the fp32 fragments of its 64 x 64 block from LDS, applies the folded input-BatchNorm affine,
+//     splits them in registers (44 VALU per fragment) and feeds 24 MFMAs per 16-deep k-step.  Software-pipelined over
+//     k-steps: the split of step s+1 is interleaved with the MFMAs of step s, across the barrier, in a pinned issue
+//     order (sched_barrier) — left alone the compiler clusters the MFMAs and the matrix pipe idles during the VALU tail.
 // Every element is split by the two waves that share its row / column block — 352 VALU per wave and k-tile beside
-// 48 MFMAs (1536 matrix-pipe cycles); the memory side is 32 KB per k-tile and CU (~21 B/clk of the ~28 B/clk a CU
-// pulls from L2 with this access shape, tools/exp/dma_probe.hip).
+// 48 MFMAs (1536 matrix-pipe cycles).  Measured 2760 cycles per k-tile: the SIMD's issue port is the bound (see the
+// comment at the kernel and DESIGN.md 3.1); gemm_p3.hip is the variant without the split.
 #include <stdint.h>
 #include <type_traits>
 #include "dgg_internal.h"

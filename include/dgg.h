@@ -24,10 +24,14 @@
  *  (b) the stream -> weight-gradient side stream map of dgg_set_wgrad_stream / dgg_enable_wgrad_stream
  *      (the latter creates and owns the side streams, reference-counted);
  *  (c) up to 4 "pending real pass" slots of dgg_cgan_d_real_prefetch, keyed by the raw step-workspace pointer
- *      (6 events each) and matched against (B, input pointers, d_params) by the next dgg_cgan_d_phase2.
+ *      (6 events each) and matched against (B, input pointers, d_params) by the next dgg_cgan_d_phase2.  A prefetched
+ *      real pass also leaves its dY13 / column sums in the workspace for the fake pass of that dgg_cgan_d_phase2, which
+ *      forms the weight gradient of the shared BPS columns on dY_real + dY_fake: until that call has run, the BPS
+ *      columns of d_grads' W13 / input-BatchNorm entries are NOT the real pass' gradient (nothing is written there);
+ *  (d) up to 4 registrations of gradient-ready events (dgg_set_grad_events), keyed by the gradient buffer.
  * Consequences: use one thread per engine (or call from one thread only); a workspace that is freed while a slot
  * refers to it must be released first with dgg_cgan_release(ws) — a new allocation at the same address with the same
- * input pointers would otherwise match a stale slot; dgg_reset() drops (b) and (c) for the calling thread
+ * input pointers would otherwise match a stale slot; dgg_reset() drops (b), (c) and (d) for the calling thread
  * (synchronising and destroying the library-owned side streams).  (a) lives until the thread exits.
  *
  * Arithmetic: the large GEMMs use the "bf16x3" scheme by default (see DGG_GEMM_BF16X3 below): fp32-accurate on
