@@ -123,3 +123,21 @@ def test_early_stopping_rule_matches_reference():
     assert es2.counter == 0
     assert es2(2.0) is False and es2.counter == 1
     assert es2(2.0) is True and es2.early_stop
+
+
+def test_grad_buckets_partition_the_flat_buffer():
+    """FlatNet.grad_buckets (the ranges of dgg_set_grad_events / parallel.BucketReducer): disjoint, cover the whole
+    parameter buffer, listed in the order a backward completes them — last ResBlock (+ heads) first, input BatchNorm +
+    block 0 last — and every named parameter lies inside exactly one bucket."""
+    from dex_gan_grasp_amd import _lib, synth
+    for net, nrb in ((_lib.NET_GEN, 2), (_lib.NET_DISC, 2), (_lib.NET_EVA, 3)):
+        fn = _lib.FlatNet(net, dict(synth.DEFAULT_CFG), "cpu", with_optim=False)
+        b = fn.grad_buckets()
+        assert len(b) == nrb
+        assert b[-1][0] == 0 and b[0][1] == fn.n_params
+        spans = sorted(b)
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+        assert [lo for lo, _ in b] == sorted((lo for lo, _ in b), reverse=True)
+        for name, off, rows, cols, kind in fn.entries:
+            if kind == 0:
+                assert sum(lo <= off and off + rows * cols <= hi for lo, hi in b) == 1, name
