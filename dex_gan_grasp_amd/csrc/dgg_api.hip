@@ -1854,6 +1854,7 @@ int dgg_cgan_release(void* ws) {
 
 int dgg_reset(void) {
     memset(g_grad_events, 0, sizeof(g_grad_events));
+    gemm_set_side_work(0);
     for (int i = 0; i < kPendingSlots; ++i) {
         g_pending[i].ws = nullptr;
         g_pending[i].valid = false;
@@ -2232,6 +2233,11 @@ int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const f
     prob_init(g.p[0], A, lda, Bm, ldb, C, ldc, M, N, K);
     g.p[0].accumulate = accumulate;
     return gemm_launch(mode, g, st);
+}
+
+int dgg_set_side_work(int on) {
+    gemm_set_side_work(on);
+    return DGG_OK;
 }
 
 int dgg_set_grad_events(const float* grads, void* const* events, int n, int accum_only) {

@@ -84,6 +84,8 @@ void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn, int K = 1 << 30);
 int gemm_occupancy(int mode, int bm, int bn);
 int gemm_algo();
 void gemm_set_algo(int a);
+int gemm_side_work();            // per thread, see dgg_set_side_work
+void gemm_set_side_work(int on);
 void gemm_x3_dispatch(int mode, const GemmBatch& batch, hipStream_t st);  // gemm_x3.hip, 128 x 128 tiles
 // gemm_p3.hip: C = A B^T on pre-split bf16 planes (forward, and the wgrad over transposed planes with wgrad = true)
 int gemm_p3_launch(GemmBatch& batch, bool wgrad, hipStream_t st);

@@ -467,6 +467,13 @@ int gemm_algo() {
 }
 void gemm_set_algo(int a) { g_algo = a < 0 ? 0 : a > 2 ? 2 : a; }
 
+// "Side work" (dgg_set_side_work, per calling thread): the launches that follow run beside a latency-critical chain on
+// another stream — their large forward products take half the chip for twice as long (the bf16x3 kernel walks two work
+// items per workgroup) so that the chain's kernels always find free CUs.
+static thread_local int g_side_work = 0;
+int gemm_side_work() { return g_side_work; }
+void gemm_set_side_work(int on) { g_side_work = on ? 1 : 0; }
+
 // All problems of one grouped launch must use the same tile shape: the launcher derives it from
 // problem 0 and re-plans the others with it.
 int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {

@@ -225,15 +225,30 @@ __device__ __forceinline__ FragAddr<KC> frag_setup(int lane, int w0) {
 // variant with half the VALU per wave ran at 2900), so 380 VALU + 48 MFMA (8 issue cycles each) + 8 DMA pieces (~60
 // each) per k-tile fill the issue port.  Next lever: operands arriving pre-split (producers emit the bf16 planes).
 template <bool A_KC, bool B_KC, bool AFF>
+__device__ __forceinline__ void gemm_x3_block(const GemmBatch& batch, const int bid, char* smem);
+
+// One workgroup per (problem, split, tile) work item — or, launched with fewer workgroups than items ("side work",
+// launch_x3), a stride loop over them: a GEMM that runs BESIDE a latency-critical chain on another stream then holds
+// half the CUs for twice as long instead of all of them, and the chain's kernels always find free CUs.  The grid
+// is a multiple of 8 so that an item's XCD (bid & 7) does not depend on which round of the loop takes it.
+template <bool A_KC, bool B_KC, bool AFF>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmBatch batch) {
     __shared__ __attribute__((aligned(16))) char smem[XS * XSTAGE];
+    for (int bid = (int)blockIdx.x; bid < batch.total_blocks; bid += (int)gridDim.x) {
+        gemm_x3_block<A_KC, B_KC, AFF>(batch, bid, smem);
+        if (bid + (int)gridDim.x < batch.total_blocks) __syncthreads();  // the epilogue's LDS scratch is done with
+    }
+}
+
+template <bool A_KC, bool B_KC, bool AFF>
+__device__ __forceinline__ void gemm_x3_block(const GemmBatch& batch, const int bid, char* smem) {
 
     // ---- work assignment: identical to gemm_f32_kernel (problem select, XCD-contiguous remap, split-K range)
     GemmProb P = batch.p[0];
 #pragma unroll
     for (int q = 1; q < 4; ++q)
-        if (q < batch.nprob && (int)blockIdx.x >= batch.p[q].blk_begin) P = batch.p[q];
-    int local = (int)blockIdx.x - P.blk_begin;
+        if (q < batch.nprob && bid >= batch.p[q].blk_begin) P = batch.p[q];
+    int local = bid - P.blk_begin;
     {
         const int nb = P.tiles_m * P.tiles_n * (P.splits > 0 ? P.splits : 1);
         const int q = nb >> 3, r = nb & 7;
@@ -560,14 +575,18 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmBatch batch) {
     stamp[5] = __builtin_amdgcn_s_memrealtime();
     stamp[6] = nkt;
     stamp[7] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
-    if (threadIdx.x == 0 && blockIdx.x < 2048)
-        for (int i = 0; i < 8; ++i) g_x3_stamp[blockIdx.x][i] = stamp[i];
+    if (threadIdx.x == 0 && bid < 2048)
+        for (int i = 0; i < 8; ++i) g_x3_stamp[bid][i] = stamp[i];
 #endif
 }
 
 template <bool A_KC, bool B_KC, bool AFF>
 static void launch_x3(const GemmBatch& b, hipStream_t st) {
-    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, AFF>), dim3(b.total_blocks), dim3(256), 0, st, b);
+    int grid = b.total_blocks;
+    // side work (dgg_set_side_work): the forward products walk two work items per workgroup — same items, same sums,
+    // half the CUs for twice as long.  (Halving the weight gradient's grid as well costs 30-70 us per step: measured.)
+    if (gemm_side_work() && A_KC && B_KC && grid > 64) grid = ((grid + 1) / 2 + 7) / 8 * 8;
+    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, AFF>), dim3(grid), dim3(256), 0, st, b);
 }
 
 // 128 x 128 tiles only.  Operand bases and pitches need 4-byte alignment only (the DMA fetches 16-byte chunks from any

@@ -16,6 +16,22 @@ from ._lib import check, lib, ptr, stream_ptr, f32c
 SEED_STRIDE = 0x9E3779B97F4A7C15   # what dgg_eva_phase_graph adds to the device-resident dropout seed per step
 
 
+class _side_work:
+    """Context: the library calls inside enqueue side work (dgg_set_side_work), switched off again on exit."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        if self.on:
+            check(lib().dgg_set_side_work(1), "dgg_set_side_work")
+
+    def __exit__(self, *exc):
+        if self.on:
+            lib().dgg_set_side_work(0)
+        return False
+
+
 class GraphStep:
     """One gen+eval train step captured into a HIP graph (TrainEngine.capture_joint_step).  The inputs are the very
     tensors given at capture: refresh their CONTENTS (copy_) between replays, keep them alive.  replay() enqueues the
@@ -391,7 +407,10 @@ class TrainEngine:
         self._mark("d_phase_end")
         self._side2_busy = None             # the D phase joins _side2 (a picked-up prefetch included) into main
         w_d = self._reduce("D", async_op=True)
-        with torch.cuda.stream(side):
+        # the evaluator update and the prefetched real pass run BESIDE the cGAN chain: their large GEMMs take half the
+        # chip for twice as long (dgg_set_side_work) so that the chain's short kernels keep finding free CUs
+        polite = two_streams and os.environ.get("DGG_SIDE_WORK", "1") != "0"
+        with torch.cuda.stream(side), _side_work(polite):
             if graph_mode:
                 check(lib().dgg_eva_phase_graph(cfg_p, ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(wse),
                                                 wse.numel(), Be, ptr(ebps), ptr(erot9), ptr(etransl), ptr(elabel),
@@ -425,9 +444,10 @@ class TrainEngine:
                     if t.dtype != torch.float32 or not t.is_contiguous() or t.device != bps.device:
                         raise _lib.DggError("next_gan_inputs must be resident contiguous float32 tensors")
                 self._keep_next = (nb, nr, nt, nj_)   # the C side remembers raw pointers
-                check(lib().dgg_cgan_d_real_prefetch(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), nb.shape[0],
-                                                     ptr(nb), ptr(nr), ptr(nt), ptr(nj_), ptr(self.losses), s2),
-                      "dgg_cgan_d_real_prefetch")
+                with _side_work(polite):
+                    check(lib().dgg_cgan_d_real_prefetch(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(),
+                                                         nb.shape[0], ptr(nb), ptr(nr), ptr(nt), ptr(nj_),
+                                                         ptr(self.losses), s2), "dgg_cgan_d_real_prefetch")
                 self._side2_busy = self._side2.record_event()
         if is_train_gen:
             parallel.wait_all(w_g)

@@ -239,6 +239,13 @@ int dgg_enable_wgrad_stream(void* stream, int enable);
  * (hip::Stream::EndCapture then recurses without end), so map weight-gradient side streams only to the capturing
  * stream itself — second compute streams (stream2 below, a caller's evaluator stream) run their dW GEMMs in line. */
 
+/* Side work (per calling thread, until switched off again): the calls that follow enqueue work that runs BESIDE a
+ * latency-critical chain on another stream — the evaluator update and the prefetched real-batch pass beside the cGAN
+ * chain in engine.TrainEngine.joint_step.  Their large forward products are then launched with half as many workgroups,
+ * each walking two work items: half the chip for twice as long instead of every CU, so that the chain's ~100 short
+ * dependent kernels always find free CUs (-3 % per step).  Same work items, same sums: results are bit-identical. */
+int dgg_set_side_work(int on);
+
 /* Gradient-ready events for data-parallel callers (per calling thread).  While `events` are registered for a gradient
  * buffer, every backward / phase call that writes parameter gradients into exactly that buffer records, in stream
  * order, events[r] (hipEvent_t, r = n-1 .. 1) as soon as ResBlock r's gradients — for the last block also the heads' —
