@@ -797,7 +797,11 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
             return DGG_ERR_LAUNCH;
         sw = c.sw;
     }
-    if (!skip_param) {  // fc2: dW2 = da2^T h (512 x 256 output, split-K)
+    // fc2: dW2 = da2^T h (512 x 256, K = B).  It rides along as one more problem of the [fc1;fc3] weight-gradient launch
+    // below — 8 tiles beside ~200, written (or accumulated) in place — unless that launch is full or runs on planes.
+    const int nx0 = (share_f ? 2 : 1);   // problems the [prefix | x_hat] segment will take
+    const bool fc2_rides = !skip_param && !use_p3 && (nseg - 1 + nx0) < 4;
+    if (!skip_param && !fc2_rides) {  // separate: split-K slabs + reduce
         GemmBatch g;
         memset(&g, 0, sizeof(g));
         g.nprob = 1;
@@ -840,6 +844,11 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
             } else {
                 add(segs[i], 0, segs[i].width, dY13, acc, nullptr);
             }
+        }
+        if (fc2_rides) {
+            GemmProb& q = g.p[np++];
+            prob_init(q, da2, L.nn, A.h, L.hid, G + R.w2, L.hid, L.nn, L.hid, B);
+            q.accumulate = acc;
         }
         g.nprob = np;
         // the widest problem decides the tile shape
