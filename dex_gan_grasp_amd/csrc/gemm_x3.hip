@@ -585,7 +585,10 @@ static void launch_x3(const GemmBatch& b, hipStream_t st) {
     int grid = b.total_blocks;
     // side work (dgg_set_side_work): the forward products walk two work items per workgroup — same items, same sums,
     // half the CUs for twice as long.  (Halving the weight gradient's grid as well costs 30-70 us per step: measured.)
-    if (gemm_side_work() && A_KC && B_KC && grid > 64) grid = ((grid + 1) / 2 + 7) / 8 * 8;
+    // diagnostics: DGG_SIDE_DIV items per workgroup (measured us per step: 1 -> 1814 / 1846, 2 -> 1757 / 1748, 3 -> 1863 /
+    // 1850, 4 -> 1923 / 1893, 6 -> 1928 / 1924)
+    static const int kdiv = [] { const char* e = getenv("DGG_SIDE_DIV"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
+    if (gemm_side_work() && A_KC && B_KC && grid > 64) grid = ((grid + kdiv - 1) / kdiv + 7) / 8 * 8;
     hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, AFF>), dim3(grid), dim3(256), 0, st, b);
 }
 
