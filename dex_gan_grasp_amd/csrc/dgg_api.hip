@@ -708,9 +708,16 @@ struct HeadBwd {
     const float* w;
     float *gw, *gb;
 };
+// Multi-column heads (the generator's 21-24 pose heads): dWh = d_out^T y_last rides in the last ResBlock's
+// weight-gradient launch as one more problem (4 tiles beside ~230) instead of a split-K GEMM + reduce of its own.
+struct HeadsRide {
+    const float* d_out;  // (B, nh)
+    int nh;
+    float* gwh;          // (nh, nn)
+};
 
 static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy, bool had_dropout, bool accum,
-                       bool skip_param, int* ibn_tiles, const HeadBwd* hb = nullptr) {
+                       bool skip_param, int* ibn_tiles, const HeadBwd* hb = nullptr, const HeadsRide* hr = nullptr) {
     const NetL& L = *c.L;
     const RbL& R = L.rb[r];
     RbW& A = c.W.rb[r];
@@ -848,6 +855,12 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
         if (fc2_rides) {
             GemmProb& q = g.p[np++];
             prob_init(q, da2, L.nn, A.h, L.hid, G + R.w2, L.hid, L.nn, L.hid, B);
+            q.accumulate = acc;
+        }
+        if (hr) {
+            if (np >= 4 || use_p3) return DGG_ERR_INVALID;  // net_backward only asks when there is room
+            GemmProb& q = g.p[np++];
+            prob_init(q, hr->d_out, hr->nh, A.y, L.nn, hr->gwh, L.nn, hr->nh, L.nn, B);
             q.accumulate = acc;
         }
         g.nprob = np;
@@ -1059,10 +1072,14 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     float* other = c.W.dXb;
     HeadBwd hb{d_out, params + L.wh, skip ? nullptr : grads + L.wh, skip ? nullptr : grads + L.bh};
     const bool fold_head = L.nh == 1;  // the outer product d_score (x) w is formed inside the last block's backward
+    // the last block's weight-gradient launch has room for the heads' dWh unless it runs on planes (problems: the input
+    // segments (<= 2) + fc2 = at most 3 of 4; Share splits the X0 segment only for the discriminator, whose head folds)
+    const bool heads_ride = !fold_head && !skip && !c.p3;
+    HeadsRide hride{d_out, L.nh, skip ? nullptr : grads + L.wh};
     if (!fold_head)
         DGG_TRY(heads_bwd_launch(c.W.rb[L.nrb - 1].y, L.nn, d_out, L.nh, B, L.nn, params + L.wh, L.nh, dy, L.nn,
                                  skip ? nullptr : grads + L.wh, skip ? nullptr : grads + L.bh, accum ? 1 : 0,
-                                 skip ? 1 : 0, c.W.part, st));
+                                 skip ? 1 : (heads_ride ? 2 : 0), c.W.part, st));
     for (int r = L.nrb - 1; r >= 0; --r) {
         Seg segs[2];
         int nseg;
@@ -1083,7 +1100,8 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
             }
         }
         DGG_TRY(rb_backward(c, r, segs, nseg, dy, drop, accum, skip, ibn_tiles,
-                            (fold_head && r == L.nrb - 1) ? &hb : nullptr));
+                            (fold_head && r == L.nrb - 1) ? &hb : nullptr,
+                            (heads_ride && r == L.nrb - 1) ? &hride : nullptr));
         // block r's parameter gradients (and, for the last block, the heads') are complete on the stream that ran its
         // weight-gradient GEMMs: a data-parallel caller starts that bucket's all-reduce behind this event
         if (ge && r >= 1 && hipEventRecord(ge->ev[r], c.sw ? c.sw : st) != hipSuccess) return DGG_ERR_LAUNCH;

@@ -199,6 +199,7 @@ int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, in
 int heads_fwd_launch(const float* y, int ldy, int B, int K, const float* wh, const float* bh, int nh, int sigmoid,
                      float* out, int ldo, float* scratch, hipStream_t st);
 // heads backward: dy = dout * Wh (written), partial dWh/dbh -> finalize into grads.
+// skip_param: 0 all gradients, 1 input gradient only, 2 input gradient + bias gradient (the caller forms dWh itself)
 int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B, int K, const float* wh, int nh,
                      float* dy, int lddy, float* gwh, float* gbh, int accumulate, int skip_param, float* scratch,
                      hipStream_t st);

@@ -1634,8 +1634,13 @@ int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B,
         // dy = dout Wh  (B x K, reduction over the nh heads)
         one_problem(g, dout, ldd, wh, K, dy, lddy, B, K, nh, 0, 0);
         int rc = gemm_launch(GEMM_NN, g, st);
-        if (rc || skip_param) return rc;
-        // dWh (+)= dout^T y  (nh x K, reduction over the batch: split-K slabs + reduce), dbh (+)= column sums of dout
+        if (rc || skip_param == 1) return rc;
+        // dbh (+)= column sums of dout
+        if (skip_param == 2) {  // the weight gradient dWh rides in the last ResBlock's weight-gradient launch (net_backward)
+            hipLaunchKernelGGL(narrow_colsum_kernel, dim3(1), dim3(1024), 0, st, dout, ldd, B, nh, gbh, accumulate);
+            return check_launch("narrow_colsum");
+        }
+        // dWh (+)= dout^T y  (nh x K, reduction over the batch: split-K slabs + reduce)
         one_problem(g, dout, ldd, y, ldy, scratch, K, nh, K, B, 8, (long long)nh * K);
         rc = gemm_launch(GEMM_TN, g, st);
         if (rc) return rc;
