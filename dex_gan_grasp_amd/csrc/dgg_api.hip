@@ -1119,12 +1119,24 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
         // partials for the pose columns only; the fake pass overwrites the BPS columns and accumulates the rest
         const bool share_ok = share && share->bwd_mode && !c.p3 && L.nprefix == 0 && share->ncols > 0 && share->ncols < L.k0;
         const int c_first = (share_ok && share->bwd_mode == 1) ? share->ncols : 0;
-        for (int r = 0; r < L.nrb; ++r) {  // part layout per block: [tiles][2][k0]; q0 -> d gamma, q1 -> d beta
-            const int noacc = (share_ok && share->bwd_mode == 2 && r == 0) ? share->ncols : 0;
-            DGG_TRY(colsum_finalize_launch(c.W.ibn_part + (size_t)r * 12 * 2 * L.k0, 1, ibn_tiles[r], 2, L.k_in - c_first,
-                                           nullptr, grads + L.ibnw + c_first, grads + L.ibnb + c_first, nullptr,
-                                           (accum || r > 0) ? 1 : 0, st, L.k0, L.nprefix + c_first, nullptr, nullptr,
-                                           nullptr, 0, nullptr, 0, nullptr, nullptr, noacc));
+        // part layout per block: [tiles][2][k0], blocks 12 * 2 * k0 apart; q0 -> d gamma, q1 -> d beta.  One launch sums
+        // the blocks (groups) when they all used the same tile count — they do within one pass
+        bool same = true;
+        for (int r = 1; r < L.nrb; ++r) same = same && ibn_tiles[r] == ibn_tiles[0];
+        const int noacc0 = (share_ok && share->bwd_mode == 2) ? share->ncols : 0;
+        if (same) {
+            DGG_TRY(colsum_finalize_launch(c.W.ibn_part, L.nrb, ibn_tiles[0], 2, L.k_in - c_first, nullptr,
+                                           grads + L.ibnw + c_first, grads + L.ibnb + c_first, nullptr, accum ? 1 : 0, st,
+                                           L.k0, L.nprefix + c_first, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr,
+                                           nullptr, noacc0, (long long)12 * 2 * L.k0));
+        } else {
+            for (int r = 0; r < L.nrb; ++r) {
+                DGG_TRY(colsum_finalize_launch(c.W.ibn_part + (size_t)r * 12 * 2 * L.k0, 1, ibn_tiles[r], 2,
+                                               L.k_in - c_first, nullptr, grads + L.ibnw + c_first,
+                                               grads + L.ibnb + c_first, nullptr, (accum || r > 0) ? 1 : 0, st, L.k0,
+                                               L.nprefix + c_first, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr,
+                                               nullptr, r == 0 ? noacc0 : 0));
+            }
         }
     }
     // everything else — block 0 and the input BatchNorm — is complete here

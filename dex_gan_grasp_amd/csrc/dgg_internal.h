@@ -250,7 +250,8 @@ int colsum_finalize_launch(const float* part, int groups, int nrb, int nq, int n
                            float* dst1, float* dst2, int accumulate, hipStream_t st, int ld = 0, int c_lo = 0,
                            float* copy0 = nullptr, float* copy2 = nullptr, float* zero0 = nullptr, int nz0 = 0,
                            float* zero1 = nullptr, int nz1 = 0, float* dst3 = nullptr, float* dst4 = nullptr,
-                           int noacc_below = 0);  // columns c < noacc_below are overwritten even when accumulating
+                           int noacc_below = 0,   // columns c < noacc_below are overwritten even when accumulating
+                           long long gstride = 0);  // distance between the groups' partial blocks (0: back to back)
 // Input BN backward: partial sums of dX0 and dX0*xhat over the concat sources.
 int ibn_bwd_stats_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col_off, const float* mean,
                          const float* rstd, int rows_per_group, int groups, float* part, hipStream_t st, int nslab = 0,

@@ -885,7 +885,8 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
                                                               float* __restrict__ copy2, float* __restrict__ zero0,
                                                               int nz0, float* __restrict__ zero1, int nz1,
                                                               float* __restrict__ d3, float* __restrict__ d4,
-                                                              int noacc_below) {
+                                                              int noacc_below, long long gstride) {
+    // gstride: distance between the groups' partial blocks (0: they lie back to back, nrb * nq * ld apart)
     __shared__ float sh[SUB][64];
     if (blockIdx.x == 0) {  // ranges the caller wants cleared alongside (saves separate memset launches)
         for (int z = threadIdx.x; z < nz0; z += 256) zero0[z] = 0.f;
@@ -905,7 +906,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
             float t[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                t[j] = part[((size_t)(g * nrb + min(b8 + j, rb_hi - 1)) * nq + q) * ld + c_lo + c];
+                t[j] = part[(size_t)g * gstride + ((size_t)min(b8 + j, rb_hi - 1) * nq + q) * ld + c_lo + c];
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (b8 + j < rb_hi) sg += t[j];
@@ -1712,11 +1713,12 @@ int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const flo
 int colsum_finalize_launch(const float* part, int groups, int nrb, int nq, int ncols, float* sums_out, float* dst0,
                            float* dst1, float* dst2, int accumulate, hipStream_t st, int ld, int c_lo, float* copy0,
                            float* copy2, float* zero0, int nz0, float* zero1, int nz1, float* dst3, float* dst4,
-                           int noacc_below) {
+                           int noacc_below, long long gstride) {
     if (ld <= 0) ld = ncols;
+    if (gstride <= 0) gstride = (long long)nrb * nq * ld;
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(nq * ncols, 64)), dim3(256), 0, st, part, groups, nrb, nq,
                        ncols, ld, c_lo, sums_out, dst0, dst1, dst2, accumulate, copy0, copy2, zero0, zero0 ? nz0 : 0,
-                       zero1, zero1 ? nz1 : 0, dst3, dst4, noacc_below);
+                       zero1, zero1 ? nz1 : 0, dst3, dst4, noacc_below, gstride);
     return check_launch("colsum_finalize");
 }
 
