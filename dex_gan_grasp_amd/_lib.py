@@ -264,6 +264,19 @@ class FlatNet:
                                       ptr(self._step_dev), ptr(self._dyn), lr, beta1, beta2, eps, weight_decay,
                                       grad_scale, stream_ptr(self.device)), "dgg_adam_l2_graph")
 
+    def adam_begin(self):
+        """Start an optimiser step that is applied range by range (adam_range): advances the step number once."""
+        self.step += 1
+        if self._step_dev is not None:
+            self._step_dev.fill_(self.step)
+
+    def adam_range(self, lo, hi, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-4, grad_scale=1.0):
+        """dgg_adam_l2 on the float range [lo, hi) of the flat buffers (bucket bounds are multiples of 4), on the current
+        stream, with the step number adam_begin set."""
+        check(lib().dgg_adam_l2(ptr(self.params[lo:hi]), ptr(self.grads[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]),
+                                hi - lo, self.step, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                                stream_ptr(self.device)), "dgg_adam_l2")
+
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-4, grad_scale=1.0):
         self.step += 1
         if self._step_dev is not None:      # keep the device-resident counter of the graph path in step

@@ -463,10 +463,11 @@ struct GradEvents {
     hipEvent_t ev[3];
     int n, accum_only;
 };
-static thread_local GradEvents g_grad_events[4] = {};
+static const int kGradEventSlots = 24;   // 3 networks x up to 8 engines per thread
+static thread_local GradEvents g_grad_events[kGradEventSlots] = {};
 static const GradEvents* grad_events_for(const float* grads) {
     if (!grads) return nullptr;
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < kGradEventSlots; ++i)
         if (g_grad_events[i].grads == grads) return &g_grad_events[i];
     return nullptr;
 }
@@ -2285,14 +2286,14 @@ int dgg_set_grad_events(const float* grads, void* const* events, int n, int accu
         return DGG_OK;
     }
     int slot = -1;
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < kGradEventSlots; ++i)
         if (g_grad_events[i].grads == grads) slot = i;
     if (!events || n <= 0) {  // unregister
         if (slot >= 0) memset(&g_grad_events[slot], 0, sizeof(GradEvents));
         return DGG_OK;
     }
     if (n > 3) return DGG_ERR_INVALID;
-    for (int i = 0; i < 4 && slot < 0; ++i)
+    for (int i = 0; i < kGradEventSlots && slot < 0; ++i)
         if (!g_grad_events[i].grads) slot = i;
     if (slot < 0) return DGG_ERR_INVALID;
     for (int i = 0; i < n; ++i) {

@@ -106,7 +106,7 @@ class TrainEngine:
         if not parallel.is_distributed():
             return None
         net = {"G": self.G, "D": self.D, "E": self.E}[which]
-        if os.environ.get("DGG_BUCKETED_AR", "1") == "0":
+        if os.environ.get("DGG_BUCKETED_AR", "1") == "0" or not self._reducers:
             w = parallel.allreduce_sum_(net.grads, async_op=async_op)
             return [w] if async_op else None
         works = self._reducers[which].reduce_async()
@@ -115,10 +115,11 @@ class TrainEngine:
         parallel.wait_all(works)
         return None
 
-    def _arm_reducers(self):
-        """Data parallel: register the gradient-ready events once (calling thread).  D's gradients are final only after
-        the pass that accumulates (fake batch) — a prefetched real-batch pass must not signal."""
-        if not parallel.is_distributed() or os.environ.get("DGG_BUCKETED_AR", "1") == "0":
+    def _arm_reducers(self, force=False):
+        """Register the gradient-ready events once (calling thread): for the bucketed all-reduce of a data-parallel run,
+        and (force) for joint_step's split optimiser step.  D's gradients are final only after the pass that accumulates
+        (fake batch) — a prefetched real-batch pass must not signal."""
+        if not force and (not parallel.is_distributed() or os.environ.get("DGG_BUCKETED_AR", "1") == "0"):
             return
         if getattr(self, "_reducers", None) is None:
             self._reducers = {"G": parallel.BucketReducer(self.G), "D": parallel.BucketReducer(self.D, accum_only=True),
@@ -126,6 +127,30 @@ class TrainEngine:
         for r in self._reducers.values():
             if not r.armed:
                 r.arm()
+
+    def _adam_split(self, which, lr, hp, works, early):
+        """The optimiser step of network `which` in two launches: the bucket the backward completes first — last ResBlock
+        + heads, about half of the parameters — on the idle stream `early` as soon as its gradients (and, data
+        parallel, its all-reduce) are there, i.e. BESIDE the backward of the remaining blocks; the rest on the current
+        stream.  Adam is element-wise: same results as one launch over the whole buffer."""
+        net = {"G": self.G, "D": self.D, "E": self.E}[which]
+        rd = self._reducers[which]
+        works = list(works) if works else [None] * len(rd.bounds)
+        if len(works) != len(rd.bounds):      # one all-reduce of the whole buffer: no early part
+            parallel.wait_all(works)
+            net.adam_step(lr, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
+            return
+        kw = (lr, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
+        net.adam_begin()
+        (lo, hi) = rd.bounds[0]
+        early.wait_event(rd.events[0])
+        with torch.cuda.stream(early):
+            parallel.wait_all(works[:1])
+            net.adam_range(lo, hi, *kw)
+            done = early.record_event()
+        parallel.wait_all(works[1:])
+        net.adam_range(0, lo, *kw)
+        torch.cuda.current_stream(self.device).wait_event(done)
 
     def flush(self):
         """Make the current stream wait for everything this engine has enqueued on its side streams (a prefetched
@@ -314,6 +339,8 @@ class TrainEngine:
         if getattr(self, "_seed_dev", None) is None:
             self._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self._seed_dev.fill_(int(seed) - (1 << 64) if int(seed) >= (1 << 63) else int(seed))
+        for r in (self._reducers or {}).values():   # no gradient-ready events inside a capture (eager steps re-arm)
+            r.disarm()
         kw = dict(is_train_gen=is_train_gen, lr_gen=lr_gen, lr_dis=lr_dis, lr_eva=lr_eva, graph_mode=True)
         # (joint_step maps no weight-gradient streams: every stream of the capture is a direct child of the capturing
         # stream — ROCm 7.2 crashes on a captured stream that waits on another forked one, see dgg.h)
@@ -400,7 +427,7 @@ class TrainEngine:
                 self._map_wgrad_streams(side)
         else:
             side = main
-        self._arm_reducers()
+        self._arm_reducers(force=two_streams and not graph_mode)
         self._mark("step_begin")
         check(lib().dgg_cgan_d_phase2(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(self.losses),
                                       stream_ptr(dev), s2), "dgg_cgan_d_phase2")
@@ -427,8 +454,12 @@ class TrainEngine:
             parallel.wait_all(w_e)
             adam(E, hp.lr_eva)
             self._mark("adam_e_end", side)
-        parallel.wait_all(w_d)
-        adam(D, hp.lr_dis)
+        split = two_streams and not graph_mode and os.environ.get("DGG_SPLIT_ADAM", "1") != "0"
+        if split:    # (_side2 is idle here: the real pass it prefetched for this step ended long ago)
+            self._adam_split("D", hp.lr_dis, hp, w_d, self._side2)
+        else:
+            parallel.wait_all(w_d)
+            adam(D, hp.lr_dis)
         self._mark("adam_d_end")
         w_g = None
         if is_train_gen:
@@ -450,8 +481,11 @@ class TrainEngine:
                                                          ptr(self.losses), s2), "dgg_cgan_d_real_prefetch")
                 self._side2_busy = self._side2.record_event()
         if is_train_gen:
-            parallel.wait_all(w_g)
-            adam(G, hp.lr_gen)
+            if split:    # (the evaluator's stream is idle by now; _side2 runs the prefetched real pass)
+                self._adam_split("G", hp.lr_gen, hp, w_g, side)
+            else:
+                parallel.wait_all(w_g)
+                adam(G, hp.lr_gen)
             self._mark("adam_g_end")
         if two_streams:
             main.wait_stream(side)

@@ -95,7 +95,7 @@ class BucketReducer:
         self.accum_only = bool(accum_only)
         self.bounds = flat.grad_buckets()
         dev = flat.grads.device
-        self.feeder = torch.cuda.Stream(device=dev)
+        self.feeder = None            # created with the first collective (a single-GPU run never needs it)
         self.events = [torch.cuda.Event() for _ in self.bounds]
         for ev in self.events:            # materialise the handles
             ev.record(torch.cuda.current_stream(dev))
@@ -125,6 +125,8 @@ class BucketReducer:
         """After the phase call: enqueue the bucket collectives behind their events.  Returns the work handles; wait()
         on each (a stream-level dependency for RCCL) before the optimiser step."""
         works = []
+        if self.feeder is None:
+            self.feeder = torch.cuda.Stream(device=self.flat.grads.device)
         for (lo, hi), ev in zip(self.bounds, self.events):
             self.feeder.wait_event(ev)
             with torch.cuda.stream(self.feeder):

@@ -28,7 +28,7 @@
  *      real pass also leaves its dY13 / column sums in the workspace for the fake pass of that dgg_cgan_d_phase2, which
  *      forms the weight gradient of the shared BPS columns on dY_real + dY_fake: until that call has run, the BPS
  *      columns of d_grads' W13 / input-BatchNorm entries are NOT the real pass' gradient (nothing is written there);
- *  (d) up to 4 registrations of gradient-ready events (dgg_set_grad_events), keyed by the gradient buffer.
+ *  (d) up to 24 registrations of gradient-ready events (dgg_set_grad_events), keyed by the gradient buffer.
  * Consequences: use one thread per engine (or call from one thread only); a workspace that is freed while a slot
  * refers to it must be released first with dgg_cgan_release(ws) — a new allocation at the same address with the same
  * input pointers would otherwise match a stale slot; dgg_reset() drops (b), (c) and (d) for the calling thread
