@@ -670,3 +670,48 @@ def test_graph_replay_equals_eager_steps():
     assert torch.equal(e1.G.params, e2.G.params) and torch.equal(e1.E.params, e2.E.params) and e2.E.step == 5
     e1.close()
     e2.close()
+
+
+@pytest.mark.parametrize("b", [33, 127, 1000])
+def test_odd_batch_sizes_vs_oracle(b):
+    """Batches that are no multiple of the 32-row statistics blocks, the 64-row GEMM tiles or the split-K chunks: the
+    fused forward stage (partial row blocks in its statistics epilogue), the slab-summing backward kernels, the shared
+    weight gradient of D's two passes and the side-work launches of joint_step — two steps with prefetch against the
+    oracle: losses to 1e-4, gradients of the last step within the kink-tolerant bound, Adam of the engine's own gradients
+    exact."""
+    from oracle import dexgan_oracle as O
+    L, ops, engine = _mods()
+    eng, sd, sde = _engine("wide")
+    ag = O.AdamState([n for n in O.param_names(sd) if n.startswith("generator.")])
+    ad = O.AdamState([n for n in O.param_names(sd) if n.startswith("discriminator.")])
+    ae = O.AdamState(O.param_names(sde))
+    gbs = [synth.make_batch(b, 3), synth.make_batch(b, 13)]
+    g_ins = [_dev_inputs(x) for x in gbs]
+    ebs = [synth.make_batch(b, 4 + 10 * i, with_label=True) for i in range(2)]
+    for i in range(2):
+        z = synth.make_z(b, 50 + i)
+        e_in = _dev_inputs(ebs[i], with_label=True)
+        before = {k: _snap_flat(fl) for k, fl in (("G", eng.G), ("D", eng.D), ("E", eng.E))}
+        got = eng.joint_step(g_ins[i], z.to(DEV), e_in, True, None, 31 + i, next_gan_inputs=g_ins[1] if i == 0 else None)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        masks = eng.eva_keep_masks(b).float().cpu()
+        ref, g_d, g_g, _ = O.cgan_step(sd, H.clone_batch(gbs[i]), z, ag, ad, CFG, True, return_grads=True)
+        refe, g_e, _ = O.eva_step(sde, H.clone_batch(ebs[i]), ae, CFG, masks, return_grads=True)
+        for k, n in enumerate(LOSS_NAMES):
+            np.testing.assert_allclose(got[k], float(ref[n]), rtol=1e-4, atol=1e-6, err_msg="step %d %s" % (i, n))
+        np.testing.assert_allclose(got[L.L_TOTAL_EVA], float(refe["total_loss_eva"]), rtol=1e-4, atol=1e-6)
+        checked = [_grad_items(eng.G, g_g, "generator.", b), _grad_items(eng.E, g_e, "", b)]
+        if i == 1:     # D's gradients of step 0 are already overwritten by the prefetched pass of step 1
+            checked.append(_grad_items(eng.D, g_d, "discriminator.", b))
+        for items in checked:
+            for name, g, r, train, batch in items:
+                H.assert_grad_tensor_close(name, g, r, train=train, batch=batch, strict=False, what="B=%d step %d " % (b, i))
+        _cmp_adam_of_own_grads(eng.G, before["G"], what="G")
+        _cmp_adam_of_own_grads(eng.E, before["E"], what="E")
+        if i == 1:
+            _cmp_adam_of_own_grads(eng.D, before["D"], what="D")
+        _adopt(eng.G, sd, ag, "generator.")
+        _adopt(eng.D, sd, ad, "discriminator.")
+        _adopt(eng.E, sde, ae, "")
+    eng.close()
