@@ -1109,7 +1109,6 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
         float* t = dy; dy = other; other = t;
     }
     // input BatchNorm backward: parameter gradients = sum over ResBlocks and row tiles of the epilogue partials
-    const int nrb = (B + kRowBlock - 1) / kRowBlock;
     if (c.sw) {  // join: everything queued after this call on `st` sees the complete gradient buffer
         hipEvent_t e = next_event();
         if (!e || hipEventRecord(e, c.sw) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess)
