@@ -398,6 +398,24 @@ def main():
     losses = eng.losses.cpu().numpy()
     assert all(map(lambda x: x == x, losses[:10])), "NaN in losses"
 
+    # where a step spends its time: timed events at the phase boundaries (engine.trace), outside the timed region
+    phase_us = None
+    if world == 1:
+        eng.trace = []
+        n_tr = 12
+        for _ in range(n_tr):
+            step()
+        torch.cuda.synchronize()
+        tr, eng.trace = eng.trace, None
+        per = len(tr) // n_tr
+        acc = {}
+        for s_ in range(2, n_tr - 1):
+            ev, nxt = dict(tr[s_ * per:(s_ + 1) * per]), dict(tr[(s_ + 1) * per:(s_ + 2) * per])
+            for name in ("d_phase_end", "adam_d_end", "g_phase_end", "adam_g_end", "e_phase_end", "adam_e_end"):
+                acc.setdefault(name, []).append(ev["step_begin"].elapsed_time(ev[name]) * 1e3)
+            acc.setdefault("next_step_begin", []).append(ev["step_begin"].elapsed_time(nxt["step_begin"]) * 1e3)
+        phase_us = {k: round(statistics.median(v), 1) for k, v in acc.items()}
+
     if rank == 0:
         value = B * world * args.steps / dt
         res = {
@@ -408,6 +426,7 @@ def main():
             "config": {"workload": "cGAN step (update_dexgangrasp) + evaluator step (update_dexevaluator), "
                                    "batch %d per GPU, BPS-4096, fp32, Adam included" % B,
                        "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "phase_us_after_step_begin": phase_us,
                        "timed_blocks": len(blocks),
                        "block_ms_per_step_min_median_max": [round(min(blocks) / args.steps * 1e3, 4),
                                                             round(dt / args.steps * 1e3, 4),
