@@ -161,11 +161,11 @@ class TrainEngine:
             self._side2_busy = None
 
     def _streams(self, two_streams, wgrad=True):
-        """(main, s2 as void* or None): the D phase forks its real-batch pass onto _side2; wgrad: every compute stream
-        also gets a library-owned weight-gradient side stream (cgan_step / eva_step on their own: up to 4 streams,
-        one per hardware queue of the default HIP runtime configuration).  joint_step runs WITHOUT them: its three
-        compute streams already keep the chip busy, and six streams on four hardware queues serialise in pairs —
-        measured 1.92 ms per step against 2.00 ms with the weight-gradient streams (tools/phase_times.py)."""
+        """(main, s2 as void* or None): the D phase forks its real-batch pass onto _side2.  wgrad: every compute stream may
+        also get a library-owned weight-gradient side stream — only with DGG_WGRAD_STREAMS=1: the HIP runtime maps streams
+        onto 4 hardware queues in creation order and never rebalances; with more streams than queues, pairs serialise
+        (joint_step with six streams: 2.00 instead of 1.92 ms; cgan_step / eva_step in a process that also ran joint_step:
+        1.51 / 0.74 instead of 1.49 / 0.74 ms, config 2 1.09 instead of 1.05 ms).  Three streams is what the engine uses."""
         main = torch.cuda.current_stream(self.device)
         if not two_streams:
             return main, None
@@ -298,7 +298,7 @@ class TrainEngine:
         created and owned by the library — streams from torch's pool are shared between users, and one that served
         as a side stream here and as a compute stream (with its own side stream) elsewhere could close a wait
         cycle."""
-        mode = os.environ.get("DGG_WGRAD_STREAMS", "1")
+        mode = os.environ.get("DGG_WGRAD_STREAMS", "0")   # opt-in ("1"): see _streams
         if mode == "0":
             return
         if mode == "main":   # diagnostics: only the stream the step is called on gets one
