@@ -715,3 +715,26 @@ def test_odd_batch_sizes_vs_oracle(b):
         _adopt(eng.D, sd, ad, "discriminator.")
         _adopt(eng.E, sde, ae, "")
     eng.close()
+
+
+def test_weight_gradient_streams_opt_in_is_bit_identical(monkeypatch):
+    """DGG_WGRAD_STREAMS=1 (library-owned weight-gradient side streams, dgg_enable_wgrad_stream — opt-in since the engine
+    keeps to three streams): cgan_step / eva_step with them give the same bits as without."""
+    L, ops, engine = _mods()
+    b = 128
+    gb = _dev_inputs(synth.make_batch(b, 1))
+    eb = _dev_inputs(synth.make_batch(b, 2, with_label=True), with_label=True)
+    z = synth.make_z(b, 3).to(DEV)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DGG_WGRAD_STREAMS", mode)
+        eng, _, _ = _engine("wide")
+        for i in range(2):
+            eng.cgan_step(*gb, z, True, two_streams=True)
+            eng.eva_step(*eb, None, 17 + i, two_streams=True)
+        torch.cuda.synchronize()
+        out[mode] = [x.params.clone() for x in (eng.G, eng.D, eng.E)]
+        assert (len(getattr(eng, "_wg_mapped", None) or ()) > 0) == (mode == "1")
+        eng.close()
+    for a, c in zip(out["0"], out["1"]):
+        assert torch.equal(a, c)
