@@ -227,15 +227,20 @@ def sub_results(cfg, dev, eng):
     out = {}
     f = lambda t: t.float().to(dev).contiguous()
 
-    def wall(fn, steps, warm=3):
+    def wall(fn, steps, warm=10, blocks=5):
+        # median of `blocks` timed blocks: a single short block after host-side set-up catches the clock ramp of an idle
+        # GPU now and then (one sub-result per run up to 1.8x off)
         for _ in range(warm):
             fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps
+        ts = []
+        for _ in range(blocks):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / steps)
+        return statistics.median(ts)
     # config 2: cGAN update only, B = 256 (train.py's generator phase)
     b = 256
     gb = synth.make_batch(b, 1)
