@@ -138,6 +138,9 @@ __device__ __forceinline__ void store_tile(float* __restrict__ S, const float (&
 }
 
 constexpr int kBnaMaxK = 256;  // fc2 forward: K = hidden width
+#ifndef DGG_FC2_ABLATE
+#define DGG_FC2_ABLATE 0   // diagnostics only: 1 no statistics merge in the prologue, 2 no statistics in the epilogue
+#endif
 
 template <int BM, int BN, bool A_KC, bool B_KC, bool BNA = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch) {
@@ -180,54 +183,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
     const int nkt = (kend - kbeg + BK - 1) / BK;
 
     const int tid = threadIdx.x;
-    if constexpr (BNA) {
-        // BatchNorm statistics of the A operand's K columns: thread = column; Chan merge of the row-block partials in
-        // row-block order, 8 loads in flight (every workgroup: same order, same bits); eval: running statistics
-        if (tid < P.K) {
-            float mean = 0.f, rstd;
-            if (P.bn_train) {
-                float cnt = 0.f, m2 = 0.f;
-                for (int b8 = 0; b8 < P.bn_nrb; b8 += 16) {  // 32 loads in flight: one round trip per 16 row blocks
-                    float mb[16], qb[16];
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const float* q = P.bn_part + (size_t)min(b8 + j, P.bn_nrb - 1) * 2 * P.K;
-                        mb[j] = q[tid];
-                        qb[j] = q[P.K + tid];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        if (b8 + j < P.bn_nrb) {
-                            const float nb = (float)min(kRowBlock, P.bn_rows - (b8 + j) * kRowBlock);
-                            const float tot = cnt + nb;
-                            const float d = mb[j] - mean;
-                            mean += d * (nb / tot);
-                            m2 += qb[j] + d * d * (cnt * nb / tot);
-                            cnt = tot;
-                        }
-                    }
-                }
-                rstd = 1.0f / sqrtf(m2 / cnt + kBnEps);
-                if (blockIdx.x == 0) {
-                    P.bn_mean_out[tid] = mean;
-                    P.bn_rstd_out[tid] = rstd;
-                    if (P.bn_run_mean) P.bn_run_mean[tid] = (1.f - kBnMom) * P.bn_run_mean[tid] + kBnMom * mean;
-                    if (P.bn_run_var) P.bn_run_var[tid] = (1.f - kBnMom) * P.bn_run_var[tid] + kBnMom * (m2 / (cnt - 1.f));
-                }
-            } else {
-                mean = P.bn_run_mean[tid];
-                rstd = 1.0f / sqrtf(P.bn_run_var[tid] + kBnEps);
-                if (blockIdx.x == 0) {
-                    P.bn_mean_out[tid] = mean;
-                    P.bn_rstd_out[tid] = rstd;
-                }
-            }
-            const float sc = rstd * P.bn_gamma[tid];
-            bna_sc[tid] = sc;
-            bna_sh[tid] = P.bn_beta[tid] - mean * sc;
-        }
-        __syncthreads();
-    }
     const int wave = tid >> 6, lane = tid & 63;
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
     const int li = lane & 31, lh = lane >> 5;
@@ -303,6 +258,71 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
     using PF1 = std::integral_constant<int, 1>;
     using PF2 = std::integral_constant<int, 2>;
 
+    auto bna_prologue = [&]() {
+        // BatchNorm statistics of the A operand's K columns: thread = column; Chan merge of the row-block partials in
+        // row-block order, 8 loads in flight (every workgroup: same order, same bits); eval: running statistics
+        if (tid < P.K) {
+            float mean = 0.f, rstd;
+            if (P.bn_train && DGG_FC2_ABLATE == 1) {
+                mean = 0.1f; rstd = 1.f;
+            } else if (P.bn_train) {
+                // Chan merge of the row-block partials: 32 row blocks per round with all 64 loads in flight (one memory
+                // round trip), merged as four interleaved chains (block j goes to chain j % 4) that are then merged in
+                // order — a quarter of the dependent divisions of one long chain.  Every workgroup: same order, same bits.
+                float cnt = 0.f, m2 = 0.f;
+                for (int b0 = 0; b0 < P.bn_nrb; b0 += 32) {
+                    float mb[32], qb[32];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) {
+                        const float* q = P.bn_part + (size_t)min(b0 + j, P.bn_nrb - 1) * 2 * P.K;
+                        mb[j] = q[tid];
+                        qb[j] = q[P.K + tid];
+                    }
+                    float cc[4] = {0.f, 0.f, 0.f, 0.f}, cm[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) {
+                        if (b0 + j < P.bn_nrb) {
+                            const int ch = j & 3;
+                            const float nb = (float)min(kRowBlock, P.bn_rows - (b0 + j) * kRowBlock);
+                            const float tot = cc[ch] + nb;
+                            const float d = mb[j] - cm[ch];
+                            cm[ch] += d * (nb / tot);
+                            cq[ch] += qb[j] + d * d * (cc[ch] * nb / tot);
+                            cc[ch] = tot;
+                        }
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) {
+                        if (cc[ch] > 0.f) {
+                            const float tot = cnt + cc[ch];
+                            const float d = cm[ch] - mean;
+                            mean += d * (cc[ch] / tot);
+                            m2 += cq[ch] + d * d * (cnt * cc[ch] / tot);
+                            cnt = tot;
+                        }
+                    }
+                }
+                rstd = 1.0f / sqrtf(m2 / cnt + kBnEps);
+                if (blockIdx.x == 0) {
+                    P.bn_mean_out[tid] = mean;
+                    P.bn_rstd_out[tid] = rstd;
+                    if (P.bn_run_mean) P.bn_run_mean[tid] = (1.f - kBnMom) * P.bn_run_mean[tid] + kBnMom * mean;
+                    if (P.bn_run_var) P.bn_run_var[tid] = (1.f - kBnMom) * P.bn_run_var[tid] + kBnMom * (m2 / (cnt - 1.f));
+                }
+            } else {
+                mean = P.bn_run_mean[tid];
+                rstd = 1.0f / sqrtf(P.bn_run_var[tid] + kBnEps);
+                if (blockIdx.x == 0) {
+                    P.bn_mean_out[tid] = mean;
+                    P.bn_rstd_out[tid] = rstd;
+                }
+            }
+            const float sc = rstd * P.bn_gamma[tid];
+            bna_sc[tid] = sc;
+            bna_sh[tid] = P.bn_beta[tid] - mean * sc;
+        }
+        __syncthreads();
+    };
     if (nkt > 0) {  // prologue: tile 0
         if (nfull > 0) {
             load_tile<BM, A_KC, true>(P.A, P.lda, m0, M, kbeg, kend, ra);
@@ -311,8 +331,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
             load_tile<BM, A_KC, false>(P.A, P.lda, m0, M, kbeg, kend, ra);
             load_tile<BN, B_KC, false>(P.B, P.ldb, n0, N, kbeg, kend, rb);
         }
-        if constexpr (BNA) bn_act_tile<BM>(ra, bna_sc, bna_sh, kbeg, kend, tn_i == 0 ? P.a_out : nullptr, P.K, m0, M);
-        else if constexpr (A_KC) { if (aff) affine_tile<BM>(ra, P.a_scale, P.a_shift, kbeg, kend); }
+        // (the statistics merge runs while tile 0's global loads are in flight)
+        if constexpr (BNA) {
+            bna_prologue();
+            bn_act_tile<BM>(ra, bna_sc, bna_sh, kbeg, kend, tn_i == 0 ? P.a_out : nullptr, P.K, m0, M);
+        } else if constexpr (A_KC) { if (aff) affine_tile<BM>(ra, P.a_scale, P.a_shift, kbeg, kend); }
         store_tile<BM, A_KC>(smem, ra);
         store_tile<BN, B_KC>(smem + BK * LDA_S, rb);
     }
@@ -342,6 +365,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
                     if (col < N) P.C[(size_t)(m0 + wm0 + rr) * P.ldc + col] = v[r];
                 }
             }
+            if (DGG_FC2_ABLATE == 2) return;
             s += __shfl_xor(s, 32);
             const float mean = s / (float)nvalid;
             float q = 0.f;
