@@ -98,7 +98,7 @@ static int build_layout(int net, const dgg_cfg* c, NetL& L) {
         return DGG_ERR_INVALID;
     }
     L.k0 = L.nprefix + L.k_in;
-    L.ldx0 = (int)align4(L.k0);
+    L.ldx0 = (int)((L.k0 + 31) / 32 * 32);   // 128-byte rows: a k-tile row segment of the GEMMs is exactly one cache line
     int64_t po = 0, bo = 0;
     auto P = [&](int64_t n) { int64_t o = po; po = align4(po + n); return o; };
     auto S = [&](int64_t n) { int64_t o = bo; bo = align4(bo + n); return o; };
