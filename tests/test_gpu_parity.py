@@ -172,6 +172,33 @@ def test_bps_batched_and_edges(B, N):
         assert not (ids[0] == 3).any()  # point 3 duplicates point 1: the lower index always wins
 
 
+def test_bps_block_argmin_keeps_lowest_index_rule():
+    """The batched kernel keeps its running argmin per block of 8 cloud points and resolves the index afterwards: ties
+    inside a block, across blocks, in the ragged tail, a cloud of identical points and a far-away cloud whose squared
+    distances overflow to +inf must all give the sequential scan's answer (the oracle's)."""
+    ops, _ = _ops()
+    from oracle import bps_oracle
+    basis = H.load("bps_real_objects.npz")["basis"]
+    B, N = 64, 101
+    clouds = synth.make_clouds(B, N, 4242)
+    clouds[0, 6] = clouds[0, 2]        # same block
+    clouds[0, 43] = clouds[0, 2]       # later block
+    clouds[0, 100] = clouds[0, 97]     # tail (N % 8 = 5)
+    clouds[0, 99] = clouds[0, 10]      # tail duplicates a full block's point
+    clouds[1, :] = clouds[1, 0]        # every point the same: index 0 everywhere
+    clouds[2, :] = 3e19                # d^2 overflows: nothing is < +inf, index 0, dist +inf
+    clouds[3, :50] = 3e19              # the finite half wins
+    dist, ids = ops.bps_encode(clouds.to(DEV), torch.from_numpy(basis).to(DEV))
+    dist, ids = dist.cpu().numpy(), ids.cpu().numpy()
+    for b in (0, 1, 2, 3, 17, 63):
+        od, oi = bps_oracle.encode_f32(clouds[b].numpy(), basis)
+        assert (ids[b] == oi).all(), b
+        assert (dist[b].view(np.int32) == od.view(np.int32)).all(), b
+    assert not np.isin(ids[0], (6, 43, 100, 99)).any()
+    assert (ids[1] == 0).all() and (ids[2] == 0).all() and np.isinf(dist[2]).all()
+    assert (ids[3] >= 50).all()
+
+
 # ------------------------------------------------------------------ A6 / A7: small ops
 def test_ortho6d_forward_backward():
     ops, _ = _ops()
