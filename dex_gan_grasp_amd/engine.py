@@ -99,7 +99,7 @@ class TrainEngine:
         vals = [G.params, G.grads, G.m, G.v, G.bn, D.params, D.grads, D.m, D.v, D.bn]
         return _lib.GanState(*[t.data_ptr() for t in vals])
 
-    def _reduce(self, which, async_op=False):
+    def _reduce(self, which, async_op=False, feeder=None):
         """Sum the gradients of network `which` ("G" / "D" / "E") over the ranks after a phase call whose backward has
         just been enqueued: per-ResBlock buckets behind the library's gradient-ready events (parallel.BucketReducer;
         DGG_BUCKETED_AR=0: one all-reduce of the whole buffer).  Returns work handles when async_op."""
@@ -109,7 +109,7 @@ class TrainEngine:
         if os.environ.get("DGG_BUCKETED_AR", "1") == "0" or not self._reducers:
             w = parallel.allreduce_sum_(net.grads, async_op=async_op)
             return [w] if async_op else None
-        works = self._reducers[which].reduce_async()
+        works = self._reducers[which].reduce_async(feeder)
         if async_op:
             return works
         parallel.wait_all(works)
@@ -433,7 +433,10 @@ class TrainEngine:
                                       stream_ptr(dev), s2), "dgg_cgan_d_phase2")
         self._mark("d_phase_end")
         self._side2_busy = None             # the D phase joins _side2 (a picked-up prefetch included) into main
-        w_d = self._reduce("D", async_op=True)
+        # data parallel: the bucket collectives are fed from a compute stream that is idle at that point, never from
+        # streams of their own (parallel.BucketReducer.reduce_async): D's from _side2 (joined above), the evaluator's
+        # simply follow its own stream, G's from the evaluator's stream (done by then)
+        w_d = self._reduce("D", async_op=True, feeder=self._side2 if two_streams else None)
         # the evaluator update and the prefetched real pass run BESIDE the cGAN chain: their large GEMMs take half the
         # chip for twice as long (dgg_set_side_work) so that the chain's short kernels keep finding free CUs
         polite = two_streams and os.environ.get("DGG_SIDE_WORK", "1") != "0"
@@ -447,14 +450,17 @@ class TrainEngine:
                 check(lib().dgg_eva_phase(cfg_p, ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(wse),
                                           wse.numel(), Be, ptr(ebps), ptr(erot9), ptr(etransl), ptr(elabel), ptr(dk),
                                           int(seed), ptr(self.losses), stream_ptr(dev)), "dgg_eva_phase")
-            w_e = self._reduce("E", async_op=True)
+            w_e = self._reduce("E", async_op=True, feeder="current" if two_streams else None)
             self._mark("e_phase_end", side)
             # the evaluator's optimiser step follows on its own stream at once (it blocks nothing else there; enqueued
             # after the G phase it would reach the GPU only when the host gets that far — behind the generator's)
             parallel.wait_all(w_e)
             adam(E, hp.lr_eva)
             self._mark("adam_e_end", side)
-        split = two_streams and not graph_mode and os.environ.get("DGG_SPLIT_ADAM", "1") != "0"
+        # (data parallel: one optimiser launch per network — the stream that would run the early half is the one feeding
+        # the collectives, and every extra cross-stream wait costs ~12 us there: 2.05 vs 1.88 ms with a one-rank group)
+        split = (two_streams and not graph_mode and os.environ.get("DGG_SPLIT_ADAM", "1") != "0"
+                 and not parallel.is_distributed())
         if split:    # (_side2 is idle here: the real pass it prefetched for this step ended long ago)
             self._adam_split("D", hp.lr_dis, hp, w_d, self._side2)
         else:
@@ -465,7 +471,7 @@ class TrainEngine:
         if is_train_gen:
             check(lib().dgg_cgan_g_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args,
                                          ptr(self.losses), stream_ptr(dev)), "dgg_cgan_g_phase")
-            w_g = self._reduce("G", async_op=True)
+            w_g = self._reduce("G", async_op=True, feeder=side if two_streams else None)
             self._mark("g_phase_end")
             # a ragged next batch (last of an epoch) is simply not prefetched: the workspace is carved per batch size
             if two_streams and next_gan_inputs is not None and next_gan_inputs[0].shape[0] == B:

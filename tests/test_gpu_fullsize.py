@@ -360,6 +360,22 @@ def test_two_rank_data_parallel_on_one_gpu(mode):
     assert out.count("dp_check %s: rank" % mode) == 2, out[-2000:]
 
 
+def test_one_rank_rccl_process_group_runs_the_collective_path():
+    """The data-parallel step over the REAL backend on this box's one GPU: a one-rank RCCL process group
+    (DGG_FORCE_DISTRIBUTED=1) sends every bucket through dist.all_reduce on RCCL's stream, behind the gradient-ready
+    events and the lent feeder streams, in front of the optimiser launches — 3 joint_steps with prefetch against the
+    oracle (tools/dp_check.py).  What the gloo rehearsal above cannot show: stream-ordered NCCL work handles."""
+    env = dict(os.environ)
+    env.update({"DGG_FORCE_DISTRIBUTED": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "4", "RANK": "0",
+                "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
+    env.pop("DGG_REHEARSE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "dp_check.py"), "engine"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-4000:]
+    assert out.count("dp_check engine: rank 0 ok") == 1, out[-2000:]
+
+
 def test_init_net_distribution_lands_in_flat_buffers():
     """A15 (dexgangrasp.py:28-62): xavier_normal(gain) on every Linear.weight, BatchNorm weight ~ N(1, gain), BatchNorm
     bias 0, Linear.bias left at torch's default; and the values ARE the library's flat buffers (the kernels see them)."""

@@ -14,6 +14,9 @@ engine : 3 joint_steps (with prefetch) on contiguous shards of a global batch; e
          other.
 wrapper: the drop-in DexGanGrasp wrapper under torchrun: replicas are identical after construction although every rank
          seeds its own init, and stay identical over update_dexgangrasp / update_dexevaluator steps on different shards.
+DGG_FORCE_DISTRIBUTED=1 python tools/dp_check.py engine   (no launcher): ONE rank with a real RCCL process group — the
+collective path as it runs on a multi-GPU node (RCCL's stream, the lent feeder streams, the work handles in front of the
+optimiser launches), checked against the same oracle.
 Exit code 0 = all checks passed on this rank.
 """
 import os
@@ -33,7 +36,9 @@ from dex_gan_grasp_amd import _lib, engine, parallel, synth  # noqa: E402
 def _all_equal(t, what):
     """Every rank holds the same tensor."""
     w = parallel.world_size()
-    t = t.detach().cpu().contiguous()      # gloo gathers host tensors only; RCCL runs take the same path
+    t = t.detach().contiguous()
+    if dist.get_backend() != "nccl":       # gloo gathers host tensors only; RCCL device tensors only
+        t = t.cpu()
     parts = [torch.zeros_like(t) for _ in range(w)]
     dist.all_gather(parts, t)
     for r in range(1, w):
@@ -44,7 +49,7 @@ def check_engine(per_rank=64, steps=3):
     import helpers as H
     from oracle import dexgan_oracle as O
     rank, world, idx = parallel.init_from_env()
-    assert world > 1 and parallel.is_distributed()
+    assert parallel.is_distributed() and (world > 1 or parallel.forced())
     dev = torch.device("cuda", idx)
     cfg = dict(synth.DEFAULT_CFG)
     B = per_rank * world
@@ -144,7 +149,9 @@ def check_wrapper(per_rank=32, steps=2):
         for nm, mod in mods:
             _all_equal(mod._require_flat().params, "%s after step %d" % (nm, i))
     # the ranks saw different shards: their losses differ, their parameters do not
-    t = torch.stack([l1["total_loss_gen"].detach().float(), l2["total_loss_eva"].detach().float()]).cpu()
+    t = torch.stack([l1["total_loss_gen"].detach().float(), l2["total_loss_eva"].detach().float()])
+    if dist.get_backend() != "nccl":
+        t = t.cpu()
     parts = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(parts, t)
     assert not torch.equal(parts[0], parts[1])
