@@ -41,17 +41,29 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int BPT, int U>
 __global__ __launch_bounds__(256) void bps_batched_kernel(const float* __restrict__ clouds, int N,
                                                           const float* __restrict__ basis, int P,
-                                                          float* __restrict__ dists, int32_t* __restrict__ ids) {
+                                                          float* __restrict__ dists, int32_t* __restrict__ ids,
+                                                          int B, int gx) {
     static_assert(BPT % 2 == 0 && (U == 8 || U == 16), "pairs of basis points, blocks of 8 / 16 cloud points");
     constexpr int H = BPT / 2;
-    const int b = blockIdx.y;
+    // 1-D grid of gx * B workgroups (gx basis slices per cloud).  Consecutive workgroup ids go round the 8 XCDs: the gx
+    // slices of one cloud take ids 8 apart, so they share an XCD's L2 and the cloud is fetched from memory once instead
+    // of gx times (the ragged last group of < 8 clouds keeps the plain order).
+    const int L = blockIdx.x, per = 8 * gx;
+    int b, slice;
+    if (L < (B / 8) * per) {
+        b = (L / per) * 8 + (L & 7);
+        slice = (L % per) >> 3;
+    } else {
+        b = L / gx;
+        slice = L % gx;
+    }
     const float* __restrict__ c = clouds + (size_t)b * N * 3;
     f32x2 bx[H], by[H], bz[H];
     float best[BPT];
     int blk[BPT];  // first point of the block that set `best`; -1: nothing was ever smaller than +inf
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
-        int i = blockIdx.x * (256 * BPT) + q * 256 + threadIdx.x;
+        int i = slice * (256 * BPT) + q * 256 + threadIdx.x;
         i = i < P ? i : P - 1;
         bx[q >> 1][q & 1] = basis[3 * i];
         by[q >> 1][q & 1] = basis[3 * i + 1];
@@ -101,7 +113,7 @@ __global__ __launch_bounds__(256) void bps_batched_kernel(const float* __restric
     }
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
-        const int i = blockIdx.x * (256 * BPT) + q * 256 + threadIdx.x;
+        const int i = slice * (256 * BPT) + q * 256 + threadIdx.x;
         // the winning block again, this lane's own addresses: the first point that reproduces the minimum
         int id = 0;
         if (blk[q] >= 0) {
@@ -185,8 +197,9 @@ int bps_encode_launch(const float* clouds, int B, int N, const float* basis, int
                       hipStream_t st) {
     if (!clouds || !basis || !dists || B <= 0 || N <= 0 || P <= 0) return DGG_ERR_INVALID;
     if (B >= 64) {
-        dim3 grid((P + 1023) / 1024, B);
-        hipLaunchKernelGGL((bps_batched_kernel<4, 16>), grid, dim3(256), 0, st, clouds, N, basis, P, dists, ids);
+        const int gx = (P + 1023) / 1024;
+        hipLaunchKernelGGL((bps_batched_kernel<4, 16>), dim3((unsigned)gx * B), dim3(256), 0, st, clouds, N, basis, P,
+                           dists, ids, B, gx);
     } else {
         dim3 grid((P + 63) / 64, B);
         hipLaunchKernelGGL(bps_single_kernel, grid, dim3(1024), 0, st, clouds, N, basis, P, dists, ids);

@@ -55,6 +55,11 @@ specs = [
     ("bps", "bps_batched_kernel", "bps_encode", {"B": 1024, "N": 2048, "P": 4096},
      "python3 tools/microbench.py bps --iters 5", 1024 * 2048 * 4096 * 8.0, 1024 * (2048 * 12 + 4096 * 8) + 4096 * 12),
 ]
+# FETCH_SIZE factor per kernel.  The guide's x2 is for 16-B-per-lane vector loads (the GEMMs' LDS-DMA); other widths have
+# to be calibrated on a known byte count: bps_batched_kernel reads its clouds through the scalar cache only, and with
+# every cloud fetched once per XCD group the raw counter gives 25.4 MB against 25.17 MB of clouds + 48 KB of basis — exact.
+FETCH_FACTOR = {"bps": (1.0, "scalar (s_load) reads: FETCH_SIZE calibrated exact on this kernel's known 25.2 MB of clouds; "
+                              "WRITE_SIZE exact")}
 for name, ksub, outname, shape, cmd, flops, alg_bytes in specs:
     c = {}
     n = {}
@@ -66,13 +71,15 @@ for name, ksub, outname, shape, cmd, flops, alg_bytes in specs:
     dur, calls = avg_duration_ns(name + "_trace", ksub)
     if dur is None:
         continue
-    fetch = c.get("FETCH_SIZE", 0.0) * 1024 * 2      # KB, x2 per the gfx950 correction
+    ffac, fnote = FETCH_FACTOR.get(name, (2.0, "gfx950: FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane loads "
+                                                "-> doubled; WRITE_SIZE exact"))
+    fetch = c.get("FETCH_SIZE", 0.0) * 1024 * ffac   # KB
     write = c.get("WRITE_SIZE", 0.0) * 1024
     out = {"round": int(tag[1:]), "kernel": ksub, "shape": shape,
            "command": "rocprofv3 --pmc <counters> -- " + cmd + " (one pass per counter group; kernel-trace in its own run)",
            "avg_duration_ns_kernel_trace": dur, "launches_in_trace": calls,
            "FETCH_SIZE_KB_raw": c.get("FETCH_SIZE"), "WRITE_SIZE_KB_raw": c.get("WRITE_SIZE"),
-           "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane loads -> doubled; WRITE_SIZE exact",
+           "correction": fnote,
            "fetch_bytes": fetch, "write_bytes": write, "traffic_bytes": fetch + write, "algorithmic_bytes": alg_bytes,
            "counters_avg_per_launch": c, "launches_per_counter": n}
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
