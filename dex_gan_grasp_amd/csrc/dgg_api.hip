@@ -273,6 +273,10 @@ static bool share_wgrad() {  // diagnostics: DGG_SHARE_WGRAD=0: both passes of D
     static const bool v = [] { const char* e = getenv("DGG_SHARE_WGRAD"); return !(e && e[0] == '0'); }();
     return v;
 }
+static bool obj_plain_fc2() {  // diagnostics: DGG_OBJ_PLAIN_FC2=0 sends the inference sweep through rb_tail's stage kernel
+    static const bool v = [] { const char* e = getenv("DGG_OBJ_PLAIN_FC2"); return !(e && e[0] == '0'); }();
+    return v;
+}
 static bool fuse_fc2() {  // diagnostics: DGG_FUSE_FC2=0 keeps bn_act / fc2 GEMM / reduce as separate launches
     static const bool v = [] { const char* e = getenv("DGG_FUSE_FC2"); return !(e && e[0] == '0'); }();
     return v;
@@ -1314,10 +1318,32 @@ static int objects_forward(const NetL& L, const float* params, float* bn, void* 
             DGG_TRY(gemm_launch(GEMM_NT, g, st));
             nslab = g.p[0].splits;
         }
+        // inference tail: expand_rows leaves h = lrelu(bn1(a1)) (running statistics) for the first `hid` columns, so fc2
+        // is a plain 128 x 128-tile product on the bf16x3 kernel (K = 256, no split: B is large) and its bias goes into
+        // the output stage — against rb_tail's f32-MFMA stage kernel, whose statistics work an eval pass does not need
+        RbW& A = c.W.rb[r];
+        const bool plain = obj_plain_fc2();
         DGG_TRY(expand_rows_launch(W.cobj[r], L.n13, n, c.W.slabs, nslab, slab, L.n13, small, sg, sbeta, srm, srv,
-                                   params + R.w13 + wcol_x0(r) + small_off, R.fin, c.W.rb[r].a13, L.n13, B, L.n13, L.hid,
-                                   L.n13, st));
-        DGG_TRY(rb_tail(c, r, 0, nullptr, 0, 0));
+                                   params + R.w13 + wcol_x0(r) + small_off, R.fin, A.a13, L.n13, B, L.n13, L.hid, L.n13,
+                                   st, plain ? A.h : nullptr, L.hid, L.hid, params + R.bn1w, params + R.bn1b,
+                                   bn + R.rm1, bn + R.rv1));
+        if (!plain) {
+            DGG_TRY(rb_tail(c, r, 0, nullptr, 0, 0));
+            continue;
+        }
+        {
+            GemmBatch g2;
+            memset(&g2, 0, sizeof(g2));
+            g2.nprob = 1;
+            prob_init(g2.p[0], A.h, L.hid, params + R.w2, L.hid, A.a2, L.nn, B, L.nn, L.hid);
+            DGG_TRY(gemm_launch(GEMM_NT, g2, st));
+        }
+        {
+            BnFused fz{c.W.part, 0, bn + R.rm2, bn + R.rv2, A.mean2, A.rstd2};
+            DGG_TRY(res_out_launch(A.a13 + L.hid, L.n13, A.a2, L.nn, B, B, L.nn, A.mean2, A.rstd2, params + R.bn2w,
+                                   params + R.bn2b, 0, nullptr, 0, 0, nullptr, A.y, L.nn, st, &fz, nullptr,
+                                   params + R.b2));
+        }
     }
     const int sig = L.net != DGG_NET_GEN;
     DGG_TRY(heads_fwd_launch(c.W.rb[L.nrb - 1].y, L.nn, B, L.nn, params + L.wh, params + L.bh, L.nh, sig, out, L.nh,

@@ -184,7 +184,9 @@ int reduce_bias_launch(const float* slabs, int nslab, long long slab_stride, int
 int expand_rows_launch(const float* cobj, int ldc, int n_per, const float* slabs, int nslab, long long slab_stride,
                        int ld_slab, const ColSrcs& small, const float* gamma, const float* beta, const float* rm,
                        const float* rv, const float* wsm, int ldw, float* out, int ld_out, int B, int N, int act_lo,
-                       int act_hi, hipStream_t st);
+                       int act_hi, hipStream_t st,
+                       float* h = nullptr, int ldh = 0, int hid = 0, const float* g1 = nullptr, const float* b1 = nullptr,
+                       const float* rm1 = nullptr, const float* rv1 = nullptr);
 // h[m][c] = lrelu((a[m][c]-mean)*rstd*gamma+beta)
 int bn_act_launch(const float* a, int lda, int B, int rows_per_group, int N, const float* mean, const float* rstd,
                   const float* gamma, const float* beta, float* h, int ldh, hipStream_t st,
@@ -194,7 +196,7 @@ int bn_act_launch(const float* a, int lda, int B, int rows_per_group, int N, con
 int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, int rows_per_group, int N,
                    const float* mean, const float* rstd, const float* gamma, const float* beta, int drop_mode,
                    const float* keep_in, uint64_t seed, uint64_t seed_off, uint8_t* keep_out, float* y, int ldy,
-                   hipStream_t st, const BnFused* fused = nullptr, const PlaneOut* planes = nullptr);
+                   hipStream_t st, const BnFused* fused = nullptr, const PlaneOut* planes = nullptr, const float* a2_bias = nullptr);
 // heads: out[m][j] = sum_k y[m][k] Wh[j][k] + bh[j]; sigmoid optionally.
 int heads_fwd_launch(const float* y, int ldy, int B, int K, const float* wh, const float* bh, int nh, int sigmoid,
                      float* out, int ldo, float* scratch, hipStream_t st);

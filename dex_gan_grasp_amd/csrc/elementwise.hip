@@ -530,7 +530,8 @@ __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ 
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       int drop_mode, const float* __restrict__ keep_in, uint64_t seed,
                                                       uint64_t seed_off, uint8_t* __restrict__ keep_out,
-                                                      float* __restrict__ y, int ldy, BnFin fin, PlaneOut PL) {
+                                                      float* __restrict__ y, int ldy, BnFin fin, PlaneOut PL,
+                                                      const float* __restrict__ a2_bias) {
     __shared__ float sh[SUB][3][64];
     __shared__ float res[2][2][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
@@ -553,6 +554,7 @@ __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ 
         return;
     }
     const float ga = gamma[c], be = beta[c];
+    const float ab = a2_bias ? a2_bias[c] : 0.f;  // a2 arrives without fc2's bias (inference path: plain GEMM output)
     const float inv_keep = 1.0f / (1.0f - kDropP);
     // drop_mode 3: `seed` carries a device pointer to the seed (graph replay: the seed lives in device memory)
     const uint64_t sd = drop_mode == 3 ? *reinterpret_cast<const uint64_t*>(seed) : seed;
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ 
     for (int r = 0; r < RS; ++r) {
         const size_t row = (size_t)(r0 + row_clamp(r, n));
         sv[r] = s[row * lds + c];
-        av[r] = a2[row * lda2 + c];
+        av[r] = a2[row * lda2 + c] + ab;
         kv[r] = drop_mode == 1 ? keep_in[row * N + c] : 1.f;
     }
 #pragma unroll
@@ -1471,59 +1473,104 @@ struct SmallIn {
     ColSrcs srcs;                           // raw per-sample columns (virtual concat), srcs.total <= 16
     const float *gamma, *beta, *rm, *rv;    // eval BatchNorm of those columns (NULL gamma: identity)
 };
+// Optional: columns [0, hid) — fc1's pre-activation — leave as h = lrelu(bn1(.)) with bn1's running statistics, written
+// to `h` (pitch ldh) instead of `out`: the fc2 product that follows is then a plain GEMM on the bf16x3 kernel.
+struct HOut {
+    float* h;
+    int ldh, hid;
+    const float *gamma, *beta, *rm, *rv;
+};
 __global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restrict__ cobj, int ldc, int n_per,
                                                           const float* __restrict__ slabs, int nslab,
                                                           long long slab_stride, int ld_slab, SmallIn sm,
                                                           const float* __restrict__ wsm, int ldw,
                                                           float* __restrict__ out, int ld_out, int B, int N, int act_lo,
-                                                          int act_hi) {
+                                                          int act_hi, HOut HO) {
+    // the workgroup's 32 rows x <= 16 small columns, eval-BatchNorm'd, staged once through LDS (every column of the
+    // output needs them: from global memory they were 128 broadcast loads per thread)
+    __shared__ __attribute__((aligned(16))) float smx[RB][16];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int ns = sm.srcs.total;
+    for (int idx = threadIdx.x; idx < RB * 16; idx += 256) {
+        const int rl = idx >> 4, j = idx & 15;
+        const int row = blockIdx.y * RB + rl;
+        float x = 0.f;
+        if (j < ns && row < B) {
+            int ld;
+            const float* p = src_col(sm.srcs, j, ld);
+            float scj = 1.f, shj = 0.f;
+            if (sm.gamma) {
+                scj = sm.gamma[j] * (1.0f / sqrtf(sm.rv[j] + kBnEps));
+                shj = sm.beta[j] - sm.rm[j] * scj;
+            }
+            x = fmaf(p[(size_t)row * ld], scj, shj);
+        }
+        smx[rl][j] = x;
+    }
+    __syncthreads();
     const int c = blockIdx.x * 64 + lane;
     if (c >= N) return;
-    const int ns = sm.srcs.total;
-    float w[16], sc[16], shf[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        w[j] = j < ns ? wsm[(size_t)c * ldw + j] : 0.f;
-        sc[j] = 1.f;
-        shf[j] = 0.f;
-        if (j < ns && sm.gamma) {
-            sc[j] = sm.gamma[j] * (1.0f / sqrtf(sm.rv[j] + kBnEps));
-            shf[j] = sm.beta[j] - sm.rm[j] * sc[j];
-        }
+    const bool to_h = HO.h && c < HO.hid;
+    float h_mu = 0.f, h_rs = 0.f, h_ga = 0.f, h_be = 0.f;
+    if (to_h) {
+        h_mu = HO.rm[c];
+        h_rs = 1.0f / sqrtf(HO.rv[c] + kBnEps);
+        h_ga = HO.gamma[c];
+        h_be = HO.beta[c];
     }
+    float w[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w[j] = j < ns ? wsm[(size_t)c * ldw + j] : 0.f;
     const bool act = c >= act_lo && c < act_hi;
     const int r0 = blockIdx.y * RB + sub * RS;
     const int n = min(RS, B - r0);
-    for (int r = 0; r < n; ++r) {
-        const int row = r0 + r;
-        float v = cobj[(size_t)(row / n_per) * ldc + c];
-        for (int s2 = 0; s2 < nslab; ++s2) v += slabs[(size_t)s2 * slab_stride + (size_t)row * ld_slab + c];
-        float t = 0.f;
+    if (n <= 0) return;
+    // all 8 rows of a wave in flight per load group (a row loop costs one memory round trip per row); per row the same
+    // order of additions as before: object row, slabs in k order, then the small-column sum
+    float v[RS], t[RS];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (j < ns) {
-                int ld;
-                const float* p = src_col(sm.srcs, j, ld);
-                t = fmaf(fmaf(p[(size_t)row * ld], sc[j], shf[j]), w[j], t);
-            }
+    for (int r = 0; r < RS; ++r) {
+        const int row = r0 + row_clamp(r, n);
+        v[r] = cobj[(size_t)(row / n_per) * ldc + c];
+        t[r] = 0.f;
+    }
+    for (int s2 = 0; s2 < nslab; ++s2) {
+        float u[RS];
+#pragma unroll
+        for (int r = 0; r < RS; ++r)
+            u[r] = slabs[(size_t)s2 * slab_stride + (size_t)(r0 + row_clamp(r, n)) * ld_slab + c];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) v[r] += u[r];
+    }
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)          // columns >= ns hold 0 with weight 0: t + 0 * 0 leaves t as it is
+            if (j < ns) t[r] = fmaf(smx[sub * RS + r][j], w[j], t[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        if (r < n) {
+            const float o = v[r] + t[r];
+            if (to_h) HO.h[(size_t)(r0 + r) * HO.ldh + c] = lrelu(fmaf((o - h_mu) * h_rs, h_ga, h_be));
+            else out[(size_t)(r0 + r) * ld_out + c] = act ? lrelu(o) : o;
         }
-        v += t;
-        out[(size_t)row * ld_out + c] = act ? lrelu(v) : v;
     }
 }
 
 int expand_rows_launch(const float* cobj, int ldc, int n_per, const float* slabs, int nslab, long long slab_stride,
                        int ld_slab, const ColSrcs& small, const float* gamma, const float* beta, const float* rm,
                        const float* rv, const float* wsm, int ldw, float* out, int ld_out, int B, int N, int act_lo,
-                       int act_hi, hipStream_t st) {
+                       int act_hi, hipStream_t st, float* h, int ldh, int hid, const float* g1, const float* b1,
+                       const float* rm1, const float* rv1) {
     if (small.total > 16 || n_per < 1) return DGG_ERR_UNSUPPORTED;
+    HOut ho = {h, ldh, hid, g1, b1, rm1, rv1};
     SmallIn sm;
     sm.srcs = small;
     sm.gamma = gamma; sm.beta = beta; sm.rm = rm; sm.rv = rv;
     dim3 grid(cdiv(N, 64), cdiv(B, RB));
     hipLaunchKernelGGL(expand_rows_kernel, grid, dim3(256), 0, st, cobj, ldc, n_per, slabs, nslab, slab_stride, ld_slab, sm,
-                       wsm, ldw, out, ld_out, B, N, act_lo, act_hi);
+                       wsm, ldw, out, ld_out, B, N, act_lo, act_hi, ho);
     return check_launch("expand_rows");
 }
 
@@ -1539,7 +1586,7 @@ int bn_act_launch(const float* a, int lda, int B, int rpg, int N, const float* m
 int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, int rpg, int N, const float* mean,
                    const float* rstd, const float* gamma, const float* beta, int drop_mode, const float* keep_in,
                    uint64_t seed, uint64_t seed_off, uint8_t* keep_out, float* y, int ldy, hipStream_t st,
-                   const BnFused* fz, const PlaneOut* planes) {
+                   const BnFused* fz, const PlaneOut* planes, const float* a2_bias) {
     BnFin fin;
     if (int rc = make_fin(fz, rpg, fin)) return rc;
     PlaneOut pl = {};
@@ -1549,7 +1596,7 @@ int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, in
     }
     dim3 grid(cdiv(N, 64), cdiv(B, RB));
     hipLaunchKernelGGL(res_out_kernel, grid, dim3(256), 0, st, s, lds, a2, lda2, B, rpg, N, mean, rstd, gamma, beta,
-                       drop_mode, keep_in, seed, seed_off, keep_out, y, ldy, fin, pl);
+                       drop_mode, keep_in, seed, seed_off, keep_out, y, ldy, fin, pl, a2_bias);
     return check_launch("res_out");
 }
 
