@@ -267,6 +267,11 @@ def sub_results(cfg, dev, eng):
     z = synth.make_z(b, 3).to(dev)
     dt = wall(lambda: eng.cgan_step(*g_in, z, True, two_streams=True), 30)
     out["cgan_step_b1024"] = {"ms_per_step": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1)}
+    # N3: the WGAN-GP variant of the same update (is_wgan: Wasserstein losses + gradient penalty through D's double backward)
+    al = torch.rand((b, 3), generator=torch.Generator().manual_seed(5)).to(dev)
+    dt = wall(lambda: eng.wgan_step(*g_in, z, al, True), 20)
+    out["wgan_gp_step_b1024"] = {"ms_per_step": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1),
+                                 "workload": "update_dexgangrasp with is_wgan=True (gradient penalty), batch 1024"}
     # the drop-in API path: DexGanGrasp.update_dexgangrasp + update_dexevaluator through the wrapper, as an unchanged
     # train.py would call them (one after the other; batches resident on the device as float32)
     from dex_gan_grasp_amd.models.dexgangrasp import DexGanGrasp
