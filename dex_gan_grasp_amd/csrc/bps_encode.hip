@@ -9,10 +9,9 @@
 //  - a lane owns basis points (registers: bx,by,bz,best,id per point); the cloud point index j is
 //    wave-uniform, so x_j,y_j,z_j arrive through the SCALAR cache (s_load) and are broadcast as SGPR
 //    operands — no LDS traffic, no per-lane loads in the inner loop;
-//  - batched clouds (B >= 64): 256-thread workgroups, 4 basis points per lane -> grid (P/1024, B);
-//  - few clouds (robot path, one 15k..73k-point cloud): 1024-thread workgroups in which the 16 waves
-//    scan 16 disjoint ranges of the cloud for the same 64 basis points and merge through LDS in
-//    range order (keeps the lowest-index tie rule) -> grid (P/64, B).
+//  - 256-thread workgroups, 4 basis points per lane (two packed pairs), P/1024 basis slices per cloud;
+//  - few clouds (robot path, one 15k..73k-point cloud): the same kernel over RANGES of the cloud, merged through the
+//    output arrays with atomicMin in two passes (see the kernel) -> the whole chip works on one cloud.
 #include "dgg_internal.h"
 
 namespace dgg {
@@ -38,19 +37,36 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //  v_fma / v_mul / v_sub on VGPR operands 2.2-2.7 (double rate) but 4.2 as soon as one operand is an SGPR, which the
 //  wave-uniform cloud point is; v_min_f32 / v_min3_f32 4.2; v_cmp + v_cndmask 6.4 — hence packed arithmetic (the SGPR
 //  pair is broadcast by op_sel at no cost) and as few compare / select instructions as the tie rule allows.
-template <int BPT, int U>
+//
+// MODE 0: one workgroup scans a whole cloud for its 1024 basis points (many clouds: the training / sweep front end).
+// MODE 1 / 2: FEW clouds with many points (the robot path: one 15k..73k-point cloud, dexgangrasp_real_robot.py:139):
+// the cloud is cut into `nchunk` ranges of `chunk_len` points (a multiple of U) so that the launch fills the chip, and
+// the ranges meet in the output arrays themselves — no workspace in the ABI:
+//   pass 1 (MODE 1): atomicMin of the range's best d^2 (non-negative floats order like their bit patterns) into dists,
+//                    pre-set to +inf;
+//   pass 2 (MODE 2): the range that holds the global minimum finds the first point reproducing it (same block rule) and
+//                    atomicMin's its index into ids, pre-set to INT_MAX — the lowest index over all ranges wins, the
+//                    sequential rule again;
+//   bps_finish_kernel: dist = sqrt(d^2), untouched ids (nothing was below +inf) -> 0.
+template <int BPT, int U, int MODE>
 __global__ __launch_bounds__(256) void bps_batched_kernel(const float* __restrict__ clouds, int N,
                                                           const float* __restrict__ basis, int P,
                                                           float* __restrict__ dists, int32_t* __restrict__ ids,
-                                                          int B, int gx) {
+                                                          int B, int gx, int nchunk, int chunk_len) {
     static_assert(BPT % 2 == 0 && (U == 8 || U == 16), "pairs of basis points, blocks of 8 / 16 cloud points");
     constexpr int H = BPT / 2;
     // 1-D grid of gx * B workgroups (gx basis slices per cloud).  Consecutive workgroup ids go round the 8 XCDs: the gx
     // slices of one cloud take ids 8 apart, so they share an XCD's L2 and the cloud is fetched from memory once instead
     // of gx times (the ragged last group of < 8 clouds keeps the plain order).
     const int L = blockIdx.x, per = 8 * gx;
-    int b, slice;
-    if (L < (B / 8) * per) {
+    int b, slice, jlo = 0, jhi = N;
+    if (MODE != 0) {  // (cloud, range, slice): slices fastest
+        slice = L % gx;
+        const int rest = L / gx;
+        b = rest / nchunk;
+        jlo = (rest % nchunk) * chunk_len;
+        jhi = min(N, jlo + chunk_len);
+    } else if (L < (B / 8) * per) {
         b = (L / per) * 8 + (L & 7);
         slice = (L % per) >> 3;
     } else {
@@ -68,7 +84,10 @@ __global__ __launch_bounds__(256) void bps_batched_kernel(const float* __restric
         bx[q >> 1][q & 1] = basis[3 * i];
         by[q >> 1][q & 1] = basis[3 * i + 1];
         bz[q >> 1][q & 1] = basis[3 * i + 2];
-        best[q] = __builtin_inff();
+        // MODE 2: `best` is the TARGET, the global minimum pass 1 left in dists (+inf: nothing was smaller, leave ids)
+        best[q] = MODE == 2 ? __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)dists + (size_t)b * P + i,
+                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                            : __builtin_inff();
         blk[q] = -1;
     }
     auto pair_d2 = [&](int h, float x, float y, float z) {
@@ -76,11 +95,18 @@ __global__ __launch_bounds__(256) void bps_batched_kernel(const float* __restric
         return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
     };
     auto offer = [&](int q, float m, int j0) {  // m: minimum of a block starting at point j0
-        const bool lt = m < best[q];
-        best[q] = lt ? m : best[q];
-        blk[q] = lt ? j0 : blk[q];
+        if (MODE == 2) {  // the first block that reaches the target
+            const bool hit = (m == best[q]) & (blk[q] < 0);
+            blk[q] = hit ? j0 : blk[q];
+        } else {
+            const bool lt = m < best[q];
+            best[q] = lt ? m : best[q];
+            blk[q] = lt ? j0 : blk[q];
+        }
     };
-    int j = 0;
+    int j = jlo;
+    const int N_ = N;
+    N = jhi;  // the scan below covers [jlo, jhi)
     for (; j + U <= N; j += U) {
         float p[3 * U];
 #pragma unroll
@@ -114,11 +140,16 @@ __global__ __launch_bounds__(256) void bps_batched_kernel(const float* __restric
 #pragma unroll
     for (int q = 0; q < BPT; ++q) {
         const int i = slice * (256 * BPT) + q * 256 + threadIdx.x;
+        if (MODE == 1) {
+            if (i < P && blk[q] >= 0)
+                atomicMin((unsigned*)dists + (size_t)b * P + i, __builtin_bit_cast(unsigned, best[q]));
+            continue;
+        }
         // the winning block again, this lane's own addresses: the first point that reproduces the minimum
         int id = 0;
         if (blk[q] >= 0) {
             const int j0 = blk[q];
-            const int n = (j0 + U <= N && j0 % U == 0) ? U : 1;  // full blocks start at multiples of U, tail blocks hold 1
+            const int n = (j0 + U <= N && (j0 - jlo) % U == 0) ? U : 1;  // full blocks: multiples of U from jlo; tail blocks hold 1
             id = j0;
             bool found = false;
             for (int u = 0; u < n; ++u) {
@@ -130,79 +161,61 @@ __global__ __launch_bounds__(256) void bps_batched_kernel(const float* __restric
                 }
             }
         }
+        if (MODE == 2) {
+            if (i < P && blk[q] >= 0 && best[q] < __builtin_inff()) atomicMin(ids + (size_t)b * P + i, id);
+            continue;
+        }
         if (i < P) {
             dists[(size_t)b * P + i] = __builtin_sqrtf(best[q]);
             if (ids) ids[(size_t)b * P + i] = id;
         }
     }
+    (void)N_;
 }
 
-// 1024 threads: wave w scans points [w*chunk, (w+1)*chunk) for basis points blockIdx.x*64 + lane.
-__global__ __launch_bounds__(1024) void bps_single_kernel(const float* __restrict__ clouds, int N,
-                                                          const float* __restrict__ basis, int P,
-                                                          float* __restrict__ dists, int32_t* __restrict__ ids) {
-    __shared__ float s_best[16][64];
-    __shared__ int s_id[16][64];
-    const int b = blockIdx.y;
-    const float* __restrict__ c = clouds + (size_t)b * N * 3;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int i = blockIdx.x * 64 + lane;
-    const bool ok = i < P;
-    i = ok ? i : P - 1;
-    const float bx = basis[3 * i], by = basis[3 * i + 1], bz = basis[3 * i + 2];
-    const int chunk = (N + 15) / 16;
-    const int j0 = w * chunk;
-    const int j1 = min(N, j0 + chunk);
-    float best = __builtin_inff();
-    int bid = 0;
-    int j = j0;
-    for (; j + 4 <= j1; j += 4) {
-        float p[12];
-#pragma unroll
-        for (int e = 0; e < 12; ++e) p[e] = c[3 * j + e];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float d2 = dist2(p[3 * u], p[3 * u + 1], p[3 * u + 2], bx, by, bz);
-            const bool lt = d2 < best;
-            best = lt ? d2 : best;
-            bid = lt ? j + u : bid;
-        }
+__global__ void bps_preset_kernel(float* __restrict__ dists, int32_t* __restrict__ ids, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        dists[i] = __builtin_inff();
+        if (ids) ids[i] = 0x7fffffff;
     }
-    for (; j < j1; ++j) {
-        const float d2 = dist2(c[3 * j], c[3 * j + 1], c[3 * j + 2], bx, by, bz);
-        const bool lt = d2 < best;
-        best = lt ? d2 : best;
-        bid = lt ? j : bid;
-    }
-    s_best[w][lane] = best;
-    s_id[w][lane] = bid;
-    __syncthreads();
-    if (w == 0) {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) {  // ascending ranges + strict '<' keep the lowest index on ties
-            const float d2 = s_best[k][lane];
-            const bool lt = d2 < best;
-            best = lt ? d2 : best;
-            bid = lt ? s_id[k][lane] : bid;
-        }
-        if (ok) {
-            dists[(size_t)b * P + i] = __builtin_sqrtf(best);
-            if (ids) ids[(size_t)b * P + i] = bid;
-        }
+}
+__global__ void bps_finish_kernel(float* __restrict__ dists, int32_t* __restrict__ ids, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        dists[i] = __builtin_sqrtf(dists[i]);
+        if (ids && ids[i] == 0x7fffffff) ids[i] = 0;
     }
 }
 
 int bps_encode_launch(const float* clouds, int B, int N, const float* basis, int P, float* dists, int32_t* ids,
                       hipStream_t st) {
     if (!clouds || !basis || !dists || B <= 0 || N <= 0 || P <= 0) return DGG_ERR_INVALID;
-    if (B >= 64) {
-        const int gx = (P + 1023) / 1024;
-        hipLaunchKernelGGL((bps_batched_kernel<4, 16>), dim3((unsigned)gx * B), dim3(256), 0, st, clouds, N, basis, P,
-                           dists, ids, B, gx);
+    const int gx = (P + 1023) / 1024;
+    // few clouds: cut them into ranges until ~768 workgroups exist, ranges of at least 256 points (multiples of 16)
+    int nchunk = 1, chunk_len = N;
+    if ((long long)gx * B < 192 && N >= 512) {
+        int want = 768 / (gx * B);
+        const int most = N / 256;
+        want = want < most ? want : most;
+        if (want > 1) {
+            chunk_len = ((N + want - 1) / want + 15) / 16 * 16;
+            nchunk = (N + chunk_len - 1) / chunk_len;
+        }
+    }
+    if (nchunk <= 1) {
+        hipLaunchKernelGGL((bps_batched_kernel<4, 16, 0>), dim3((unsigned)gx * B), dim3(256), 0, st, clouds, N, basis, P,
+                           dists, ids, B, gx, 1, N);
     } else {
-        dim3 grid((P + 63) / 64, B);
-        hipLaunchKernelGGL(bps_single_kernel, grid, dim3(1024), 0, st, clouds, N, basis, P, dists, ids);
+        const int n = B * P;
+        const dim3 grid((unsigned)gx * B * nchunk);
+        hipLaunchKernelGGL(bps_preset_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dists, ids, n);
+        hipLaunchKernelGGL((bps_batched_kernel<4, 16, 1>), grid, dim3(256), 0, st, clouds, N, basis, P, dists, ids, B, gx,
+                           nchunk, chunk_len);
+        if (ids)
+            hipLaunchKernelGGL((bps_batched_kernel<4, 16, 2>), grid, dim3(256), 0, st, clouds, N, basis, P, dists, ids, B,
+                               gx, nchunk, chunk_len);
+        hipLaunchKernelGGL(bps_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dists, ids, n);
     }
     return check_launch("bps_encode");
 }

@@ -199,6 +199,39 @@ def test_bps_block_argmin_keeps_lowest_index_rule():
     assert (ids[3] >= 50).all()
 
 
+@pytest.mark.parametrize("B,N", [(1, 3001), (2, 20000), (5, 777)])
+def test_bps_few_clouds_ranges_keep_lowest_index_rule(B, N):
+    """Few clouds with many points (the robot path) are scanned as ranges that meet in the output arrays through
+    atomicMin (two passes): duplicates of a point in other ranges, an all-equal cloud and an overflowing one must give
+    the sequential scan's ids, bit-identical distances."""
+    ops, _lib = _ops()
+    from oracle import bps_oracle
+    basis = H.load("bps_real_objects.npz")["basis"]
+    clouds = synth.make_clouds(B, N, 900 + B + N)
+    clouds[0, N - 1] = clouds[0, 3]          # last range duplicates a point of the first
+    clouds[0, N // 2] = clouds[0, 3]         # a middle range too
+    clouds[0, N // 2 + 1] = clouds[0, N // 3]
+    if B > 1:
+        clouds[1, :] = clouds[1, 7]          # every point the same: index 0 everywhere
+    if B > 2:
+        clouds[2, :] = 3e19                  # nothing is below +inf: index 0, dist +inf
+        clouds[3, : N // 2] = 3e19           # the finite half wins
+    dist, ids = ops.bps_encode(clouds.to(DEV), torch.from_numpy(basis).to(DEV))
+    dist, ids = dist.cpu().numpy(), ids.cpu().numpy()
+    for b in range(B):
+        od, oi = bps_oracle.encode_f32(clouds[b].numpy(), basis)
+        assert (ids[b] == oi).all(), b
+        assert (dist[b].view(np.int32) == od.view(np.int32)).all(), b
+    assert not np.isin(ids[0], (N - 1, N // 2, N // 2 + 1)).any()
+    # distances only (ids = NULL in the ABI): same bits
+    lib = _lib.lib()
+    d2 = torch.empty((B, basis.shape[0]), device=DEV)
+    cl, bs = clouds.to(DEV).contiguous(), torch.from_numpy(basis).to(DEV)
+    _lib.check(lib.dgg_bps_encode(_lib.ptr(cl), B, N, _lib.ptr(bs), basis.shape[0], _lib.ptr(d2), None,
+                                  _lib.stream_ptr()))
+    assert (d2.cpu().numpy().view(np.int32) == dist.view(np.int32)).all()
+
+
 # ------------------------------------------------------------------ A6 / A7: small ops
 def test_ortho6d_forward_backward():
     ops, _ = _ops()
