@@ -1,5 +1,5 @@
 import ctypes as C, os, sys, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dex_gan_grasp_amd import _lib
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 4120
 M, N, S = 1024, 768, 4
