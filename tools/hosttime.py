@@ -4,8 +4,9 @@ import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from dex_gan_grasp_amd import _lib, engine, synth
+from dex_gan_grasp_amd import _lib, engine, parallel, synth
 
+parallel.init_from_env()   # DGG_FORCE_DISTRIBUTED=1: host cost of the collective path (one-rank RCCL group)
 dev = torch.device("cuda", 0)
 cfg = dict(synth.DEFAULT_CFG)
 B = 1024
@@ -20,14 +21,14 @@ g_in = (f(gb["bps_object"]), f(gb["rot_matrix"]).reshape(B, 9), f(gb["transl"]),
 e_in = (f(eb["bps_object"]), f(eb["rot_matrix"]).reshape(B, 9), f(eb["transl"]), f(eb["label"]))
 z = synth.make_z(B, 3).to(dev)
 for i in range(10):
-    eng.joint_step(g_in, z, e_in, True, None, i)
+    eng.joint_step(g_in, z, e_in, True, None, i, next_gan_inputs=g_in)
 torch.cuda.synchronize()
 N = 40
 host = []
 t0 = time.perf_counter()
 for i in range(N):
     a = time.perf_counter()
-    eng.joint_step(g_in, z, e_in, True, None, i)
+    eng.joint_step(g_in, z, e_in, True, None, i, next_gan_inputs=g_in)
     host.append(time.perf_counter() - a)
 t1 = time.perf_counter()
 torch.cuda.synchronize()
