@@ -434,8 +434,11 @@ class TrainEngine:
         self._mark("d_phase_end")
         self._side2_busy = None             # the D phase joins _side2 (a picked-up prefetch included) into main
         # data parallel: the bucket collectives are fed from a compute stream that is idle at that point, never from
-        # streams of their own (parallel.BucketReducer.reduce_async): D's from _side2 (joined above), the evaluator's
-        # simply follow its own stream, G's from the evaluator's stream (done by then)
+        # streams of their own (parallel.BucketReducer.reduce_async): D's from _side2 (joined above); the evaluator's
+        # from _side2 as well, behind D's — RCCL runs a group's collectives in issue order, and fed from the evaluator's
+        # own stream its 42.6 MB would start only when its phase ends and sit in front of G's buckets; the prefetched
+        # real pass queues behind those waits (it has the whole G phase to run in); G's from the evaluator's stream
+        # (done by then)
         w_d = self._reduce("D", async_op=True, feeder=self._side2 if two_streams else None)
         # the evaluator update and the prefetched real pass run BESIDE the cGAN chain: their large GEMMs take half the
         # chip for twice as long (dgg_set_side_work) so that the chain's short kernels keep finding free CUs
@@ -450,7 +453,7 @@ class TrainEngine:
                 check(lib().dgg_eva_phase(cfg_p, ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(wse),
                                           wse.numel(), Be, ptr(ebps), ptr(erot9), ptr(etransl), ptr(elabel), ptr(dk),
                                           int(seed), ptr(self.losses), stream_ptr(dev)), "dgg_eva_phase")
-            w_e = self._reduce("E", async_op=True, feeder="current" if two_streams else None)
+            w_e = self._reduce("E", async_op=True, feeder=self._side2 if two_streams else None)
             self._mark("e_phase_end", side)
             # the evaluator's optimiser step follows on its own stream at once (it blocks nothing else there; enqueued
             # after the G phase it would reach the GPU only when the host gets that far — behind the generator's)
