@@ -421,8 +421,10 @@ def main():
         acc = {}
         for s_ in range(2, n_tr - 1):
             ev, nxt = dict(tr[s_ * per:(s_ + 1) * per]), dict(tr[(s_ + 1) * per:(s_ + 2) * per])
-            for name in ("d_phase_end", "adam_d_end", "g_phase_end", "adam_g_end", "e_phase_end", "adam_e_end"):
-                acc.setdefault(name, []).append(ev["step_begin"].elapsed_time(ev[name]) * 1e3)
+            for name in ("d_phase_end", "adam_d_end", "g_phase_end", "adam_g_end", "e_phase_end", "adam_e_end",
+                         "prefetch_begin", "prefetch_end"):
+                if name in ev:
+                    acc.setdefault(name, []).append(ev["step_begin"].elapsed_time(ev[name]) * 1e3)
             acc.setdefault("next_step_begin", []).append(ev["step_begin"].elapsed_time(nxt["step_begin"]) * 1e3)
         phase_us = {k: round(statistics.median(v), 1) for k, v in acc.items()}
 

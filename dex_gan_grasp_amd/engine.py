@@ -170,7 +170,11 @@ class TrainEngine:
         if not two_streams:
             return main, None
         if self._side2 is None:
-            self._side2 = torch.cuda.Stream(device=self.device)
+            if parallel.is_distributed() and self.device.type == "cuda":
+                # data parallel: side streams that share a hardware queue with neither RCCL's stream nor this one
+                self._side2, self._side = parallel.pick_side_streams(self.device, 2)
+            else:
+                self._side2 = torch.cuda.Stream(device=self.device)
         if wgrad:
             self._map_wgrad_streams(main, self._side2)
         else:
@@ -474,7 +478,6 @@ class TrainEngine:
         if is_train_gen:
             check(lib().dgg_cgan_g_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args,
                                          ptr(self.losses), stream_ptr(dev)), "dgg_cgan_g_phase")
-            w_g = self._reduce("G", async_op=True, feeder=side if two_streams else None)
             self._mark("g_phase_end")
             # a ragged next batch (last of an epoch) is simply not prefetched: the workspace is carved per batch size
             if two_streams and next_gan_inputs is not None and next_gan_inputs[0].shape[0] == B:
@@ -484,11 +487,15 @@ class TrainEngine:
                     if t.dtype != torch.float32 or not t.is_contiguous() or t.device != bps.device:
                         raise _lib.DggError("next_gan_inputs must be resident contiguous float32 tensors")
                 self._keep_next = (nb, nr, nt, nj_)   # the C side remembers raw pointers
+                self._mark("prefetch_begin", self._side2)
                 with _side_work(polite):
                     check(lib().dgg_cgan_d_real_prefetch(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(),
                                                          nb.shape[0], ptr(nb), ptr(nr), ptr(nt), ptr(nj_),
                                                          ptr(self.losses), s2), "dgg_cgan_d_real_prefetch")
                 self._side2_busy = self._side2.record_event()
+                self._mark("prefetch_end", self._side2)
+            # (G's collectives are issued AFTER the prefetch is enqueued: see below)
+            w_g = self._reduce("G", async_op=True, feeder=side if two_streams else None)
         if is_train_gen:
             if split:    # (the evaluator's stream is idle by now; _side2 runs the prefetched real pass)
                 self._adam_split("G", hp.lr_gen, hp, w_g, side)

@@ -10,6 +10,7 @@ The same code runs on the CPU with the gloo backend (tests/test_parallel_cpu.py,
 from __future__ import annotations
 
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -155,6 +156,93 @@ class BucketReducer:
             with torch.cuda.stream(feeder):
                 works.append(dist.all_reduce(self.flat.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         return works
+
+
+_picked = {}
+
+
+def _blocked_behind(cand, run_blocker, dev, sleep_cycles):
+    """Does a tiny launch on stream `cand` have to wait for a long spin that `run_blocker` puts in front of SOMETHING
+    else?  True = `cand` shares a hardware queue with that something."""
+    main = torch.cuda.current_stream(dev)
+    x = torch.zeros(64, device=dev)
+    torch.cuda.synchronize(dev)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record(cand)
+    run_blocker(sleep_cycles)
+    with torch.cuda.stream(cand):
+        x.add_(1.0)
+    t1.record(cand)
+    torch.cuda.synchronize(dev)
+    del main
+    return t0.elapsed_time(t1)
+
+
+def pick_side_streams(dev, n=2, candidates=8):
+    """n side streams for a data-parallel step that share a hardware queue neither with the caller's current stream, nor
+    with RCCL's stream, nor with each other.
+
+    Why: the HIP runtime binds every stream to one of 4 hardware queues when it is created (round robin: streams 4 apart
+    share one) and a queue runs its packets in order — ALSO the event waits of another stream bound to it.  RCCL's
+    collectives sit on a stream of torch's pool behind a wait for the producing stream; whichever compute stream shares
+    that queue stalls behind that wait (measured with a one-rank group: the prefetched real pass held back until the G
+    phase had ended, or Adam(G) until the prefetch had, or the evaluator phase by 0.7 ms, depending on where the pool
+    index fell: 1.97 / 2.03 / 2.12 ms per step against 1.79 with a free queue; tools/exp/queue_probe.py prints the
+    matrix).  Nothing in the API reports the binding, so it is probed once per process: a long device-side spin is put
+    in front of X and a tiny launch on Y — Y finishing only after the spin means X and Y share a queue.  The candidates
+    are sorted into queue classes that way, the classes of the current stream and of RCCL's stream (an all-reduce issued
+    behind a spin on the current stream) are excluded, and the side streams come from different remaining classes.
+    ~30 ms."""
+    key = (torch.device(dev).index, n)
+    if key in _picked:
+        return _picked[key]
+    dev = torch.device(dev)
+    spin = 3_000_000          # ~1.3 ms at 2.4 GHz
+    thresh = 0.5              # ms
+    probe = torch.zeros(256, device=dev)
+    dbg = os.environ.get("DGG_PICK_DEBUG") == "1"
+
+    def block_main(cycles):
+        torch.cuda._sleep(cycles)
+
+    def block_main_and_rccl(cycles):   # RCCL's stream waits for the current stream's tail = the spin
+        torch.cuda._sleep(cycles)
+        block_main_and_rccl.work = dist.all_reduce(probe, op=dist.ReduceOp.SUM, async_op=True)
+
+    def blocker_on(stream):
+        def run(cycles):
+            with torch.cuda.stream(stream):
+                torch.cuda._sleep(cycles)
+        return run
+
+    dist.all_reduce(probe)   # the communicator and its stream exist from here on
+    pool = [torch.cuda.Stream(device=dev) for _ in range(candidates)]
+    for cand in pool:        # first use of a stream creates its queue (milliseconds): not part of a measurement
+        _blocked_behind(cand, lambda c: None, dev, 0)
+    classes = []             # lists of streams sharing a queue
+    for cand in pool:
+        for cl in classes:
+            if _blocked_behind(cand, blocker_on(cl[0]), dev, spin) > thresh:
+                cl.append(cand)
+                break
+        else:
+            classes.append([cand])
+    with_main = [_blocked_behind(cl[0], block_main, dev, spin) > thresh for cl in classes]
+    with_rccl = [False] * len(classes)
+    if dist.get_backend() == "nccl":
+        with_rccl = [(not m) and _blocked_behind(cl[0], block_main_and_rccl, dev, spin) > thresh
+                     for cl, m in zip(classes, with_main)]
+    torch.cuda.synchronize(dev)
+    free = [cl for cl, m, r in zip(classes, with_main, with_rccl) if not m and not r]
+    if dbg:
+        print("pick_side_streams: %d queue classes of sizes %s; current stream in %s, RCCL in %s; %d free"
+              % (len(classes), [len(c) for c in classes], [i for i, m in enumerate(with_main) if m],
+                 [i for i, r in enumerate(with_rccl) if r], len(free)), file=sys.stderr, flush=True)
+    chosen = [cl[0] for cl in free[:n]]
+    while len(chosen) < n:     # not enough free queues (other libraries' streams): plain streams, as on one GPU
+        chosen.append(torch.cuda.Stream(device=dev))
+    _picked[key] = chosen
+    return chosen
 
 
 def wait_all(works):
