@@ -170,8 +170,9 @@ class TrainEngine:
         if not two_streams:
             return main, None
         if self._side2 is None:
-            if parallel.is_distributed() and self.device.type == "cuda":
-                # data parallel: side streams that share a hardware queue with neither RCCL's stream nor this one
+            if self.device.type == "cuda" and os.environ.get("DGG_PICK_STREAMS", "1") != "0":
+                # side streams on hardware queues of their own: shared with neither this stream nor (data parallel)
+                # RCCL's — where a plain torch.cuda.Stream() lands depends on how many streams the process made before
                 self._side2, self._side = parallel.pick_side_streams(self.device, 2)
             else:
                 self._side2 = torch.cuda.Stream(device=self.device)

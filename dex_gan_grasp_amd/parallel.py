@@ -179,8 +179,8 @@ def _blocked_behind(cand, run_blocker, dev, sleep_cycles):
 
 
 def pick_side_streams(dev, n=2, candidates=8):
-    """n side streams for a data-parallel step that share a hardware queue neither with the caller's current stream, nor
-    with RCCL's stream, nor with each other.
+    """n side streams that share a hardware queue neither with the caller's current stream, nor (data parallel) with
+    RCCL's stream, nor with each other.
 
     Why: the HIP runtime binds every stream to one of 4 hardware queues when it is created (round robin: streams 4 apart
     share one) and a queue runs its packets in order — ALSO the event waits of another stream bound to it.  RCCL's
@@ -215,7 +215,9 @@ def pick_side_streams(dev, n=2, candidates=8):
                 torch.cuda._sleep(cycles)
         return run
 
-    dist.all_reduce(probe)   # the communicator and its stream exist from here on
+    rccl = is_distributed() and dist.get_backend() == "nccl"
+    if rccl:
+        dist.all_reduce(probe)   # the communicator and its stream exist from here on
     pool = [torch.cuda.Stream(device=dev) for _ in range(candidates)]
     for cand in pool:        # first use of a stream creates its queue (milliseconds): not part of a measurement
         _blocked_behind(cand, lambda c: None, dev, 0)
@@ -229,7 +231,7 @@ def pick_side_streams(dev, n=2, candidates=8):
             classes.append([cand])
     with_main = [_blocked_behind(cl[0], block_main, dev, spin) > thresh for cl in classes]
     with_rccl = [False] * len(classes)
-    if dist.get_backend() == "nccl":
+    if rccl:
         with_rccl = [(not m) and _blocked_behind(cl[0], block_main_and_rccl, dev, spin) > thresh
                      for cl, m in zip(classes, with_main)]
     torch.cuda.synchronize(dev)
