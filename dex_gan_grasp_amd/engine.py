@@ -173,7 +173,10 @@ class TrainEngine:
             if self.device.type == "cuda" and os.environ.get("DGG_PICK_STREAMS", "1") != "0":
                 # side streams on hardware queues of their own: shared with neither this stream nor (data parallel)
                 # RCCL's — where a plain torch.cuda.Stream() lands depends on how many streams the process made before
-                self._side2, self._side = parallel.pick_side_streams(self.device, 2)
+                try:
+                    self._side2, self._side = parallel.pick_side_streams(self.device, 2)
+                except (AttributeError, RuntimeError):   # no torch.cuda._sleep / probing impossible: plain streams
+                    self._side2 = torch.cuda.Stream(device=self.device)
             else:
                 self._side2 = torch.cuda.Stream(device=self.device)
         if wgrad:
