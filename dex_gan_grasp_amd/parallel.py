@@ -139,7 +139,7 @@ class BucketReducer:
         compute streams, RCCL's stream and a feeder per network, the collectives of one network queued up behind the
         kernels of an unrelated stream (measured with a one-rank group, DGG_FORCE_DISTRIBUTED=1: 1.73 -> 2.07 ms per
         step, Adam(D) held back until the evaluator phase had drained).  So the caller lends a compute stream that is
-        idle at that point (engine.joint_step); without one a single process-wide feeder stream is used.
+        idle at that point (engine.joint_step); without one the first picked side stream feeds (pick_side_streams).
         feeder="current": no event waits at all — the collectives follow the current stream's tail (a phase that is not
         on the critical path and whose stream has nothing else to do)."""
         works = []
@@ -147,9 +147,12 @@ class BucketReducer:
             for lo, hi in self.bounds:
                 works.append(dist.all_reduce(self.flat.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
             return works
-        if feeder is None:
+        if feeder is None:       # the serial entry points: the (idle) first side stream, on a queue of its own
             if BucketReducer._shared_feeder is None:
-                BucketReducer._shared_feeder = torch.cuda.Stream(device=self.flat.grads.device)
+                try:
+                    BucketReducer._shared_feeder = pick_side_streams(self.flat.grads.device, 2)[0]
+                except (AttributeError, RuntimeError):
+                    BucketReducer._shared_feeder = torch.cuda.Stream(device=self.flat.grads.device)
             feeder = BucketReducer._shared_feeder
         for (lo, hi), ev in zip(self.bounds, self.events):
             feeder.wait_event(ev)
