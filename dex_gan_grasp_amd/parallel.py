@@ -196,7 +196,8 @@ def pick_side_streams(dev, n=2, candidates=8):
     are sorted into queue classes that way, the classes of the current stream and of RCCL's stream (an all-reduce issued
     behind a spin on the current stream) are excluded, and the side streams come from different remaining classes.
     ~30 ms."""
-    key = (torch.device(dev).index, n)
+    rccl = is_distributed() and dist.get_backend() == "nccl"
+    key = (torch.device(dev).index, n, rccl)     # a process group created later: probe again, RCCL's stream included
     if key in _picked:
         return _picked[key]
     dev = torch.device(dev)
@@ -218,7 +219,6 @@ def pick_side_streams(dev, n=2, candidates=8):
                 torch.cuda._sleep(cycles)
         return run
 
-    rccl = is_distributed() and dist.get_backend() == "nccl"
     if rccl:
         dist.all_reduce(probe)   # the communicator and its stream exist from here on
     pool = [torch.cuda.Stream(device=dev) for _ in range(candidates)]
@@ -235,8 +235,10 @@ def pick_side_streams(dev, n=2, candidates=8):
     with_main = [_blocked_behind(cl[0], block_main, dev, spin) > thresh for cl in classes]
     with_rccl = [False] * len(classes)
     if rccl:
-        with_rccl = [(not m) and _blocked_behind(cl[0], block_main_and_rccl, dev, spin) > thresh
-                     for cl, m in zip(classes, with_main)]
+        # one collective per CANDIDATE, whatever was measured: every rank issues the same number of them
+        hit = [_blocked_behind(cand, block_main_and_rccl, dev, spin) > thresh for cand in pool]
+        for i, (cl, m) in enumerate(zip(classes, with_main)):
+            with_rccl[i] = (not m) and hit[pool.index(cl[0])]
     torch.cuda.synchronize(dev)
     free = [cl for cl, m, r in zip(classes, with_main, with_rccl) if not m and not r]
     if dbg:
