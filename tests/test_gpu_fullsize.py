@@ -376,6 +376,34 @@ def test_one_rank_rccl_process_group_runs_the_collective_path():
     assert out.count("dp_check engine: rank 0 ok") == 1, out[-2000:]
 
 
+def test_side_streams_sit_on_hardware_queues_of_their_own():
+    """parallel.pick_side_streams: the runtime binds streams to its 4 hardware queues round robin at creation and a queue
+    is strictly in order, so where a plain torch.cuda.Stream() lands depends on the process's history (the step ran 2.05 -
+    2.14 instead of 1.74 ms after 2 - 3 earlier streams).  The picked pair must not wait behind a long spin on the current
+    stream nor on each other, even when the process has already created a few streams."""
+    from dex_gan_grasp_amd import parallel
+    dev = torch.device(DEV)
+    junk = []
+    for _ in range(3):
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            junk.append(torch.zeros(8, device=dev))
+        junk.append(st)
+    a, b = parallel.pick_side_streams(dev, 2)
+    spin = 3_000_000
+
+    def on(st):
+        def run(c):
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(c)
+        return run
+    for cand, blockers in ((a, (lambda c: torch.cuda._sleep(c), on(b))), (b, (lambda c: torch.cuda._sleep(c), on(a)))):
+        parallel._blocked_behind(cand, lambda c: None, dev, 0)
+        for blk in blockers:
+            ms = min(parallel._blocked_behind(cand, blk, dev, spin) for _ in range(2))
+            assert ms < 0.5, ms
+
+
 def test_init_net_distribution_lands_in_flat_buffers():
     """A15 (dexgangrasp.py:28-62): xavier_normal(gain) on every Linear.weight, BatchNorm weight ~ N(1, gain), BatchNorm
     bias 0, Linear.bias left at torch's default; and the values ARE the library's flat buffers (the kernels see them)."""
