@@ -107,6 +107,8 @@ SIGNATURES = {
     "dgg_cgan_release": (_I, [_VP]),
     "dgg_reset": (_I, []),
     "dgg_eva_keep_offset": (_I64, [_CFG, _I, _I]),
+    "dgg_ws_offset": (_I64, [_I, _CFG, _I, _I, _I]),
+    "dgg_cgan_ws_offset": (_I64, [_CFG, _I, _I]),
     "dgg_resblock_param_floats": (_I64, [_I]),
     "dgg_resblock_bnstat_floats": (_I64, [_I]),
     "dgg_resblock_table": (_I, [_I, C.POINTER(Entry), _I]),
@@ -181,6 +183,23 @@ def new_workspace(nbytes, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
+def kink_sides(net, ccfg, ws, B, base=0):
+    """Which side of every LeakyReLU kink (networks.py:41) the last train-mode pass of network `net` took, read back from
+    the activations it left in its workspace `ws` (uint8 tensor; `base`: byte offset of the network workspace inside it,
+    dgg_cgan_ws_offset): per ResBlock three bool tensors [fc3 branch (B,512), bn1 branch (B,256), block output (B,512)],
+    True = positive side, in the order a CPU evaluation of the same pass meets its LeakyReLUs.  Dropped units (evaluator)
+    read False: their gradient is zero either way."""
+    nrb = 3 if net == NET_EVA else 2
+    out = []
+    for r in range(nrb):
+        offs = [int(lib().dgg_ws_offset(net, C.byref(ccfg), B, r, w)) for w in (0, 1, 2)]
+        if base < 0 or min(offs) < 0:
+            raise DggError("dgg_ws_offset / dgg_cgan_ws_offset: bad arguments")
+        f = lambda off, n: ws[base + off: base + off + 4 * B * n].view(torch.float32).view(B, n)
+        out += [f(offs[0], 768)[:, 256:] > 0, f(offs[1], 256) > 0, f(offs[2], 512) > 0]
+    return out
+
+
 class FlatNet:
     """Flat device buffers of one network in the library's layout (dgg_table) with named views.
 
@@ -202,10 +221,22 @@ class FlatNet:
         self.grads = z(self.n_params)
         self.m = z(self.n_params) if with_optim else None
         self.v = z(self.n_params) if with_optim else None
-        self.step = 0
         self._ws = {}
         self._step_dev = None   # graph mode: the step number in device memory (int64) + 2 floats of scratch
         self._dyn = None
+        self._step = 0
+
+    @property
+    def step(self):
+        """Adam's step number.  Assigning it (optimiser state loaded from a checkpoint, replicas synchronised) also
+        refreshes the device-resident copy the graph path reads (dgg_adam_l2_graph)."""
+        return self._step
+
+    @step.setter
+    def step(self, v):
+        self._step = int(v)
+        if self._step_dev is not None:
+            self._step_dev.fill_(self._step)
 
     def _shape_view(self, buf, e):
         name, off, rows, cols, kind = e
@@ -267,8 +298,6 @@ class FlatNet:
     def adam_begin(self):
         """Start an optimiser step that is applied range by range (adam_range): advances the step number once."""
         self.step += 1
-        if self._step_dev is not None:
-            self._step_dev.fill_(self.step)
 
     def adam_range(self, lo, hi, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-4, grad_scale=1.0):
         """dgg_adam_l2 on the float range [lo, hi) of the flat buffers (bucket bounds are multiples of 4), on the current
@@ -278,8 +307,6 @@ class FlatNet:
                                 stream_ptr(self.device)), "dgg_adam_l2")
 
     def adam_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=5e-4, grad_scale=1.0):
-        self.step += 1
-        if self._step_dev is not None:      # keep the device-resident counter of the graph path in step
-            self._step_dev.fill_(self.step)
+        self.step += 1      # (the setter keeps the device-resident counter of the graph path in step)
         check(lib().dgg_adam_l2(ptr(self.params), ptr(self.grads), ptr(self.m), ptr(self.v), self.n_params, self.step,
                                 lr, beta1, beta2, eps, weight_decay, grad_scale, stream_ptr(self.device)), "dgg_adam_l2")

@@ -1948,6 +1948,26 @@ int64_t dgg_eva_keep_offset(const dgg_cfg* cfg, int batch, int r) {
     return (int64_t)(reinterpret_cast<char*>(W.rb[r].keep) - fake);
 }
 
+int64_t dgg_ws_offset(int net, const dgg_cfg* cfg, int batch, int r, int what) {
+    NetL L;
+    if (batch < 1 || build_layout(net, cfg, L) || r < 0 || r >= L.nrb || what < 0 || what > 3) return DGG_ERR_INVALID;
+    NetW W;
+    char* fake = reinterpret_cast<char*>((uintptr_t)1 << 40);
+    carve(L, batch, fake, W);
+    const RbW& R = W.rb[r];
+    const void* p = what == 0 ? (const void*)R.a13 : what == 1 ? (const void*)R.h : what == 2 ? (const void*)R.y : (const void*)R.keep;
+    return (int64_t)(reinterpret_cast<const char*>(p) - fake);
+}
+
+int64_t dgg_cgan_ws_offset(const dgg_cfg* cfg, int batch, int which) {
+    if (batch < 1 || which < 0 || which > 2) return DGG_ERR_INVALID;
+    StepW S;
+    char* fake = reinterpret_cast<char*>((uintptr_t)1 << 40);
+    if (carve_step(cfg, batch, fake, S)) return DGG_ERR_INVALID;
+    const void* p = which == 0 ? S.ws_g : which == 1 ? S.ws_dr : S.ws_df;
+    return (int64_t)(reinterpret_cast<const char*>(p) - fake);
+}
+
 // ---- A2: stand-alone ResBlock (networks.py:43-56, final_nl = True) ------------------------------
 int64_t dgg_resblock_param_floats(int fin) {
     NetL L;

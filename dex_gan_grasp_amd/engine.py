@@ -35,7 +35,10 @@ class _side_work:
 class GraphStep:
     """One gen+eval train step captured into a HIP graph (TrainEngine.capture_joint_step).  The inputs are the very
     tensors given at capture: refresh their CONTENTS (copy_) between replays, keep them alive.  replay() enqueues the
-    whole step — ~230 kernel launches on 6 streams — as one graph launch on the current stream."""
+    whole step — ~200 kernel launches on 3 streams — as one graph launch on the current stream.
+    Baked into the captured kernels as arguments: the three learning rates, Adam's betas / eps / weight decay and the
+    loss weights — a scheduler step or a changed hyper-parameter needs a new capture.  Not baked: Adam's step numbers and
+    the dropout seed (device memory; FlatNet.step's setter refreshes the former when optimiser state is loaded)."""
 
     def __init__(self, eng, graph, keep, is_train_gen):
         self.eng, self.graph, self.keep, self.is_train_gen = eng, graph, keep, is_train_gen
@@ -43,10 +46,11 @@ class GraphStep:
     def replay(self):
         self.graph.replay()
         e = self.eng
-        e.D.step += 1
-        e.E.step += 1
+        # the device-resident counters advanced themselves inside the graph: only the host copies follow
+        e.D._step += 1
+        e.E._step += 1
         if self.is_train_gen:
-            e.G.step += 1
+            e.G._step += 1
         return e.losses
 
 
@@ -203,6 +207,8 @@ class TrainEngine:
         self._arm_reducers()
         check(lib().dgg_cgan_d_phase2(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(self.losses),
                                       stream_ptr(dev), s2), "dgg_cgan_d_phase2")
+        if getattr(self, "after_d_phase", None) is not None:   # tests: the fake pass' LeakyReLU sides (kink_sides)
+            self.after_d_phase(self, B)
         self._reduce("D")
         self.D.adam_step(hp.lr_dis, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
         if is_train_gen:
@@ -282,6 +288,20 @@ class TrainEngine:
             out.append(ws[off:off + B * 512].view(B, 512).clone())
         return torch.stack(out)
 
+    def kink_sides(self, which, B, ws=None):
+        """Which side of every LeakyReLU kink (networks.py:41) the last train-mode pass of a network took, read back
+        from its workspace: a list of bool tensors [fc3 branch (B,512), bn1 branch (B,256), block output (B,512)] per
+        ResBlock, True = positive side — the order a CPU evaluation of the same pass meets them.  which: "G", "Dreal",
+        "Dfake" (cGAN step workspace of batch B; "Dfake" holds the D phase's fake pass until the G phase's pass through
+        the updated discriminator overwrites it) or "E".  ws: a snapshot (clone) of the workspace taken earlier.
+        Dropped units of the evaluator read False (their gradient is zero either way).  Parity tests hand these to the
+        oracle (oracle.dexgan_oracle.forced_slopes) so that gradient comparisons are strict on every data set."""
+        net = {"G": _lib.NET_GEN, "Dreal": _lib.NET_DISC, "Dfake": _lib.NET_DISC, "E": _lib.NET_EVA}[which]
+        if which == "E":
+            return _lib.kink_sides(net, self.ccfg, self._eva_ws(B) if ws is None else ws, B)
+        base = int(lib().dgg_cgan_ws_offset(C.byref(self.ccfg), B, {"G": 0, "Dreal": 1, "Dfake": 2}[which]))
+        return _lib.kink_sides(net, self.ccfg, self._cgan_ws(B) if ws is None else ws, B, base)
+
     def close(self):
         """Release what the library remembers about this engine: pending-prefetch slots keyed by its workspaces and
         its weight-gradient side streams (one disable per enable).  Must run on the thread that used the engine."""
@@ -357,7 +377,6 @@ class TrainEngine:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self.joint_step(gan_inputs, z, eva_inputs, **kw)
-        # the capture itself executed nothing: undo the host-side step counters the captured call advanced
         return GraphStep(self, g, keep, is_train_gen)
 
     def _mark(self, name, stream=None):
@@ -440,6 +459,8 @@ class TrainEngine:
         check(lib().dgg_cgan_d_phase2(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(self.losses),
                                       stream_ptr(dev), s2), "dgg_cgan_d_phase2")
         self._mark("d_phase_end")
+        if getattr(self, "after_d_phase", None) is not None:   # tests: snapshot the fake pass' workspace (kink_sides)
+            self.after_d_phase(self, B)
         self._side2_busy = None             # the D phase joins _side2 (a picked-up prefetch included) into main
         # data parallel: the bucket collectives are fed from a compute stream that is idle at that point, never from
         # streams of their own (parallel.BucketReducer.reduce_async): D's from _side2 (joined above); the evaluator's
@@ -511,9 +532,9 @@ class TrainEngine:
             main.wait_stream(side)
         if graph_mode:       # eager priming step: the host counters follow the device's (a captured call runs nothing)
             if not torch.cuda.is_current_stream_capturing():
-                D.step += 1
-                E.step += 1
+                D._step += 1
+                E._step += 1
                 if is_train_gen:
-                    G.step += 1
+                    G._step += 1
             return self.losses
         return self.losses.clone()

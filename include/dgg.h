@@ -158,6 +158,18 @@ int dgg_eva_backward(const dgg_cfg* cfg, const float* params, float* grads, void
  * {0,1}) that the last train-mode forward wrote for dropout site r (0..2) and that the backward reads.  Lets a
  * caller (tests; a checkpoint of an in-flight step) read back the masks drawn in-kernel.  <0 on bad arguments. */
 int64_t dgg_eva_keep_offset(const dgg_cfg* cfg, int batch, int r);
+/* Byte offsets of the activations a train-mode forward of network `net` leaves in its workspace for ResBlock r and
+ * that its backward reads (networks.py:43-56): what = 0: a13 = [a1 | lrelu(fc3(x))] (batch x 768 floats), 1: h =
+ * lrelu(bn1(fc1(x))) (batch x 256), 2: y = the block output after the final LeakyReLU [and dropout] (batch x 512),
+ * 3: the dropout keep bytes (= dgg_eva_keep_offset).  The SIGN of an element of (0 / columns 256.., 1, 2) is the side
+ * of the LeakyReLU kink the backward takes for it: parity tests read it back so that a CPU evaluation takes the same
+ * side where a pre-activation lies within rounding distance of zero (tests/helpers.py).  <0 on bad arguments. */
+int64_t dgg_ws_offset(int net, const dgg_cfg* cfg, int batch, int r, int what);
+/* Byte offset, inside a dgg_cgan_workspace_bytes(cfg, batch) workspace, of the network workspaces the cGAN phases use:
+ * which = 0: generator (forward of the D phase, read by the G phase's backward), 1: discriminator, real-batch pass,
+ * 2: discriminator, fake-batch pass of the D phase — overwritten by the G phase's pass through the updated
+ * discriminator (dexgangrasp.py:808).  <0 on bad arguments. */
+int64_t dgg_cgan_ws_offset(const dgg_cfg* cfg, int batch, int which);
 
 /* Config 5 (dexgangrasp_offline.py:147-162 over many objects) — eval-mode forward of O objects x n samples each,
  * factorised per object: DexGanGrasp.generate_grasps / filter_grasps tile ONE BPS row over an object's n samples

@@ -73,6 +73,70 @@ def class_labels_from_logits(p, thresh):
 
 
 # ----------------------------------------------------------------------------------------------
+# LeakyReLU sites (networks.py:41).  F.leaky_relu multiplies by 1 or 0.2 according to the SIGN of its input; where a
+# pre-activation lies within fp32 rounding distance of zero, two correct evaluations (different summation orders) take
+# different sides, and that one (sample, unit) pair changes every upstream gradient by O(1/sqrt(B)) of a tensor.  So that
+# a gradient comparison can be strict on every data set, the checker may hand this restatement the side the OTHER
+# evaluation took: inside `with forced_slopes(masks):` the i-th LeakyReLU call (call order: per ResBlock fc3 branch,
+# bn1 branch, block output) uses masks[i] (bool, True = slope 1) instead of x > 0.  Where the two agree — everywhere but
+# at such kink crossings — nothing changes, bit for bit; `with record_slopes() as rec:` collects (x > 0) per call.
+# ----------------------------------------------------------------------------------------------
+_SLOPES = None   # None: plain F.leaky_relu;  ("force", list, [pos]) / ("record", list)
+
+
+class forced_slopes:
+    def __init__(self, masks):
+        self.masks = list(masks)
+        self.flips = 0           # elements where the forced side differs from this evaluation's own
+
+    def __enter__(self):
+        global _SLOPES
+        assert _SLOPES is None
+        _SLOPES = ("force", self, [0])
+        return self
+
+    def __exit__(self, *exc):
+        global _SLOPES
+        used = _SLOPES[2][0]
+        _SLOPES = None
+        if exc[0] is None:
+            assert used == len(self.masks), "forced_slopes: %d masks given, %d LeakyReLU calls made" % (len(self.masks), used)
+        return False
+
+
+class record_slopes:
+    def __enter__(self):
+        global _SLOPES
+        assert _SLOPES is None
+        self.masks = []
+        _SLOPES = ("record", self.masks)
+        return self
+
+    def __exit__(self, *exc):
+        global _SLOPES
+        _SLOPES = None
+        return False
+
+
+def _lrelu(x):
+    if _SLOPES is None:
+        return F.leaky_relu(x, LRELU)
+    if _SLOPES[0] == "record":
+        _SLOPES[1].append((x.detach() > 0))
+        return F.leaky_relu(x, LRELU)
+    ctx, pos = _SLOPES[1], _SLOPES[2]
+    assert pos[0] < len(ctx.masks), "forced_slopes: more LeakyReLU calls than the %d masks given" % len(ctx.masks)
+    m = ctx.masks[pos[0]]
+    pos[0] += 1
+    if m is None:
+        return F.leaky_relu(x, LRELU)
+    m = m.to(torch.bool)
+    assert m.shape == x.shape, (tuple(m.shape), tuple(x.shape))
+    ctx.flips += int((m != (x.detach() > 0)).sum())
+    return torch.where(m, x, LRELU * x)
+
+
+# ----------------------------------------------------------------------------------------------
 # networks.py
 # ----------------------------------------------------------------------------------------------
 def _bn(sd, prefix, x, train):
@@ -88,12 +152,12 @@ def _bn(sd, prefix, x, train):
 
 def resblock(sd, prefix, x, train):
     """networks.py:43-56 (final_nl is True at every call site; Fin != Fout always)."""
-    xin = F.leaky_relu(F.linear(x, sd[prefix + "fc3.weight"], sd[prefix + "fc3.bias"]), LRELU)
+    xin = _lrelu(F.linear(x, sd[prefix + "fc3.weight"], sd[prefix + "fc3.bias"]))
     h = F.linear(x, sd[prefix + "fc1.weight"], sd[prefix + "fc1.bias"])
-    h = F.leaky_relu(_bn(sd, prefix + "bn1.", h, train), LRELU)
+    h = _lrelu(_bn(sd, prefix + "bn1.", h, train))
     o = F.linear(h, sd[prefix + "fc2.weight"], sd[prefix + "fc2.bias"])
     o = _bn(sd, prefix + "bn2.", o, train)
-    return F.leaky_relu(xin + o, LRELU)
+    return _lrelu(xin + o)
 
 
 def generator_forward(sd, z, bps, train, prefix=""):
@@ -278,14 +342,33 @@ def cgan_g_part(sd, ctx, cfg):
     return {k: v.detach() for k, v in dict_g.items()}, g_g
 
 
-def cgan_step(sd, batch, z, adam_g, adam_d, cfg, is_train_gen=True, return_grads=False):
+class _no_ctx:
+    flips = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def cgan_step(sd, batch, z, adam_g, adam_d, cfg, is_train_gen=True, return_grads=False, slopes=None):
     """dexgangrasp.py:757-823 (BCE branch).  `sd` holds the DexGANGrasp state_dict
-    ('generator.*', 'discriminator.*'), modified in place.  z is the injected latent (:770)."""
-    out, g_d, ctx = cgan_d_part(sd, batch, z, cfg)
+    ('generator.*', 'discriminator.*'), modified in place.  z is the injected latent (:770).
+    slopes (checker only, see forced_slopes): {"d": masks of G fwd + D(real) + D(fake) (18), "g": masks of the G phase's
+    D pass (6)}; the number of elements where a forced side differed lands in slopes["flips"]."""
+    with (forced_slopes(slopes["d"]) if slopes else _no_ctx()) as fs:
+        out, g_d, ctx = cgan_d_part(sd, batch, z, cfg)
+    nflip = fs.flips
     adam_step(sd, g_d, adam_d, lr=cfg["lr_dis"], b1=cfg["beta1"], wd=cfg["weight_decay"])  # :794
     g_g = None
     if is_train_gen:
-        dict_g, g_g = cgan_g_part(sd, ctx, cfg)
+        with (forced_slopes(slopes["g"]) if slopes else _no_ctx()) as fs:
+            dict_g, g_g = cgan_g_part(sd, ctx, cfg)
+        nflip += fs.flips
+    if slopes is not None:
+        slopes["flips"] = nflip
+    if is_train_gen:
         adam_step(sd, g_g, adam_g, lr=cfg["lr_gen"], b1=cfg["beta1"], wd=cfg["weight_decay"])  # :816
         out.update(dict_g)
     _set_requires_grad(sd, ctx["gn"] + ctx["dn"], False)
@@ -440,15 +523,18 @@ def eva_step_dp(sds, shards, adam_e, cfg, masks):
     return outs, g_e
 
 
-def eva_step(sd, batch, adam_e, cfg, drop_masks=None, return_grads=False):
-    """dexgangrasp.py:739-755."""
+def eva_step(sd, batch, adam_e, cfg, drop_masks=None, return_grads=False, slopes=None):
+    """dexgangrasp.py:739-755.  slopes (checker only, see forced_slopes): {"e": 9 masks}."""
     bw = float(cfg.get("bce_weight", 1))
     en = param_names(sd)
     _set_requires_grad(sd, en, True)
     label = batch["label"].float().unsqueeze(-1)  # networks.py:312
-    p = evaluator_forward(sd, batch["bps_object"], batch["rot_matrix"], batch["transl"], True, drop_masks)
-    l_e, dict_e = loss_evaluator(p, label, bw)
-    g_e = _grads(l_e, sd, en)
+    with (forced_slopes(slopes["e"]) if slopes else _no_ctx()) as fs:
+        p = evaluator_forward(sd, batch["bps_object"], batch["rot_matrix"], batch["transl"], True, drop_masks)
+        l_e, dict_e = loss_evaluator(p, label, bw)
+        g_e = _grads(l_e, sd, en)
+    if slopes is not None:
+        slopes["flips"] = fs.flips
     adam_step(sd, g_e, adam_e, lr=cfg["lr"], b1=cfg["beta1"], wd=cfg["weight_decay"])
     _set_requires_grad(sd, en, False)
     out = {k: v.detach() for k, v in dict_e.items()}

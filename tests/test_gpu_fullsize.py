@@ -49,17 +49,31 @@ def _grad_items(flat, ref, prefix, batch):
     return [(n[len(prefix):], gv[n[len(prefix):]], r, True, batch) for n, r in ref.items()]
 
 
-def _check_loose_collect_strict(items, strict_ok, key):
-    """Every tensor within the kink-tolerant bound (helpers.assert_grad_tensor_close); remember whether this
-    (network, step) also passes the strict bound on all its tensors."""
-    ok = True
+def _check_strict(items, key):
+    """Every tensor within 2e-3 of its maximum, on every data set (helpers.assert_grad_tensor_close)."""
     for name, got, ref, train, batch in items:
-        H.assert_grad_tensor_close(name, got, ref, train=train, batch=batch, strict=False, what=key + " ")
-        try:
-            H.assert_grad_tensor_close(name, got, ref, train=train, batch=batch, strict=True)
-        except AssertionError:
-            ok = False
-    strict_ok.setdefault(key.split("/")[0], []).append(ok)
+        H.assert_grad_tensor_close(name, got, ref, train=train, batch=batch, what=key + " ")
+
+
+def _sides_hook(store):
+    """engine.after_d_phase: the LeakyReLU sides of D's real and fake pass, before the G phase's pass through the updated
+    discriminator overwrites the fake pass' workspace."""
+    def hook(e, B):
+        store["Dreal"] = e.kink_sides("Dreal", B)
+        store["Dfake"] = e.kink_sides("Dfake", B)
+    return hook
+
+
+def _slopes_after(eng, store, b=None, be=None):
+    """What the oracle needs to take the HIP step's side at every LeakyReLU (oracle.forced_slopes), after the step:
+    {"gan": {"d": G fwd + D(real) + D(fake), "g": the G phase's D pass}, "eva": {"e": ...}}."""
+    out = {}
+    if b is not None:
+        out["gan"] = {"d": H.cpu_masks(eng.kink_sides("G", b) + store["Dreal"] + store["Dfake"]),
+                      "g": H.cpu_masks(eng.kink_sides("Dfake", b))}
+    if be is not None:
+        out["eva"] = {"e": H.cpu_masks(eng.kink_sides("E", be))}
+    return out
 
 
 def _adopt(flat, sd, adam, prefix):
@@ -132,25 +146,55 @@ def _update_close(name, t, r, prev, l2_frac, lr=1e-4):
     assert err <= l2_frac * upd + 1e-12, "%s: update L2 error %.3e vs update norm %.3e" % (name, err, upd)
 
 
-@pytest.mark.parametrize("b", [1024, 256])
-def test_benched_joint_step_with_prefetch_and_philox_vs_oracle(b):
-    """What bench.py times, at its size: 3 x joint_step(next_gan_inputs=...) with the evaluator's dropout masks drawn
+def _config4_batches(b, n_points):
+    """BASELINE config 4's per-rank share: synthetic clouds -> dgg_bps_encode on the device -> batch dicts
+    (data/synthetic_data_set.py); for the oracle the SAME clouds are encoded by the CPU brute force (oracle/bps_oracle.c),
+    which must reproduce the device block bit for bit."""
+    from oracle import bps_oracle
+    from dex_gan_grasp_amd.data.synthetic_data_set import SyntheticGraspBatches
+    basis = H.load("bps_real_objects.npz")["basis"]
+    ds = SyntheticGraspBatches(CFG, b, 5, basis, n_points=n_points, seed=21, with_label=True)
+    out = []
+    for i in range(5):
+        dev_b = ds.batch(i)
+        clouds = ds.clouds(i).cpu().numpy()
+        enc = np.stack([bps_oracle.encode_f32(clouds[j], basis)[0] for j in range(b)])
+        assert np.array_equal(dev_b["bps_object"].cpu().numpy(), enc), "batch %d: device encode != oracle encode" % i
+        cpu_b = {k: v for k, v in dev_b.items() if k != "obj_name"}
+        cpu_b["bps_object"] = torch.from_numpy(enc)
+        out.append(cpu_b)
+    return out[:2], out[2:]
+
+
+@pytest.mark.parametrize("b,variant,front", [(1024, "wide", "direct"), (256, "wide", "direct"), (1024, "init", "direct"),
+                                             (512, "wide", "config4")])
+def test_benched_joint_step_with_prefetch_and_philox_vs_oracle(b, variant, front):
+    """What bench.py times, at its sizes: 3 x joint_step(next_gan_inputs=...) with the evaluator's dropout masks drawn
     in-kernel.  Per step: the 10 losses (1e-4), the gradients of G and E (D's are overwritten by the prefetched pass of
-    the next step: compared on the last step), every parameter after Adam, the masks read back from the workspace and
-    fed to the oracle.  BatchNorm running statistics at the end."""
+    the next step: compared on the last step) strictly, the masks read back from the workspace and fed to the oracle,
+    Adam of the engine's own gradients exactly, every parameter after Adam.  BatchNorm running statistics at the end.
+    (1024, "init"): the reference-style 0.02-gain weights bench.py runs (the other cases use the "wide" variant, whose
+    gradients sit above Adam's eps: with "init" weights whole tensors have |g| ~ 1e-9, where Adam's update
+    lr g / (|g| + eps) amplifies rounding differences — helpers.assert_state_close — so the element-wise parameter
+    comparison after the step is left to the exact Adam-of-own-gradients statement).
+    (512, "config4"): BASELINE config 4's per-rank share, 512 clouds x 2048 points through dgg_bps_encode in front."""
     from oracle import dexgan_oracle as O
     L, ops, engine = _mods()
-    eng, sd, sde = _engine("wide")
+    eng, sd, sde = _engine(variant)
     ag = O.AdamState([n for n in O.param_names(sd) if n.startswith("generator.")])
     ad = O.AdamState([n for n in O.param_names(sd) if n.startswith("discriminator.")])
     ae = O.AdamState(O.param_names(sde))
-    gbs = [synth.make_batch(b, 1), synth.make_batch(b, 11)]
+    if front == "config4":
+        gbs, ebs = _config4_batches(b, 2048)
+    else:
+        gbs = [synth.make_batch(b, 1), synth.make_batch(b, 11)]
+        # a fresh evaluator batch per step, as in training (seed 2 has a pre-activation on a LeakyReLU kink in rb1: the
+        # forced-slope comparison covers it)
+        ebs = [synth.make_batch(b, 2 + 10 * i, with_label=True) for i in range(3)]
     g_ins = [_dev_inputs(x) for x in gbs]
-    # a fresh evaluator batch per step, as in training: a pre-activation that sits on the LeakyReLU kink in one batch
-    # (seed 2 has one in rb1) would otherwise fail the strict criterion on every step
-    ebs = [synth.make_batch(b, 2 + 10 * i, with_label=True) for i in range(3)]
-    strict_ok = {}
     steps = 3
+    store, flips = {}, 0
+    eng.after_d_phase = _sides_hook(store)
     for i in range(steps):
         eb = ebs[i]
         e_in = _dev_inputs(eb, with_label=True)
@@ -164,29 +208,37 @@ def test_benched_joint_step_with_prefetch_and_philox_vs_oracle(b):
         assert keep.dtype == torch.uint8 and int(keep.max()) == 1 and int(keep.min()) == 0
         masks = keep.float().cpu()
         prev, preve = {k: v.clone() for k, v in sd.items()}, {k: v.clone() for k, v in sde.items()}
-        ref, g_d, g_g, _ = O.cgan_step(sd, H.clone_batch(gbs[i % 2]), z, ag, ad, CFG, True, return_grads=True)
-        refe, g_e, _ = O.eva_step(sde, H.clone_batch(eb), ae, CFG, masks, return_grads=True)
+        sl = _slopes_after(eng, store, b, b)
+        ref, g_d, g_g, _ = O.cgan_step(sd, H.clone_batch(gbs[i % 2]), z, ag, ad, CFG, True, return_grads=True,
+                                       slopes=sl["gan"])
+        refe, g_e, _ = O.eva_step(sde, H.clone_batch(eb), ae, CFG, masks, return_grads=True, slopes=sl["eva"])
+        flips += sl["gan"]["flips"] + sl["eva"]["flips"]
         for k, n in enumerate(LOSS_NAMES):
             np.testing.assert_allclose(got[k], float(ref[n]), rtol=1e-4, atol=1e-6, err_msg="step %d %s" % (i, n))
         np.testing.assert_allclose(got[L.L_TOTAL_EVA], float(refe["total_loss_eva"]), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(got[L.L_BCE_EVA], float(refe["bce_loss"]), rtol=1e-4, atol=1e-6)
-        _check_loose_collect_strict(_grad_items(eng.G, g_g, "generator.", b), strict_ok, "G/%d" % i)
-        _check_loose_collect_strict(_grad_items(eng.E, g_e, "", b), strict_ok, "E/%d" % i)
+        _check_strict(_grad_items(eng.G, g_g, "generator.", b), "G/%d" % i)
+        _check_strict(_grad_items(eng.E, g_e, "", b), "E/%d" % i)
         if nxt is None:
-            _check_loose_collect_strict(_grad_items(eng.D, g_d, "discriminator.", b), strict_ok, "D/%d" % i)
+            _check_strict(_grad_items(eng.D, g_d, "discriminator.", b), "D/%d" % i)
         _cmp_adam_of_own_grads(eng.G, before["G"], what="G step %d" % i)
         _cmp_adam_of_own_grads(eng.E, before["E"], what="E step %d" % i)
         if nxt is None:
             _cmp_adam_of_own_grads(eng.D, before["D"], what="D step %d" % i)
-        _cmp_update(eng.G, sd, prev, "generator.", skip_running=True, l2_frac=0.1)
-        _cmp_update(eng.D, sd, prev, "discriminator.", skip_running=True, l2_frac=0.1)
-        _cmp_update(eng.E, sde, preve, "", skip_running=True, l2_frac=0.1)
+        if variant != "init":
+            _cmp_update(eng.G, sd, prev, "generator.", skip_running=True, l2_frac=0.1)
+            _cmp_update(eng.D, sd, prev, "discriminator.", skip_running=True, l2_frac=0.1)
+            _cmp_update(eng.E, sde, preve, "", skip_running=True, l2_frac=0.1)
+        else:      # every element within Adam's reach all the same
+            for fl, s_, pre in ((eng.G, sd, "generator."), (eng.D, sd, "discriminator."), (eng.E, sde, "")):
+                for n, t in fl.state_dict().items():
+                    if "running_" not in n:
+                        assert float((t - s_[pre + n]).abs().max()) <= 2.5e-4, n
         _adopt(eng.G, sd, ag, "generator.")
         _adopt(eng.D, sd, ad, "discriminator.")
         _adopt(eng.E, sde, ae, "")
-    # a LeakyReLU kink crossing is a rare data-dependent event (helpers.assert_grad_tensor_close): G and E must be
-    # strictly right on at least one of their three steps
-    assert any(strict_ok["G"]) and any(strict_ok["E"]), strict_ok
+    print("B=%d %s %s: the oracle took the HIP path's side at %d LeakyReLU kink crossing(s) over %d steps"
+          % (b, variant, front, flips, steps))
     # running statistics integrate three steps of batch statistics (real, fake, fake for D)
     for flat, s, pre in ((eng.G, sd, "generator."), (eng.D, sd, "discriminator."), (eng.E, sde, "")):
         for n, t in flat.state_dict().items():
@@ -207,20 +259,19 @@ def test_evaluator_step_at_1024_vs_oracle():
     ae = O.AdamState(O.param_names(sde))
     eb = synth.make_batch(b, 2, with_label=True)
     e_in = _dev_inputs(eb, with_label=True)
-    strict_ok = {}
     for i in range(2):
         masks = synth.make_dropout_masks(b, 50 + i)
         preve = {k: v.clone() for k, v in sde.items()}
-        refe, g_e, _ = O.eva_step(sde, H.clone_batch(eb), ae, CFG, masks, return_grads=True)
         before = _snap_flat(eng.E)
         got = eng.eva_step(*e_in, masks.to(DEV), 0, two_streams=True).cpu().numpy()
+        refe, g_e, _ = O.eva_step(sde, H.clone_batch(eb), ae, CFG, masks, return_grads=True,
+                                  slopes=_slopes_after(eng, {}, None, b)["eva"])
         np.testing.assert_allclose(got[L.L_TOTAL_EVA], float(refe["total_loss_eva"]), rtol=1e-4, atol=1e-6)
         assert torch.equal(eng.eva_keep_masks(b).cpu(), masks.to(torch.uint8))   # given masks land in the workspace
-        _check_loose_collect_strict(_grad_items(eng.E, g_e, "", b), strict_ok, "E/%d" % i)
+        _check_strict(_grad_items(eng.E, g_e, "", b), "E/%d" % i)
         _cmp_adam_of_own_grads(eng.E, before, what="E step %d" % i)
         _cmp_update(eng.E, sde, preve, "", l2_frac=0.1)
         _adopt(eng.E, sde, ae, "")
-    assert any(strict_ok["E"])
     eng.close()
 
 
@@ -235,24 +286,25 @@ def test_cgan_step_at_256_vs_oracle():
     ad = O.AdamState([n for n in O.param_names(sd) if n.startswith("discriminator.")])
     gb = synth.make_batch(b, 1)
     g_in = _dev_inputs(gb)
-    strict_ok = {}
+    store = {}
+    eng.after_d_phase = _sides_hook(store)
     for i in range(2):
         z = synth.make_z(b, 100 + i)
         prev = {k: v.clone() for k, v in sd.items()}
-        ref, g_d, g_g, _ = O.cgan_step(sd, H.clone_batch(gb), z, ag, ad, CFG, True, return_grads=True)
         before = {k: _snap_flat(fl) for k, fl in (("G", eng.G), ("D", eng.D))}
         got = eng.cgan_step(*g_in, z.to(DEV), True, two_streams=True).cpu().numpy()
+        ref, g_d, g_g, _ = O.cgan_step(sd, H.clone_batch(gb), z, ag, ad, CFG, True, return_grads=True,
+                                       slopes=_slopes_after(eng, store, b)["gan"])
         for k, n in enumerate(LOSS_NAMES):
             np.testing.assert_allclose(got[k], float(ref[n]), rtol=1e-4, atol=1e-6, err_msg=n)
-        _check_loose_collect_strict(_grad_items(eng.G, g_g, "generator.", b), strict_ok, "G/%d" % i)
-        _check_loose_collect_strict(_grad_items(eng.D, g_d, "discriminator.", b), strict_ok, "D/%d" % i)
+        _check_strict(_grad_items(eng.G, g_g, "generator.", b), "G/%d" % i)
+        _check_strict(_grad_items(eng.D, g_d, "discriminator.", b), "D/%d" % i)
         _cmp_adam_of_own_grads(eng.G, before["G"], what="G step %d" % i)
         _cmp_adam_of_own_grads(eng.D, before["D"], what="D step %d" % i)
         _cmp_update(eng.G, sd, prev, "generator.", l2_frac=0.05)
         _cmp_update(eng.D, sd, prev, "discriminator.", l2_frac=0.05)
         _adopt(eng.G, sd, ag, "generator.")
         _adopt(eng.D, sd, ad, "discriminator.")
-    assert any(strict_ok["G"])
     eng.close()
 
 
@@ -615,7 +667,6 @@ def test_wgan_gp_phases_vs_oracle(b):
         batch = synth.make_batch(b, seed)
         z = synth.make_z(b, 100 + seed)
         al = _alphas(b, 200 + seed)
-        ref, g_d, ctx = O.wgan_d_part(sd, H.clone_batch(batch), z, al, CFG)
         f = lambda t: t.float().to(DEV).contiguous()
         ins = (f(batch["bps_object"]), f(batch["rot_matrix"]).reshape(b, 9), f(batch["transl"]), f(batch["joint_conf"]))
         ald = torch.cat([al[0].view(b, 1), al[1], al[2]], 1).to(DEV).contiguous()
@@ -626,6 +677,14 @@ def test_wgan_gp_phases_vs_oracle(b):
         L.check(L.lib().dgg_wgan_d_phase(C.byref(eng.ccfg), C.byref(st), C.byref(hp), L.ptr(ws), ws.numel(), b, *args,
                                          L.ptr(ald), 10.0, L.ptr(eng.losses), L.stream_ptr()))
         got = eng.losses.cpu().numpy()
+        # the LeakyReLU sides of the four passes (G, D real, D fake, D interpolates: the WGAN workspace is the cGAN step's
+        # followed by the interpolates' pass), handed to the oracle (helpers.assert_grad_tensor_close)
+        cfg_p = C.byref(eng.ccfg)
+        base_i = int(L.lib().dgg_cgan_workspace_bytes(cfg_p, b))
+        sides = eng.kink_sides("G", b, ws) + eng.kink_sides("Dreal", b, ws) + eng.kink_sides("Dfake", b, ws) + \
+            L.kink_sides(L.NET_DISC, eng.ccfg, ws, b, base_i)
+        with O.forced_slopes(H.cpu_masks(sides)):
+            ref, g_d, ctx = O.wgan_d_part(sd, H.clone_batch(batch), z, al, CFG)
         np.testing.assert_allclose(got[L.L_BCE_REAL], float(ref["bce_loss_real"]), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(got[L.L_BCE_FAKE], float(ref["bce_loss_fake"]), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(got[L.L_GRAD_PENALTY], float(ref["gradient_penalty"]), rtol=2e-4, atol=1e-6)
@@ -635,10 +694,11 @@ def test_wgan_gp_phases_vs_oracle(b):
         ad = O.AdamState([n for n in O.param_names(sd) if n.startswith("discriminator.")])
         O.adam_step(sd, g_d, ad, lr=CFG["lr_dis"], b1=CFG["beta1"], wd=CFG["weight_decay"])
         eng.D.load_state_dict(sd, "discriminator.")      # identical D on both sides for the G phase
-        refg, g_g = O.wgan_g_part(sd, ctx, CFG)
         L.check(L.lib().dgg_wgan_g_phase(C.byref(eng.ccfg), C.byref(st), C.byref(hp), L.ptr(ws), ws.numel(), b, *args,
                                          L.ptr(eng.losses), L.stream_ptr()))
         got = eng.losses.cpu().numpy()
+        with O.forced_slopes(H.cpu_masks(eng.kink_sides("Dfake", b, ws))):
+            refg, g_g = O.wgan_g_part(sd, ctx, CFG)
         for k, n in ((L.L_GEN_FAKE, "gen_loss_fake"), (L.L_TRANSL, "transl_loss"), (L.L_ROT, "rot_loss"),
                      (L.L_CONF, "conf_loss"), (L.L_TOTAL_GEN, "total_loss_gen")):
             np.testing.assert_allclose(got[k], float(refg[n]), rtol=1e-4, atol=1e-6, err_msg=n)
@@ -721,8 +781,8 @@ def test_odd_batch_sizes_vs_oracle(b):
     """Batches that are no multiple of the 32-row statistics blocks, the 64-row GEMM tiles or the split-K chunks: the
     fused forward stage (partial row blocks in its statistics epilogue), the slab-summing backward kernels, the shared
     weight gradient of D's two passes and the side-work launches of joint_step — two steps with prefetch against the
-    oracle: losses to 1e-4, gradients of the last step within the kink-tolerant bound, Adam of the engine's own gradients
-    exact."""
+    oracle: losses to 1e-4, gradients strictly (the oracle takes the HIP path's side at LeakyReLU kink crossings), Adam of
+    the engine's own gradients exact."""
     from oracle import dexgan_oracle as O
     L, ops, engine = _mods()
     eng, sd, sde = _engine("wide")
@@ -732,6 +792,8 @@ def test_odd_batch_sizes_vs_oracle(b):
     gbs = [synth.make_batch(b, 3), synth.make_batch(b, 13)]
     g_ins = [_dev_inputs(x) for x in gbs]
     ebs = [synth.make_batch(b, 4 + 10 * i, with_label=True) for i in range(2)]
+    store = {}
+    eng.after_d_phase = _sides_hook(store)
     for i in range(2):
         z = synth.make_z(b, 50 + i)
         e_in = _dev_inputs(ebs[i], with_label=True)
@@ -740,8 +802,9 @@ def test_odd_batch_sizes_vs_oracle(b):
         torch.cuda.synchronize()
         got = got.cpu().numpy()
         masks = eng.eva_keep_masks(b).float().cpu()
-        ref, g_d, g_g, _ = O.cgan_step(sd, H.clone_batch(gbs[i]), z, ag, ad, CFG, True, return_grads=True)
-        refe, g_e, _ = O.eva_step(sde, H.clone_batch(ebs[i]), ae, CFG, masks, return_grads=True)
+        sl = _slopes_after(eng, store, b, b)
+        ref, g_d, g_g, _ = O.cgan_step(sd, H.clone_batch(gbs[i]), z, ag, ad, CFG, True, return_grads=True, slopes=sl["gan"])
+        refe, g_e, _ = O.eva_step(sde, H.clone_batch(ebs[i]), ae, CFG, masks, return_grads=True, slopes=sl["eva"])
         for k, n in enumerate(LOSS_NAMES):
             np.testing.assert_allclose(got[k], float(ref[n]), rtol=1e-4, atol=1e-6, err_msg="step %d %s" % (i, n))
         np.testing.assert_allclose(got[L.L_TOTAL_EVA], float(refe["total_loss_eva"]), rtol=1e-4, atol=1e-6)
@@ -750,7 +813,7 @@ def test_odd_batch_sizes_vs_oracle(b):
             checked.append(_grad_items(eng.D, g_d, "discriminator.", b))
         for items in checked:
             for name, g, r, train, batch in items:
-                H.assert_grad_tensor_close(name, g, r, train=train, batch=batch, strict=False, what="B=%d step %d " % (b, i))
+                H.assert_grad_tensor_close(name, g, r, train=train, batch=batch, what="B=%d step %d " % (b, i))
         _cmp_adam_of_own_grads(eng.G, before["G"], what="G")
         _cmp_adam_of_own_grads(eng.E, before["E"], what="E")
         if i == 1:

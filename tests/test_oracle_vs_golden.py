@@ -229,3 +229,42 @@ def test_wgan_gp_steps_vs_reference(variant, bname):
     # the discriminator runs FOUR train-mode forwards per step here (real, fake, interpolates, generator phase)
     assert int(sd["discriminator.disc_bn1.num_batches_tracked"]) == 8
     assert int(sd["generator.gen_bn1.num_batches_tracked"]) == 2
+
+
+def test_forced_slopes_reproduce_and_steer_the_oracle():
+    """oracle.forced_slopes (the device for strict gradient comparisons, helpers.assert_grad_tensor_close): with the
+    sides the oracle itself took, outputs and gradients are unchanged bit for bit; with one side flipped, exactly that
+    element's slope changes (its gradient contribution scales by 0.2 or 5)."""
+    from oracle import dexgan_oracle as O
+    import helpers as H
+    sde = H.eva_sd("wide")
+    batch = H.eva_batch("syn64")
+    masks = synth.make_dropout_masks(64, 3)
+    cfg = dict(synth.DEFAULT_CFG)
+
+    def run(slopes=None, rec=False):
+        sd = {k: v.clone() for k, v in sde.items()}
+        st = O.AdamState(O.param_names(sd))
+        if rec:
+            with O.record_slopes() as r:
+                out, g, p = O.eva_step(sd, H.clone_batch(batch), st, cfg, masks, return_grads=True)
+            return out, g, p, r.masks
+        s = {"e": slopes} if slopes is not None else None
+        out, g, p = O.eva_step(sd, H.clone_batch(batch), st, cfg, masks, return_grads=True, slopes=s)
+        return out, g, p, (s or {}).get("flips")
+
+    out0, g0, p0, sides = run(rec=True)
+    assert len(sides) == 9 and sides[0].shape == (64, 512) and sides[1].shape == (64, 256)
+    out1, g1, p1, flips = run([m.clone() for m in sides])
+    assert flips == 0 and torch.equal(p0, p1)
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+    flipped = [m.clone() for m in sides]
+    flipped[1][5, 7] = ~flipped[1][5, 7]          # rb1's bn1 branch, sample 5, unit 7
+    out2, g2, p2, flips = run(flipped)
+    assert flips >= 1      # (a far-from-zero flip also moves downstream pre-activations across their forced sides)
+    assert not torch.equal(g0["rb1.fc1.weight"][7], g2["rb1.fc1.weight"][7])
+    with pytest.raises(AssertionError):
+        with O.forced_slopes(sides[:3]):
+            O.evaluator_forward({k: v.clone() for k, v in sde.items()}, batch["bps_object"], batch["rot_matrix"],
+                                batch["transl"], True, masks)
