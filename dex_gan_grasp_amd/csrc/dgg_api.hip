@@ -258,17 +258,19 @@ struct NetW {
     float* dYs[3];               // dY13 of this pass + dY13 of the discriminator's other pass (Share::bwd_mode 2)
     float *slabs_w;              // split-K slabs of the fc2 weight gradient
     int64_t slab_floats;
-    // bf16 planes of the large GEMMs' operands (gemm_p3.hip); carved for train-sized batches only (p3)
+    // bf16 planes of the large GEMMs' operands (gemm_p4.hip), carved for train-sized batches only (p3).  Only the BPS
+    // block of the input — in_bps of the k0 columns, the same for every ResBlock of the net — runs on planes:
     bool p3;
-    int ldk0, ldB;               // pitches: round64(k0), round64(B)
-    __bf16 *X0p, *X0t;           // [3][B][ldk0]: gamma x_hat + beta (forward);  [3][k0][ldB]: x_hat transposed (wgrad)
-    __bf16 *Wp0[3], *Wp1[3];     // per block: W13[:, X0 columns] [3][n13][ldk0];  W13[:, previous-block columns] [3][n13][nn]
-    __bf16 *Yp[3], *Yt[3];       // block output y as the next block's operand: [3][B][nn], [3][nn][ldB]
+    int ldB;                     // round64(B): pitch of the transposed planes
+    __bf16 *Xb, *Xbt;            // x_hat of the BPS block: [3][B][in_bps] (forward), [3][in_bps][ldB] transposed (wgrad)
+    __bf16 *Wb;                  // [3][n13 * nrb][in_bps]: gamma[k] * W13[n][BPS column k] of all ResBlocks, stacked
+    float* cbias;                // [n13 * nrb]: b13[n] + sum_k beta[k] W13[n][BPS column k] (what the folded affine adds)
+    float* xslabs;               // [xsplits][B][n13 * nrb]: the BPS products of all ResBlocks, ONE launch per pass
+    int xsplits;
     __bf16 *dYt[3];              // dY13 transposed: [3][n13][ldB]
     size_t bytes;
 };
 static const int kP3MaxB = 8192;   // larger batches (inference sweeps) never train: no planes carved for them
-// diagnostics: DGG_P3_FWD=0 / DGG_P3_WGRAD=0 keep the forward / the weight gradient on the in-register-split kernel
 static bool share_wgrad() {  // diagnostics: DGG_SHARE_WGRAD=0: both passes of D form their own BPS weight gradient
     static const bool v = [] { const char* e = getenv("DGG_SHARE_WGRAD"); return !(e && e[0] == '0'); }();
     return v;
@@ -281,13 +283,23 @@ static bool fuse_fc2() {  // diagnostics: DGG_FUSE_FC2=0 keeps bn_act / fc2 GEMM
     static const bool v = [] { const char* e = getenv("DGG_FUSE_FC2"); return !(e && e[0] == '0'); }();
     return v;
 }
-static bool p3_use_fwd() {
-    static const bool v = [] { const char* e = getenv("DGG_P3_FWD"); return !(e && e[0] == '0'); }();
-    return v;
-}
-static bool p3_use_wgrad() {
-    static const bool v = [] { const char* e = getenv("DGG_P3_WGRAD"); return !(e && e[0] == '0'); }();
-    return v;
+// Split-K of the batched BPS product (M = B, N = n13 * nrb, K = in_bps; 128 x 128 tiles, one workgroup per CU): the
+// fewest splits that fill >= 90 % of the last round of 256 workgroups with at least 8 k-tiles each
+static int plan_xsplits(int B, int N, int K) {
+    const long tiles = (long)((B + 127) / 128) * ((N + 127) / 128);
+    const int kt = (K + 31) / 32;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int s = 1; s <= 16 && kt / s >= 8; ++s) {
+        const int per = (kt + s - 1) / s;
+        const int used = (kt + per - 1) / per;
+        if (used != s) continue;
+        const long wg = tiles * s;
+        const double eff = (double)wg / (double)(((wg + 255) / 256) * 256);
+        if (eff > best_eff + 0.03) { best_eff = eff; best = s; }
+        if (best_eff >= 0.9) break;
+    }
+    return best;
 }
 
 struct Bump {
@@ -406,19 +418,18 @@ static void carve(const NetL& L, int B, void* base, NetW& W) {
     W.dX0 = b.take<float>(Bz * L.ldx0);
     W.dXa = b.take<float>(Bz * L.nn);
     W.dXb = b.take<float>(Bz * L.nn);
-    W.p3 = B <= kP3MaxB;
-    W.ldk0 = (int)round64(L.k0);
+    W.p3 = B <= kP3MaxB && B >= 2 && L.net != kNetResBlock && L.in_bps >= 1024 && (L.in_bps % 64) == 0;
     W.ldB = (int)round64(B);
+    W.xsplits = 0;
     if (W.p3) {
-        W.X0p = b.take<__bf16>(3 * Bz * W.ldk0);
-        W.X0t = b.take<__bf16>(3 * (size_t)L.k0 * W.ldB);
-        for (int r = 0; r < L.nrb; ++r) {
-            W.Wp0[r] = b.take<__bf16>(3 * (size_t)L.n13 * W.ldk0);
-            W.Wp1[r] = r > 0 ? b.take<__bf16>(3 * (size_t)L.n13 * L.nn) : nullptr;
-            W.Yp[r] = r + 1 < L.nrb ? b.take<__bf16>(3 * Bz * L.nn) : nullptr;
-            W.Yt[r] = r + 1 < L.nrb ? b.take<__bf16>(3 * (size_t)L.nn * W.ldB) : nullptr;
-            W.dYt[r] = b.take<__bf16>(3 * (size_t)L.n13 * W.ldB);
-        }
+        const size_t nall = (size_t)L.n13 * L.nrb;
+        W.Xb = b.take<__bf16>(3 * Bz * L.in_bps);
+        W.Xbt = b.take<__bf16>(3 * (size_t)L.in_bps * W.ldB);
+        W.Wb = b.take<__bf16>(3 * nall * L.in_bps);
+        W.cbias = b.take<float>(nall);
+        W.xsplits = plan_xsplits(B, (int)nall, L.in_bps);
+        W.xslabs = b.take<float>((size_t)W.xsplits * Bz * nall);
+        for (int r = 0; r < L.nrb; ++r) W.dYt[r] = b.take<__bf16>(3 * (size_t)L.n13 * W.ldB);
     }
     W.bytes = (b.off + 255) & ~(size_t)255;
 }
@@ -511,6 +522,14 @@ struct Share {
     int bwd_mode;
     const float* dY13_other[3];
     const float* cs13_other[3];
+    // Planes mode (NetW::p3): the producer's ONE batched BPS product of all ResBlocks [xnslab][B][n13 * nrb] and its
+    // combined bias (the folded BatchNorm shift), `xready` recorded behind the launch; and, for the fake pass' shared
+    // weight gradient, the producer's transposed x_hat planes
+    const float* xslabs;
+    const float* xcbias;
+    int xnslab;
+    hipEvent_t xready;
+    const __bf16* xbt;
 };
 static const int kShareSlabs = 16;  // plan13 never gives one piece more
 
@@ -529,9 +548,16 @@ struct Ctx {
     // the next rb_backward's first stage instead of the `dy` it is given)
     int dy_nslab = 0;
     long long dy_stride = 0;
-    bool p3 = false;      // this pass runs its large GEMMs on pre-split planes (train pass, planes carved, algorithm 2)
-    bool p3_fwd = false;  // ... including the forward (a D fake pass that consumes shared BPS products has no large one)
-    bool p3_t = false;    // forward: a weight-gradient pass follows — emit the transposed planes of X0 and of the block outputs
+    bool p3 = false;      // this pass runs the BPS block's GEMMs on pre-split planes (train pass, planes carved, algorithm 2)
+    bool p3_fwd = false;  // forward: ... and forms the batched BPS product itself (a D fake pass consumes the real pass')
+    bool p3_t = false;    // forward: a weight-gradient pass follows — emit the transposed planes of x_hat
+    // forward, planes mode: the batched BPS products to add to every block's pre-activations, and the bias that goes
+    // with them (NetW::cbias of this pass or of the Share's producer)
+    const float* xs = nullptr;
+    const float* xcbias = nullptr;
+    int xs_n = 0;
+    // backward, planes mode: transposed x_hat planes of the BPS block (this pass' or the Share producer's)
+    const __bf16* xbt = nullptr;
 };
 
 static int rb_tail(Ctx& c, int r, int drop_mode, const float* keep_in, uint64_t seed, uint64_t seed_off);
@@ -549,8 +575,14 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
     Piece pc[4];
     int np = 0;
     Share* sh = c.share;
+    const bool planes = c.xs != nullptr;   // the BPS block's product of this block comes out of the pass' batched launch
     for (int i = 0; i < nseg; ++i) {
-        if (sh && segs[i].is_x0 && L.nprefix == 0 && sh->ncols > 0 && sh->ncols < segs[i].width) {
+        if (planes && segs[i].is_x0) {      // only what lies around the BPS block: the prefix / the pose columns
+            const int lo = L.nprefix, hi = L.nprefix + L.in_bps;
+            if (lo > 0) pc[np++] = Piece{segs[i].p, segs[i].ld, lo, segs[i].wcol, 0, true, false};
+            if (hi < segs[i].width)
+                pc[np++] = Piece{segs[i].p + hi, segs[i].ld, segs[i].width - hi, segs[i].wcol + hi, hi, true, false};
+        } else if (sh && segs[i].is_x0 && L.nprefix == 0 && sh->ncols > 0 && sh->ncols < segs[i].width) {
             pc[np++] = Piece{segs[i].p, segs[i].ld, sh->ncols, segs[i].wcol, 0, true, true};
             pc[np++] = Piece{segs[i].p + sh->ncols, segs[i].ld, segs[i].width - sh->ncols, segs[i].wcol + sh->ncols,
                              sh->ncols, true, false};
@@ -560,7 +592,7 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
     }
     int widths[4], sp[4];
     for (int i = 0; i < np; ++i) widths[i] = pc[i].width;
-    plan13(B, L.n13, widths, np, sp);
+    if (np > 0) plan13(B, L.n13, widths, np, sp);
     GemmBatch gb;
     memset(&gb, 0, sizeof(gb));
     const long long slab = (long long)B * L.n13;
@@ -587,45 +619,19 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
     }
     gb.nprob = nq;
     if ((int64_t)nslab * slab > c.W.slab_floats) return DGG_ERR_WORKSPACE;
-    int widest = 0;
-    for (int i = 0; i < np; ++i)
-        if (!(pc[i].shared && sh->mode == 2) && pc[i].width > widest) widest = pc[i].width;
-    if (c.p3_fwd && widest >= 1024) {
-        // the launch's operands as bf16 planes: [gamma x_hat + beta] / block r-1's output against the matching columns of
-        // W13 (net_forward / rb_tail produced them); K rounds up to 32 inside the planes' zero padding
-        int q = 0;
-        for (int i = 0; i < np; ++i) {
-            if (pc[i].shared && sh->mode == 2) continue;
-            GemmProb& g = gb.p[q++];
-            if (pc[i].x0) {
-                g.A = reinterpret_cast<const float*>(c.W.X0p + pc[i].x0_off);
-                g.lda = c.W.ldk0;
-                g.a_plane = (long long)B * c.W.ldk0;
-                g.B = reinterpret_cast<const float*>(c.W.Wp0[r] + pc[i].x0_off);
-                g.ldb = c.W.ldk0;
-                g.b_plane = (long long)L.n13 * c.W.ldk0;
-            } else {
-                g.A = reinterpret_cast<const float*>(c.W.Yp[r - 1]);
-                g.lda = L.nn;
-                g.a_plane = (long long)B * L.nn;
-                g.B = reinterpret_cast<const float*>(c.W.Wp1[r]);
-                g.ldb = L.nn;
-                g.b_plane = (long long)L.n13 * L.nn;
-            }
-            g.a_scale = g.a_shift = nullptr;
-            g.K = (pc[i].width + 31) / 32 * 32;
-            const int want = g.splits;
-            prob_split(g, want, slab);
-            if (g.splits != want) return DGG_ERR_INVALID;  // same K tiling as planned: the slab count is already booked
-        }
-        DGG_TRY(gemm_p3_launch(gb, false, c.st));
-    } else {
-        DGG_TRY(gemm_launch(GEMM_NT, gb, c.st));
-    }
-    const bool shared_here = sh && np > nseg;
+    if (nq > 0) DGG_TRY(gemm_launch(GEMM_NT, gb, c.st));
+    const bool shared_here = sh && !planes && np > nseg;
     if (shared_here && sh->events) {
         if (sh->mode == 1 && hipEventRecord(sh->ready[r], c.st) != hipSuccess) return DGG_ERR_LAUNCH;
         if (sh->mode == 2 && hipStreamWaitEvent(c.st, sh->ready[r], 0) != hipSuccess) return DGG_ERR_LAUNCH;
+    }
+    if (planes) {
+        // 2. batched BPS slabs (pitch n13 * nrb, this block's columns) + the pieces above + the combined bias
+        const int nall = L.n13 * L.nrb;
+        DGG_TRY(reduce_bias_launch(c.xs + (size_t)r * L.n13, c.xs_n, (long long)B * nall, nall, c.xcbias + (size_t)r * L.n13,
+                                   A.a13, L.n13, B, B, 1, L.n13, 0, L.hid, L.hid, L.n13, c.W.part, c.st, 0,
+                                   nslab > 0 ? c.W.slabs : nullptr, nslab, slab, L.n13));
+        return rb_tail(c, r, drop_mode, keep_in, seed, seed_off);
     }
     // 2. sum slabs (k order: shared BPS chunks first) + bias; a1 -> statistics, a3 -> s = lrelu(a3)
     if (shared_here)
@@ -692,13 +698,8 @@ static int rb_tail(Ctx& c, int r, int drop_mode, const float* keep_in, uint64_t 
     {
         BnFused fz{part_bn2, c.train ? 1 : 0, c.bn ? c.bn + R.rm2 : nullptr, c.bn ? c.bn + R.rv2 : nullptr, A.mean2,
                    A.rstd2};
-        // y is the next block's second operand: its planes for that block's forward and (transposed) weight gradient
-        const bool more = (c.p3_fwd || c.p3_t) && r + 1 < L.nrb;
-        PlaneOut pl = {(more && c.p3_fwd) ? c.W.Yp[r] : nullptr, L.nn, 0, (long long)B * L.nn,
-                       (more && c.p3_t) ? c.W.Yt[r] : nullptr, c.W.ldB, 0, (long long)L.nn * c.W.ldB};
         DGG_TRY(res_out_launch(A.a13 + L.hid, L.n13, A.a2, L.nn, B, B, L.nn, A.mean2, A.rstd2, c.P + R.bn2w,
-                               c.P + R.bn2b, drop_mode, keep_in, seed, seed_off, A.keep, A.y, L.nn, c.st, &fz,
-                               more ? &pl : nullptr));
+                               c.P + R.bn2b, drop_mode, keep_in, seed, seed_off, A.keep, A.y, L.nn, c.st, &fz, nullptr));
     }
     return DGG_OK;
 }
@@ -736,22 +737,27 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     float* cs13 = c.W.cs13[r];
     // 1. through the output LeakyReLU / dropout; split into the bn2 branch (dpre) and the fc3 branch (da3)
     const int nq1 = (hb && !skip_param) ? 5 : 3;
-    // planes GEMM: dY13 goes out transposed as well ([n13][B]: rows 0 .. hid-1 from stage 4, the rest from stage 1)
-    const bool use_p3 = c.p3 && !skip_param && L.net != kNetResBlock;
-    const PlaneOut plt1 = {nullptr, 0, 0, 0, use_p3 ? c.W.dYt[r] : nullptr, c.W.ldB, 0, (long long)L.n13 * c.W.ldB};
-    const PlaneOut plt3 = {nullptr, 0, 0, 0, use_p3 ? c.W.dYt[r] : nullptr, c.W.ldB, L.hid, (long long)L.n13 * c.W.ldB};
     // shared BPS weight gradient of the discriminator's two passes (Share::bwd_mode)
     const Share* sh = c.share;
-    const bool share_ok = sh && sh->bwd_mode && !skip_param && !use_p3 && L.nprefix == 0 && sh->ncols > 0 && sh->ncols < L.k0;
+    const bool share_ok = sh && sh->bwd_mode && !skip_param && L.nprefix == 0 && sh->ncols > 0 && sh->ncols < L.k0;
     const bool share_r = share_ok && sh->bwd_mode == 1, share_f = share_ok && sh->bwd_mode == 2;
-    const SumOut so1 = {share_f ? sh->dY13_other[r] : nullptr, c.W.dYs[r], L.n13};
-    const SumOut so3 = {share_f ? sh->dY13_other[r] + L.hid : nullptr, share_f ? c.W.dYs[r] + L.hid : nullptr, L.n13};
+    // planes GEMM for the BPS block's weight gradient: dY13 goes out transposed as well ([n13][B]: rows 0 .. hid-1 from
+    // stage 4, the rest from stage 1) — as the SUM with the other pass' dY13 in the fake pass of a shared gradient; the
+    // real pass of one forms no BPS weight gradient and needs no planes
+    const bool use_p3 = c.p3 && !skip_param && L.net != kNetResBlock;
+    const bool dyt = use_p3 && !share_r;
+    const PlaneOut plt1 = {nullptr, 0, 0, 0, dyt ? c.W.dYt[r] : nullptr, c.W.ldB, 0, (long long)L.n13 * c.W.ldB, 0, 0};
+    const PlaneOut plt3 = {nullptr, 0, 0, 0, dyt ? c.W.dYt[r] : nullptr, c.W.ldB, L.hid, (long long)L.n13 * c.W.ldB, 0, 0};
+    // (x3 mode keeps the fp32 sum dYs for the in-register-split kernel; planes mode only the planes of the sum)
+    const SumOut so1 = {share_f ? sh->dY13_other[r] : nullptr, (share_f && !use_p3) ? c.W.dYs[r] : nullptr, L.n13};
+    const SumOut so3 = {share_f ? sh->dY13_other[r] + L.hid : nullptr, (share_f && !use_p3) ? c.W.dYs[r] + L.hid : nullptr,
+                        L.n13};
     const bool dy_slabs = !hb && c.dy_nslab > 1;
     DGG_TRY(res_out_bwd_launch(hb ? nullptr : (dy_slabs ? c.W.slabs : dy), L.nn, A.y, L.nn,
                                had_dropout ? A.keep : nullptr, A.a13 + L.hid, L.n13, A.a2, L.nn, A.mean2, A.rstd2, B, B,
                                L.nn, c.W.dpre, dY13 + L.hid, L.n13, c.W.part, c.st, hb ? hb->d_score : nullptr,
                                hb ? hb->w : nullptr, nq1, dy_slabs ? c.dy_nslab : 0, c.dy_stride,
-                               use_p3 ? &plt3 : nullptr, share_f ? &so3 : nullptr));
+                               dyt ? &plt3 : nullptr, share_f ? &so3 : nullptr));
     c.dy_nslab = 0;
     // fc1.bias / fc2.bias feed a train-mode BatchNorm: their gradient is EXACTLY zero (the batch-mean subtraction
     // removes any per-column constant; the reference stores fp32 rounding noise there) — cleared by this launch
@@ -789,7 +795,7 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     {
         ColFin fin = {c.W.part, 2, {gp(R.bn1b), gp(R.bn1w), nullptr, nullptr, nullptr}, acc, nullptr, nullptr, nullptr, 0, 0};
         DGG_TRY(bn_bwd_apply_launch(c.W.dh, L.hid, A.a13, L.n13, A.mean1, A.rstd1, c.P + R.bn1w, nullptr, c.train, B, B,
-                                    L.hid, dY13, L.n13, c.W.part2, c.st, &fin, use_p3 ? &plt1 : nullptr,
+                                    L.hid, dY13, L.n13, c.W.part2, c.st, &fin, dyt ? &plt1 : nullptr,
                                     share_f ? &so1 : nullptr));
     }
     // fc1.bias: same argument as fc2.bias above; in eval mode the real column sum is also kept in cs13[0:hid]
@@ -810,9 +816,11 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
         sw = c.sw;
     }
     // fc2: dW2 = da2^T h (512 x 256, K = B).  It rides along as one more problem of the [fc1;fc3] weight-gradient launch
-    // below — 8 tiles beside ~200, written (or accumulated) in place — unless that launch is full or runs on planes.
-    const int nx0 = (share_f ? 2 : 1);   // problems the [prefix | x_hat] segment will take
-    const bool fc2_rides = !skip_param && !use_p3 && (nseg - 1 + nx0) < 4;
+    // below — 8 tiles beside ~200, written (or accumulated) in place — unless that launch is full.
+    const int bps_lo = L.nprefix, bps_hi = L.nprefix + L.in_bps;   // the BPS block inside the [prefix | x_hat] segment
+    int nx0 = share_f ? 2 : 1;           // problems the [prefix | x_hat] segment takes in the fp32 launch
+    if (use_p3) nx0 = (bps_lo > 0 ? 1 : 0) + (bps_hi < L.k0 ? 1 : 0);
+    const bool fc2_rides = !skip_param && (nseg - 1 + nx0) < 4;
     if (!skip_param && !fc2_rides) {  // separate: split-K slabs + reduce
         GemmBatch g;
         memset(&g, 0, sizeof(g));
@@ -827,28 +835,55 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     if (!skip_param) {
         GemmBatch g;
         memset(&g, 0, sizeof(g));
-        int np = 0, ix0 = -1;
+        int np = 0;
+        bool has_x0 = false;
+        // the BatchNorm-aware epilogue of a problem over the columns [lo, ..) of the [prefix | x_hat] segment
+        auto ep_x0 = [&](GemmProb& q, int wcol, int lo, const float* cs1b) {
+            q.ep_gamma = c.W.aff_scale + lo;
+            q.ep_beta = c.W.aff_shift + lo;
+            q.ep_cs0 = c.train ? nullptr : cs13;
+            q.ep_cs1 = cs13 + L.hid;
+            q.ep_cs1b = cs1b;
+            q.ep_split = L.hid;
+            q.ep_w = c.P + R.w13 + wcol + lo;
+            q.ep_ldw = R.fin;
+            q.ep_part = c.W.ibn_part + (size_t)r * 12 * 2 * L.k0 + lo;
+            q.ep_part_ld = L.k0;
+        };
         // one problem per column range [lo, hi) of a segment; A: whose dY13 it takes
         auto add = [&](const Seg& sg, int lo, int hi, const float* Aop, int accumulate, const float* cs1b) {
             GemmProb& q = g.p[np++];
             prob_init(q, Aop, L.n13, sg.p + lo, sg.ld, G + R.w13 + sg.wcol + lo, R.fin, L.n13, hi - lo, B);
             q.accumulate = accumulate;
             if (sg.is_x0) {
-                ix0 = np - 1;
-                q.ep_gamma = c.W.aff_scale + lo;
-                q.ep_beta = c.W.aff_shift + lo;
-                q.ep_cs0 = c.train ? nullptr : cs13;
-                q.ep_cs1 = cs13 + L.hid;
-                q.ep_cs1b = cs1b;
-                q.ep_split = L.hid;
-                q.ep_w = c.P + R.w13 + sg.wcol + lo;
-                q.ep_ldw = R.fin;
-                q.ep_part = c.W.ibn_part + (size_t)r * 12 * 2 * L.k0 + lo;
-                q.ep_part_ld = L.k0;
+                has_x0 = true;
+                ep_x0(q, sg.wcol, lo, cs1b);
             }
         };
         for (int i = 0; i < nseg; ++i) {
-            if (segs[i].is_x0 && share_r) {            // real pass: the pose columns only
+            if (segs[i].is_x0 && use_p3) {             // planes mode: the BPS block has a launch of its own (below)
+                if (bps_lo > 0) add(segs[i], 0, bps_lo, dY13, acc, nullptr);
+                if (bps_hi < segs[i].width) add(segs[i], bps_hi, segs[i].width, dY13, acc, nullptr);
+                if (!share_r) {
+                    // dW13[n][k] = sum_b dY13[b][n] x_hat[b][k] over the transposed planes dY13^T [n13][B], x_hat^T
+                    // [in_bps][B] ("NT"), BatchNorm-aware epilogue; the fake pass of a shared gradient multiplies
+                    // dY_real + dY_fake and OVERWRITES (the real pass wrote nothing there)
+                    GemmBatch gp;
+                    memset(&gp, 0, sizeof(gp));
+                    gp.nprob = 1;
+                    GemmProb& q = gp.p[0];
+                    prob_init(q, reinterpret_cast<const float*>(c.W.dYt[r]), c.W.ldB, reinterpret_cast<const float*>(c.xbt),
+                              c.W.ldB, G + R.w13 + segs[i].wcol + bps_lo, R.fin, L.n13, L.in_bps, (B + 31) / 32 * 32);
+                    q.a_plane = (long long)L.n13 * c.W.ldB;
+                    q.b_plane = (long long)L.in_bps * c.W.ldB;
+                    q.accumulate = share_f ? 0 : acc;
+                    ep_x0(q, segs[i].wcol, bps_lo, share_f ? sh->cs13_other[r] + L.hid : nullptr);
+                    if (!c.xbt) return DGG_ERR_INVALID;
+                    DGG_TRY(gemm_planes_launch(gp, true, sw));
+                    ibn_tiles[r] = (L.n13 + 127) / 128;
+                    if (ibn_tiles[r] > 12) return DGG_ERR_INVALID;
+                }
+            } else if (segs[i].is_x0 && share_r) {     // real pass: the pose columns only
                 add(segs[i], sh->ncols, segs[i].width, dY13, acc, nullptr);
             } else if (segs[i].is_x0 && share_f) {     // fake pass: BPS columns on dY_real + dY_fake, pose columns on its own
                 add(segs[i], 0, sh->ncols, c.W.dYs[r], 0, sh->cs13_other[r] + L.hid);
@@ -863,39 +898,25 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
             q.accumulate = acc;
         }
         if (hr) {
-            if (np >= 4 || use_p3) return DGG_ERR_INVALID;  // net_backward only asks when there is room
+            if (np >= 4) return DGG_ERR_INVALID;  // net_backward only asks when there is room
             GemmProb& q = g.p[np++];
             prob_init(q, hr->d_out, hr->nh, A.y, L.nn, hr->gwh, L.nn, hr->nh, L.nn, B);
             q.accumulate = acc;
         }
         g.nprob = np;
-        // the widest problem decides the tile shape
-        for (int i = 1; i < np; ++i)
-            if (g.p[i].N > g.p[0].N) {
-                GemmProb t = g.p[0]; g.p[0] = g.p[i]; g.p[i] = t;
-                if (ix0 == i) ix0 = 0; else if (ix0 == 0) ix0 = i;
-            }
-        if (use_p3) {
-            // dW13[n][k] = sum_b dY13[b][n] X[b][k] over the transposed planes dY13^T [n13][B], X^T [width][B]
-            for (int i = 0; i < np; ++i) {
-                GemmProb& q = g.p[i];
-                const bool x0 = q.ep_gamma != nullptr;  // set above for the [prefix | x_hat] segment only
-                q.A = reinterpret_cast<const float*>(c.W.dYt[r]);
-                q.lda = c.W.ldB;
-                q.a_plane = (long long)L.n13 * c.W.ldB;
-                q.B = reinterpret_cast<const float*>(x0 ? c.W.X0t : c.W.Yt[r - 1]);
-                q.ldb = c.W.ldB;
-                q.b_plane = (long long)(x0 ? L.k0 : L.nn) * c.W.ldB;
-                q.K = (B + 31) / 32 * 32;
-            }
-            ibn_tiles[r] = (L.n13 + 127) / 128;
-            if (ibn_tiles[r] > 12 || ix0 < 0) return DGG_ERR_INVALID;
-            DGG_TRY(gemm_p3_launch(g, true, sw));
-        } else {
+        if (np > 0) {
+            // the tile shape gemm_launch will pick (the problem with the most work decides): the row-tile count of the
+            // epilogue's per-tile partials
+            int big = 0;
+            for (int i = 1; i < np; ++i)
+                if ((double)g.p[i].M * g.p[i].N * g.p[i].K > (double)g.p[big].M * g.p[big].N * g.p[big].K) big = i;
             int bm, bn;
-            gemm_tile_shape(GEMM_TN, g.p[0].M, g.p[0].N, bm, bn, g.p[0].K);
-            ibn_tiles[r] = (L.n13 + bm - 1) / bm;
-            if (ibn_tiles[r] > 12 || (ix0 < 0 && L.net != kNetResBlock)) return DGG_ERR_INVALID;
+            gemm_tile_shape(GEMM_TN, g.p[big].M, g.p[big].N, bm, bn, g.p[big].K);
+            const int tiles = (L.n13 + bm - 1) / bm;
+            if (tiles > 12) return DGG_ERR_INVALID;
+            if (use_p3) ibn_tiles[3 + r] = has_x0 ? tiles : 0;   // the columns around the BPS block
+            else ibn_tiles[r] = tiles;
+            if (!use_p3 && !has_x0 && L.net != kNetResBlock) return DGG_ERR_INVALID;
             DGG_TRY(gemm_launch(GEMM_TN, g, sw));
         }
     }
@@ -963,42 +984,80 @@ static int net_forward(const NetL& L, const float* params, float* bn, void* ws, 
     carve(L, B, ws, c.W);
     if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
     if (!bn) return DGG_ERR_INVALID;
-    // (not with the planes GEMM: the fake-batch pass of a D phase has no large forward product and left no X0 planes)
-    const bool reuse_norm = c.train && (flags & DGG_REUSE_INPUT_NORM) != 0 && !(c.W.p3 && gemm_algo() == 2);
-    if (c.train && !reuse_norm) DGG_TRY(ibn_stats_launch(srcs, B, 1, c.W.part, st));
-    // Train pass on the planes GEMM (gemm_p3.hip): the operands are split where they are produced — the input
-    // BatchNorm emits [gamma x_hat + beta] row-major for the forward and x_hat transposed for the weight gradient,
-    // every block's output and dY13 follow in rb_tail / rb_backward — and W13's column pieces in one launch here
+    // Train pass on the planes GEMM (gemm_p4.hip): the BPS block of the input — in_bps of the k0 columns, the same
+    // operand for every ResBlock — is split into bf16 planes where it is produced (ibn_apply: x_hat row-major for the
+    // forward, transposed for the weight gradient), the matching columns of every block's W13 go out as planes with the
+    // BatchNorm scale folded in (gamma[k] W[n][k]; the shift becomes a bias, NetW::cbias), and ONE launch forms the BPS
+    // products of all ResBlocks of the pass ahead of the block chain.  A fake-batch pass of a D phase (share mode 2)
+    // takes the real pass' products instead: same BPS rows, same batch statistics, same parameters.
     c.p3 = c.train && c.W.p3 && gemm_algo() == 2;
-    c.p3_fwd = c.p3 && p3_use_fwd() && !(share && share->mode == 2);
-    c.p3_t = c.p3 && p3_use_wgrad() && !(flags & DGG_SKIP_PARAM_GRADS);
+    const bool consumer = share && share->mode == 2;
+    c.p3_fwd = c.p3 && !consumer;
+    c.p3_t = c.p3 && !consumer && !(flags & DGG_SKIP_PARAM_GRADS);
+    // (input-norm reuse needs this workspace's planes: a consumer pass left none)
+    const bool reuse_norm = c.train && (flags & DGG_REUSE_INPUT_NORM) != 0 && !c.p3;
+    if (c.train && !reuse_norm) DGG_TRY(ibn_stats_launch(srcs, B, 1, c.W.part, st));
     if (reuse_norm) {
-        // x_hat, its planes, mean and rstd of this workspace are those of the previous train forward over these inputs
+        // x_hat, mean and rstd of this workspace are those of the previous train forward over these inputs
         DGG_TRY(ibn_refresh_launch(c.W.imean, c.W.ivaru, bn + L.irm, bn + L.irv, params + L.ibnw, params + L.ibnb,
                                    c.W.aff_scale, c.W.aff_shift, L.nprefix, L.k_in, st));
     } else {
         BnFused fz{c.W.part, c.train ? 1 : 0, bn + L.irm, bn + L.irv, c.W.imean, c.W.irstd, c.W.ivaru};
-        PlaneOut pl = {c.p3_fwd ? c.W.X0p : nullptr, c.W.ldk0, 0, (long long)B * c.W.ldk0,
-                       c.p3_t ? c.W.X0t : nullptr, c.W.ldB, 0, (long long)L.k0 * c.W.ldB};
+        PlaneOut pl = {c.p3_fwd ? c.W.Xb : nullptr, L.in_bps, 0, (long long)B * L.in_bps,
+                       c.p3_t ? c.W.Xbt : nullptr, c.W.ldB, 0, (long long)L.in_bps * c.W.ldB, L.nprefix, L.in_bps};
         DGG_TRY(ibn_apply_launch(srcs, B, B, c.W.imean, c.W.irstd, nullptr, nullptr, prefix, L.nprefix, c.W.X0, L.ldx0,
                                  params + L.ibnw, params + L.ibnb, c.W.aff_scale, c.W.aff_shift, st, &fz,
                                  (c.p3_fwd || c.p3_t) ? &pl : nullptr));
     }
     if (c.p3_fwd) {
+        const int nall = L.n13 * L.nrb;
         PlanesJobs jobs;
         jobs.n = 0;
+        RowDotJobs rd;
+        rd.n = 0;
         for (int r = 0; r < L.nrb; ++r) {
             Seg segs[2];
             int nseg;
             make_segs(L, c.W, r, segs, nseg);
             for (int i = 0; i < nseg; ++i) {
-                const bool x0 = segs[i].is_x0;
-                DGG_TRY(planes_add(jobs, params + L.rb[r].w13 + segs[i].wcol, L.rb[r].fin, L.n13, segs[i].width, nullptr,
-                                   nullptr, x0 ? c.W.Wp0[r] : c.W.Wp1[r], x0 ? c.W.ldk0 : L.nn,
-                                   (long long)L.n13 * (x0 ? c.W.ldk0 : L.nn), nullptr, 0, 0));
+                if (!segs[i].is_x0) continue;
+                const float* wb = params + L.rb[r].w13 + segs[i].wcol + L.nprefix;   // W13[:, first BPS column]
+                // (the BatchNorm's BPS columns are its first in_bps: the concat starts with bps in every network)
+                DGG_TRY(planes_add(jobs, wb, L.rb[r].fin, L.n13, L.in_bps, params + L.ibnw, nullptr,
+                                   c.W.Wb + (size_t)r * L.n13 * L.in_bps, L.in_bps, (long long)nall * L.in_bps, nullptr, 0, 0));
+                DGG_TRY(rowdot_add(rd, wb, L.rb[r].fin, L.n13, L.in_bps, params + L.ibnb, params + L.rb[r].b13,
+                                   c.W.cbias + (size_t)r * L.n13));
             }
         }
         DGG_TRY(planes_run(jobs, st));
+        DGG_TRY(rowdot_run(rd, st));
+        GemmBatch gb;
+        memset(&gb, 0, sizeof(gb));
+        gb.nprob = 1;
+        GemmProb& q = gb.p[0];
+        prob_init(q, reinterpret_cast<const float*>(c.W.Xb), L.in_bps, reinterpret_cast<const float*>(c.W.Wb), L.in_bps,
+                  c.W.xslabs, nall, B, nall, L.in_bps);
+        q.a_plane = (long long)B * L.in_bps;
+        q.b_plane = (long long)nall * L.in_bps;
+        prob_split(q, c.W.xsplits, (long long)B * nall);
+        if (q.splits != c.W.xsplits) return DGG_ERR_INVALID;
+        DGG_TRY(gemm_planes_launch(gb, false, st));
+        c.xs = c.W.xslabs;
+        c.xs_n = q.splits;
+        c.xcbias = c.W.cbias;
+        if (share && share->mode == 1) {
+            share->xslabs = c.W.xslabs;
+            share->xnslab = q.splits;
+            share->xcbias = c.W.cbias;
+            share->xbt = c.W.Xbt;
+            if (share->events && hipEventRecord(share->xready, st) != hipSuccess) return DGG_ERR_LAUNCH;
+        }
+    } else if (c.p3 && consumer) {
+        if (!share->xslabs || !share->xcbias) return DGG_ERR_INVALID;
+        c.xs = share->xslabs;
+        c.xs_n = share->xnslab;
+        c.xcbias = share->xcbias;
+        if (share->events && hipStreamWaitEvent(st, share->xready, 0) != hipSuccess) return DGG_ERR_LAUNCH;
     }
     const bool drop = (L.net == DGG_NET_EVA) && c.train;
     for (int r = 0; r < L.nrb; ++r) {
@@ -1052,7 +1111,9 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     if (c.sw == st) c.sw = nullptr;
     carve(L, B, ws, c.W);
     if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
-    c.p3 = c.train && c.W.p3 && gemm_algo() == 2 && p3_use_wgrad() && !skip;  // the forward left X0^T / y^T planes
+    // the forward left x_hat^T planes of the BPS block (this pass', or — fake pass of a shared D gradient — the real pass')
+    c.p3 = c.train && c.W.p3 && gemm_algo() == 2 && !skip;
+    c.xbt = (share && share->mode == 2) ? share->xbt : c.W.Xbt;
     const bool want_in = d_in && d_in_hi > d_in_lo;
     // columns of X0 whose gradient is needed: only those for which the caller wants INPUT gradients —
     // the input BatchNorm's parameter gradients come out of the wgrad epilogue
@@ -1068,7 +1129,7 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     const int pose_used = splits_used(L.n13, kPoseKs);
     const bool pose_slabs = want_in && !(d_prefix && L.nprefix > 0) && x_hi - x_lo <= kPoseLd && x_lo == L.nprefix + d_in_lo &&
                             L.n13 >= kPoseKs * 4 * 32 && (int64_t)L.nrb * pose_used * kPoseLd <= L.ldx0;
-    int ibn_tiles[3] = {0, 0, 0};
+    int ibn_tiles[6] = {0, 0, 0, 0, 0, 0};   // [r]: row tiles of block r's epilogue partials; planes mode: [3 + r] for the columns around the BPS block
     const bool drop = (L.net == DGG_NET_EVA) && c.train;
     const GradEvents* ge = skip ? nullptr : grad_events_for(grads);
     if (ge && (ge->n != L.nrb || (ge->accum_only && !accum))) ge = nullptr;
@@ -1077,9 +1138,9 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     float* other = c.W.dXb;
     HeadBwd hb{d_out, params + L.wh, skip ? nullptr : grads + L.wh, skip ? nullptr : grads + L.bh};
     const bool fold_head = L.nh == 1;  // the outer product d_score (x) w is formed inside the last block's backward
-    // the last block's weight-gradient launch has room for the heads' dWh unless it runs on planes (problems: the input
-    // segments (<= 2) + fc2 = at most 3 of 4; Share splits the X0 segment only for the discriminator, whose head folds)
-    const bool heads_ride = !fold_head && !skip && !c.p3;
+    // the last block's weight-gradient launch has room for the heads' dWh (problems: the input segments (<= 2) + fc2 = at
+    // most 3 of 4; Share splits the X0 segment only for the discriminator, whose head folds)
+    const bool heads_ride = !fold_head && !skip;
     HeadsRide hride{d_out, L.nh, skip ? nullptr : grads + L.wh};
     if (!fold_head)
         DGG_TRY(heads_bwd_launch(c.W.rb[L.nrb - 1].y, L.nn, d_out, L.nh, B, L.nn, params + L.wh, L.nh, dy, L.nn,
@@ -1121,25 +1182,42 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     if (!skip) {
         // shared BPS weight gradient (Share::bwd_mode, same conditions as in rb_backward): the real pass produced
         // partials for the pose columns only; the fake pass overwrites the BPS columns and accumulates the rest
-        const bool share_ok = share && share->bwd_mode && !c.p3 && L.nprefix == 0 && share->ncols > 0 && share->ncols < L.k0;
-        const int c_first = (share_ok && share->bwd_mode == 1) ? share->ncols : 0;
+        const bool share_ok = share && share->bwd_mode && L.nprefix == 0 && share->ncols > 0 && share->ncols < L.k0;
         // part layout per block: [tiles][2][k0], blocks 12 * 2 * k0 apart; q0 -> d gamma, q1 -> d beta.  One launch sums
-        // the blocks (groups) when they all used the same tile count — they do within one pass
-        bool same = true;
-        for (int r = 1; r < L.nrb; ++r) same = same && ibn_tiles[r] == ibn_tiles[0];
-        const int noacc0 = (share_ok && share->bwd_mode == 2) ? share->ncols : 0;
-        if (same) {
-            DGG_TRY(colsum_finalize_launch(c.W.ibn_part, L.nrb, ibn_tiles[0], 2, L.k_in - c_first, nullptr,
-                                           grads + L.ibnw + c_first, grads + L.ibnb + c_first, nullptr, accum ? 1 : 0, st,
-                                           L.k0, L.nprefix + c_first, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr,
-                                           nullptr, noacc0, (long long)12 * 2 * L.k0));
-        } else {
+        // the blocks (groups) of a column range when they all used the same tile count — they do within one pass.
+        // fin(c_lo, ncols, tiles, noacc): BatchNorm columns [c_lo, c_lo + ncols); noacc: overwrite even when accumulating
+        auto fin = [&](int c_lo, int ncols, const int* tiles, bool noacc) -> int {
+            if (ncols <= 0) return DGG_OK;
+            bool same = true;
+            for (int r = 1; r < L.nrb; ++r) same = same && tiles[r] == tiles[0];
+            if (same) {
+                if (tiles[0] <= 0) return DGG_ERR_INVALID;
+                return colsum_finalize_launch(c.W.ibn_part, L.nrb, tiles[0], 2, ncols, nullptr, grads + L.ibnw + c_lo,
+                                              grads + L.ibnb + c_lo, nullptr, accum ? 1 : 0, st, L.k0, L.nprefix + c_lo,
+                                              nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr,
+                                              noacc ? ncols : 0, (long long)12 * 2 * L.k0);
+            }
             for (int r = 0; r < L.nrb; ++r) {
-                DGG_TRY(colsum_finalize_launch(c.W.ibn_part + (size_t)r * 12 * 2 * L.k0, 1, ibn_tiles[r], 2,
-                                               L.k_in - c_first, nullptr, grads + L.ibnw + c_first,
-                                               grads + L.ibnb + c_first, nullptr, (accum || r > 0) ? 1 : 0, st, L.k0,
-                                               L.nprefix + c_first, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr,
-                                               nullptr, r == 0 ? noacc0 : 0));
+                if (tiles[r] <= 0) return DGG_ERR_INVALID;
+                DGG_TRY(colsum_finalize_launch(c.W.ibn_part + (size_t)r * 12 * 2 * L.k0, 1, tiles[r], 2, ncols, nullptr,
+                                               grads + L.ibnw + c_lo, grads + L.ibnb + c_lo, nullptr,
+                                               (accum || r > 0) ? 1 : 0, st, L.k0, L.nprefix + c_lo, nullptr, nullptr,
+                                               nullptr, 0, nullptr, 0, nullptr, nullptr, (r == 0 && noacc) ? ncols : 0));
+            }
+            return DGG_OK;
+        };
+        if (c.p3) {
+            // the BPS block's partials come from the planes launch (none in the real pass of a shared gradient, whose
+            // fake pass overwrites them), those of the columns around it from the fp32 launch
+            if (!(share_ok && share->bwd_mode == 1)) DGG_TRY(fin(0, L.in_bps, ibn_tiles, share_ok && share->bwd_mode == 2));
+            DGG_TRY(fin(L.in_bps, L.k_in - L.in_bps, ibn_tiles + 3, false));
+        } else {
+            const int c_first = (share_ok && share->bwd_mode == 1) ? share->ncols : 0;
+            if (share_ok && share->bwd_mode == 2) {
+                DGG_TRY(fin(0, share->ncols, ibn_tiles, true));
+                DGG_TRY(fin(share->ncols, L.k_in - share->ncols, ibn_tiles, false));
+            } else {
+                DGG_TRY(fin(c_first, L.k_in - c_first, ibn_tiles, false));
             }
         }
     }
@@ -1655,7 +1733,7 @@ struct PendingReal {
     int step_B;           // batch size of the step whose G phase left the D-free mark (the workspace is carved for it)
     const float *bps, *rot9, *transl, *joint;
     const float* d_params;  // the discriminator the prefetched pass was computed with
-    hipEvent_t ev[6];     // fwd_done, bwd_done, 3 x share.ready, D-free; created with the slot
+    hipEvent_t ev[7];     // fwd_done, bwd_done, 3 x share.ready, D-free, share.xready; created with the slot
     bool events_ok, dfree_set;
     Share share;
     unsigned long long stamp;
@@ -1675,7 +1753,7 @@ static PendingReal* pending_slot(const void* ws, bool create) {
     }
     if (!create) return nullptr;
     if (!lru->events_ok) {
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < 7; ++i)
             if (hipEventCreateWithFlags(&lru->ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         lru->events_ok = true;
     }
@@ -1736,6 +1814,7 @@ int dgg_cgan_d_real_prefetch(const dgg_cfg* cfg, const dgg_gan_state* s, const d
         P.share.slabs[r] = S.dshare[r];
         P.share.ready[r] = P.ev[2 + r];
     }
+    P.share.xready = P.ev[6];
     P.valid = false;
     DGG_TRY(real_pass(cfg, s, hp, S, Ld, B, bps, rot9, transl, joint, losses + kLossRealNext, sb, P.share, P.ev[0],
                       P.ev[1]));
@@ -1787,6 +1866,7 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
             share.slabs[r] = S.dshare[r];
             if (fork && !(share.ready[r] = next_event())) return DGG_ERR_LAUNCH;
         }
+        if (fork && !(share.xready = next_event())) return DGG_ERR_LAUNCH;
         // ---- stream B: the real-batch pass
         DGG_TRY(real_pass(cfg, s, hp, S, Ld, B, bps, rot9, transl, joint, losses + DGG_L_BCE_REAL, sb, share, ev[1],
                           ev[2]));
@@ -2028,7 +2108,7 @@ int dgg_resblock_backward(int fin, const float* params, float* grads, void* ws, 
     memset(&seg, 0, sizeof(seg));
     seg.p = x; seg.ld = ldx; seg.width = fin; seg.wcol = 0; seg.is_x0 = false;
     if (dx) { seg.dp = dx; seg.dld = fin; seg.d_lo = 0; seg.d_hi = fin; seg.d_accum = 0; }
-    int ibn_tiles[3] = {0, 0, 0};
+    int ibn_tiles[6] = {0, 0, 0, 0, 0, 0};
     return rb_backward(c, 0, &seg, 1, dy, false, (flags & DGG_ACCUM_GRADS) != 0, skip, ibn_tiles);
 }
 
@@ -2383,7 +2463,7 @@ int dgg_gemm_planes(int a_kmajor, int b_kmajor, int M, int N, int K, const float
     }
     g.p[0].a_plane = apl;
     g.p[0].b_plane = bpl;
-    DGG_TRY(gemm_p3_launch(g, false, st));
+    DGG_TRY(gemm_planes_launch(g, false, st));
     if (splits >= 1 && C)
         return reduce_bias_launch(slabs, g.p[0].splits, (long long)M * N, N, nullptr, C, ldc, M, M, 1, N, 0, 0, 0, 0, nullptr,
                                   st);

@@ -89,11 +89,15 @@ void gemm_set_side_work(int on);
 void gemm_x3_dispatch(int mode, const GemmBatch& batch, hipStream_t st);  // gemm_x3.hip, 128 x 128 tiles
 // gemm_p3.hip: C = A B^T on pre-split bf16 planes (forward, and the wgrad over transposed planes with wgrad = true)
 int gemm_p3_launch(GemmBatch& batch, bool wgrad, hipStream_t st);
+// gemm_p4.hip: the same product (same operands, same bits) with specialised waves — 4 MFMA waves + 4 LDS-DMA loader waves
+int gemm_p4_launch(GemmBatch& batch, bool wgrad, hipStream_t st);
+// the planes GEMM in use: gemm_p4 unless DGG_PLANES_KERNEL=p3
+int gemm_planes_launch(GemmBatch& batch, bool wgrad, hipStream_t st);
 // dx / da3 of THIS pass plus the same tensor of another pass, written next to the plain output (the discriminator's
 // weight gradient over the BPS columns takes dY_real + dY_fake in one product, see Share::bwd_mode)
 struct SumOut {
     const float* other;   // NULL: none
-    float* sum;
+    float* sum;           // NULL: the fp32 sum is not stored (only the transposed planes, which then hold the SUM)
     int ld;               // pitch of both
 };
 // Plane outputs of the column kernels (ibn_apply, res_out, bn_bwd_apply, res_out_bwd; one batch group only): what the
@@ -107,6 +111,9 @@ struct PlaneOut {
     __bf16* pT;     // NULL: none
     int ldT, colT0;
     long long planeT;
+    // ibn_apply only: win_n > 0 restricts the planes to the output columns [win_lo, win_lo + win_n) of X0 — the BPS
+    // block —, stored at plane column (c - win_lo) + col0 / transposed row (c - win_lo) + colT0
+    int win_lo, win_n;
 };
 // fp32 [R][C] -> planes [3][R][ldp] (affine per column optional) and / or transposed planes [3][C][ldpT]
 static const int kPlanesJobs = 6;
@@ -131,6 +138,19 @@ int planes_add(PlanesJobs& jobs, const float* src, int ld, int R, int C, const f
 int planes_run(const PlanesJobs& jobs, hipStream_t st);
 int planes_launch(const float* src, int ld, int R, int C, const float* scale, const float* shift, void* dst, int ldp,
                   long long dplane, void* dstT, int ldpT, long long tplane, hipStream_t st);
+// out[n] = bias[n] + sum_c W[n][c] * v[c]  for up to 3 matrices in one launch (one wave per row, fixed summation order):
+// the bias the folded BatchNorm shift adds to the BPS products (NetW::cbias)
+struct RowDotJob {
+    const float *w, *v, *bias;
+    float* out;
+    int ld, R, C;
+};
+struct RowDotJobs {
+    RowDotJob j[3];
+    int n;
+};
+int rowdot_add(RowDotJobs& jobs, const float* w, int ld, int R, int C, const float* v, const float* bias, float* out);
+int rowdot_run(const RowDotJobs& jobs, hipStream_t st);
 int gemm_x3_occupancy(int mode);
 
 // ---------------------------------------------------------------- BPS encode (bps_encode.hip)
@@ -170,15 +190,16 @@ int ibn_apply_launch(const ColSrcs& srcs, int B, int rows_per_group, const float
                      const float* gamma, const float* beta, const float* prefix, int nprefix, float* X0, int ldx,
                      const float* aff_gamma, const float* aff_beta, float* aff_scale, float* aff_shift,
                      hipStream_t st, const BnFused* fused = nullptr, const PlaneOut* planes = nullptr);
-// planes (ibn_apply): row-major = aff_gamma * x_hat + aff_beta (prefix columns as they are), zero-filled up to its
-// pitch; transposed = x_hat
+// planes (ibn_apply): x_hat, row-major and / or transposed (prefix columns as they are; PlaneOut::win_* restricts them
+// to the BPS block)
 
 // out[m][c] = sum_s slabs[s][m][c] (+ sum_s slabs2[s][m][c], same stride / pitch) + bias[c];  columns [stat_lo, stat_hi) get partial statistics,
 // columns [act_lo, act_hi) get LeakyReLU applied before the store.
 int reduce_bias_launch(const float* slabs, int nslab, long long slab_stride, int ld_slab, const float* bias,
                        float* out, int ld_out, int B, int rows_per_group, int groups, int N, int stat_lo,
                        int stat_hi, int act_lo, int act_hi, float* part, hipStream_t st, int accumulate = 0,
-                       const float* slabs2 = nullptr, int nslab2 = 0);
+                       const float* slabs2 = nullptr, int nslab2 = 0,
+                       long long stride2 = 0, int ld2 = 0);  // 0: the second stack has the first one's stride / pitch
 // Per-object factorised first layer (eval mode): out[m][c] = cobj[m / n_per][c] + sum_s slabs[s][m][c]
 //   + sum_j bn_eval(small)(m, j) * wsm[c * ldw + j]; LeakyReLU on [act_lo, act_hi).  small.total <= 16.
 int expand_rows_launch(const float* cobj, int ldc, int n_per, const float* slabs, int nslab, long long slab_stride,

@@ -309,6 +309,10 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
     const int groups = B / rpg;
     const bool fused = fin.mean_out != nullptr;
     if (fused) bn_block_stats(fin, rpg, groups, S.total, c, bnc, blockIdx.y == 0, sh, res);
+    // planes window (PlaneOut::win_n): only the BPS block of X0 goes out as planes, at column oc - win_lo
+    const bool pwin = PL.win_n > 0;
+    const bool pin = !pwin || (oc >= PL.win_lo && oc < PL.win_lo + PL.win_n);
+    const int pc = pwin ? oc - PL.win_lo : oc;
     if (aff_scale && ook && blockIdx.y == 0 && sub == 0) {
         aff_scale[oc] = oc < nprefix ? 1.f : aff_gamma[oc - nprefix];
         aff_shift[oc] = oc < nprefix ? 0.f : aff_beta[oc - nprefix];
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
         const int n = min(RS, B - r0);
         const bool last_block = rbk == nrb_total - 1;
         if (!ook) {  // columns between the operand's width and the planes' pitch: the forward GEMM's K padding
-            if (PL.p && oc < PL.ld && n > 0) {
+            if (PL.p && !pwin && oc < PL.ld && n > 0) {
                 float zv[RS];
 #pragma unroll
                 for (int r = 0; r < RS; ++r) zv[r] = 0.f;
@@ -349,11 +353,11 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
             continue;
         }
         if (n <= 0) {
-            if (PL.pT) {
+            if (PL.pT && pin) {
                 float zv[RS];
 #pragma unroll
                 for (int r = 0; r < RS; ++r) zv[r] = 0.f;
-                planes_store_cols(PL, oc, r0, 0, zv, last_block);
+                planes_store_cols(PL, pc, r0, 0, zv, last_block);
             }
             continue;
         }
@@ -361,8 +365,8 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
 #pragma unroll
             for (int r = 0; r < RS; ++r)
                 if (r < n) X0[(size_t)(r0 + r) * ldx + oc] = xv[k][r];
-            if (PL.p) planes_store_rows(PL, oc, r0, n, xv[k]);
-            if (PL.pT) planes_store_cols(PL, oc, r0, n, xv[k], last_block);
+            if (PL.p && pin) planes_store_rows(PL, pc, r0, n, xv[k]);
+            if (PL.pT && pin) planes_store_cols(PL, pc, r0, n, xv[k], last_block);
             continue;
         }
 #pragma unroll
@@ -376,13 +380,10 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
             xv[k][r] = fmaf(xv[k][r], sc, shf);
             if (r < n) X0[(size_t)row * ldx + oc] = xv[k][r];
         }
-        if (PL.pT) planes_store_cols(PL, oc, r0, n, xv[k], last_block);
-        if (PL.p) {  // the forward operand carries the BatchNorm affine the stored x_hat leaves to the GEMM
-            const float ag = aff_gamma[c], ab = aff_beta[c];
-#pragma unroll
-            for (int r = 0; r < RS; ++r) xv[k][r] = fmaf(xv[k][r], ag, ab);
-            planes_store_rows(PL, oc, r0, n, xv[k]);
-        }
+        if (PL.pT && pin) planes_store_cols(PL, pc, r0, n, xv[k], last_block);
+        // (the row-major planes hold x_hat as well: the BatchNorm scale is folded into the weight planes, the shift into
+        // the bias — net_forward —, so that the operand does not depend on the parameters)
+        if (PL.p && pin) planes_store_rows(PL, pc, r0, n, xv[k]);
     }
 }
 
@@ -393,7 +394,8 @@ __global__ __launch_bounds__(256) void reduce_bias_kernel(const float* __restric
                                                           int ld_out, int rpg, int nrb, int N, int stat_lo,
                                                           int stat_hi, int act_lo, int act_hi,
                                                           float* __restrict__ part, int accumulate,
-                                                          const float* __restrict__ slabs2, int nslab2) {
+                                                          const float* __restrict__ slabs2, int nslab2,
+                                                          long long stride2, int ld2) {
     __shared__ float sh[SUB][2][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -414,18 +416,21 @@ __global__ __launch_bounds__(256) void reduce_bias_kernel(const float* __restric
         // slabs [0, nslab) come from `slabs`, [nslab, nslab + nslab2) from `slabs2` (same stride and pitch): a
         // partial product computed once and shared by two reduces (D real / fake pass) needs no copy
         const int ntot = nslab + nslab2;
-        auto slab = [&](int i) -> const float* {
-            return (i < nslab ? slabs + (size_t)i * slab_stride : slabs2 + (size_t)(i - nslab) * slab_stride) +
-                   row0 * ld_slab + c;
+        // (the second stack may have a geometry of its own: stride2 / ld2)
+        auto slab = [&](int i, int& ld) -> const float* {
+            ld = i < nslab ? ld_slab : ld2;
+            return i < nslab ? slabs + (size_t)i * slab_stride + row0 * ld_slab + c
+                             : slabs2 + (size_t)(i - nslab) * stride2 + row0 * ld2 + c;
         };
         int s = 0;
         for (; s + 4 <= ntot; s += 4) {
             float t[4][RS];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float* p = slab(s + u);
+                int ld;
+                const float* p = slab(s + u, ld);
 #pragma unroll
-                for (int r = 0; r < RS; ++r) t[u][r] = (r < ns) ? p[(size_t)r * ld_slab] : 0.f;
+                for (int r = 0; r < RS; ++r) t[u][r] = (r < ns) ? p[(size_t)r * ld] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -433,10 +438,11 @@ __global__ __launch_bounds__(256) void reduce_bias_kernel(const float* __restric
                 for (int r = 0; r < RS; ++r) v[r] += t[u][r];
         }
         for (; s < ntot; ++s) {
-            const float* p = slab(s);
+            int ld;
+            const float* p = slab(s, ld);
 #pragma unroll
             for (int r = 0; r < RS; ++r)
-                if (r < ns) v[r] += p[(size_t)r * ld_slab];
+                if (r < ns) v[r] += p[(size_t)r * ld];
         }
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
@@ -699,9 +705,9 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
                 if (cok) dpre[row * N + c] = d;
                 const float xh = (av_[r] - mu) * rs;
                 const float d3 = d * lrelu_grad(sv_[r]);
-                d3v[r] = d3;
+                d3v[r] = SO.other ? d3 + ov_[r] : d3;   // the planes carry the SUM where another pass' tensor is given
                 if (cok) da3[row * ldda3 + c] = d3;
-                if (SO.other && cok) SO.sum[row * SO.ld + c] = d3 + ov_[r];
+                if (SO.sum && cok) SO.sum[row * SO.ld + c] = d3 + ov_[r];
                 s0 += d;
                 s1 = fmaf(d, xh, s1);
                 s2 += d3;
@@ -806,8 +812,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 const float xh = (av_[r] - mu) * rs;
                 const float v = k * (dv_[r] - m0 - xh * m1);
                 if (cok) dx[row * lddx + c] = v;
-                if (SO.other && cok) SO.sum[row * SO.ld + c] = v + ov_[r];
-                xo[r] = v;
+                if (SO.sum && cok) SO.sum[row * SO.ld + c] = v + ov_[r];
+                xo[r] = SO.other ? v + ov_[r] : v;   // (planes only: the column sum below stays this pass' own)
                 sb += v;
             }
         }
@@ -1444,7 +1450,8 @@ int ibn_apply_launch(const ColSrcs& srcs, int B, int rpg, const float* mean, con
     if (planes) {
         if (B != rpg || gamma || !aff_gamma || !aff_beta) return DGG_ERR_INVALID;  // x_hat stored un-affined, one group
         pl = *planes;
-        if (pl.p && pl.ld > width) width = pl.ld;
+        if (pl.p && pl.win_n == 0 && pl.ld > width) width = pl.ld;
+        if (pl.win_n > 0 && (pl.win_lo < 0 || pl.win_lo + pl.win_n > nprefix + srcs.total)) return DGG_ERR_INVALID;
     }
     dim3 grid(cdiv(width, 64), cdiv(B, RB * kIbnBlocks));
     hipLaunchKernelGGL(ibn_apply_kernel, grid, dim3(256), 0, st, srcs, B, rpg, mean, rstd, gamma, beta, prefix,
@@ -1455,12 +1462,12 @@ int ibn_apply_launch(const ColSrcs& srcs, int B, int rpg, const float* mean, con
 int reduce_bias_launch(const float* slabs, int nslab, long long slab_stride, int ld_slab, const float* bias,
                        float* out, int ld_out, int B, int rpg, int groups, int N, int stat_lo, int stat_hi,
                        int act_lo, int act_hi, float* part, hipStream_t st, int accumulate, const float* slabs2,
-                       int nslab2) {
+                       int nslab2, long long stride2, int ld2) {
     (void)B;
     dim3 grid(cdiv(N, 64), groups * nrb_of(rpg));
     hipLaunchKernelGGL(reduce_bias_kernel, grid, dim3(256), 0, st, slabs, nslab, slab_stride, ld_slab, bias, out,
                        ld_out, rpg, nrb_of(rpg), N, stat_lo, stat_hi, act_lo, act_hi, part, accumulate, slabs2,
-                       slabs2 ? nslab2 : 0);
+                       slabs2 ? nslab2 : 0, stride2 ? stride2 : slab_stride, ld2 ? ld2 : ld_slab);
     return check_launch("reduce_bias");
 }
 

@@ -477,15 +477,16 @@ static void launch_shape(int bm, int bn, const GemmBatch& b, hipStream_t st) {
         hipLaunchKernelGGL((gemm_f32_kernel<64, 64, A_KC, B_KC>), grid, block, 0, st, b);
 }
 
-// Which kernel family executes the large GEMMs: 1 = bf16x3 with the split done in the GEMM's registers (gemm_x3.hip,
-// default), 2 = bf16x3 on operands pre-split into bf16 planes by their producers (gemm_p3.hip; train passes; falls back
-// to 1 wherever no planes exist) — 20 % faster as a kernel, but no faster as a step —, 0 = native f32 MFMA
-// (this file).  Process-wide; DGG_GEMM_ALGO=f32 / planes select 0 / 2 at start-up.
+// Which kernel family executes the large GEMMs: 2 (default) = the BPS block of a train pass — the K = 4096 part of every
+// fused fc1 || fc3 product and of its weight gradient — runs on operands pre-split into bf16 planes by their producers
+// (gemm_p4.hip: one batched launch per pass forward, one launch per ResBlock backward), everything else as 1;
+// 1 = bf16x3 with the split done in the GEMM's registers (gemm_x3.hip); 0 = native f32 MFMA (this file).
+// Process-wide; DGG_GEMM_ALGO=f32 / x3 select 0 / 1 at start-up.
 static int g_algo = -1;
 int gemm_algo() {
     if (g_algo < 0) {
         const char* e = getenv("DGG_GEMM_ALGO");
-        g_algo = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : (e && (e[0] == 'p' || e[0] == '2')) ? 2 : 1;
+        g_algo = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : (e && (e[0] == 'x' || e[0] == '1')) ? 1 : 2;
     }
     return g_algo;
 }

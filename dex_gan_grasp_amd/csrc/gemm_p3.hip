@@ -378,6 +378,42 @@ int planes_run(const PlanesJobs& jobs, hipStream_t st) {
     return check_launch("planes");
 }
 
+// out[n] = bias[n] + sum_c W[n][c] v[c]: one wave per row, lane l takes the columns l, l + 64, ... in order, then a fixed
+// butterfly: deterministic.  grid (ceil(maxR / 4), jobs), 256 threads.
+__global__ __launch_bounds__(256) void rowdot_kernel(const RowDotJobs jobs) {
+    const RowDotJob J = jobs.j[blockIdx.y];
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= J.R) return;  // wave-uniform
+    const float* __restrict__ w = J.w + (size_t)row * J.ld;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int c = lane;
+    for (; c + 192 < J.C; c += 256) {   // four independent chains: 4 loads in flight per lane
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = __builtin_fmaf(w[c + 64 * u], J.v[c + 64 * u], acc[u]);
+    }
+    for (; c < J.C; c += 64) acc[0] = __builtin_fmaf(w[c], J.v[c], acc[0]);
+    float t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) J.out[row] = (J.bias ? J.bias[row] : 0.f) + t;
+}
+
+int rowdot_add(RowDotJobs& jobs, const float* w, int ld, int R, int C, const float* v, const float* bias, float* out) {
+    if (jobs.n >= 3 || !w || !v || !out || R < 1 || C < 1) return DGG_ERR_INVALID;
+    RowDotJob& J = jobs.j[jobs.n++];
+    J.w = w; J.v = v; J.bias = bias; J.out = out; J.ld = ld; J.R = R; J.C = C;
+    return DGG_OK;
+}
+
+int rowdot_run(const RowDotJobs& jobs, hipStream_t st) {
+    if (jobs.n < 1) return DGG_OK;
+    int maxr = 0;
+    for (int i = 0; i < jobs.n; ++i)
+        if (jobs.j[i].R > maxr) maxr = jobs.j[i].R;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((maxr + 3) / 4, jobs.n), dim3(256), 0, st, jobs);
+    return check_launch("rowdot");
+}
+
 int planes_launch(const float* src, int ld, int R, int C, const float* scale, const float* shift, void* dst, int ldp,
                   long long dplane, void* dstT, int ldpT, long long tplane, hipStream_t st) {
     PlanesJobs jobs;

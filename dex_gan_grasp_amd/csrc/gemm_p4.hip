@@ -20,6 +20,7 @@
 // Loader waves leave the kernel after the last M_t (s_barrier counts surviving waves only); the consumers run the shared
 // epilogue (gemm_epilogue.h).
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "dgg_internal.h"
 #include "gemm_epilogue.h"
@@ -242,6 +243,11 @@ int gemm_p4_launch(GemmBatch& batch, bool wgrad, hipStream_t st) {
     if (wgrad) hipLaunchKernelGGL((gemm_p4_kernel<true>), dim3(blocks), dim3(512), 0, st, batch);
     else hipLaunchKernelGGL((gemm_p4_kernel<false>), dim3(blocks), dim3(512), 0, st, batch);
     return check_launch("gemm_p4");
+}
+
+int gemm_planes_launch(GemmBatch& batch, bool wgrad, hipStream_t st) {
+    static const bool use_p3 = [] { const char* e = getenv("DGG_PLANES_KERNEL"); return e && e[0] == 'p' && e[1] == '3'; }();
+    return use_p3 ? gemm_p3_launch(batch, wgrad, st) : gemm_p4_launch(batch, wgrad, st);
 }
 
 }  // namespace dgg

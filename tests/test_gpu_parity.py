@@ -92,7 +92,7 @@ def test_gemm_bf16x3_variants(mode, shape, align):
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K + mode)
     lib = _lib.lib()
     default_algo = lib.dgg_get_gemm_algo()
-    assert default_algo == 1, "bf16x3 must be the default GEMM arithmetic"
+    assert default_algo == 2, "bf16x3 (BPS block on planes, the rest split in registers) must be the default GEMM arithmetic"
     try:
         for kind in ["int", "real", "wide"]:
             if kind == "int":
@@ -606,9 +606,10 @@ def test_gemm_planes_vs_fp64(shape):
 
 
 def test_train_step_on_planes_matches_in_register_split():
-    """DGG_GEMM_PLANES (operands split by their producers: ibn_apply, res_out, bn_bwd_apply, res_out_bwd, one pass over
-    W13) against the default in-register split on the same joint steps: same arithmetic up to the summation order of the
-    k tiles — losses to 1e-5, every parameter after 2 Adam steps within the Adam-of-own-gradients bound."""
+    """The default (the BPS block's products on bf16 planes split by their producers — ibn_apply, bn_bwd_apply,
+    res_out_bwd, one pass over W13 with the BatchNorm scale folded in —, one batched launch per pass) against the
+    in-register split (DGG_GEMM_ALGO=x3) on the same joint steps: same arithmetic up to the summation order of the k
+    tiles and the rounding of gamma * W — losses to 2e-5, every parameter after 2 Adam steps within Adam's reach."""
     import test_gpu_fullsize as F
     _, _lib = _ops()
     lib = _lib.lib()
@@ -620,19 +621,29 @@ def test_train_step_on_planes_matches_in_register_split():
         for algo in (1, 2):
             assert lib.dgg_set_gemm_algo(algo) == 0
             eng, _, _ = F._engine("wide")
-            losses = []
+            store = {}
+            eng.after_d_phase = F._sides_hook(store)
+            losses, grads, sides = [], [], []
             for i in range(2):
                 z = synth.make_z(b, 100 + i).to(DEV)
                 losses.append(eng.joint_step(gb, z, eb, True, None, 77 + i).cpu())
-            torch.cuda.synchronize()
-            out[algo] = (losses, [x.grads.clone() for x in (eng.G, eng.D, eng.E)], [x.params.clone() for x in (eng.G, eng.D, eng.E)])
+                torch.cuda.synchronize()
+                grads.append([x.grads.clone() for x in (eng.G, eng.D, eng.E)])
+                sl = F._slopes_after(eng, store, b, b)
+                sides.append(sl["gan"]["d"] + sl["gan"]["g"] + sl["eva"]["e"])
+            out[algo] = (losses, grads, [x.params.clone() for x in (eng.G, eng.D, eng.E)], sides)
             eng.close()
     finally:
-        lib.dgg_set_gemm_algo(1)
+        lib.dgg_set_gemm_algo(2)
     for l1, l2 in zip(out[1][0], out[2][0]):
         np.testing.assert_allclose(l2[:10].numpy(), l1[:10].numpy(), rtol=2e-5, atol=1e-7)
-    for g1, g2 in zip(out[1][1], out[2][1]):
+    # the first step starts from identical parameters: its gradients agree to rounding — unless the two arithmetics put a
+    # pre-activation on different sides of a LeakyReLU kink (helpers.assert_grad_tensor_close), which the sides read back
+    # from the two runs show
+    flips = sum(int((m1 != m2).sum()) for m1, m2 in zip(out[1][3][0], out[2][3][0]))
+    for g1, g2 in zip(out[1][1][0], out[2][1][0]):
         rel = float((g1 - g2).double().norm() / g1.double().norm())
-        assert rel < 2e-4, rel      # step-2 gradients of parameters that differ by Adam-amplified rounding noise
+        assert rel < (2e-4 if flips == 0 else 0.3 / np.sqrt(b)), (rel, flips)
+    print("planes vs in-register split: %d LeakyReLU sides differ in step 1" % flips)
     for p1, p2 in zip(out[1][2], out[2][2]):
         assert float((p1 - p2).abs().max()) <= 2.5 * 1e-4 * 2   # hard Adam bound: 2 steps of at most ~lr each
