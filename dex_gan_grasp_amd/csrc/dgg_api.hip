@@ -820,7 +820,8 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     const int bps_lo = L.nprefix, bps_hi = L.nprefix + L.in_bps;   // the BPS block inside the [prefix | x_hat] segment
     int nx0 = share_f ? 2 : 1;           // problems the [prefix | x_hat] segment takes in the fp32 launch
     if (use_p3) nx0 = (bps_lo > 0 ? 1 : 0) + (bps_hi < L.k0 ? 1 : 0);
-    const bool fc2_rides = !skip_param && (nseg - 1 + nx0) < 4;
+    if (use_p3 && !share_r) ++nx0;      // ... plus the BPS block's own problem on planes
+    const bool fc2_rides = !skip_param && (nseg - 1 + nx0) + (hr ? 1 : 0) < kMaxProb;
     if (!skip_param && !fc2_rides) {  // separate: split-K slabs + reduce
         GemmBatch g;
         memset(&g, 0, sizeof(g));
@@ -839,6 +840,7 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
         bool has_x0 = false;
         // the BatchNorm-aware epilogue of a problem over the columns [lo, ..) of the [prefix | x_hat] segment
         auto ep_x0 = [&](GemmProb& q, int wcol, int lo, const float* cs1b) {
+            has_x0 = true;
             q.ep_gamma = c.W.aff_scale + lo;
             q.ep_beta = c.W.aff_shift + lo;
             q.ep_cs0 = c.train ? nullptr : cs13;
@@ -855,34 +857,26 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
             GemmProb& q = g.p[np++];
             prob_init(q, Aop, L.n13, sg.p + lo, sg.ld, G + R.w13 + sg.wcol + lo, R.fin, L.n13, hi - lo, B);
             q.accumulate = accumulate;
-            if (sg.is_x0) {
-                has_x0 = true;
-                ep_x0(q, sg.wcol, lo, cs1b);
-            }
+            if (sg.is_x0) ep_x0(q, sg.wcol, lo, cs1b);
         };
         for (int i = 0; i < nseg; ++i) {
-            if (segs[i].is_x0 && use_p3) {             // planes mode: the BPS block has a launch of its own (below)
-                if (bps_lo > 0) add(segs[i], 0, bps_lo, dY13, acc, nullptr);
-                if (bps_hi < segs[i].width) add(segs[i], bps_hi, segs[i].width, dY13, acc, nullptr);
+            if (segs[i].is_x0 && use_p3) {
+                // planes mode: the BPS block as one problem on planes — dW13[n][k] = sum_b dY13[b][n] x_hat[b][k] over the
+                // transposed planes dY13^T [n13][B], x_hat^T [in_bps][B] ("NT"), BatchNorm-aware epilogue; the fake pass of a
+                // shared gradient multiplies dY_real + dY_fake and OVERWRITES (the real pass wrote nothing there) —, what
+                // lies around it as fp32 riders of the same launch
                 if (!share_r) {
-                    // dW13[n][k] = sum_b dY13[b][n] x_hat[b][k] over the transposed planes dY13^T [n13][B], x_hat^T
-                    // [in_bps][B] ("NT"), BatchNorm-aware epilogue; the fake pass of a shared gradient multiplies
-                    // dY_real + dY_fake and OVERWRITES (the real pass wrote nothing there)
-                    GemmBatch gp;
-                    memset(&gp, 0, sizeof(gp));
-                    gp.nprob = 1;
-                    GemmProb& q = gp.p[0];
+                    if (!c.xbt) return DGG_ERR_INVALID;
+                    GemmProb& q = g.p[np++];
                     prob_init(q, reinterpret_cast<const float*>(c.W.dYt[r]), c.W.ldB, reinterpret_cast<const float*>(c.xbt),
                               c.W.ldB, G + R.w13 + segs[i].wcol + bps_lo, R.fin, L.n13, L.in_bps, (B + 31) / 32 * 32);
                     q.a_plane = (long long)L.n13 * c.W.ldB;
                     q.b_plane = (long long)L.in_bps * c.W.ldB;
                     q.accumulate = share_f ? 0 : acc;
                     ep_x0(q, segs[i].wcol, bps_lo, share_f ? sh->cs13_other[r] + L.hid : nullptr);
-                    if (!c.xbt) return DGG_ERR_INVALID;
-                    DGG_TRY(gemm_planes_launch(gp, true, sw));
-                    ibn_tiles[r] = (L.n13 + 127) / 128;
-                    if (ibn_tiles[r] > 12) return DGG_ERR_INVALID;
                 }
+                if (bps_lo > 0) add(segs[i], 0, bps_lo, dY13, acc, nullptr);
+                if (bps_hi < segs[i].width) add(segs[i], bps_hi, segs[i].width, dY13, acc, nullptr);
             } else if (segs[i].is_x0 && share_r) {     // real pass: the pose columns only
                 add(segs[i], sh->ncols, segs[i].width, dY13, acc, nullptr);
             } else if (segs[i].is_x0 && share_f) {     // fake pass: BPS columns on dY_real + dY_fake, pose columns on its own
@@ -898,25 +892,25 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
             q.accumulate = acc;
         }
         if (hr) {
-            if (np >= 4) return DGG_ERR_INVALID;  // net_backward only asks when there is room
+            if (np >= kMaxProb) return DGG_ERR_INVALID;  // net_backward only asks when there is room
             GemmProb& q = g.p[np++];
             prob_init(q, hr->d_out, hr->nh, A.y, L.nn, hr->gwh, L.nn, hr->nh, L.nn, B);
             q.accumulate = acc;
         }
         g.nprob = np;
         if (np > 0) {
-            // the tile shape gemm_launch will pick (the problem with the most work decides): the row-tile count of the
-            // epilogue's per-tile partials
+            // the tile shape gemm_launch will pick (the problem with the most work decides; 128 x 128 with a planes
+            // problem): the row-tile count of the epilogue's per-tile partials
             int big = 0;
+            bool planes = false;
+            for (int i = 0; i < np; ++i) planes = planes || g.p[i].a_plane != 0;
             for (int i = 1; i < np; ++i)
                 if ((double)g.p[i].M * g.p[i].N * g.p[i].K > (double)g.p[big].M * g.p[big].N * g.p[big].K) big = i;
             int bm, bn;
             gemm_tile_shape(GEMM_TN, g.p[big].M, g.p[big].N, bm, bn, g.p[big].K);
-            const int tiles = (L.n13 + bm - 1) / bm;
-            if (tiles > 12) return DGG_ERR_INVALID;
-            if (use_p3) ibn_tiles[3 + r] = has_x0 ? tiles : 0;   // the columns around the BPS block
-            else ibn_tiles[r] = tiles;
-            if (!use_p3 && !has_x0 && L.net != kNetResBlock) return DGG_ERR_INVALID;
+            if (planes) bm = 128;
+            ibn_tiles[r] = (L.n13 + bm - 1) / bm;
+            if (ibn_tiles[r] > 12 || (!has_x0 && L.net != kNetResBlock)) return DGG_ERR_INVALID;
             DGG_TRY(gemm_launch(GEMM_TN, g, sw));
         }
     }
@@ -1129,7 +1123,7 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     const int pose_used = splits_used(L.n13, kPoseKs);
     const bool pose_slabs = want_in && !(d_prefix && L.nprefix > 0) && x_hi - x_lo <= kPoseLd && x_lo == L.nprefix + d_in_lo &&
                             L.n13 >= kPoseKs * 4 * 32 && (int64_t)L.nrb * pose_used * kPoseLd <= L.ldx0;
-    int ibn_tiles[6] = {0, 0, 0, 0, 0, 0};   // [r]: row tiles of block r's epilogue partials; planes mode: [3 + r] for the columns around the BPS block
+    int ibn_tiles[3] = {0, 0, 0};   // row tiles of block r's epilogue partials
     const bool drop = (L.net == DGG_NET_EVA) && c.train;
     const GradEvents* ge = skip ? nullptr : grad_events_for(grads);
     if (ge && (ge->n != L.nrb || (ge->accum_only && !accum))) ge = nullptr;
@@ -1206,19 +1200,12 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
             }
             return DGG_OK;
         };
-        if (c.p3) {
-            // the BPS block's partials come from the planes launch (none in the real pass of a shared gradient, whose
-            // fake pass overwrites them), those of the columns around it from the fp32 launch
-            if (!(share_ok && share->bwd_mode == 1)) DGG_TRY(fin(0, L.in_bps, ibn_tiles, share_ok && share->bwd_mode == 2));
-            DGG_TRY(fin(L.in_bps, L.k_in - L.in_bps, ibn_tiles + 3, false));
+        const int c_first = (share_ok && share->bwd_mode == 1) ? share->ncols : 0;
+        if (share_ok && share->bwd_mode == 2) {
+            DGG_TRY(fin(0, share->ncols, ibn_tiles, true));
+            DGG_TRY(fin(share->ncols, L.k_in - share->ncols, ibn_tiles, false));
         } else {
-            const int c_first = (share_ok && share->bwd_mode == 1) ? share->ncols : 0;
-            if (share_ok && share->bwd_mode == 2) {
-                DGG_TRY(fin(0, share->ncols, ibn_tiles, true));
-                DGG_TRY(fin(share->ncols, L.k_in - share->ncols, ibn_tiles, false));
-            } else {
-                DGG_TRY(fin(c_first, L.k_in - c_first, ibn_tiles, false));
-            }
+            DGG_TRY(fin(c_first, L.k_in - c_first, ibn_tiles, false));
         }
     }
     // everything else — block 0 and the input BatchNorm — is complete here
@@ -2108,7 +2095,7 @@ int dgg_resblock_backward(int fin, const float* params, float* grads, void* ws, 
     memset(&seg, 0, sizeof(seg));
     seg.p = x; seg.ld = ldx; seg.width = fin; seg.wcol = 0; seg.is_x0 = false;
     if (dx) { seg.dp = dx; seg.dld = fin; seg.d_lo = 0; seg.d_hi = fin; seg.d_accum = 0; }
-    int ibn_tiles[6] = {0, 0, 0, 0, 0, 0};
+    int ibn_tiles[3] = {0, 0, 0};
     return rb_backward(c, 0, &seg, 1, dy, false, (flags & DGG_ACCUM_GRADS) != 0, skip, ibn_tiles);
 }
 

@@ -68,8 +68,9 @@ struct GemmProb {
     // bf16 elements); 0 = fp32 operand
     long long a_plane, b_plane;
 };
+constexpr int kMaxProb = 6;   // problems of one grouped launch
 struct GemmBatch {
-    GemmProb p[4];
+    GemmProb p[kMaxProb];
     int nprob;
     int total_blocks;
 };
@@ -87,7 +88,10 @@ void gemm_set_algo(int a);
 int gemm_side_work();            // per thread, see dgg_set_side_work
 void gemm_set_side_work(int on);
 void gemm_x3_dispatch(int mode, const GemmBatch& batch, hipStream_t st);  // gemm_x3.hip, 128 x 128 tiles
-// gemm_p3.hip: C = A B^T on pre-split bf16 planes (forward, and the wgrad over transposed planes with wgrad = true)
+// gemm_p3.hip: C = A B^T on pre-split bf16 planes (forward, and the wgrad over transposed planes with wgrad = true).
+// A weight-gradient (TN) launch of gemm_launch may carry ONE such problem beside its fp32 problems (a_plane != 0: "NT
+// over transposed planes", gemm_p3_block.h inside gemm_x3_kernel): the BPS block's weight gradient and its riders —
+// the columns around it, the previous block's segment, fc2, the heads — stay one launch.
 int gemm_p3_launch(GemmBatch& batch, bool wgrad, hipStream_t st);
 // gemm_p4.hip: the same product (same operands, same bits) with specialised waves — 4 MFMA waves + 4 LDS-DMA loader waves
 int gemm_p4_launch(GemmBatch& batch, bool wgrad, hipStream_t st);

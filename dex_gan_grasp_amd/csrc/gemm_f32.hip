@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
     // (copy by scalar selects, not by a dynamic index: every field stays in SGPRs)
     GemmProb P = batch.p[0];
 #pragma unroll
-    for (int q = 1; q < 4; ++q)
+    for (int q = 1; q < kMaxProb; ++q)
         if (q < batch.nprob && (int)blockIdx.x >= batch.p[q].blk_begin) P = batch.p[q];
     // XCD-aware work assignment: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with
     // its own 4 MiB L2), so ids congruent mod 8 share an L2.  Give each XCD a CONTIGUOUS run of work items
@@ -477,16 +477,16 @@ static void launch_shape(int bm, int bn, const GemmBatch& b, hipStream_t st) {
         hipLaunchKernelGGL((gemm_f32_kernel<64, 64, A_KC, B_KC>), grid, block, 0, st, b);
 }
 
-// Which kernel family executes the large GEMMs: 2 (default) = the BPS block of a train pass — the K = 4096 part of every
-// fused fc1 || fc3 product and of its weight gradient — runs on operands pre-split into bf16 planes by their producers
-// (gemm_p4.hip: one batched launch per pass forward, one launch per ResBlock backward), everything else as 1;
-// 1 = bf16x3 with the split done in the GEMM's registers (gemm_x3.hip); 0 = native f32 MFMA (this file).
-// Process-wide; DGG_GEMM_ALGO=f32 / x3 select 0 / 1 at start-up.
+// Which kernel family executes the large GEMMs: 1 (default) = bf16x3 on fp32 operands, split inside the GEMM (gemm_x4.hip /
+// gemm_x3.hip); 2 = the BPS block of a train pass — the K = 4096 part of every fused fc1 || fc3 product and of its weight
+// gradient — on operands pre-split into bf16 planes by their producers (gemm_p4.hip: one batched launch per pass forward;
+// backward one planes problem inside the block's weight-gradient launch), everything else as 1; 0 = native f32 MFMA
+// (this file).  Process-wide; DGG_GEMM_ALGO=f32 / planes select 0 / 2 at start-up.
 static int g_algo = -1;
 int gemm_algo() {
     if (g_algo < 0) {
         const char* e = getenv("DGG_GEMM_ALGO");
-        g_algo = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : (e && (e[0] == 'x' || e[0] == '1')) ? 1 : 2;
+        g_algo = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : (e && (e[0] == 'p' || e[0] == '2')) ? 2 : 1;
     }
     return g_algo;
 }
@@ -502,12 +502,27 @@ void gemm_set_side_work(int on) { g_side_work = on ? 1 : 0; }
 // All problems of one grouped launch must use the same tile shape: the launcher derives it from
 // problem 0 and re-plans the others with it.
 int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
-    if (batch.nprob < 1 || batch.nprob > 4) return DGG_ERR_INVALID;
+    if (batch.nprob < 1 || batch.nprob > kMaxProb) return DGG_ERR_INVALID;
     int bm, bn;
     int big = 0;  // the problem with the most work decides the tile shape
+    bool planes = false;
     for (int i = 1; i < batch.nprob; ++i)
         if ((double)batch.p[i].M * batch.p[i].N * batch.p[i].K > (double)batch.p[big].M * batch.p[big].N * batch.p[big].K) big = i;
+    for (int i = 0; i < batch.nprob; ++i) planes = planes || batch.p[i].a_plane != 0;
     gemm_tile_shape(mode, batch.p[big].M, batch.p[big].N, bm, bn, batch.p[big].K);
+    if (planes) {
+        // a problem on pre-split planes (weight-gradient launches): 128 x 128 tiles on the bf16x3 kernel only, operands as
+        // gemm_p3_launch wants them
+        if (mode != GEMM_TN || gemm_algo() < 1) return DGG_ERR_INVALID;
+        bm = bn = 128;
+        for (int i = 0; i < batch.nprob; ++i) {
+            const GemmProb& p = batch.p[i];
+            if (!p.a_plane) continue;
+            if (!p.b_plane || p.splits > 0 || (p.K & 31) || (p.lda & 7) || (p.ldb & 7) || (p.a_plane & 7) || (p.b_plane & 7) ||
+                p.lda < p.K || p.ldb < p.K || (((uintptr_t)p.A | (uintptr_t)p.B) & 15))
+                return DGG_ERR_INVALID;
+        }
+    }
     int blocks = 0;
     for (int i = 0; i < batch.nprob; ++i) {
         GemmProb& p = batch.p[i];

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512) void gemm_p4_kernel(const GemmBatch batch) {
     // ---- work assignment: as gemm_p3_kernel (problem select, XCD-contiguous remap, split-K range)
     GemmProb P = batch.p[0];
 #pragma unroll
-    for (int q = 1; q < 4; ++q)
+    for (int q = 1; q < kMaxProb; ++q)
         if (q < batch.nprob && (int)blockIdx.x >= batch.p[q].blk_begin) P = batch.p[q];
     int local = (int)blockIdx.x - P.blk_begin;
     {
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512) void gemm_p4_kernel(const GemmBatch batch) {
 // Operands: planes (a_plane / b_plane != 0), 16-byte aligned bases, pitches and plane distances multiples of 8 elements,
 // K (and a split's kchunk) a multiple of 32 with the padding zero-filled.  128 x 128 tiles, 512 threads.
 int gemm_p4_launch(GemmBatch& batch, bool wgrad, hipStream_t st) {
-    if (batch.nprob < 1 || batch.nprob > 4) return DGG_ERR_INVALID;
+    if (batch.nprob < 1 || batch.nprob > kMaxProb) return DGG_ERR_INVALID;
     int blocks = 0;
     for (int i = 0; i < batch.nprob; ++i) {
         GemmProb& p = batch.p[i];

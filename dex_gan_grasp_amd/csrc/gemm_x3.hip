@@ -31,6 +31,7 @@
 #include <type_traits>
 #include "dgg_internal.h"
 #include "gemm_epilogue.h"
+#include "gemm_p3_block.h"
 
 namespace dgg {
 
@@ -231,11 +232,21 @@ __device__ __forceinline__ void gemm_x3_block(const GemmBatch& batch, const int 
 // launch_x3), a stride loop over them: a GEMM that runs BESIDE a latency-critical chain on another stream then holds
 // half the CUs for twice as long instead of all of them, and the chain's kernels always find free CUs.  The grid
 // is a multiple of 8 so that an item's XCD (bid & 7) does not depend on which round of the loop takes it.
-template <bool A_KC, bool B_KC, bool AFF>
+// PL (weight-gradient launches only): the launch carries a problem on pre-split planes (GemmProb::a_plane != 0, "NT over
+// transposed planes": the BPS block's weight gradient) beside its fp32 riders; its work items run gemm_p3_block.
+template <bool A_KC, bool B_KC, bool AFF, bool PL = false>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmBatch batch) {
-    __shared__ __attribute__((aligned(16))) char smem[XS * XSTAGE];
+    constexpr int kSmem = (PL && PS * PSTAGE > XS * XSTAGE) ? PS * PSTAGE : XS * XSTAGE;
+    __shared__ __attribute__((aligned(16))) char smem[kSmem];
     for (int bid = (int)blockIdx.x; bid < batch.total_blocks; bid += (int)gridDim.x) {
-        gemm_x3_block<A_KC, B_KC, AFF>(batch, bid, smem);
+        bool planes = false;
+        if constexpr (PL) {
+#pragma unroll
+            for (int q = 0; q < kMaxProb; ++q)   // workgroup-uniform
+                if (q < batch.nprob && bid >= batch.p[q].blk_begin) planes = batch.p[q].a_plane != 0;
+        }
+        if (planes) gemm_p3_block<true>(batch, bid, smem);
+        else gemm_x3_block<A_KC, B_KC, AFF>(batch, bid, smem);
         if (bid + (int)gridDim.x < batch.total_blocks) __syncthreads();  // the epilogue's LDS scratch is done with
     }
 }
@@ -246,7 +257,7 @@ __device__ __forceinline__ void gemm_x3_block(const GemmBatch& batch, const int 
     // ---- work assignment: identical to gemm_f32_kernel (problem select, XCD-contiguous remap, split-K range)
     GemmProb P = batch.p[0];
 #pragma unroll
-    for (int q = 1; q < 4; ++q)
+    for (int q = 1; q < kMaxProb; ++q)
         if (q < batch.nprob && bid >= batch.p[q].blk_begin) P = batch.p[q];
     int local = bid - P.blk_begin;
     {
@@ -580,7 +591,7 @@ __device__ __forceinline__ void gemm_x3_block(const GemmBatch& batch, const int 
 #endif
 }
 
-template <bool A_KC, bool B_KC, bool AFF>
+template <bool A_KC, bool B_KC, bool AFF, bool PL = false>
 static void launch_x3(const GemmBatch& b, hipStream_t st) {
     int grid = b.total_blocks;
     // side work (dgg_set_side_work): the forward products walk two work items per workgroup — same items, same sums,
@@ -589,7 +600,7 @@ static void launch_x3(const GemmBatch& b, hipStream_t st) {
     // 1850, 4 -> 1923 / 1893, 6 -> 1928 / 1924)
     static const int kdiv = [] { const char* e = getenv("DGG_SIDE_DIV"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
     if (gemm_side_work() && A_KC && B_KC && grid > 64) grid = ((grid + kdiv - 1) / kdiv + 7) / 8 * 8;
-    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, AFF>), dim3(grid), dim3(256), 0, st, b);
+    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, AFF, PL>), dim3(grid), dim3(256), 0, st, b);
 }
 
 // 128 x 128 tiles only.  Operand bases and pitches need 4-byte alignment only (the DMA fetches 16-byte chunks from any
@@ -605,7 +616,10 @@ void gemm_x3_dispatch(int mode, const GemmBatch& batch, hipStream_t st) {
     } else if (mode == GEMM_NN) {
         launch_x3<true, false, false>(batch, st);
     } else {
-        launch_x3<false, false, false>(batch, st);
+        bool planes = false;
+        for (int i = 0; i < batch.nprob; ++i) planes = planes || batch.p[i].a_plane != 0;
+        if (planes) launch_x3<false, false, false, true>(batch, st);
+        else launch_x3<false, false, false>(batch, st);
     }
 }
 

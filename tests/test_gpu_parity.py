@@ -92,7 +92,7 @@ def test_gemm_bf16x3_variants(mode, shape, align):
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K + mode)
     lib = _lib.lib()
     default_algo = lib.dgg_get_gemm_algo()
-    assert default_algo == 2, "bf16x3 (BPS block on planes, the rest split in registers) must be the default GEMM arithmetic"
+    assert default_algo == 1, "bf16x3 must be the default GEMM arithmetic"
     try:
         for kind in ["int", "real", "wide"]:
             if kind == "int":
@@ -606,10 +606,10 @@ def test_gemm_planes_vs_fp64(shape):
 
 
 def test_train_step_on_planes_matches_in_register_split():
-    """The default (the BPS block's products on bf16 planes split by their producers — ibn_apply, bn_bwd_apply,
+    """DGG_GEMM_ALGO=planes (the BPS block's products on bf16 planes split by their producers — ibn_apply, bn_bwd_apply,
     res_out_bwd, one pass over W13 with the BatchNorm scale folded in —, one batched launch per pass) against the
-    in-register split (DGG_GEMM_ALGO=x3) on the same joint steps: same arithmetic up to the summation order of the k
-    tiles and the rounding of gamma * W — losses to 2e-5, every parameter after 2 Adam steps within Adam's reach."""
+    default split inside the GEMM on the same joint steps: same arithmetic up to the summation order of the k tiles and
+    the rounding of gamma * W — losses to 2e-5, every parameter after 2 Adam steps within Adam's reach."""
     import test_gpu_fullsize as F
     _, _lib = _ops()
     lib = _lib.lib()
@@ -634,7 +634,7 @@ def test_train_step_on_planes_matches_in_register_split():
             out[algo] = (losses, grads, [x.params.clone() for x in (eng.G, eng.D, eng.E)], sides)
             eng.close()
     finally:
-        lib.dgg_set_gemm_algo(2)
+        lib.dgg_set_gemm_algo(1)
     for l1, l2 in zip(out[1][0], out[2][0]):
         np.testing.assert_allclose(l2[:10].numpy(), l1[:10].numpy(), rtol=2e-5, atol=1e-7)
     # the first step starts from identical parameters: its gradients agree to rounding — unless the two arithmetics put a
