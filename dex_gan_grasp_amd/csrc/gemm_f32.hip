@@ -477,8 +477,8 @@ static void launch_shape(int bm, int bn, const GemmBatch& b, hipStream_t st) {
         hipLaunchKernelGGL((gemm_f32_kernel<64, 64, A_KC, B_KC>), grid, block, 0, st, b);
 }
 
-// Which kernel family executes the large GEMMs: 1 (default) = bf16x3 on fp32 operands, split inside the GEMM (gemm_x4.hip /
-// gemm_x3.hip); 2 = the BPS block of a train pass — the K = 4096 part of every fused fc1 || fc3 product and of its weight
+// Which kernel family executes the large GEMMs: 1 (default) = bf16x3 on fp32 operands, split inside the GEMM (gemm_x3.hip;
+// DGG_X4=1: by loader waves, gemm_x4.hip); 2 = the BPS block of a train pass — the K = 4096 part of every fused fc1 || fc3 product and of its weight
 // gradient — on operands pre-split into bf16 planes by their producers (gemm_p4.hip: one batched launch per pass forward;
 // backward one planes problem inside the block's weight-gradient launch), everything else as 1; 0 = native f32 MFMA
 // (this file).  Process-wide; DGG_GEMM_ALGO=f32 / planes select 0 / 2 at start-up.
@@ -535,6 +535,11 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
     batch.total_blocks = blocks;
     if (mode != GEMM_NT && mode != GEMM_NN && mode != GEMM_TN) return DGG_ERR_INVALID;
     if (gemm_algo() >= 1 && bm == 128 && bn == 128) {
+        // (a planes problem rides in gemm_x3_kernel)
+        if (gemm_x4_enabled() && !planes) {
+            gemm_x4_dispatch(mode, batch, st);
+            return check_launch("gemm_x4");
+        }
         gemm_x3_dispatch(mode, batch, st);
         return check_launch("gemm_x3");
     }
