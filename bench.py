@@ -464,8 +464,26 @@ def main():
         res["roofline"] = tn
         res["roofline_kernels"] = {"gemm_wgrad_tn": tn, "gemm_forward_nt": nt, "bps_encode": bps_roofline(dev),
                                    "adam": adam_roofline(dev)}
+        # what the hardware-queue probe behind the engine's side streams found (parallel.pick_side_streams): a fallback to
+        # plain streams costs 15-20 % and would otherwise go unnoticed
+        res["side_streams"] = dict(parallel.pick_report) if parallel.pick_report else {"mode": "not created"}
+        nbytes = 4 * (fg.n_params + fd.n_params + fe.n_params)
+        res["rccl_ranks"] = {"world_size": world,
+                             "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
+                             "allreduce_bytes_per_step_per_rank": nbytes if world > 1 else 0,
+                             "buckets": "per ResBlock, behind in-backward events (parallel.BucketReducer)" if world > 1 else None,
+                             "evaluator_group": os.environ.get("DGG_EVA_GROUP", "0") == "1"}
         if world == 1 and not args.no_sub:
             res["sub_results"] = sub_results(cfg, dev, eng)
+            sr = res["sub_results"]
+            # `value` is the interleaved engine step (evaluator update beside the cGAN update, one-batch look-ahead on D's
+            # real pass).  What the reference's own call pattern gets:
+            #   value_serial = B / (t_cGAN + t_eval), SURVEY 8(d)'s formula on the two engine steps run one after the other
+            #   value_dropin = the unchanged train.py order through the drop-in wrapper (update_dexgangrasp, then
+            #                  update_dexevaluator, per batch)
+            t_serial = (sr["cgan_step_b1024"]["ms_per_step"] + sr["config3_eva_step_b1024"]["ms_per_step"]) * 1e-3
+            res["value_serial"] = round(1024 / t_serial, 1) if B == 1024 else None
+            res["value_dropin"] = sr["api_path_b1024"]["grasps_per_s"] if B == 1024 else None
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, B)
         print(json.dumps(res))

@@ -105,6 +105,7 @@ SIGNATURES = {
     "dgg_eva_phase_graph": (_I, [_CFG, _VP, _VP, _VP, C.POINTER(HParams), _VP, _SZ, _I, _VP, _VP, _VP, _VP, _VP, _VP,
                                  _VP]),
     "dgg_cgan_release": (_I, [_VP]),
+    "dgg_cgan_drop_prefetch": (_I, [_VP, _VP]),
     "dgg_reset": (_I, []),
     "dgg_eva_keep_offset": (_I64, [_CFG, _I, _I]),
     "dgg_ws_offset": (_I64, [_I, _CFG, _I, _I, _I]),

@@ -1425,7 +1425,8 @@ struct StepW {
     float *heads, *rfake, *f_transl, *f_joint, *p_real, *p_fake, *p_gen, *dl_real, *dl_fake, *dl_gen, *d_pose,
         *d_heads;
     float* dshare[3];  // per ResBlock of D: split-K slabs of the BPS-column product shared by the real and fake pass
-    int d_nrb, d_n13;
+    float* bn_snap;    // D's running statistics as they were before a prefetched real pass advanced them (dropped pass: restored)
+    int d_nrb, d_n13, d_nbn;
     size_t bytes;
 };
 
@@ -1458,6 +1459,8 @@ static int carve_step(const dgg_cfg* cfg, int B, void* base, StepW& S) {
     S.d_heads = b.take<float>(Bz * (nj + 9));
     S.d_nrb = Ld.nrb;
     S.d_n13 = Ld.n13;
+    S.d_nbn = (int)Ld.nbn;
+    S.bn_snap = b.take<float>((size_t)Ld.nbn);
     for (int r = 0; r < 3; ++r) {
         S.dshare[r] = nullptr;
         if (r >= Ld.nrb) continue;
@@ -1720,6 +1723,9 @@ struct PendingReal {
     int step_B;           // batch size of the step whose G phase left the D-free mark (the workspace is carved for it)
     const float *bps, *rot9, *transl, *joint;
     const float* d_params;  // the discriminator the prefetched pass was computed with
+    float* d_bn;            // its running statistics (advanced by the pass) and their state before it
+    const float* bn_snap;
+    int nbn;
     hipEvent_t ev[7];     // fwd_done, bwd_done, 3 x share.ready, D-free, share.xready; created with the slot
     bool events_ok, dfree_set;
     Share share;
@@ -1803,10 +1809,14 @@ int dgg_cgan_d_real_prefetch(const dgg_cfg* cfg, const dgg_gan_state* s, const d
     }
     P.share.xready = P.ev[6];
     P.valid = false;
+    // the pass advances D's running statistics one batch early: keep what they were, so that a pass that is not picked
+    // up (another batch follows, a serial entry point, a checkpoint: dgg_cgan_drop_prefetch) leaves no trace
+    DGG_TRY(copy_cols_launch(s->d_bn, S.d_nbn, S.bn_snap, S.d_nbn, 1, S.d_nbn, sb));
     DGG_TRY(real_pass(cfg, s, hp, S, Ld, B, bps, rot9, transl, joint, losses + kLossRealNext, sb, P.share, P.ev[0],
                       P.ev[1]));
     P.B = B; P.bps = bps; P.rot9 = rot9; P.transl = transl; P.joint = joint;
     P.d_params = s->d_params;
+    P.d_bn = s->d_bn; P.bn_snap = S.bn_snap; P.nbn = S.d_nbn;
     P.valid = true;
     return DGG_OK;
 }
@@ -1829,6 +1839,10 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
     PendingReal* Pp = pending_slot(ws, false);
     const bool pre = fork && Pp && Pp->valid && Pp->B == B && Pp->bps == bps && Pp->rot9 == rot9 &&
                      Pp->transl == transl && Pp->joint == joint && Pp->d_params == s->d_params;
+    if (Pp && Pp->valid && !pre) {   // dropped: undo its running-statistics update once it has run (its gradients are overwritten)
+        if (hipStreamWaitEvent(st, Pp->ev[1], 0) != hipSuccess) return DGG_ERR_LAUNCH;
+        DGG_TRY(copy_cols_launch(Pp->bn_snap, Pp->nbn, Pp->d_bn, Pp->nbn, 1, Pp->nbn, st));
+    }
     if (Pp) Pp->valid = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     Share share;
@@ -1972,6 +1986,16 @@ int dgg_eva_phase(const dgg_cfg* cfg, const float* e_params, float* e_grads, flo
 }
 
 // ---- hidden-state management -------------------------------------------------------------------
+int dgg_cgan_drop_prefetch(void* ws, void* stream) {
+    PendingReal* Pp = ws ? pending_slot(ws, false) : nullptr;
+    if (!Pp || !Pp->valid) return DGG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipStreamWaitEvent(st, Pp->ev[1], 0) != hipSuccess) return DGG_ERR_LAUNCH;
+    DGG_TRY(copy_cols_launch(Pp->bn_snap, Pp->nbn, Pp->d_bn, Pp->nbn, 1, Pp->nbn, st));
+    Pp->valid = false;
+    return DGG_OK;
+}
+
 int dgg_cgan_release(void* ws) {
     for (int i = 0; i < kPendingSlots; ++i)
         if (g_pending[i].ws == ws && ws) {

@@ -127,7 +127,7 @@ class TrainEngine:
             return
         if getattr(self, "_reducers", None) is None:
             self._reducers = {"G": parallel.BucketReducer(self.G), "D": parallel.BucketReducer(self.D, accum_only=True),
-                              "E": parallel.BucketReducer(self.E)}
+                              "E": parallel.BucketReducer(self.E, group=parallel.evaluator_group())}
         for r in self._reducers.values():
             if not r.armed:
                 r.arm()
@@ -163,6 +163,12 @@ class TrainEngine:
         if self._side2_busy is not None:
             torch.cuda.current_stream(self.device).wait_event(self._side2_busy)
             self._side2_busy = None
+            # a prefetched pass that nobody has picked up yet: dropped without a trace (D's running statistics go back
+            # to what this step left; the next D phase runs its own real pass), so that what the caller reads or does
+            # next is the unpipelined order's state
+            for key, ws in self._ws.items():
+                if not isinstance(key, tuple):
+                    check(lib().dgg_cgan_drop_prefetch(ptr(ws), stream_ptr(self.device)), "dgg_cgan_drop_prefetch")
 
     def _streams(self, two_streams, wgrad=True):
         """(main, s2 as void* or None): the D phase forks its real-batch pass onto _side2.  wgrad: every compute stream may
@@ -177,11 +183,10 @@ class TrainEngine:
             if self.device.type == "cuda" and os.environ.get("DGG_PICK_STREAMS", "1") != "0":
                 # side streams on hardware queues of their own: shared with neither this stream nor (data parallel)
                 # RCCL's — where a plain torch.cuda.Stream() lands depends on how many streams the process made before
-                try:
-                    self._side2, self._side = parallel.pick_side_streams(self.device, 2)
-                except (AttributeError, RuntimeError):   # no torch.cuda._sleep / probing impossible: plain streams
-                    self._side2 = torch.cuda.Stream(device=self.device)
+                # (parallel.pick_report says what was found; a failing probe is fatal under RCCL, see there)
+                self._side2, self._side = parallel.side_streams_or_plain(self.device, 2)
             else:
+                parallel.pick_report.update({"mode": "plain", "why": "DGG_PICK_STREAMS=0"})
                 self._side2 = torch.cuda.Stream(device=self.device)
         if wgrad:
             self._map_wgrad_streams(main, self._side2)
@@ -421,7 +426,10 @@ class TrainEngine:
         next_gan_inputs (optional, is_train_gen only): the NEXT call's gan_inputs, already resident on the device as
         contiguous float32 tensors (a prefetching data loader has them).  The real-batch pass of the next D phase is
         then enqueued behind this step's third D forward and overlaps its G phase (dgg_cgan_d_real_prefetch); the next
-        call must pass the very same tensors as gan_inputs.  Same results, bit for bit."""
+        call must pass the very same tensors as gan_inputs.  Same results, bit for bit: parameters, Adam state, losses —
+        and D's running statistics and gradient buffer once the prefetched pass has been picked up by that next call or
+        dropped by flush() (any serial entry point, checkpoint or evaluation goes through flush()); in between they hold
+        the next batch's real-pass contribution."""
         dev = self.device
         bps, rot9, transl, joint = (f32c(t, dev) for t in gan_inputs)
         if not two_streams:

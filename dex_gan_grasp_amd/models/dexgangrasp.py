@@ -48,29 +48,29 @@ def build_network(cfg, device, is_train):
     return gen, eva
 
 
+# weight_init_type -> initialiser of a Linear / Conv weight (same names, distributions and gains as dexgangrasp.py:39-62)
+_WEIGHT_INIT = {
+    "normal": lambda w, gain: torch.nn.init.normal_(w, 0.0, gain),
+    "xavier": lambda w, gain: torch.nn.init.xavier_normal_(w, gain=gain),
+    "kaiming": lambda w, gain: torch.nn.init.kaiming_normal_(w, a=0, mode="fan_in"),
+    "orthogonal": lambda w, gain: torch.nn.init.orthogonal_(w, gain=gain),
+}
+
+
 def init_net(net):
-    """dexgangrasp.py:39-62."""
-    init_type = net.cfg["weight_init_type"]
-    init_gain = net.cfg["init_gain"]
-
-    def init_func(m):
-        classname = m.__class__.__name__
-        if hasattr(m, 'weight') and (classname.find('Conv') != -1 or classname.find('Linear') != -1):
-            if init_type == 'normal':
-                torch.nn.init.normal_(m.weight.data, 0.0, init_gain)
-            elif init_type == 'xavier':
-                torch.nn.init.xavier_normal_(m.weight.data, gain=init_gain)
-            elif init_type == 'kaiming':
-                torch.nn.init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
-            elif init_type == 'orthogonal':
-                torch.nn.init.orthogonal_(m.weight.data, gain=init_gain)
-            else:
-                raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
-        elif classname.find('BatchNorm') != -1:
-            torch.nn.init.normal_(m.weight.data, 1.0, init_gain)
+    """Initialise a freshly built network the way the reference does (dexgangrasp.py:39-62): every Linear / Conv weight
+    by cfg["weight_init_type"] with cfg["init_gain"], every BatchNorm weight ~ N(1, gain) with bias 0; an unknown type
+    raises NotImplementedError.  The parameters are views of the library's flat buffers: the values land there."""
+    kind, gain = net.cfg["weight_init_type"], net.cfg["init_gain"]
+    for m in net.modules():
+        name = type(m).__name__
+        if "BatchNorm" in name:
+            torch.nn.init.normal_(m.weight.data, 1.0, gain)
             torch.nn.init.constant_(m.bias.data, 0.0)
-
-    net.apply(init_func)
+        elif getattr(m, "weight", None) is not None and ("Linear" in name or "Conv" in name):
+            if kind not in _WEIGHT_INIT:
+                raise NotImplementedError('initialization method [%s] is not implemented' % kind)
+            _WEIGHT_INIT[kind](m.weight.data, gain)
 
 
 class DexGanGrasp(object):
@@ -575,6 +575,51 @@ class DexGanGrasp(object):
                                    two_streams=_API_STREAMS)
         self._bump(eva, 1)
         return {'total_loss_eva': out[_lib.L_TOTAL_EVA], 'bce_loss': out[_lib.L_BCE_EVA]}
+
+    def update_joint(self, real_data, eva_data, is_train_gen=True, next_real_data=None):
+        """update_dexgangrasp(real_data, is_train_gen) and update_dexevaluator(eva_data) as ONE interleaved step
+        (engine.joint_step): the two updates touch disjoint networks, batches and optimisers, so the evaluator's runs
+        beside the cGAN's on a second stream — same parameters afterwards, bit for bit, as the two calls one after the
+        other (train.py:249-276 runs them in two epoch loops).  next_real_data: the NEXT step's generator batch when it
+        is already resident on the device as contiguous float32 tensors (a look-ahead loader): its discriminator
+        real-batch pass is then enqueued one step ahead.  Returns (cGAN loss dict, evaluator loss dict).  The latent and
+        the dropout seed are drawn exactly as the two separate calls draw them (Z first)."""
+        if self.is_wgan:
+            return self.update_dexgangrasp(real_data, is_train_gen), self.update_dexevaluator(eva_data)
+        gan, eva = self.DexGANGrasp, self.DexEvaluator
+        gan.train()
+        eva.train()
+        dev = gan.device
+        n = real_data["bps_object"].shape[0]
+        Zgen = self._draw_z(n)
+        g_in = (_lib.f32c(real_data["bps_object"], dev), _lib.f32c(real_data["rot_matrix"], dev).reshape(n, 9),
+                _lib.f32c(real_data["transl"], dev), _lib.f32c(real_data["joint_conf"], dev))
+        eva.set_input(eva_data)
+        seed = 0
+        if self._drop_keep is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        nxt = None
+        if next_real_data is not None and is_train_gen and next_real_data["bps_object"].shape[0] == n:
+            cand = (next_real_data["bps_object"], next_real_data["rot_matrix"].reshape(n, 9), next_real_data["transl"],
+                    next_real_data["joint_conf"])
+            if all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in cand):
+                nxt = cand
+        out = self._eng().joint_step(g_in, Zgen, (eva.bps_object, eva.rot_matrix, eva.transl, eva.gt_label), is_train_gen,
+                                     self._drop_keep, seed, self.optim_dexgangrasp_generator.param_groups[0]['lr'],
+                                     self.optim_dexgangrasp_discriminator.param_groups[0]['lr'],
+                                     self.optim_dexevaluator.param_groups[0]['lr'], next_gan_inputs=nxt)
+        self._bump(gan.generator, 1)
+        self._bump(gan.discriminator, 2 + (1 if is_train_gen else 0))
+        self._bump(eva, 1)
+        loss_dict = {'total_loss_disc': out[_lib.L_TOTAL_DISC], 'bce_loss_real': out[_lib.L_BCE_REAL],
+                     'bce_loss_fake': out[_lib.L_BCE_FAKE]}
+        if is_train_gen:
+            real_data["rot_matrix"] = real_data["rot_matrix"].view(n, -1)  # :810 mutates the caller's dict
+            self.last_loss_dict_gen = {'gen_loss_fake': out[_lib.L_GEN_FAKE], 'transl_loss': out[_lib.L_TRANSL],
+                                       'rot_loss': out[_lib.L_ROT], 'conf_loss': out[_lib.L_CONF],
+                                       'total_loss_gen': out[_lib.L_TOTAL_GEN]}
+        loss_dict.update(self.last_loss_dict_gen)
+        return loss_dict, {'total_loss_eva': out[_lib.L_TOTAL_EVA], 'bce_loss': out[_lib.L_BCE_EVA]}
 
     def update_dexgangrasp(self, real_data, is_train_gen=True):
         """dexgangrasp.py:757-823: discriminator phase, Adam(D), generator phase, Adam(G) — the 13

@@ -25,17 +25,21 @@ from .. import _lib, ops, parallel
 from ..utils import utils
 
 
+# lr_policy -> scheduler factory (the two policies of networks.py:12-23, same hyper-parameters)
+_SCHEDULERS = {
+    "step": lambda opt, cfg: lr_scheduler.StepLR(opt, step_size=cfg["lr_decay_iters"], gamma=0.1),
+    "plateau": lambda opt, cfg: lr_scheduler.ReduceLROnPlateau(
+        opt, mode="min", factor=0.2, threshold=cfg["threshold_lr_policy_plateau"],
+        patience=cfg["patience_lr_policy_plateau"]),
+}
+
+
 def get_scheduler(optimizer, cfg):
-    """networks.py:12-23."""
-    if cfg["lr_policy"] == 'step':
-        scheduler = lr_scheduler.StepLR(optimizer, step_size=cfg["lr_decay_iters"], gamma=0.1)
-    elif cfg["lr_policy"] == 'plateau':
-        scheduler = lr_scheduler.ReduceLROnPlateau(optimizer, mode='min', factor=0.2,
-                                                   threshold=cfg["threshold_lr_policy_plateau"],
-                                                   patience=cfg["patience_lr_policy_plateau"])
-    else:
+    """The learning-rate scheduler cfg["lr_policy"] names; anything else: NotImplementedError (networks.py:12-23)."""
+    make = _SCHEDULERS.get(cfg["lr_policy"])
+    if make is None:
         raise NotImplementedError('Scheduler not implemented.')
-    return scheduler
+    return make(optimizer, cfg)
 
 
 def _default_device(cfg):

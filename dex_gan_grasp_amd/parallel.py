@@ -90,6 +90,24 @@ def allreduce_sum_(flat_grads, async_op=False):
     return dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
+_eva_group = None
+
+
+def evaluator_group():
+    """DGG_EVA_GROUP=1: a process group (communicator, stream) of its own for the evaluator's gradient buckets.  RCCL runs
+    the collectives of ONE group in issue order on one stream; the evaluator's 42.6 MB, issued during its backward
+    (0.7-1.2 ms into the step), sit in front of the generator's first bucket (~1.5 ms) if the ring is slower than that —
+    whether they are out of the way by then depends on the node's real ring bandwidth, which no 1-GPU box can show
+    (DESIGN.md 6), so the first run on an 8-GPU node can A/B the two layouts with this switch.  Collective on every rank
+    (dist.new_group): all ranks must call it at the same point — engine._arm_reducers does, once.  None = default group."""
+    global _eva_group
+    if os.environ.get("DGG_EVA_GROUP", "0") != "1" or not is_distributed():
+        return None
+    if _eva_group is None:
+        _eva_group = dist.new_group()
+    return _eva_group
+
+
 class BucketReducer:
     """All-reduce of one network's flat gradient buffer in the buckets a backward completes them in
     (FlatNet.grad_buckets / dgg_set_grad_events): the library records an event per bucket inside the backward's launch
@@ -97,9 +115,10 @@ class BucketReducer:
     ResBlocks (their W13 is ~half of the network) runs while the earlier blocks are still being back-propagated, and
     only the last bucket is exposed.  Same sums as one all-reduce of the whole buffer (element-wise, disjoint ranges)."""
 
-    def __init__(self, flat, accum_only=False):
+    def __init__(self, flat, accum_only=False, group=None):
         from . import _lib
         self.flat = flat
+        self.group = group            # process group of this network's collectives (None: the default group)
         self.accum_only = bool(accum_only)
         self.bounds = flat.grad_buckets()
         dev = flat.grads.device
@@ -145,23 +164,41 @@ class BucketReducer:
         works = []
         if feeder == "current":
             for lo, hi in self.bounds:
-                works.append(dist.all_reduce(self.flat.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+                works.append(dist.all_reduce(self.flat.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True, group=self.group))
             return works
         if feeder is None:       # the serial entry points: the (idle) first side stream, on a queue of its own
             if BucketReducer._shared_feeder is None:
-                try:
-                    BucketReducer._shared_feeder = pick_side_streams(self.flat.grads.device, 2)[0]
-                except (AttributeError, RuntimeError):
-                    BucketReducer._shared_feeder = torch.cuda.Stream(device=self.flat.grads.device)
+                BucketReducer._shared_feeder = side_streams_or_plain(self.flat.grads.device, 2)[0]
             feeder = BucketReducer._shared_feeder
         for (lo, hi), ev in zip(self.bounds, self.events):
             feeder.wait_event(ev)
             with torch.cuda.stream(feeder):
-                works.append(dist.all_reduce(self.flat.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+                works.append(dist.all_reduce(self.flat.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True, group=self.group))
         return works
 
 
 _picked = {}
+pick_report = {}     # what the last pick_side_streams / side_streams_or_plain call found (bench.py prints it)
+
+
+def side_streams_or_plain(dev, n=2):
+    """pick_side_streams where the probe can run, plain torch streams where it cannot — and the choice on record
+    (pick_report).  The probe needs torch.cuda._sleep (a private API): its absence is known before anything is issued, so
+    every rank takes the same branch.  Under RCCL the probe issues collectives: an error in it is NOT swallowed — a rank
+    that stopped half way would leave its peers waiting in a collective —; on a single GPU a failing probe
+    falls back to plain streams (15-20 % slower when they land on a busy queue) and says so."""
+    dev = torch.device(dev)
+    if not hasattr(torch.cuda, "_sleep"):
+        pick_report.update({"mode": "plain", "why": "torch.cuda._sleep unavailable: hardware queues not probed"})
+        return [torch.cuda.Stream(device=dev) for _ in range(n)]
+    rccl = is_distributed() and dist.get_backend() == "nccl"
+    try:
+        return pick_side_streams(dev, n)
+    except RuntimeError as e:
+        if rccl:
+            raise
+        pick_report.update({"mode": "plain", "why": "queue probe failed: %s" % str(e)[:120]})
+        return [torch.cuda.Stream(device=dev) for _ in range(n)]
 
 
 def _blocked_behind(cand, run_blocker, dev, sleep_cycles):
@@ -246,6 +283,10 @@ def pick_side_streams(dev, n=2, candidates=8):
               % (len(classes), [len(c) for c in classes], [i for i, m in enumerate(with_main) if m],
                  [i for i, r in enumerate(with_rccl) if r], len(free)), file=sys.stderr, flush=True)
     chosen = [cl[0] for cl in free[:n]]
+    pick_report.update({"mode": "probed", "queue_classes": [len(c) for c in classes],
+                        "current_stream_in": [i for i, m in enumerate(with_main) if m],
+                        "rccl_stream_in": [i for i, r in enumerate(with_rccl) if r], "free_classes": len(free),
+                        "picked_from_free": len(chosen), "plain_fill": max(0, n - len(chosen))})
     while len(chosen) < n:     # not enough free queues (other libraries' streams): plain streams, as on one GPU
         chosen.append(torch.cuda.Stream(device=dev))
     _picked[key] = chosen

@@ -286,14 +286,21 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hpa
  * once this thread's last dgg_cgan_g_phase on the same workspace has passed its D forward (D's parameters and
  * BatchNorm running statistics are then final for this step).  The next dgg_cgan_d_phase2 call on this thread with
  * the same workspace, batch size, input pointers, d_params and a stream2 picks it up and runs only the generator /
- * fake-batch half; with anything else the prefetched pass is dropped and redone (D's BatchNorm running statistics
- * then hold one extra real-batch update).  B must equal the batch size of the step in flight on this workspace
+ * fake-batch half; with anything else the prefetched pass is dropped and redone — without a trace: the pass' update of
+ * D's BatchNorm running statistics is undone from a snapshot taken in front of it (the step workspace holds it), its
+ * gradients are overwritten by the redone pass.  Until the pass is picked up or dropped, d_bn and d_grads hold the NEXT
+ * batch's real-pass contribution: a caller that reads them in between (checkpoint, evaluation forward) calls
+ * dgg_cgan_drop_prefetch first.  B must equal the batch size of the step in flight on this workspace
  * (the workspace is carved per batch size): otherwise DGG_ERR_INVALID, nothing is enqueued.  Results are
  * bit-identical to the unpipelined order.  Uses losses[12] as scratch; up to 4 workspaces per thread can be in
  * flight. */
 int dgg_cgan_d_real_prefetch(const dgg_cfg* cfg, const dgg_gan_state* st, const dgg_hparams* hp, void* ws,
                              size_t ws_bytes, int B, const float* bps, const float* rot9, const float* transl,
                              const float* joint, float* losses, void* stream2);
+/* Drop a prefetched real pass of workspace `ws` that has not been picked up: `stream` waits for it and restores D's
+ * running statistics to what they were before it (d_grads keeps the dropped pass' values until the next D phase
+ * overwrites them).  The next dgg_cgan_d_phase2 then runs its own real pass.  No-op without a pending pass. */
+int dgg_cgan_drop_prefetch(void* ws, void* stream);
 /* Forget the pending-prefetch slot keyed by workspace `ws` (call before freeing / reusing that memory). */
 int dgg_cgan_release(void* ws);
 /* Drop this thread's hidden state (see the header comment): pending prefetches and the wgrad side-stream map;
@@ -365,16 +372,28 @@ int dgg_translate_along_axis(float* transl, const float* rot9, int B, int axis, 
  *   DGG_GEMM_BF16X3 : each fp32 operand split exactly into three bf16 pieces, the six leading partial products
  *                     accumulated in fp32 on v_mfma_f32_32x32x16_bf16 — error below the fp32 accumulation's own
  *                     rounding, 6/16 of the f32-MFMA cost;
- *   DGG_GEMM_PLANES : the same bf16x3 arithmetic, with the split hoisted out of the GEMM: the kernels that produce the
- *                     operands of the large products of a TRAIN pass (input BatchNorm, block outputs, dY, and one pass
- *                     over W13 per forward) also emit their three bf16 planes, and the product runs without vector ALU
- *                     work in its k loop (csrc/gemm_p3.hip).  Everything else runs as under DGG_GEMM_BF16X3.  The
- *                     kernel is 20 % faster than the in-register split, the train step is not: optional. */
+ *   DGG_GEMM_PLANES : the same bf16x3 arithmetic, with the split hoisted out of the GEMM for the BPS block of a TRAIN pass
+ *                     (the K = in_bps part of every fused fc1 || fc3 product and of its weight gradient): the input
+ *                     BatchNorm emits x_hat's bf16 planes, one pass over W13 per forward the weights' (BatchNorm scale
+ *                     folded in, shift as a bias), bn_bwd_apply / res_out_bwd those of dY; ONE batched launch per pass
+ *                     forms the BPS products of all ResBlocks (csrc/gemm_p4.hip), the weight gradient is one planes
+ *                     problem inside the block's weight-gradient launch (csrc/gemm_p3_block.h).  Everything else runs as
+ *                     under DGG_GEMM_BF16X3.  Faster kernels (0.38-0.46 of the bf16x3 bound against 0.27), slower step
+ *                     (1.93 vs 1.74 ms: DESIGN.md 3.1): optional. */
 enum { DGG_GEMM_F32 = 0, DGG_GEMM_BF16X3 = 1, DGG_GEMM_PLANES = 2 };
 int dgg_set_gemm_algo(int algo);
 int dgg_get_gemm_algo(void);
 /* Diagnostic: workgroups of the GEMM variant (mode, tile) resident per CU according to the HIP occupancy API. */
 int dgg_gemm_occupancy(int mode, int bm, int bn);
+/* Diagnostic / test entry of the fp32 GEMM family (gemm_f32 / gemm_x3 / gemm_x4 kernels): mode 0 NT (A [M][K], B [N][K]),
+ * 1 NN (B [K][N]), 2 TN (A [K][M], B [K][N]); splits >= 1: split-K partial products into `slabs` [splits][M][N]
+ * (summed into C too when C != NULL).  Operand bases and pitches need 4-byte alignment only.  PADDING: the bf16x3
+ * kernel (gemm_x3_kernel, the default for 128 x 128 tiles) stages operands in 16-byte chunks and clamps, it does not
+ * mask — on a partial last k-tile of a k-contiguous operand, and on the last 4-column group of a k-strided one, it
+ * reads up to 12 bytes past the last element of an operand ROW (never used in a result).  Inside the library every
+ * operand lies in a larger buffer (flat parameter buffers, workspaces); a caller-owned A / B whose last row ends exactly
+ * at the end of its allocation with K % 4 != 0 (or, k-strided, a row count % 4 != 0) must be padded by 12 bytes — or run
+ * with DGG_X4=1 / DGG_GEMM_ALGO=f32, whose k-tails are fetched element by element. */
 int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C,
                  int ldc, int splits, float* slabs, int accumulate, void* stream);
 /* Diagnostic / test entry of the pre-split GEMM the train step uses for its large products (csrc/gemm_p3.hip):

@@ -346,6 +346,60 @@ def gen_magd_golden(eval_rows_full):
     print("magd golden:", out["result"])
 
 
+def _load_ref_eval():
+    """eval.py of the reference as a module (its unrelated GUI / robot imports stubbed as they fail)."""
+    import importlib.util
+    for name in ["open3d", "transforms3d", "h5py", "cv2", "pandas_dummy"]:
+        sys.modules.setdefault(name, types.ModuleType(name))
+    for _ in range(40):
+        try:
+            spec = importlib.util.spec_from_file_location("ref_eval", os.path.join(REF, "eval.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            return mod
+        except ModuleNotFoundError as e:
+            stub = types.ModuleType(e.name)
+            stub.__path__ = []
+            stub.__getattr__ = lambda name, _n=e.name: type(name, (), {})
+            sys.modules[e.name] = stub
+    raise RuntimeError("eval.py: too many missing modules")
+
+
+def gen_magd_eval_batch_golden(cfg):
+    """BASELINE config 1 / SURVEY 8(f) N2: eval.py:309-344 on data/eval_batch.pth with the data set's per-object ground
+    truth replaced by what the batch itself holds — the rows of one obj_name are that object's ground-truth grasps — :
+    per object, the reference's generate_grasps on the object's BPS row (n_samples = number of ground-truth grasps as in
+    eval.py:334-338, default z_offset, latent seeded) and the reference's magd_for_grasp_distribution(out, grasps_gt)."""
+    mod = _load_ref_eval()
+    d = torch.load(os.path.join(REF, "data/eval_batch.pth"), map_location="cpu", weights_only=False)
+    names = list(d["obj_name"])
+    objs = sorted(set(names), key=names.index)
+    out = {"obj_index": np.array([objs.index(n) for n in names], np.int32), "objects": np.array(objs),
+           "rot_matrix": d["rot_matrix"].numpy(), "transl": d["transl"].numpy(), "joint_conf": d["joint_conf"].numpy()}
+    first = [names.index(o) for o in objs]
+    out["bps_rows"] = d["bps_object"][first].numpy()
+    for variant in WEIGHT_VARIANTS:
+        m = build_reference(cfg, variant, is_train=False)
+        m.DexGANGrasp.eval()
+        for oi, o in enumerate(objs):
+            rows = [i for i, n in enumerate(names) if n == o]
+            gt = {"rot_matrix": d["rot_matrix"][rows].numpy(), "transl": d["transl"][rows].numpy(),
+                  "joint_conf": np.array(d["joint_conf"][rows].numpy())}
+            n = len(rows)
+            torch.manual_seed(900 + oi)
+            z = torch.randn((n, 5))
+            torch.manual_seed(900 + oi)
+            pred = m.generate_grasps(out["bps_rows"][oi], n_samples=n, return_arr=True)
+            key = "%s/%d/" % (variant, oi)
+            out[key + "z"] = z.numpy()
+            for k in ("rot_matrix", "transl", "joint_conf"):
+                out[key + "pred/" + k] = np.asarray(pred[k])
+            t, r, j, c = mod.magd_for_grasp_distribution({k: np.asarray(v).copy() for k, v in pred.items()}, gt)
+            out[key + "magd"] = np.array([t, r, j, c], np.float64)
+            print("magd", variant, o, n, out[key + "magd"])
+    np.savez_compressed(os.path.join(HERE, "magd_eval_batch.npz"), **out)
+
+
 def main():
     import yaml
     install_shims()
@@ -353,6 +407,9 @@ def main():
     cfg["save_dir"] = "/tmp/dgg_ref_ckpt"
     cfg["eval_dir"] = "/tmp/dgg_ref_ckpt"
     cfg["train_ffhevaluator"] = True
+    if len(sys.argv) > 1 and sys.argv[1] == "magd":     # only the config-1 MAGD fixture
+        gen_magd_eval_batch_golden(cfg)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "wgan":     # only the N3 fixture (the others are unchanged)
         d = np.load(os.path.join(HERE, "eval_batch_rows16.npz"))
         gen_wgan_goldens(cfg, {k: torch.from_numpy(d[k].copy()) for k in d.files})
@@ -364,6 +421,7 @@ def main():
     gen_step_goldens(cfg, rows)
     gen_inference_goldens(cfg)
     gen_magd_golden(rows)
+    gen_magd_eval_batch_golden(cfg)
 
 
 if __name__ == "__main__":

@@ -383,7 +383,21 @@ def test_ragged_last_batch_under_pipelining():
     e4.cgan_step(*seq[1], z, True)
     torch.cuda.synchronize()
     assert torch.equal(e3.G.params, e4.G.params) and torch.equal(e3.D.params, e4.D.params)
-    for e in (e1, e2, e3, e4):
+    assert torch.equal(e3.D.bn, e4.D.bn) and torch.equal(e3.G.bn, e4.G.bn)     # the dropped pass left no trace
+    # ... nor does a state read between two pipelined steps: flush() drops the pass that is in flight
+    e5, _, _ = _engine("wide")
+    e6, _, _ = _engine("wide")
+    e5.joint_step(seq[0], z, e_in, True, None, 1, next_gan_inputs=seq[1])
+    e6.joint_step(seq[0], z, e_in, True, None, 1)
+    e5.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(e5.D.bn, e6.D.bn) and torch.equal(e5.D.params, e6.D.params)
+    e5.joint_step(seq[1], z, e_in, True, None, 2, next_gan_inputs=seq[0])     # (the dropped pass is simply redone)
+    e6.joint_step(seq[1], z, e_in, True, None, 2)
+    e5.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(e5.D.bn, e6.D.bn) and torch.equal(e5.D.params, e6.D.params) and torch.equal(e5.G.params, e6.G.params)
+    for e in (e1, e2, e3, e4, e5, e6):
         e.close()
 
 
@@ -395,21 +409,49 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("mode", ["engine", "wrapper", "sweep"])
-def test_two_rank_data_parallel_on_one_gpu(mode):
-    """BASELINE config 4's code path (engine world > 1): two fresh processes, both on cuda:0, collectives over gloo
-    (DGG_REHEARSE) — tools/dp_check.py compares every rank with the data-parallel oracle and the ranks with each
-    other.  The children initialise the GPU themselves, after the launcher started them."""
+def _torchrun(nproc, script_args, extra_env=None, timeout=900):
     env = dict(os.environ)
-    env.update({"DGG_REHEARSE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "4"})
+    env.update({"DGG_REHEARSE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "3"})
+    env.update(extra_env or {})
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "dp_check.py"), mode]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
-    out = r.stdout.decode(errors="replace")
-    assert r.returncode == 0, out[-4000:]
-    assert out.count("dp_check %s: rank" % mode) == 2, out[-2000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port())] + script_args
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    return r.returncode, r.stdout.decode(errors="replace")
+
+
+@pytest.mark.parametrize("mode,world,env", [("engine", 2, None), ("wrapper", 2, None), ("sweep", 2, None),
+                                            ("engine", 2, {"DGG_EVA_GROUP": "1"}),
+                                            ("engine", 5, {"DGG_DP_PER_RANK": "32"})])
+def test_multi_rank_data_parallel_on_one_gpu(mode, world, env):
+    """BASELINE config 4's code path (engine world > 1): fresh processes, all on cuda:0, collectives over gloo
+    (DGG_REHEARSE) — tools/dp_check.py compares every rank with the data-parallel oracle and the ranks with each
+    other.  The children initialise the GPU themselves, after the launcher started them.  World 5: as many ranks as a
+    GPU box admits beside this process (6 processes on the card at once) — sharding, bucket bounds and the collective
+    issue order at a world size that is neither 2 nor a power of two; DGG_EVA_GROUP=1: the evaluator's buckets on a
+    process group of their own (parallel.evaluator_group)."""
+    rc, out = _torchrun(world, [os.path.join(ROOT, "tools", "dp_check.py"), mode], env)
+    assert rc == 0, out[-4000:]
+    assert out.count("dp_check %s: rank" % mode) == world, out[-2000:]
+
+
+def test_bench_py_runs_its_multi_rank_branches_in_rehearsal():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank, barrier + MAX over
+    ranks), two ranks on this one GPU over gloo: the world > 1 branches run before a real multi-GPU node is the first
+    to execute them.  One JSON line from rank 0 with the contract's fields; the numbers of a rehearsal mean nothing."""
+    import json
+    rc, out = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats",
+                            "2", "--batch", "64", "--no-sub", "--no-cpu-baseline"])
+    assert rc == 0, out[-4000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, out[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 128
+    assert d["rccl_ranks"]["world_size"] == 2 and d["rccl_ranks"]["backend"] == "gloo"
+    assert d["rccl_ranks"]["allreduce_bytes_per_step_per_rank"] == 4 * (6979096 + 6998068 + 10661660) or \
+        d["rccl_ranks"]["allreduce_bytes_per_step_per_rank"] > 9e7
+    assert d["value"] > 0 and "roofline" in d and d["side_streams"]["mode"] in ("probed", "plain")
 
 
 def test_one_rank_rccl_process_group_runs_the_collective_path():

@@ -378,6 +378,44 @@ def test_wrapper_inference_vs_reference_goldens(variant):
     np.testing.assert_allclose(fd["transl"], g[key + "filt_disc/transl"], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("variant", ["init", "wide"])
+def test_config1_magd_on_eval_batch_objects(variant):
+    """BASELINE config 1 (eval.py:309-344 on data/eval_batch.pth) through the HIP path: per object of the
+    batch, generate_grasps on its BPS row with the reference's latent, MAGD (eval.metrics, host NumPy by design: at most
+    a few dozen grasps per object) against the object's rows — equal to the reference's own four numbers (fixture
+    magd_eval_batch.npz, generated by running the reference) and to the oracle's on the oracle's grasps."""
+    from dex_gan_grasp_amd.eval import metrics
+    from oracle import dexgan_oracle as O
+    g = H.load("magd_eval_batch.npz")
+    m = _wrapper(variant, is_train=False)
+    m.DexGANGrasp.eval()
+    sd = H.gan_sd(variant)
+    tot, tot_ref = np.zeros(4), np.zeros(4)
+    for oi in range(len(g["objects"])):
+        rows = np.nonzero(g["obj_index"] == oi)[0]
+        gt = {k: g[k][rows] for k in ("rot_matrix", "transl", "joint_conf")}
+        key = "%s/%d/" % (variant, oi)
+        z = torch.from_numpy(g[key + "z"])
+        orig = torch.randn
+        try:
+            torch.randn = lambda *a, **k: z.to(k.get("device", "cpu"))
+            pred = m.generate_grasps(g["bps_rows"][oi], n_samples=len(rows), return_arr=True)
+        finally:
+            torch.randn = orig
+        for k in ("rot_matrix", "transl", "joint_conf"):
+            np.testing.assert_allclose(pred[k], g[key + "pred/" + k], rtol=1e-4, atol=1e-4, err_msg=k)
+        got = np.array(metrics.magd_for_grasp_distribution({k: np.asarray(v).copy() for k, v in pred.items()}, gt))
+        op = O.generate_grasps(sd, g["bps_rows"][oi], z)
+        r = O.magd(gt, op)
+        # the sums move with the grasps (1e-4 on poses); the nearest-neighbour assignment — coverage — is the same
+        np.testing.assert_allclose(got[:3], g[key + "magd"][:3], rtol=2e-4)
+        np.testing.assert_allclose(got[:3], [r["transl"], r["rot"], r["joint"]], rtol=2e-4)
+        assert got[3] == g[key + "magd"][3] == r["coverage"]
+        tot += got
+        tot_ref += g[key + "magd"]
+    np.testing.assert_allclose(tot[:3], tot_ref[:3], rtol=2e-4)      # eval.py:346-359 sums these over the objects
+
+
 def test_refine_grasps_gradient_matches_oracle():
     """N4 (dexgangrasp.py:516-541, 619-660): the gradient-refinement loop, step for step, against the same loop
     written with torch autograd over the oracle's evaluator (gradients accumulate in .grad, as in the reference)."""

@@ -189,6 +189,35 @@ def test_magd_mirror_vs_reference():
     assert (t2, c2) == (t, c)
 
 
+@pytest.mark.parametrize("variant", ["init", "wide"])
+def test_magd_on_eval_batch_grouped_by_object_vs_reference(variant):
+    """BASELINE config 1 / SURVEY 8(f) N2 (eval.py:309-344): data/eval_batch.pth grouped by obj_name — the rows of an
+    object are its ground-truth grasps —, the reference's generate_grasps on the object's BPS row with a seeded latent
+    and the reference's magd_for_grasp_distribution (tests/golden/make_goldens.py: gen_magd_eval_batch_golden).  The
+    oracle's generator reproduces the reference's grasps; the oracle's MAGD and the package's metrics mirror reproduce
+    the reference's four numbers, on the reference's grasps and on the oracle's own."""
+    from dex_gan_grasp_amd.eval import metrics
+    g = H.load("magd_eval_batch.npz")
+    sd = H.gan_sd(variant)
+    nobj = len(g["objects"])
+    assert nobj == 6 and g["rot_matrix"].shape == (64, 3, 3)
+    for oi in range(nobj):
+        rows = np.nonzero(g["obj_index"] == oi)[0]
+        gt = {k: g[k][rows] for k in ("rot_matrix", "transl", "joint_conf")}
+        key = "%s/%d/" % (variant, oi)
+        ref_pred = {k: g[key + "pred/" + k] for k in ("rot_matrix", "transl", "joint_conf")}
+        want = g[key + "magd"]
+        mine = O.generate_grasps(sd, g["bps_rows"][oi], torch.from_numpy(g[key + "z"]))
+        for k in ref_pred:
+            np.testing.assert_allclose(mine[k], ref_pred[k], rtol=1e-5, atol=1e-6, err_msg=k)
+        for pred in (ref_pred, mine):
+            r = O.magd(gt, pred)
+            np.testing.assert_allclose([r["transl"], r["rot"], r["joint"], r["coverage"]], want, rtol=1e-5)
+            t, rr, j, c = metrics.magd_for_grasp_distribution({k: np.asarray(v).copy() for k, v in pred.items()},
+                                                              {k: v.copy() for k, v in gt.items()})
+            np.testing.assert_allclose([t, rr, j, c], want, rtol=1e-5)
+
+
 # ------------------------------------------------------------------ N3: WGAN-GP
 @pytest.mark.parametrize("variant,bname", [("wide", "real16"), ("wide", "syn64"), ("init", "syn64")])
 def test_wgan_gp_steps_vs_reference(variant, bname):

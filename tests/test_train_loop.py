@@ -1,0 +1,117 @@
+"""The thin train-loop driver (dex_gan_grasp_amd/train.py, the loop of the reference's train.py:231-310): call order,
+gen_train_freq, save / eval hooks — on a recording fake model (CPU) — and, on the GPU, that the interleaved order ends
+with the very parameters of the reference order."""
+import numpy as np
+import pytest
+import torch
+
+from dex_gan_grasp_amd import synth
+
+
+class _Fake:
+    """Records what train() calls, in order."""
+    train_dexgenerator = True
+    train_dexevaluator = True
+
+    def __init__(self):
+        self.calls = []
+
+    def update_dexgangrasp(self, data, is_train_gen=True):
+        self.calls.append(("gan", data["id"], bool(is_train_gen)))
+        return {"total_loss_disc": 0.0}
+
+    def update_dexevaluator(self, data):
+        self.calls.append(("eva", data["id"]))
+        return {"total_loss_eva": 0.0}
+
+    def update_joint(self, real_data, eva_data, is_train_gen=True, next_real_data=None):
+        self.calls.append(("joint", real_data["id"], eva_data["id"], bool(is_train_gen),
+                           None if next_real_data is None else next_real_data["id"]))
+        return {"total_loss_disc": 0.0}, {"total_loss_eva": 0.0}
+
+    def save_dexgenerator(self, name, epoch):
+        self.calls.append(("save_g", name, epoch))
+
+    def save_dexevaluator(self, name, epoch):
+        self.calls.append(("save_e", name, epoch))
+
+
+def _lists(ng, ne):
+    t = torch.zeros(1)
+    g = [{"id": "g%d" % i, "bps_object": t, "rot_matrix": t, "transl": t, "joint_conf": t} for i in range(ng)]
+    e = [{"id": "e%d" % i} for i in range(ne)]
+    return g, e
+
+
+def test_reference_order_is_two_epoch_loops_with_gen_train_freq_and_hooks():
+    from dex_gan_grasp_amd.train import train
+    m = _Fake()
+    g, e = _lists(3, 2)
+    cfg = {"num_epochs": 2, "gen_train_freq": 2, "save_freq": 2, "print_freq": 4, "batch_size": 4}
+    evals, logged = [], []
+    n = train(m, cfg, g, e, mode="reference", eval_fn=lambda mod, ep: evals.append(ep) or {"x": 1},
+              on_train_loss=lambda ep, it, ld: logged.append((ep, it)))
+    one = [("gan", "g0", True), ("gan", "g1", False), ("gan", "g2", True), ("eva", "e0"), ("eva", "e1")]
+    assert m.calls == one + one + [("save_g", "2", 2), ("save_e", "2", 2)]      # train.py:243-252, :276, :289-295
+    assert evals == [2] and n == 2 * 5 * 4                                      # eval right after the save (:302-306)
+    assert logged and all(it % 4 == 0 for _, it in logged)
+
+
+def test_interleaved_order_pairs_batches_with_one_batch_look_ahead():
+    from dex_gan_grasp_amd.train import train
+    m = _Fake()
+    g, e = _lists(3, 4)
+    cfg = {"num_epochs": 1, "gen_train_freq": 1, "save_freq": 5, "print_freq": 0, "batch_size": 2}
+    train(m, cfg, g, e, mode="interleaved")
+    assert m.calls == [("joint", "g0", "e0", True, "g1"), ("joint", "g1", "e1", True, "g2"),
+                       ("joint", "g2", "e2", True, None), ("eva", "e3")]
+    m2 = _Fake()
+    g, e = _lists(3, 1)
+    train(m2, cfg, g, e, mode="interleaved")
+    assert m2.calls == [("joint", "g0", "e0", True, "g1"), ("gan", "g1", True), ("gan", "g2", True)]
+    m3 = _Fake()
+    m3.train_dexevaluator = False
+    train(m3, cfg, g, e, mode="interleaved")                    # one network only: the reference loop
+    assert [c[0] for c in m3.calls] == ["gan"] * 3
+    with pytest.raises(ValueError):
+        train(m, cfg, g, e, mode="nope")
+
+
+@pytest.mark.gpu
+def test_interleaved_mode_ends_with_the_reference_order_parameters(tmp_path):
+    """Two epochs of three batches per data set (gen_train_freq 2: steps without a generator update in between), synthetic
+    clouds through dgg_bps_encode in front: the interleaved order (update_joint, look-ahead) and the reference order (two
+    epoch loops) end with identical parameters, BatchNorm statistics, Adam moments and step counts — bit for bit — and
+    write loadable checkpoints where train.py writes them."""
+    import os
+    from dex_gan_grasp_amd.train import train
+    from dex_gan_grasp_amd.data.synthetic_data_set import SyntheticGraspBatches
+    from dex_gan_grasp_amd.models.dexgangrasp import DexGanGrasp
+    import helpers as H
+    basis = H.load("bps_real_objects.npz")["basis"]
+    b = 96
+    out = {}
+    for mode in ("reference", "interleaved"):
+        cfg = dict(synth.DEFAULT_CFG)
+        cfg.update({"num_epochs": 2, "batch_size": b, "train_ffhevaluator": True, "train_ffhgenerator": True,
+                    "save_freq": 2, "print_freq": 0, "gen_train_freq": 2, "save_dir": str(tmp_path / mode)})
+        os.makedirs(cfg["save_dir"], exist_ok=True)
+        m = DexGanGrasp(cfg)
+        m.DexGANGrasp.load_state_dict(H.gan_sd("wide"))
+        m.DexEvaluator.load_state_dict(H.eva_sd("wide"))
+        gen = SyntheticGraspBatches(cfg, b, 3, basis, n_points=300, seed=1, device_tensors=True)
+        eva = SyntheticGraspBatches(cfg, b, 3, basis, n_points=300, seed=2, with_label=True, device_tensors=True)
+        torch.manual_seed(1234)      # the latent (device generator) and the dropout seeds (host generator)
+        evals = []
+        train(m, cfg, gen, eva, mode=mode, eval_fn=lambda mod, ep: evals.append(ep) or {})
+        torch.cuda.synchronize()
+        assert evals == [2]
+        eng = m._eng()
+        eng.flush()
+        out[mode] = [t.clone() for net in (eng.G, eng.D, eng.E) for t in (net.params, net.bn, net.m, net.v)] + \
+                    [torch.tensor([eng.G.step, eng.D.step, eng.E.step])]
+        files = sorted(os.listdir(cfg["save_dir"]))
+        assert any("2" in f for f in files) and len(files) >= 2, files
+        assert (eng.G.step, eng.D.step, eng.E.step) == (4, 6, 6)       # gen_train_freq 2: G updates on batches 0 and 2
+    for a, c in zip(out["reference"], out["interleaved"]):
+        assert torch.equal(a, c)

@@ -187,7 +187,10 @@ def check_sweep(n_obj=37, n=64):
 
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "engine"
-    {"engine": check_engine, "wrapper": check_wrapper, "sweep": check_sweep}[mode]()
+    if mode == "engine":
+        check_engine(per_rank=int(os.environ.get("DGG_DP_PER_RANK", "64")))   # (rows per rank: smaller for many ranks)
+    else:
+        {"wrapper": check_wrapper, "sweep": check_sweep}[mode]()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

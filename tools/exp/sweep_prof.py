@@ -1,5 +1,7 @@
-#!/usr/bin/env python3
-"""Config-5 sweep (1250 objects x 200 grasps) alone, for rocprofv3 --kernel-trace --stats."""
+"""Config-5 sweep (1250 objects x 200 grasps) alone, for the profiler.  Run it as the profiler's own child — never through env, a shell or a
+shebang (rocprofv3 has initialised the GPU by then; an exec behind it takes the box down):
+    cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d <outdir> -o t -- python3 <repo>/tools/exp/sweep_prof.py
+"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
