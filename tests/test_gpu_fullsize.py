@@ -423,13 +423,14 @@ def _torchrun(nproc, script_args, extra_env=None, timeout=900):
 
 @pytest.mark.parametrize("mode,world,env", [("engine", 2, None), ("wrapper", 2, None), ("sweep", 2, None),
                                             ("engine", 2, {"DGG_EVA_GROUP": "1"}),
-                                            ("engine", 5, {"DGG_DP_PER_RANK": "32"})])
+                                            ("engine", 3, {"DGG_DP_PER_RANK": "32"})])
 def test_multi_rank_data_parallel_on_one_gpu(mode, world, env):
     """BASELINE config 4's code path (engine world > 1): fresh processes, all on cuda:0, collectives over gloo
     (DGG_REHEARSE) — tools/dp_check.py compares every rank with the data-parallel oracle and the ranks with each
-    other.  The children initialise the GPU themselves, after the launcher started them.  World 5: as many ranks as a
-    GPU box admits beside this process (6 processes on the card at once) — sharding, bucket bounds and the collective
-    issue order at a world size that is neither 2 nor a power of two; DGG_EVA_GROUP=1: the evaluator's buckets on a
+    other.  The children initialise the GPU themselves, after the launcher started them.  World 3: what a GPU box's
+    process guard leaves room for beside this process and the launcher (6 processes on the card at once; 5 ranks were
+    killed by it) — sharding, bucket bounds and the collective issue order at a world size that is neither 2 nor a
+    power of two; DGG_EVA_GROUP=1: the evaluator's buckets on a
     process group of their own (parallel.evaluator_group)."""
     rc, out = _torchrun(world, [os.path.join(ROOT, "tools", "dp_check.py"), mode], env)
     assert rc == 0, out[-4000:]

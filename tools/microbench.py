@@ -32,7 +32,7 @@ def time_it(fn, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gemm", "bps", "bps1"])
+    ap.add_argument("what", choices=["gemm", "planes", "bps", "bps1"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--k", type=int, default=4613)
     ap.add_argument("--m", type=int, default=1024)
@@ -41,7 +41,23 @@ def main():
     ap.add_argument("--splits", type=int, default=10)
     a = ap.parse_args()
     dev = "cuda"
-    if a.what == "gemm":
+    if a.what == "planes":
+        # the planes GEMM (gemm_p4_kernel; DGG_PLANES_KERNEL=p3: gemm_p3_kernel) through dgg_gemm_planes: NT, split-K slabs;
+        # every call also runs the two planes_kernel launches that split the operands (separate kernels in a trace)
+        M, N, K, S = a.m, a.n, a.k, max(1, a.splits)
+        g = torch.Generator().manual_seed(0)
+        A = torch.randn((M, K), generator=g).to(dev)
+        W = torch.randn((N, K), generator=g).to(dev)
+        lib = _lib.lib()
+        nws = int(lib.dgg_gemm_planes_workspace_bytes(M, N, K))
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        slabs = torch.empty((S * M * N,), device=dev)
+        fn = lambda: _lib.check(lib.dgg_gemm_planes(0, 0, M, N, K, _lib.ptr(A), K, _lib.ptr(W), K, None, N, S, _lib.ptr(slabs), 0,
+                                                    _lib.ptr(ws), nws, _lib.stream_ptr()))
+        ms = time_it(fn, a.iters)
+        print(json.dumps({"kernel": "gemm_p4_kernel<false> + 2 x planes_kernel", "M": M, "N": N, "K": K, "splits": S,
+                          "ms_incl_planes": ms, "tflops_incl_planes": 2.0 * M * N * K / ms / 1e9}))
+    elif a.what == "gemm":
         M, N, K, S = a.m, a.n, a.k, a.splits
         g = torch.Generator().manual_seed(0)
         # mode 0: A[M][K] B[N][K];  1: A[M][K] B[K][N];  2: A[K][M] B[K][N]
