@@ -91,14 +91,13 @@ void gemm_x3_dispatch(int mode, const GemmBatch& batch, hipStream_t st);  // gem
 // gemm_x4.hip: the same products with the split done by loader waves (opt-in: DGG_X4=1)
 void gemm_x4_dispatch(int mode, const GemmBatch& batch, hipStream_t st);
 bool gemm_x4_enabled();
-// gemm_p3.hip: C = A B^T on pre-split bf16 planes (forward, and the wgrad over transposed planes with wgrad = true).
+// gemm_p4.hip / gemm_p3_block.h: C = A B^T on pre-split bf16 planes (forward, and the wgrad over transposed planes).
 // A weight-gradient (TN) launch of gemm_launch may carry ONE such problem beside its fp32 problems (a_plane != 0: "NT
 // over transposed planes", gemm_p3_block.h inside gemm_x3_kernel): the BPS block's weight gradient and its riders —
 // the columns around it, the previous block's segment, fc2, the heads — stay one launch.
-int gemm_p3_launch(GemmBatch& batch, bool wgrad, hipStream_t st);
 // gemm_p4.hip: the same product (same operands, same bits) with specialised waves — 4 MFMA waves + 4 LDS-DMA loader waves
 int gemm_p4_launch(GemmBatch& batch, bool wgrad, hipStream_t st);
-// the planes GEMM in use: gemm_p4 unless DGG_PLANES_KERNEL=p3
+// the stand-alone planes GEMM (forward): gemm_p4
 int gemm_planes_launch(GemmBatch& batch, bool wgrad, hipStream_t st);
 // dx / da3 of THIS pass plus the same tensor of another pass, written next to the plain output (the discriminator's
 // weight gradient over the BPS columns takes dY_real + dY_fake in one product, see Share::bwd_mode)

@@ -512,7 +512,7 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
     gemm_tile_shape(mode, batch.p[big].M, batch.p[big].N, bm, bn, batch.p[big].K);
     if (planes) {
         // a problem on pre-split planes (weight-gradient launches): 128 x 128 tiles on the bf16x3 kernel only, operands as
-        // gemm_p3_launch wants them
+        // gemm_p4_launch wants them
         if (mode != GEMM_TN || gemm_algo() < 1) return DGG_ERR_INVALID;
         bm = bn = 128;
         for (int i = 0; i < batch.nprob; ++i) {

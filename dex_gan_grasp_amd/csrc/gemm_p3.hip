@@ -10,6 +10,9 @@
 //   global -> LDS by LDS-DMA (global_load_lds_dwordx4, 48 pieces of 1 KiB per k-tile and workgroup, 12 per wave),
 //   LDS -> VGPR by ds_read_b128 (one per plane and 32-row block: the 8 consecutive-k bf16 a lane feeds to the MFMA),
 //   48 v_mfma_f32_32x32x16_bf16 per wave and k-tile.
+// (The loop lives in gemm_p3_block.h: it serves the planes problem inside a grouped gemm_x3_kernel weight-gradient launch;
+// the stand-alone kernel of round 2 is gone — gemm_p4.hip, the same product with specialised waves, runs the forward.
+// This file keeps the PRODUCERS: planes_kernel, rowdot_kernel.)
 // Tile 128 x 128 x 32, 256 threads = 4 waves (2 x 2 of 64 x 64), ring of 3 stages x 48 KB.  A staged operand plane is
 // [128 rows][64 B]; its four 16-byte chunks are XOR-swizzled by (row >> 2) & 3 on the SOURCE side of the DMA (the LDS
 // image of a DMA is lane-linear), which makes the fragment reads bank-conflict-free: 16 consecutive rows x one logical
@@ -26,34 +29,6 @@
 #include "gemm_p3_block.h"
 
 namespace dgg {
-
-template <bool WGRAD>
-__global__ __launch_bounds__(256) void gemm_p3_kernel(const GemmBatch batch) {
-    __shared__ __attribute__((aligned(16))) char smem[PS * PSTAGE];
-    gemm_p3_block<WGRAD>(batch, (int)blockIdx.x, smem);
-}
-
-// Operands: planes (a_plane / b_plane != 0), 16-byte aligned bases, pitches and plane distances multiples of 8 elements,
-// K (and a split's kchunk) a multiple of 32 with the padding zero-filled.  128 x 128 tiles.
-int gemm_p3_launch(GemmBatch& batch, bool wgrad, hipStream_t st) {
-    if (batch.nprob < 1 || batch.nprob > kMaxProb) return DGG_ERR_INVALID;
-    int blocks = 0;
-    for (int i = 0; i < batch.nprob; ++i) {
-        GemmProb& p = batch.p[i];
-        if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.A || !p.B || !p.C || !p.a_plane || !p.b_plane) return DGG_ERR_INVALID;
-        if ((p.K & 31) || (p.lda & 7) || (p.ldb & 7) || (p.a_plane & 7) || (p.b_plane & 7) || p.lda < p.K || p.ldb < p.K ||
-            (((uintptr_t)p.A | (uintptr_t)p.B) & 15) || (p.splits > 0 && (p.kchunk & 31)))
-            return DGG_ERR_INVALID;
-        p.tiles_m = (p.M + PT - 1) / PT;
-        p.tiles_n = (p.N + PT - 1) / PT;
-        p.blk_begin = blocks;
-        blocks += p.tiles_m * p.tiles_n * (p.splits > 0 ? p.splits : 1);
-    }
-    batch.total_blocks = blocks;
-    if (wgrad) hipLaunchKernelGGL((gemm_p3_kernel<true>), dim3(blocks), dim3(256), 0, st, batch);
-    else hipLaunchKernelGGL((gemm_p3_kernel<false>), dim3(blocks), dim3(256), 0, st, batch);
-    return check_launch("gemm_p3");
-}
 
 // ------------------------------------------------------------------------------------------------
 // Producer: fp32 matrix [R][C] (pitch ld) -> bf16 planes.

@@ -245,9 +245,6 @@ int gemm_p4_launch(GemmBatch& batch, bool wgrad, hipStream_t st) {
     return check_launch("gemm_p4");
 }
 
-int gemm_planes_launch(GemmBatch& batch, bool wgrad, hipStream_t st) {
-    static const bool use_p3 = [] { const char* e = getenv("DGG_PLANES_KERNEL"); return e && e[0] == 'p' && e[1] == '3'; }();
-    return use_p3 ? gemm_p3_launch(batch, wgrad, st) : gemm_p4_launch(batch, wgrad, st);
-}
+int gemm_planes_launch(GemmBatch& batch, bool wgrad, hipStream_t st) { return gemm_p4_launch(batch, wgrad, st); }
 
 }  // namespace dgg

@@ -175,6 +175,13 @@ class DexGanGrasp(object):
             self._engine.E = self.DexEvaluator._require_flat()
         return self._engine
 
+    def _flush(self):
+        """Before anything reads the networks' state outside the train steps (evaluation forwards, inference,
+        checkpoints): join the engine's side streams and drop a look-ahead pass that is still in flight
+        (TrainEngine.flush) — the state is then the unpipelined order's."""
+        if self._engine is not None:
+            self._engine.flush()
+
     @staticmethod
     def _bump(mod, times):
         for m in mod.modules():
@@ -241,6 +248,7 @@ class DexGanGrasp(object):
     # ------------------------------------------------------------------ eval helpers
     def eval_dexevaluator_accuracy(self, data):
         """dexgangrasp.py:309-322."""
+        self._flush()
         with torch.no_grad():
             logits = self.DexEvaluator(data)
         pred_label = utils.class_labels_from_logits(logits.clone(), self.logit_thresh)
@@ -249,6 +257,7 @@ class DexGanGrasp(object):
 
     def eval_dexevaluator_loss(self, data):
         """dexgangrasp.py:325-332."""
+        self._flush()
         self.DexEvaluator.eval()
         with torch.no_grad():
             out = self.DexEvaluator(data)
@@ -259,6 +268,7 @@ class DexGanGrasp(object):
 
     def eval_dexgangrasp_generator_loss(self, real_data):
         """dexgangrasp.py:334-365."""
+        self._flush()
         self.DexGANGrasp.eval()
         with torch.no_grad():
             n_samples = real_data["bps_object"].shape[0]
@@ -277,6 +287,7 @@ class DexGanGrasp(object):
     # ------------------------------------------------------------------ inference
     def evaluate_grasps(self, bps, grasps, thresh=0.5, return_arr=True):
         """dexgangrasp.py:367-391."""
+        self._flush()
         n_samples = grasps['rot_matrix'].shape[0]
         if len(bps.shape) > 1:
             bps = bps.squeeze()
@@ -314,6 +325,7 @@ class DexGanGrasp(object):
         re-runs the evaluator for every threshold (dexgangrasp.py:406-411), the scores are identical each time.
         Returns a list with, per threshold, the filtered dict (sorted by descending score, entries as
         filter_grasps returns them) or None where filter_grasps would raise ValueError (best score < thresh)."""
+        self._flush()
         scorer = scorer or self.DexEvaluator
         n_samples = grasps['rot_matrix'].shape[0]
         if len(bps.shape) > 1:
@@ -372,6 +384,7 @@ class DexGanGrasp(object):
         'score' (O,n), 'order' (O,n: indices by descending score) and 'count' (T,O): grasps with score > threshold —
         object o's filter_grasps(thresholds[t]) result is rows order[o, :count[t, o]].  Objects are processed
         chunk_objects at a time (activations of chunk_objects * n_samples rows live in the workspaces)."""
+        self._flush()
         bps_objects = torch.as_tensor(bps_objects, dtype=self.dtype, device=self.device)
         if bps_objects.shape[0] > chunk_objects:
             parts = []
@@ -421,6 +434,7 @@ class DexGanGrasp(object):
 
     def generate_grasps(self, bps, n_samples, return_arr=True, z_offset=0.025):
         """dexgangrasp.py:495-514."""
+        self._flush()
         if len(bps.shape) > 1:
             bps = bps.squeeze()
         bps = np.tile(bps, (n_samples, 1))
@@ -449,6 +463,7 @@ class DexGanGrasp(object):
     def refine_grasps(self, data, refine_method, num_refine_steps=10, dtype=torch.float32):
         """dexgangrasp.py:619-660.  `refine_method == "gradient"` only: the sampling-based variant of the reference
         calls helpers that do not exist in its tree (`utils.control_points_from_rot_and_trans`, `self.grasp_evaluator`)."""
+        self._flush()
         data = utils.data_dict_to_dtype(data, dtype)
         if refine_method != "gradient":
             raise NotImplementedError("refine method [%s] is not implemented" % refine_method)

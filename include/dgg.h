@@ -396,8 +396,7 @@ int dgg_gemm_occupancy(int mode, int bm, int bn);
  * with DGG_X4=1 / DGG_GEMM_ALGO=f32, whose k-tails are fetched element by element. */
 int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C,
                  int ldc, int splits, float* slabs, int accumulate, void* stream);
-/* Diagnostic / test entry of the pre-split GEMM of the optional planes path (csrc/gemm_p4.hip; DGG_PLANES_KERNEL=p3:
- * gemm_p3.hip): C[M,N] = sum_k A(m,k) B(n,k) with both fp32 operands first split into their three bf16 planes in `ws`
+/* Diagnostic / test entry of the pre-split GEMM of the optional planes path (csrc/gemm_p4.hip): C[M,N] = sum_k A(m,k) B(n,k) with both fp32 operands first split into their three bf16 planes in `ws`
  * (dgg_gemm_planes_workspace_bytes).  a_kmajor / b_kmajor != 0: the operand lies [K][rows] in memory (the weight
  * gradient's operands) and goes through the producer's transposing branch.  splits / slabs / accumulate as above.
  * A == NULL and Bm == NULL: multiply the planes a previous call left in `ws` for the same (M, N, K) again — the GEMM

@@ -575,7 +575,7 @@ def test_other_hand_configs():
                                    (300, 200, 77, 0, 0, 0), (768, 4120, 1024, 1, 1, 0), (130, 515, 300, 1, 1, 0),
                                    (1024, 768, 517, 0, 0, 2)])
 def test_gemm_planes_vs_fp64(shape):
-    """gemm_p3_kernel behind dgg_gemm_planes: both producer branches (row-major and transposing), K tails inside the
+    """gemm_p4_kernel behind dgg_gemm_planes: both producer branches (row-major and transposing), K tails inside the
     zero padding, M / N tails, split-K; integers exact, N(0,1) data at fp32-accumulation error."""
     _, _lib = _ops()
     lib = _lib.lib()

@@ -1,4 +1,4 @@
-"""Planes GEMM timing shapes (run under rocprofv3 --kernel-trace --stats; DGG_PLANES_KERNEL=p3 selects the round-2 kernel):
+"""Planes GEMM timing shapes (run under rocprofv3 --kernel-trace; the round-3 comparison with gemm_p3_kernel is in profiles/r03_experiments.txt):
     rocprofv3 --kernel-trace --stats -d gpurun_out/p4 -o p4 -- python3 tools/exp/p4_time.py
 Shapes: the per-ResBlock forward (1024 x 768 x 4120, split-K 4 / 5) and weight gradient (768 x 4120 x 1024), and the
 products of all ResBlocks of a network over the shared BPS block in one launch (N = 1536 / 2304 / 3072, K = 4096)."""

@@ -42,7 +42,7 @@ def main():
     a = ap.parse_args()
     dev = "cuda"
     if a.what == "planes":
-        # the planes GEMM (gemm_p4_kernel; DGG_PLANES_KERNEL=p3: gemm_p3_kernel) through dgg_gemm_planes: NT, split-K slabs;
+        # the planes GEMM (gemm_p4_kernel) through dgg_gemm_planes: NT, split-K slabs;
         # every call also runs the two planes_kernel launches that split the operands (separate kernels in a trace)
         M, N, K, S = a.m, a.n, a.k, max(1, a.splits)
         g = torch.Generator().manual_seed(0)
