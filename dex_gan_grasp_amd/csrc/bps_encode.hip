@@ -13,6 +13,8 @@
 //  - few clouds (robot path, one 15k..73k-point cloud): the same kernel over RANGES of the cloud, merged through the
 //    output arrays with atomicMin in two passes (see the kernel) -> the whole chip works on one cloud.
 #include "dgg_internal.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace dgg {
 
@@ -173,6 +175,177 @@ __global__ __launch_bounds__(256) void bps_batched_kernel(const float* __restric
     (void)N_;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Many clouds, coarse pass on the matrix cores (round 3).  The scan above spends ~3.7 vector instructions per PAIR of
+// (basis point, cloud point); the fp32 matrix instruction evaluates 32 x 32 pairs per 128 cycles with no vector work:
+//     v_ij = x_j.(-2 b_i) + |x_j|^2  =  |x_j - b_i|^2 - |b_i|^2                         (K = 4: x, y, z, |x|^2  against  -2bx, -2by, -2bz, 1)
+// as two v_mfma_f32_32x32x2_f32 per 32 x 32 tile.  v orders the cloud points of one basis point like the squared
+// distance does, but NOT bit for bit like the contract's  d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx)).  So v only SELECTS:
+//   - a lane sees 16 of a tile's 32 points for its basis point (the accumulator rows of its half-wave) = one block; it
+//     keeps the three blocks with the smallest block minimum (values by v_med3 / v_min, indices by compare-select) and
+//     the fourth smallest minimum;
+//   - |v_ij + |b_i|^2 - d2_ij| <= eps_i := 2^-20 (R + |b_i|)^2, R = the cloud's largest |x_j|: the K = 4 chain rounds
+//     4 times on terms whose magnitudes sum to at most (R + |b|)^2 (4u), |x|^2 itself carries 3u, the contract's d2 is
+//     within 6u of the true squared distance (u = 2^-24): 13u < 16u.  Hence every point whose d2 can be the minimum or
+//     tie with it has v <= v_min + 2 eps, and sits in a block whose minimum is <= v_min + 2 eps;
+//   - those blocks (1 always, 2 or 3 when their minima are that close, a few % of basis points) are re-evaluated with the
+//     contract's own instructions and the answer is the lexicographic minimum of (d2, j) — the sequential scan's
+//     lowest-index rule.  A fourth block within 2 eps, a cloud or basis point with a coordinate that is not below 1e3 in
+//     magnitude (NaN, inf, the 3e19 cases of the tests) or a degenerate scale send the lane through ALL its points with
+//     the exact formula: always right, never fast.
+// The two half-waves of a basis point meet through one lane exchange at the end.  Ids and distances are bit-identical to
+// the scan's (same tests); the matrix pipe is the bound: 2 x 64 cycles per 1024 pairs and SIMD.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct __attribute__((aligned(16))) Pt4 { float x, y, z, n2; };
+
+template <int NT>  // 32-wide basis tiles per wave
+__global__ __launch_bounds__(256) void bps_mfma_kernel(const float* __restrict__ clouds, int N,
+                                                       const float* __restrict__ basis, int P,
+                                                       float* __restrict__ dists, int32_t* __restrict__ ids, int B,
+                                                       int gx) {
+    extern __shared__ Pt4 pts[];  // the cloud, padded to a multiple of 32 points with (0, 0, 0, +inf)
+    __shared__ int s_r2, s_bad;
+    const int L = blockIdx.x, per = 8 * gx;
+    int b, slice;
+    if (L < (B / 8) * per) {  // the gx slices of a cloud on one XCD (see bps_batched_kernel)
+        b = (L / per) * 8 + (L & 7);
+        slice = (L % per) >> 3;
+    } else {
+        b = L / gx;
+        slice = L % gx;
+    }
+    const float* __restrict__ c = clouds + (size_t)b * N * 3;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, col = lane & 31, h = lane >> 5;
+    const int ntile = (N + 31) >> 5;
+    if (tid == 0) {
+        s_r2 = 0;
+        s_bad = 0;
+    }
+    __syncthreads();
+    {
+        float r2 = 0.f;
+        bool bad = false;
+        for (int j = tid; j < ntile * 32; j += 256) {
+            Pt4 v{0.f, 0.f, 0.f, __builtin_inff()};
+            if (j < N) {
+                v.x = c[3 * j];
+                v.y = c[3 * j + 1];
+                v.z = c[3 * j + 2];
+                v.n2 = __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x));
+                bad |= !(__builtin_fabsf(v.x) < 1e3f && __builtin_fabsf(v.y) < 1e3f && __builtin_fabsf(v.z) < 1e3f);
+                r2 = __builtin_fmaxf(r2, v.n2);
+            }
+            pts[j] = v;
+        }
+        if (bad) atomicOr(&s_bad, 1);
+        else atomicMax(&s_r2, __builtin_bit_cast(int, r2));  // non-negative floats order like their bits
+    }
+    __syncthreads();
+    const bool cloud_bad = s_bad != 0;
+    const float R = __builtin_sqrtf(__builtin_bit_cast(float, s_r2));
+
+    float bx[NT], by[NT], bz[NT], b1[NT], b2[NT], thr[NT];
+    bool full[NT];
+    float v1[NT], v2[NT], v3[NT], v4[NT];
+    int i1[NT], i2[NT], i3[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int i = (slice * 4 + w) * (NT * 32) + t * 32 + col;
+        i = i < P ? i : P - 1;
+        bx[t] = basis[3 * i];
+        by[t] = basis[3 * i + 1];
+        bz[t] = basis[3 * i + 2];
+        b1[t] = -2.f * (h ? by[t] : bx[t]);
+        b2[t] = h ? 1.f : -2.f * bz[t];
+        const float nb = __builtin_sqrtf(__builtin_fmaf(bz[t], bz[t], __builtin_fmaf(by[t], by[t], bx[t] * bx[t])));
+        const float S = (R + nb) * (R + nb);
+        thr[t] = S * 0x1p-19f;  // 2 eps
+        full[t] = cloud_bad ||
+                  !(__builtin_fabsf(bx[t]) < 1e3f && __builtin_fabsf(by[t]) < 1e3f && __builtin_fabsf(bz[t]) < 1e3f) ||
+                  !(S > 1e-20f);
+        v1[t] = v2[t] = v3[t] = v4[t] = __builtin_inff();
+        i1[t] = i2[t] = i3[t] = -1;
+    }
+    if (!cloud_bad) {
+        const float* pf = reinterpret_cast<const float*>(pts) + col * 4 + h;
+        float a1 = pf[0], a2 = pf[2];
+        for (int i = 0; i < ntile; ++i) {
+            const float c1 = a1, c2 = a2;
+            const int nx = i + 1 < ntile ? i + 1 : i;
+            a1 = pf[nx * 128];
+            a2 = pf[nx * 128 + 2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, b1[t], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c2, b2[t], acc, 0, 0, 0);
+                auto min3 = [](float a, float b_, float c_) { return __builtin_fminf(__builtin_fminf(a, b_), c_); };
+                const float m0 = min3(acc[0], acc[1], acc[2]), m1 = min3(acc[3], acc[4], acc[5]);
+                const float m2 = min3(acc[6], acc[7], acc[8]), m3 = min3(acc[9], acc[10], acc[11]);
+                const float m4 = min3(acc[12], acc[13], acc[14]);
+                const float m = min3(min3(m0, m1, m2), min3(m3, m4, acc[15]), __builtin_inff());
+                const bool l1 = m < v1[t], l2 = m < v2[t], l3 = m < v3[t];
+                int n3 = l3 ? i : i3[t], n2 = l2 ? i : i2[t];  // plain selects (nested ones become branches)
+                n3 = l2 ? i2[t] : n3;
+                n2 = l1 ? i1[t] : n2;
+                i3[t] = n3;
+                i2[t] = n2;
+                i1[t] = l1 ? i : i1[t];
+                v4[t] = __builtin_amdgcn_fmed3f(v3[t], v4[t], m);
+                v3[t] = __builtin_amdgcn_fmed3f(v2[t], v3[t], m);
+                v2[t] = __builtin_amdgcn_fmed3f(v1[t], v2[t], m);
+                v1[t] = __builtin_fminf(v1[t], m);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float best = __builtin_inff();
+        int bid = 0;
+        const float X = bx[t], Y = by[t], Z = bz[t];
+        auto block = [&](int i) {  // this lane's 16 rows of point tile i, the contract's arithmetic
+#pragma unroll 4
+            for (int r = 0; r < 16; ++r) {
+                const int j = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const Pt4 p = pts[j];
+                const float d2 = dist2(p.x, p.y, p.z, X, Y, Z);
+                const bool take = (j < N) & ((d2 < best) | ((d2 == best) & (j < bid)));
+                best = take ? d2 : best;
+                bid = take ? j : bid;
+            }
+        };
+        const float lim = v1[t] + thr[t];
+#if defined(BPS_ABLATE) && BPS_ABLATE == 1   // no exact stage at all
+        best = v1[t];
+        bid = i1[t];
+#elif defined(BPS_ABLATE) && BPS_ABLATE == 2  // first block only
+        block(i1[t] < 0 ? 0 : i1[t]);
+#elif defined(BPS_ABLATE) && BPS_ABLATE == 3  // no full fallback
+        block(i1[t] < 0 ? 0 : i1[t]);
+        if (i2[t] >= 0 && !(v2[t] > lim)) block(i2[t]);
+        if (i3[t] >= 0 && !(v3[t] > lim)) block(i3[t]);
+#else
+        if (full[t] || !(v4[t] > lim)) {
+            for (int i = 0; i < ntile; ++i) block(i);
+        } else {
+            block(i1[t]);
+            if (i2[t] >= 0 && !(v2[t] > lim)) block(i2[t]);
+            if (i3[t] >= 0 && !(v3[t] > lim)) block(i3[t]);
+        }
+#endif
+        const float od = __shfl_xor(best, 32);
+        const int oi = __shfl_xor(bid, 32);
+        const bool take = (od < best) | ((od == best) & (oi < bid));
+        best = take ? od : best;
+        bid = take ? oi : bid;
+        const int i = (slice * 4 + w) * (NT * 32) + t * 32 + col;
+        if (h == 0 && i < P) {
+            dists[(size_t)b * P + i] = __builtin_sqrtf(best);
+            if (ids) ids[(size_t)b * P + i] = bid;
+        }
+    }
+}
+
 __global__ void bps_preset_kernel(float* __restrict__ dists, int32_t* __restrict__ ids, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -203,7 +376,16 @@ int bps_encode_launch(const float* clouds, int B, int N, const float* basis, int
             nchunk = (N + chunk_len - 1) / chunk_len;
         }
     }
-    if (nchunk <= 1) {
+    static const bool valu_only = [] {  // DGG_BPS=valu: the vector-ALU scan for every shape (A/B timing, tests)
+        const char* e = getenv("DGG_BPS");
+        return e && !strcmp(e, "valu");
+    }();
+    if (nchunk <= 1 && N >= 64 && N <= 4096 && !valu_only) {
+        const int g5 = (P + 511) / 512;
+        const size_t lds = (size_t)((N + 31) / 32) * 32 * sizeof(Pt4);
+        hipLaunchKernelGGL((bps_mfma_kernel<4>), dim3((unsigned)g5 * B), dim3(256), lds, st, clouds, N, basis, P, dists, ids,
+                           B, g5);
+    } else if (nchunk <= 1) {
         hipLaunchKernelGGL((bps_batched_kernel<4, 16, 0>), dim3((unsigned)gx * B), dim3(256), 0, st, clouds, N, basis, P,
                            dists, ids, B, gx, 1, N);
     } else {
