@@ -25,6 +25,18 @@ __device__ __forceinline__ float dist2(float x, float y, float z, float bx, floa
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Three consecutive floats as THREE single-dword loads.  Left to itself the compiler merges them into one
+// global_load_dwordx3, and on gfx950 (ROCm 7.2) a dwordx3 load issued among dwordx4 loads was seen to deliver its data
+// AFTER the s_waitcnt vmcnt(N) that in-order return says covers it: the exact stage below then computed distances
+// against the previous work item's basis point in lanes 32-63 — a handful of 4.2 M outputs wrong in one run of three,
+// only with other workgroups busy on the same CU (tools/exp/bps_race.sh: 9 of 24 runs with the dwordx3, 0 of 20 without).
+__device__ __forceinline__ void load3(const float* p, float& x, float& y, float& z) {
+    const volatile float* v = p;
+    x = v[0];
+    y = v[1];
+    z = v[2];
+}
+
 // Batched clouds.  Two things keep the vector ALU's issue slots for the distance arithmetic itself:
 //  - two basis points of a lane sit side by side in 64-bit register pairs, so the subtract, the square and the two fused
 //    multiply-adds are packed fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two IEEE results per lane and
@@ -83,9 +95,11 @@ __global__ __launch_bounds__(256) void bps_batched_kernel(const float* __restric
     for (int q = 0; q < BPT; ++q) {
         int i = slice * (256 * BPT) + q * 256 + threadIdx.x;
         i = i < P ? i : P - 1;
-        bx[q >> 1][q & 1] = basis[3 * i];
-        by[q >> 1][q & 1] = basis[3 * i + 1];
-        bz[q >> 1][q & 1] = basis[3 * i + 2];
+        float tx, ty, tz;
+        load3(basis + 3 * i, tx, ty, tz);
+        bx[q >> 1][q & 1] = tx;
+        by[q >> 1][q & 1] = ty;
+        bz[q >> 1][q & 1] = tz;
         // MODE 2: `best` is the TARGET, the global minimum pass 1 left in dists (+inf: nothing was smaller, leave ids)
         best[q] = MODE == 2 ? __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)dists + (size_t)b * P + i,
                                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
@@ -155,8 +169,9 @@ __global__ __launch_bounds__(256) void bps_batched_kernel(const float* __restric
             id = j0;
             bool found = false;
             for (int u = 0; u < n; ++u) {
-                const float d2 = dist2(c[3 * (j0 + u)], c[3 * (j0 + u) + 1], c[3 * (j0 + u) + 2], bx[q >> 1][q & 1],
-                                       by[q >> 1][q & 1], bz[q >> 1][q & 1]);
+                float px, py, pz;
+                load3(c + 3 * (j0 + u), px, py, pz);
+                const float d2 = dist2(px, py, pz, bx[q >> 1][q & 1], by[q >> 1][q & 1], bz[q >> 1][q & 1]);
                 if (!found && d2 == best[q]) {
                     id = j0 + u;
                     found = true;
@@ -176,35 +191,70 @@ __global__ __launch_bounds__(256) void bps_batched_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Many clouds, coarse pass on the matrix cores (round 3).  The scan above spends ~3.7 vector instructions per PAIR of
-// (basis point, cloud point); the fp32 matrix instruction evaluates 32 x 32 pairs per 128 cycles with no vector work:
-//     v_ij = x_j.(-2 b_i) + |x_j|^2  =  |x_j - b_i|^2 - |b_i|^2                         (K = 4: x, y, z, |x|^2  against  -2bx, -2by, -2bz, 1)
-// as two v_mfma_f32_32x32x2_f32 per 32 x 32 tile.  v orders the cloud points of one basis point like the squared
-// distance does, but NOT bit for bit like the contract's  d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx)).  So v only SELECTS:
-//   - a lane sees 16 of a tile's 32 points for its basis point (the accumulator rows of its half-wave) = one block; it
-//     keeps the three blocks with the smallest block minimum (values by v_med3 / v_min, indices by compare-select) and
-//     the fourth smallest minimum;
-//   - |v_ij + |b_i|^2 - d2_ij| <= eps_i := 2^-20 (R + |b_i|)^2, R = the cloud's largest |x_j|: the K = 4 chain rounds
-//     4 times on terms whose magnitudes sum to at most (R + |b|)^2 (4u), |x|^2 itself carries 3u, the contract's d2 is
-//     within 6u of the true squared distance (u = 2^-24): 13u < 16u.  Hence every point whose d2 can be the minimum or
-//     tie with it has v <= v_min + 2 eps, and sits in a block whose minimum is <= v_min + 2 eps;
-//   - those blocks (1 always, 2 or 3 when their minima are that close, a few % of basis points) are re-evaluated with the
-//     contract's own instructions and the answer is the lexicographic minimum of (d2, j) — the sequential scan's
-//     lowest-index rule.  A fourth block within 2 eps, a cloud or basis point with a coordinate that is not below 1e3 in
-//     magnitude (NaN, inf, the 3e19 cases of the tests) or a degenerate scale send the lane through ALL its points with
-//     the exact formula: always right, never fast.
+// Many clouds: a coarse pass on the matrix cores SELECTS, the contract's arithmetic DECIDES (round 3).
+// The scan above spends ~3.7 vector instructions per (basis point, cloud point) pair.  Here one pair costs 1/16 of a
+// vector min3 and 1/1024 of two matrix instructions:
+//     v_ij = x_j.(-2 b_i) + |x_j|^2 + c_i  =  |x_j - b_i|^2 + bias_i            (c_i ~ |b_i|^2 + bias_i, any constant does)
+// as a dot product of bf16 values: every fp32 operand is split EXACTLY into three bf16 planes (h + m + l, by truncation)
+// and the six largest of the nine plane products are kept per coordinate (as in gemm_x3.hip).  Two
+// v_mfma_f32_32x32x16_bf16 evaluate 32 points x 32 basis points (64 cycles of the matrix pipe, which runs beside the
+// vector ALU of other waves; the fp32 matrix instruction of the first version does not: it runs at the vector rate and
+// its time ADDED to the vector work, 1.12x only).  Operand rows (k-slots in pairs, one 32-bit word each):
+//     point, lanes 0-31  : (xh,xm) (xl,xh) (yh,ym) (yl,yh)      lanes 32-63: (zh,zm) (zl,zh) (nh,nm) (nl,1)     n = |x|^2
+//     basis, 1st MFMA    : (qh,qh) (qh,ql) per coordinate        ...          (qzh,qzh) (qzh,qzl) (1,1) (1,ch)   q = -2b
+//     basis, 2nd MFMA    : (qm,qm) (0,0)   per coordinate        ...          (qzm,qzm) (0,0) (0,0) (0,cm)
+// — the SAME point registers feed both instructions (hh + mh, lh + hl, then hm + mm per coordinate), so a point costs 32 B
+// of LDS and one ds_read_b128 per lane and tile.  v orders the cloud points of one basis point like the squared distance
+// does, but not bit for bit like the contract's  d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx)),  so:
+//   - a lane sees 16 of a tile's 32 points for its basis point (the accumulator rows of its half-wave) = one BLOCK.  The
+//     block minimum (8 v_min3_f32) gets the tile index written over its 7 lowest mantissa bits: one register is value
+//     and index, and the four smallest keys are kept by three v_med3_f32 and a v_min_u32 — no compare / select.
+//     (v > 0 thanks to the bias, so the keys order like the values; the overwritten bits cost 2^-17 v.)
+//   - |v_ij - (c_i - |b_i|^2) - d2_ij| <= eps_i = 35u S_i + 2^-17 v_ij,  S_i = (R + |b_i|)^2, R = the cloud's largest
+//     |x_j|, u = 2^-24: dropped plane products 2.1u S, at most 24 accumulations of terms whose magnitudes sum to <= S:
+//     24u S (worst case, whatever the order inside the instruction), |x|^2 3u S, the contract's own d2 within 5u of the
+//     true squared distance.  Hence every point whose d2 can be the minimum or tie with it lies in a block whose key is
+//     <= k1 + 2 eps =: lim (k1 the smallest key).
+//   - the (at most three) blocks with keys <= lim are re-evaluated with the contract's instructions on the cloud's own
+//     fp32 coordinates (global memory, 3 x 16-byte loads per 4 consecutive points), the answer is the lexicographic
+//     minimum of (d2, j): the sequential scan's lowest-index rule.  A fourth key <= lim, a cloud or basis point with a
+//     coordinate not below 1e3 in magnitude (NaN, inf, the 3e19 cases of the tests) or a degenerate scale send the lane
+//     through ALL its points with the exact formula: always right, never fast.
 // The two half-waves of a basis point meet through one lane exchange at the end.  Ids and distances are bit-identical to
-// the scan's (same tests); the matrix pipe is the bound: 2 x 64 cycles per 1024 pairs and SIMD.
+// the scan's (tests/test_gpu_parity.py, tools/exp/bps_ab.py on 4.2 M outputs).
+// 512-thread workgroups (8 waves x 128 basis points) share one staged cloud; 64 KB at 2048 points: two per CU, so one
+// workgroup's staging / exact stage runs beside the other's matrix work.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-struct __attribute__((aligned(16))) Pt4 { float x, y, z, n2; };
+typedef float bf32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned bu32x4 __attribute__((ext_vector_type(4)));
 
-template <int NT>  // 32-wide basis tiles per wave
-__global__ __launch_bounds__(256) void bps_mfma_kernel(const float* __restrict__ clouds, int N,
-                                                       const float* __restrict__ basis, int P,
-                                                       float* __restrict__ dists, int32_t* __restrict__ ids, int B,
-                                                       int gx) {
-    extern __shared__ Pt4 pts[];  // the cloud, padded to a multiple of 32 points with (0, 0, 0, +inf)
+struct Planes3 { unsigned h, m, l; };  // bf16 values in the UPPER halves; x == h + m + l exactly
+__device__ __forceinline__ Planes3 split3(float x) {
+    Planes3 p;
+    p.h = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, p.h);   // exact
+    p.m = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+    const float r2 = r1 - __builtin_bit_cast(float, p.m);  // exact, at most 8 significant bits left
+    p.l = __builtin_bit_cast(unsigned, r2) & 0xffff0000u;
+    return p;
+}
+__device__ __forceinline__ unsigned pk2(unsigned even, unsigned odd) { return (even >> 16) | odd; }  // k-slots 2n, 2n+1
+
+constexpr int kBpsMfmaMaxN = 2560;  // 32 B of LDS per point, tile index in 7 bits
+constexpr int kBpsQueue = 512;      // work-list entries per wave (128 winners + further candidates; the rest in place)
+#ifndef BPS_NW
+#define BPS_NW 8
+#endif
+
+template <int NT, int NW>  // 32-wide basis tiles per wave, waves per workgroup
+__global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __restrict__ clouds, int N,
+                                                           const float* __restrict__ basis, int P,
+                                                           float* __restrict__ dists, int32_t* __restrict__ ids, int B,
+                                                           int gx) {
+    extern __shared__ bu32x4 planes[];  // [ntile * 32][2]: the operand words of lanes 0-31 | lanes 32-63
     __shared__ int s_r2, s_bad;
+    __shared__ int s_qn[NW];  // entries on each wave's work list
     const int L = blockIdx.x, per = 8 * gx;
     int b, slice;
     if (L < (B / 8) * per) {  // the gx slices of a cloud on one XCD (see bps_batched_kernel)
@@ -214,9 +264,10 @@ __global__ __launch_bounds__(256) void bps_mfma_kernel(const float* __restrict__
         b = L / gx;
         slice = L % gx;
     }
-    const float* __restrict__ c = clouds + (size_t)b * N * 3;
+    const float* __restrict__ c = clouds + (size_t)b * N * 3;  // 16-byte aligned, N % 4 == 0 (launcher)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, col = lane & 31, h = lane >> 5;
     const int ntile = (N + 31) >> 5;
+    constexpr unsigned ONE = 0x3f800000u;
     if (tid == 0) {
         s_r2 = 0;
         s_bad = 0;
@@ -225,17 +276,32 @@ __global__ __launch_bounds__(256) void bps_mfma_kernel(const float* __restrict__
     {
         float r2 = 0.f;
         bool bad = false;
-        for (int j = tid; j < ntile * 32; j += 256) {
-            Pt4 v{0.f, 0.f, 0.f, __builtin_inff()};
-            if (j < N) {
-                v.x = c[3 * j];
-                v.y = c[3 * j + 1];
-                v.z = c[3 * j + 2];
-                v.n2 = __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x));
-                bad |= !(__builtin_fabsf(v.x) < 1e3f && __builtin_fabsf(v.y) < 1e3f && __builtin_fabsf(v.z) < 1e3f);
-                r2 = __builtin_fmaxf(r2, v.n2);
+        // four points = three 16-byte loads (the cloud is 16-byte aligned and N % 4 == 0: launcher)
+        for (int g = tid; g < ntile * 8; g += NW * 64) {
+            const int j0 = 4 * g;
+            float xs[4] = {0.f, 0.f, 0.f, 0.f}, ys[4] = {0.f, 0.f, 0.f, 0.f}, zs[4] = {0.f, 0.f, 0.f, 0.f};
+            const bool in = j0 < N;
+            if (in) {
+                const bf32x4* pq = reinterpret_cast<const bf32x4*>(c + 3 * j0);
+                const bf32x4 p0 = pq[0], p1 = pq[1], p2 = pq[2];
+                xs[0] = p0[0], ys[0] = p0[1], zs[0] = p0[2];
+                xs[1] = p0[3], ys[1] = p1[0], zs[1] = p1[1];
+                xs[2] = p1[2], ys[2] = p1[3], zs[2] = p2[0];
+                xs[3] = p2[1], ys[3] = p2[2], zs[3] = p2[3];
             }
-            pts[j] = v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float x = xs[k], y = ys[k], z = zs[k];
+                float n2 = 1e30f;  // padding: far away, never NaN
+                if (in) {
+                    n2 = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+                    bad |= !(__builtin_fabsf(x) < 1e3f && __builtin_fabsf(y) < 1e3f && __builtin_fabsf(z) < 1e3f);
+                    r2 = __builtin_fmaxf(r2, n2);
+                }
+                const Planes3 X = split3(x), Y = split3(y), Z = split3(z), Q = split3(n2);
+                planes[2 * (j0 + k)] = bu32x4{pk2(X.h, X.m), pk2(X.l, X.h), pk2(Y.h, Y.m), pk2(Y.l, Y.h)};
+                planes[2 * (j0 + k) + 1] = bu32x4{pk2(Z.h, Z.m), pk2(Z.l, Z.h), pk2(Q.h, Q.m), pk2(Q.l, ONE)};
+            }
         }
         if (bad) atomicOr(&s_bad, 1);
         else atomicMax(&s_r2, __builtin_bit_cast(int, r2));  // non-negative floats order like their bits
@@ -244,104 +310,183 @@ __global__ __launch_bounds__(256) void bps_mfma_kernel(const float* __restrict__
     const bool cloud_bad = s_bad != 0;
     const float R = __builtin_sqrtf(__builtin_bit_cast(float, s_r2));
 
-    float bx[NT], by[NT], bz[NT], b1[NT], b2[NT], thr[NT];
-    bool full[NT];
-    float v1[NT], v2[NT], v3[NT], v4[NT];
-    int i1[NT], i2[NT], i3[NT];
+    // per basis point: coordinates, S = (R + |b|)^2, and whether the coarse pass can be trusted for it at all
+    auto basis_point = [&](int t, float& X, float& Y, float& Z, float& bb, float& S) {
+        int i = (slice * NW + w) * (NT * 32) + t * 32 + col;
+        i = i < P ? i : P - 1;
+        load3(basis + 3 * i, X, Y, Z);
+        bb = __builtin_fmaf(Z, Z, __builtin_fmaf(Y, Y, X * X));
+        const float nb = __builtin_sqrtf(bb);
+        S = (R + nb) * (R + nb);
+        return cloud_bad || !(__builtin_fabsf(X) < 1e3f && __builtin_fabsf(Y) < 1e3f && __builtin_fabsf(Z) < 1e3f) ||
+               !(S > 1e-20f);
+    };
+    bu32x4 B1[NT], B2[NT];
+    float k1[NT], k2[NT], k3[NT], k4[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        int i = (slice * 4 + w) * (NT * 32) + t * 32 + col;
-        i = i < P ? i : P - 1;
-        bx[t] = basis[3 * i];
-        by[t] = basis[3 * i + 1];
-        bz[t] = basis[3 * i + 2];
-        b1[t] = -2.f * (h ? by[t] : bx[t]);
-        b2[t] = h ? 1.f : -2.f * bz[t];
-        const float nb = __builtin_sqrtf(__builtin_fmaf(bz[t], bz[t], __builtin_fmaf(by[t], by[t], bx[t] * bx[t])));
-        const float S = (R + nb) * (R + nb);
-        thr[t] = S * 0x1p-19f;  // 2 eps
-        full[t] = cloud_bad ||
-                  !(__builtin_fabsf(bx[t]) < 1e3f && __builtin_fabsf(by[t]) < 1e3f && __builtin_fabsf(bz[t]) < 1e3f) ||
-                  !(S > 1e-20f);
-        v1[t] = v2[t] = v3[t] = v4[t] = __builtin_inff();
-        i1[t] = i2[t] = i3[t] = -1;
+        float bx, by, bz, bb, S;
+        basis_point(t, bx, by, bz, bb, S);
+        const Planes3 X = split3(-2.f * bx), Y = split3(-2.f * by), Z = split3(-2.f * bz);
+        const Planes3 C = split3(bb + S * 0x1p-14f);  // |b|^2 + bias; two planes of it are used: bias > 2^-16 c + eps
+        B1[t] = h ? bu32x4{pk2(Z.h, Z.h), pk2(Z.h, Z.l), pk2(ONE, ONE), pk2(ONE, C.h)}
+                  : bu32x4{pk2(X.h, X.h), pk2(X.h, X.l), pk2(Y.h, Y.h), pk2(Y.h, Y.l)};
+        B2[t] = h ? bu32x4{pk2(Z.m, Z.m), 0u, 0u, pk2(0u, C.m)} : bu32x4{pk2(X.m, X.m), 0u, pk2(Y.m, Y.m), 0u};
+        k1[t] = k2[t] = k3[t] = k4[t] = __builtin_inff();
     }
+#if defined(BPS_ABLATE) && BPS_ABLATE == 7   // staging only (timing build)
+    if (N < 0) {
+#else
     if (!cloud_bad) {
-        const float* pf = reinterpret_cast<const float*>(pts) + col * 4 + h;
-        float a1 = pf[0], a2 = pf[2];
+#endif
+        const bu32x4* pl = planes + col * 2 + h;
+        bu32x4 a = pl[0];
         for (int i = 0; i < ntile; ++i) {
-            const float c1 = a1, c2 = a2;
-            const int nx = i + 1 < ntile ? i + 1 : i;
-            a1 = pf[nx * 128];
-            a2 = pf[nx * 128 + 2];
+            const bu32x4 cur = a;
+            a = pl[(i + 1 < ntile ? i + 1 : i) * 64];
+            const unsigned iv = (unsigned)i, keep = ~127u;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, b1[t], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c2, b2[t], acc, 0, 0, 0);
-                auto min3 = [](float a, float b_, float c_) { return __builtin_fminf(__builtin_fminf(a, b_), c_); };
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bbf16x8, cur),
+                                                              __builtin_bit_cast(bbf16x8, B1[t]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bbf16x8, cur),
+                                                              __builtin_bit_cast(bbf16x8, B2[t]), acc, 0, 0, 0);
+                // (all values are positive and finite: they order like their bit patterns, and v_min_u32 comes without
+                //  the quieting v_max the compiler puts in front of a two-operand v_min_f32)
+                auto min3 = [](float a_, float b_, float c_) { return __builtin_fminf(__builtin_fminf(a_, b_), c_); };
+                auto min2 = [](float a_, float b_) {
+                    const unsigned ua = __builtin_bit_cast(unsigned, a_), ub = __builtin_bit_cast(unsigned, b_);
+                    return __builtin_bit_cast(float, __builtin_elementwise_min(ua, ub));
+                };
                 const float m0 = min3(acc[0], acc[1], acc[2]), m1 = min3(acc[3], acc[4], acc[5]);
                 const float m2 = min3(acc[6], acc[7], acc[8]), m3 = min3(acc[9], acc[10], acc[11]);
                 const float m4 = min3(acc[12], acc[13], acc[14]);
-                const float m = min3(min3(m0, m1, m2), min3(m3, m4, acc[15]), __builtin_inff());
-                const bool l1 = m < v1[t], l2 = m < v2[t], l3 = m < v3[t];
-                int n3 = l3 ? i : i3[t], n2 = l2 ? i : i2[t];  // plain selects (nested ones become branches)
-                n3 = l2 ? i2[t] : n3;
-                n2 = l1 ? i1[t] : n2;
-                i3[t] = n3;
-                i2[t] = n2;
-                i1[t] = l1 ? i : i1[t];
-                v4[t] = __builtin_amdgcn_fmed3f(v3[t], v4[t], m);
-                v3[t] = __builtin_amdgcn_fmed3f(v2[t], v3[t], m);
-                v2[t] = __builtin_amdgcn_fmed3f(v1[t], v2[t], m);
-                v1[t] = __builtin_fminf(v1[t], m);
+#if defined(BPS_ABLATE) && BPS_ABLATE == 4   // matrix instructions only
+                const float m = acc[0];
+                (void)m0; (void)m1; (void)m2; (void)m3; (void)m4;
+#else
+                const float m = min2(min3(m0, m1, m2), min3(m3, m4, acc[15]));
+#endif
+                float kf;  // (m & ~127) | tile index, one instruction
+                asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(kf) : "v"(m), "v"(keep), "v"(iv));
+                k4[t] = __builtin_amdgcn_fmed3f(k3[t], k4[t], kf);
+                k3[t] = __builtin_amdgcn_fmed3f(k2[t], k3[t], kf);
+                k2[t] = __builtin_amdgcn_fmed3f(k1[t], k2[t], kf);
+                k1[t] = min2(k1[t], kf);
             }
         }
     }
+    // ---- exact stage.  Every evaluated block offers (d2 bits, j) as one 64-bit key to its basis point's LDS slot:
+    // ds_min_u64 IS the lexicographic minimum, for the two half-waves and for blocks in any order.  The candidate blocks
+    // (keys <= lim, lim from the smaller k1 of the two half-waves) go onto a per-wave work list and are evaluated 64 at
+    // a time by all lanes: ~128 winners + a few % further candidates = 3 passes of 16 rows, where "every lane its own
+    // blocks" took 4 passes for the first candidates alone and 2 mostly idle ones per basis tile for the others.
+    // The operand planes are dead once every wave has left the main loop: slots and lists live there.
+    __syncthreads();
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(planes) + w * (NT * 32 + kBpsQueue / 2);
+    unsigned* q = reinterpret_cast<unsigned*>(slot + NT * 32);
+    slot[lane] = ~0ull;
+    slot[lane + 64] = ~0ull;
+    if (lane == 0) s_qn[w] = 0;
+    __builtin_amdgcn_wave_barrier();
+    auto block = [&](int i, int hh, float X, float Y, float Z, float& bb, int& bj) {
+        // 16 rows of point tile i as half-wave hh sees them, the contract's arithmetic; rows ascend: strict '<'
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int j0 = i * 32 + 8 * g + 4 * hh;
+            const bool in = j0 < N;  // N % 4 == 0: four points or none
+            const bf32x4* pq = reinterpret_cast<const bf32x4*>(c + 3 * (in ? j0 : 0));
+            const bf32x4 p0 = pq[0], p1 = pq[1], p2 = pq[2];
+            // two points per packed instruction (v_pk_add / v_pk_mul / v_pk_fma_f32: each half bit-identical to dist2())
+            const f32x2 bX = {X, X}, bY = {Y, Y}, bZ = {Z, Z};
+            const f32x2 ax = f32x2{p0[0], p0[3]} - bX, ay = f32x2{p0[1], p1[0]} - bY, az = f32x2{p0[2], p1[1]} - bZ;
+            const f32x2 cx = f32x2{p1[2], p2[1]} - bX, cy = f32x2{p1[3], p2[2]} - bY, cz = f32x2{p2[0], p2[3]} - bZ;
+            const f32x2 da = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
+            const f32x2 dc = __builtin_elementwise_fma(cz, cz, __builtin_elementwise_fma(cy, cy, cx * cx));
+            const float d0 = da[0], d1 = da[1], d2 = dc[0], d3 = dc[1];
+            bool lt = in & (d0 < bb);
+            bb = lt ? d0 : bb, bj = lt ? j0 : bj;
+            lt = in & (d1 < bb);
+            bb = lt ? d1 : bb, bj = lt ? j0 + 1 : bj;
+            lt = in & (d2 < bb);
+            bb = lt ? d2 : bb, bj = lt ? j0 + 2 : bj;
+            lt = in & (d3 < bb);
+            bb = lt ? d3 : bb, bj = lt ? j0 + 3 : bj;
+        }
+    };
+    auto offer = [&](int bl, float bb, int bj) {
+        if (bb < __builtin_inff())
+            atomicMin(&slot[bl], ((unsigned long long)__builtin_bit_cast(unsigned, bb) << 32) | (unsigned)bj);
+    };
+    auto tile_of = [](float k) { return (int)(__builtin_bit_cast(unsigned, k) & 127u); };
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        float best = __builtin_inff();
-        int bid = 0;
-        const float X = bx[t], Y = by[t], Z = bz[t];
-        auto block = [&](int i) {  // this lane's 16 rows of point tile i, the contract's arithmetic
-#pragma unroll 4
-            for (int r = 0; r < 16; ++r) {
-                const int j = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const Pt4 p = pts[j];
-                const float d2 = dist2(p.x, p.y, p.z, X, Y, Z);
-                const bool take = (j < N) & ((d2 < best) | ((d2 == best) & (j < bid)));
-                best = take ? d2 : best;
-                bid = take ? j : bid;
-            }
-        };
-        const float lim = v1[t] + thr[t];
-#if defined(BPS_ABLATE) && BPS_ABLATE == 1   // no exact stage at all
-        best = v1[t];
-        bid = i1[t];
-#elif defined(BPS_ABLATE) && BPS_ABLATE == 2  // first block only
-        block(i1[t] < 0 ? 0 : i1[t]);
-#elif defined(BPS_ABLATE) && BPS_ABLATE == 3  // no full fallback
-        block(i1[t] < 0 ? 0 : i1[t]);
-        if (i2[t] >= 0 && !(v2[t] > lim)) block(i2[t]);
-        if (i3[t] >= 0 && !(v3[t] > lim)) block(i3[t]);
+        float X, Y, Z, bq, S;  // (again from memory: nothing of this lives through the main loop)
+        const bool full = basis_point(t, X, Y, Z, bq, S);
+        const int bl = t * 32 + col;
+        const float o1 = __shfl_xor(k1[t], 32);
+        const float g1 = __builtin_bit_cast(float, __builtin_elementwise_min(__builtin_bit_cast(unsigned, k1[t]),
+                                                                             __builtin_bit_cast(unsigned, o1)));
+        const float lim = g1 + (S * 0x1.4p-18f + g1 * 0x1p-16f);  // 2 eps: 2 * 35u S rounded up, + 2 * 2^-17 v
+#if defined(BPS_ABLATE)   // timing builds (tools/exp/bps_ablate.sh): no exact stage, results are NOT the answer
+        if (k1[t] == g1) slot[bl] = ((unsigned long long)__builtin_bit_cast(unsigned, g1) << 32) | (unsigned)tile_of(g1);
+        (void)full;
 #else
-        if (full[t] || !(v4[t] > lim)) {
-            for (int i = 0; i < ntile; ++i) block(i);
+        if (full || !(k4[t] > lim)) {
+            float bb = __builtin_inff();
+            int bj = 0;
+            for (int i = 0; i < ntile; ++i) block(i, h, X, Y, Z, bb, bj);
+            offer(bl, bb, bj);
         } else {
-            block(i1[t]);
-            if (i2[t] >= 0 && !(v2[t] > lim)) block(i2[t]);
-            if (i3[t] >= 0 && !(v3[t] > lim)) block(i3[t]);
+            // keys ascend: the candidates are a prefix of (k1, k2, k3)
+            const int cnt = (!(k1[t] > lim) ? 1 : 0) + (!(k2[t] > lim) ? 1 : 0) + (!(k3[t] > lim) ? 1 : 0);
+            if (cnt > 0) {
+                const int pos = atomicAdd(&s_qn[w], cnt);
+                const float ks[3] = {k1[t], k2[t], k3[t]};
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                    if (e < cnt) {
+                        if (pos + e < kBpsQueue) {
+                            q[pos + e] = ((unsigned)bl << 8) | ((unsigned)h << 7) | (unsigned)tile_of(ks[e]);
+                        } else {  // list full: in place
+                            float b2 = __builtin_inff();
+                            int j2 = 0;
+                            block(tile_of(ks[e]), h, X, Y, Z, b2, j2);
+                            offer(bl, b2, j2);
+                        }
+                    }
+            }
         }
 #endif
-        const float od = __shfl_xor(best, 32);
-        const int oi = __shfl_xor(bid, 32);
-        const bool take = (od < best) | ((od == best) & (oi < bid));
-        best = take ? od : best;
-        bid = take ? oi : bid;
-        const int i = (slice * 4 + w) * (NT * 32) + t * 32 + col;
-        if (h == 0 && i < P) {
-            dists[(size_t)b * P + i] = __builtin_sqrtf(best);
-            if (ids) ids[(size_t)b * P + i] = bid;
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int n = min(s_qn[w], kBpsQueue);
+        const int first = (slice * NW + w) * (NT * 32);
+        for (int base = 0; base < n; base += 64) {
+            if (base + lane < n) {
+                const unsigned it = q[base + lane];
+                const int bl = it >> 8;
+                int i = first + bl;
+                i = i < P ? i : P - 1;
+                float X, Y, Z, bb = __builtin_inff();
+                int bj = 0;
+                load3(basis + 3 * i, X, Y, Z);
+                block(it & 127u, (it >> 7) & 1u, X, Y, Z, bb, bj);
+                offer(bl, bb, bj);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int bl = lane + 64 * e, i = first + bl;
+            const unsigned long long k = slot[bl];
+            if (i < P) {
+                const bool none = k == ~0ull;  // nothing was below +inf: the scan's answer
+                dists[(size_t)b * P + i] = none ? __builtin_inff() : __builtin_sqrtf(__builtin_bit_cast(float, (unsigned)(k >> 32)));
+                if (ids) ids[(size_t)b * P + i] = none ? 0 : (int)(unsigned)k;
+            }
         }
     }
 }
@@ -380,11 +525,17 @@ int bps_encode_launch(const float* clouds, int B, int N, const float* basis, int
         const char* e = getenv("DGG_BPS");
         return e && !strcmp(e, "valu");
     }();
-    if (nchunk <= 1 && N >= 64 && N <= 4096 && !valu_only) {
-        const int g5 = (P + 511) / 512;
-        const size_t lds = (size_t)((N + 31) / 32) * 32 * sizeof(Pt4);
-        hipLaunchKernelGGL((bps_mfma_kernel<4>), dim3((unsigned)g5 * B), dim3(256), lds, st, clouds, N, basis, P, dists, ids,
-                           B, g5);
+    if (nchunk <= 1 && N >= 64 && N <= kBpsMfmaMaxN && N % 4 == 0 && ((uintptr_t)clouds & 15) == 0 && !valu_only) {
+        constexpr int NW = BPS_NW;
+        const int g = (P + NW * 128 - 1) / (NW * 128);
+        size_t lds = (size_t)((N + 31) / 32) * 32 * 32;                      // operand planes, then reused by the exact stage:
+        const size_t lds_exact = (size_t)NW * (4 * 32 + kBpsQueue / 2) * 8;   // per wave 128 slots + the work list
+        lds = lds > lds_exact ? lds : lds_exact;
+        static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&bps_mfma_kernel<4, NW>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+        (void)big_lds;
+        hipLaunchKernelGGL((bps_mfma_kernel<4, NW>), dim3((unsigned)g * B), dim3(NW * 64), lds, st, clouds, N, basis, P,
+                           dists, ids, B, g);
     } else if (nchunk <= 1) {
         hipLaunchKernelGGL((bps_batched_kernel<4, 16, 0>), dim3((unsigned)gx * B), dim3(256), 0, st, clouds, N, basis, P,
                            dists, ids, B, gx, 1, N);

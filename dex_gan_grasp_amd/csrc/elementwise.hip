@@ -1373,7 +1373,11 @@ __global__ __launch_bounds__(256) void translate_axis_kernel(float* __restrict__
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B) return;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) transl[(size_t)i * 3 + r] -= rot9[(size_t)i * 9 + 3 * r + axis] * offset;
+    // (volatile reads: three single-dword loads, never a global_load_dwordx3 — see load3() in bps_encode.hip)
+    for (int r = 0; r < 3; ++r) {
+        const float t = static_cast<const volatile float*>(transl)[(size_t)i * 3 + r];
+        transl[(size_t)i * 3 + r] = t - rot9[(size_t)i * 9 + 3 * r + axis] * offset;
+    }
 }
 
 __global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict__ src, int lds,

@@ -104,7 +104,9 @@ __global__ __launch_bounds__(256) void gp_value_kernel(const float* __restrict__
     const int lo[3] = {0, 9, 12}, hi[3] = {9, 12, 12 + nj};
     float pen = 0.f;
     for (int b = threadIdx.x; b < B; b += 256) {
-        const float* gr = g + (size_t)b * np;
+        // (volatile: single-dword loads only — the 3-float translation part would become a global_load_dwordx3 among
+        //  dwordx4 loads, the pattern that returned late in bps_encode.hip, see load3() there)
+        const volatile float* gr = g + (size_t)b * np;
         for (int part = 0; part < 3; ++part) {
             float s = 0.f;
             for (int j = lo[part]; j < hi[part]; ++j) s = fmaf(gr[j], gr[j], s);

@@ -2,7 +2,9 @@
 
     DGG_BPS=valu python3 tools/exp/bps_ab.py run gpurun_out/bps_valu.npz [B N]
     python3 tools/exp/bps_ab.py run gpurun_out/bps_mfma.npz [B N]
-    python3 tools/exp/bps_ab.py cmp gpurun_out/bps_valu.npz gpurun_out/bps_mfma.npz
+    python3 tools/exp/bps_ab.py cmp gpurun_out/bps_valu.npz gpurun_out/bps_mfma.npz [x B N]
+cmp lists the first differing outputs and checks each side's (id, distance) pair against the contract's arithmetic on the
+CPU — a distance that is not the distance to its id came from mixed-up data, not from a tie.
 Also prints the kernel time (events over 10 launches).  The clouds: synth.make_clouds plus duplicated points, a cloud of
 identical points, a near-degenerate cloud (all points within 1e-6 of each other) and one far-away cloud.
 """
@@ -15,10 +17,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
-def run(out, B=1024, N=2048):
-    from dex_gan_grasp_amd import _lib, synth
-    dev = torch.device("cuda:0")
-    basis = np.load(os.path.join(os.path.dirname(__file__), "..", "..", "tests", "golden", "bps_real_objects.npz"))["basis"]
+def make_clouds(B, N):
+    from dex_gan_grasp_amd import synth
     clouds = synth.make_clouds(B, N, 31337)
     clouds[0, 7] = clouds[0, 3]
     clouds[0, N - 1] = clouds[0, 3]
@@ -27,6 +27,14 @@ def run(out, B=1024, N=2048):
         clouds[2] = clouds[2, :1] + 1e-6 * torch.randn((N, 3), generator=torch.Generator().manual_seed(5))
         clouds[3, : N // 2] = 3e19
         clouds[4] = clouds[4] + 50.0
+    return clouds
+
+
+def run(out, B=1024, N=2048):
+    from dex_gan_grasp_amd import _lib
+    dev = torch.device("cuda:0")
+    basis = np.load(os.path.join(os.path.dirname(__file__), "..", "..", "tests", "golden", "bps_real_objects.npz"))["basis"]
+    clouds = make_clouds(B, N)
     cl = clouds.to(dev).contiguous()
     bs = torch.from_numpy(basis).to(dev)
     P = basis.shape[0]
@@ -52,8 +60,22 @@ def cmp(a, b):
     nd = int((A["dist"] != Bz["dist"]).sum())
     print("ids differ: %d   distance bits differ: %d   of %d" % (ni, nd, A["ids"].size))
     if ni or nd:
-        w = np.argwhere(A["ids"] != Bz["ids"])[:10]
+        w = np.argwhere((A["ids"] != Bz["ids"]) | (A["dist"] != Bz["dist"]))[:10]
         print(w, A["ids"][tuple(w.T)], Bz["ids"][tuple(w.T)])
+        # is each side's (id, distance) pair self-consistent?  (the contract's arithmetic on the CPU)
+        from dex_gan_grasp_amd import synth
+        import torch
+        B, N = A["ids"].shape[0], int(sys.argv[5]) if len(sys.argv) > 5 else 2048
+        clouds = make_clouds(B, N)
+        basis = np.load(os.path.join(os.path.dirname(__file__), "..", "..", "tests", "golden", "bps_real_objects.npz"))["basis"]
+        f = np.float32
+        for b, i in w:
+            for name, Z in (("a", A), ("b", Bz)):
+                j = int(Z["ids"][b, i])
+                d = clouds[b, j].numpy().astype(f) - basis[i]
+                d2 = f(np.float64(d[2]) * np.float64(d[2]) + np.float64(f(np.float64(d[1]) * np.float64(d[1]) + np.float64(f(d[0] * d[0])))))
+                print(name, "cloud", b, "basis", i, "id", j, "dist bits", hex(int(Z["dist"][b, i]) & 0xffffffff), "sqrt(d2(id)) bits",
+                      hex(int(np.sqrt(d2).astype(f).view(np.int32)) & 0xffffffff))
         sys.exit(1)
 
 

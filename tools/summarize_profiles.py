@@ -13,7 +13,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-dst = os.path.join(ROOT, "profiles")
+dst = os.environ.get("PROFILES_DST") or os.path.join(ROOT, "profiles")   # PROFILES_DST: scratch summaries of an experiment
+os.makedirs(dst, exist_ok=True)
 
 
 def rows(path):
@@ -64,8 +65,10 @@ specs = [
     ("p4_batched_e", "gemm_p4_kernel<false>", "gemm_p4_batched_e", {"M": 1024, "N": 2304, "K": 4096, "splits": 5},
      "python3 tools/microbench.py planes --m 1024 --n 2304 --k 4096 --splits 5 --iters 10", 2.0 * 1024 * 2304 * 4096,
      6 * (1024 * 4096 + 2304 * 4096) + 5 * 4 * 1024 * 2304),
-    ("bps", "bps_batched_kernel", "bps_encode", {"B": 1024, "N": 2048, "P": 4096},
+    ("bps", "bps_mfma_kernel", "bps_encode", {"B": 1024, "N": 2048, "P": 4096},
      "python3 tools/microbench.py bps --iters 5", 1024 * 2048 * 4096 * 8.0, 1024 * (2048 * 12 + 4096 * 8) + 4096 * 12),
+    ("bps_valu", "bps_batched_kernel", "bps_encode_valu", {"B": 1024, "N": 2048, "P": 4096},
+     "DGG_BPS=valu python3 tools/microbench.py bps --iters 5", 1024 * 2048 * 4096 * 8.0, 1024 * (2048 * 12 + 4096 * 8) + 4096 * 12),
 ]
 # FETCH_SIZE factor per kernel.  The guide's x2 is for 16-B-per-lane vector loads (the GEMMs' LDS-DMA); other widths have
 # to be calibrated on a known byte count: bps_batched_kernel reads its clouds through the scalar cache only, and with
@@ -87,7 +90,7 @@ for name, ksub, outname, shape, cmd, flops, alg_bytes in specs:
                                                 "-> doubled; WRITE_SIZE exact"))
     fetch = c.get("FETCH_SIZE", 0.0) * 1024 * ffac   # KB
     write = c.get("WRITE_SIZE", 0.0) * 1024
-    out = {"round": int(tag[1:]), "kernel": ksub, "shape": shape,
+    out = {"round": int("".join(ch for ch in tag if ch.isdigit())[:2] or 0), "kernel": ksub, "shape": shape,
            "command": "rocprofv3 --pmc <counters> -- " + cmd + " (one pass per counter group; kernel-trace in its own run)",
            "avg_duration_ns_kernel_trace": dur, "launches_in_trace": calls,
            "FETCH_SIZE_KB_raw": c.get("FETCH_SIZE"), "WRITE_SIZE_KB_raw": c.get("WRITE_SIZE"),
