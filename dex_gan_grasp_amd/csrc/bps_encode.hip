@@ -25,16 +25,12 @@ __device__ __forceinline__ float dist2(float x, float y, float z, float bx, floa
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Three consecutive floats as THREE single-dword loads.  Left to itself the compiler merges them into one
-// global_load_dwordx3, and on gfx950 (ROCm 7.2) a dwordx3 load issued among dwordx4 loads was seen to deliver its data
-// AFTER the s_waitcnt vmcnt(N) that in-order return says covers it: the exact stage below then computed distances
-// against the previous work item's basis point in lanes 32-63 — a handful of 4.2 M outputs wrong in one run of three,
-// only with other workgroups busy on the same CU (tools/exp/bps_race.sh: 9 of 24 runs with the dwordx3, 0 of 20 without).
+// Three consecutive floats (a basis point, a cloud point).  The compiler makes one global_load_dwordx3 of it; where such a
+// load is in flight TOGETHER with 16-byte loads its consumer must wait with vmcnt(0) — see block() in bps_mfma_kernel.
 __device__ __forceinline__ void load3(const float* p, float& x, float& y, float& z) {
-    const volatile float* v = p;
-    x = v[0];
-    y = v[1];
-    z = v[2];
+    x = p[0];
+    y = p[1];
+    z = p[2];
 }
 
 // Batched clouds.  Two things keep the vector ALU's issue slots for the distance arithmetic itself:
@@ -311,10 +307,20 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
     const float R = __builtin_sqrtf(__builtin_bit_cast(float, s_r2));
 
     // per basis point: coordinates, S = (R + |b|)^2, and whether the coarse pass can be trusted for it at all
-    auto basis_point = [&](int t, float& X, float& Y, float& Z, float& bb, float& S) {
-        int i = (slice * NW + w) * (NT * 32) + t * 32 + col;
-        i = i < P ? i : P - 1;
-        load3(basis + 3 * i, X, Y, Z);
+    // (the lane's NT basis points are loaded together and waited for with vmcnt(0), see block())
+    auto load_basis = [&](float (&X)[NT], float (&Y)[NT], float (&Z)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int i = (slice * NW + w) * (NT * 32) + t * 32 + col;
+            i = i < P ? i : P - 1;
+            load3(basis + 3 * i, X[t], Y[t], Z[t]);
+        }
+        static_assert(NT == 4, "the wait below names 4 basis points");
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(X[0]), "+v"(Y[0]), "+v"(Z[0]), "+v"(X[1]), "+v"(Y[1]), "+v"(Z[1]), "+v"(X[2]), "+v"(Y[2]),
+                       "+v"(Z[2]), "+v"(X[3]), "+v"(Y[3]), "+v"(Z[3]));
+    };
+    auto basis_point = [&](float X, float Y, float Z, float& bb, float& S) {
         bb = __builtin_fmaf(Z, Z, __builtin_fmaf(Y, Y, X * X));
         const float nb = __builtin_sqrtf(bb);
         S = (R + nb) * (R + nb);
@@ -323,16 +329,21 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
     };
     bu32x4 B1[NT], B2[NT];
     float k1[NT], k2[NT], k3[NT], k4[NT];
+    {
+    float bxs[NT], bys[NT], bzs[NT];
+    load_basis(bxs, bys, bzs);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        float bx, by, bz, bb, S;
-        basis_point(t, bx, by, bz, bb, S);
+        const float bx = bxs[t], by = bys[t], bz = bzs[t];
+        float bb, S;
+        basis_point(bx, by, bz, bb, S);
         const Planes3 X = split3(-2.f * bx), Y = split3(-2.f * by), Z = split3(-2.f * bz);
         const Planes3 C = split3(bb + S * 0x1p-14f);  // |b|^2 + bias; two planes of it are used: bias > 2^-16 c + eps
         B1[t] = h ? bu32x4{pk2(Z.h, Z.h), pk2(Z.h, Z.l), pk2(ONE, ONE), pk2(ONE, C.h)}
                   : bu32x4{pk2(X.h, X.h), pk2(X.h, X.l), pk2(Y.h, Y.h), pk2(Y.h, Y.l)};
         B2[t] = h ? bu32x4{pk2(Z.m, Z.m), 0u, 0u, pk2(0u, C.m)} : bu32x4{pk2(X.m, X.m), 0u, pk2(Y.m, Y.m), 0u};
         k1[t] = k2[t] = k3[t] = k4[t] = __builtin_inff();
+    }
     }
 #if defined(BPS_ABLATE) && BPS_ABLATE == 7   // staging only (timing build)
     if (N < 0) {
@@ -392,12 +403,28 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
     __builtin_amdgcn_wave_barrier();
     auto block = [&](int i, int hh, float X, float Y, float Z, float& bb, int& bj) {
         // 16 rows of point tile i as half-wave hh sees them, the contract's arithmetic; rows ascend: strict '<'
+        bf32x4 pt[4][3];
+        bool in[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int j0 = i * 32 + 8 * g + 4 * hh;
-            const bool in = j0 < N;  // N % 4 == 0: four points or none
-            const bf32x4* pq = reinterpret_cast<const bf32x4*>(c + 3 * (in ? j0 : 0));
-            const bf32x4 p0 = pq[0], p1 = pq[1], p2 = pq[2];
+            in[g] = j0 < N;  // N % 4 == 0: four points or none
+            const bf32x4* pq = reinterpret_cast<const bf32x4*>(c + 3 * (in[g] ? j0 : 0));
+            pt[g][0] = pq[0], pt[g][1] = pq[1], pt[g][2] = pq[2];
+        }
+        // Everything this evaluation loaded — the 12 point vectors and the caller's basis point — is waited for HERE,
+        // with vmcnt(0), not by the compiler's counted waits: with the basis point's load (12 B at a 4-byte aligned
+        // address, compiled to global_load_dwordx3 or dwordx2 + dword) among the 16-byte point loads, lanes 32-63
+        // computed distances from registers the load had not written yet, a handful of 4.2 M outputs in one run of
+        // three and only with another workgroup busy on the CU (tools/exp/bps_race.sh; ROCm 7.2, gfx950).
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(pt[0][0]), "+v"(pt[0][1]), "+v"(pt[0][2]), "+v"(pt[1][0]), "+v"(pt[1][1]), "+v"(pt[1][2]),
+                       "+v"(pt[2][0]), "+v"(pt[2][1]), "+v"(pt[2][2]), "+v"(pt[3][0]), "+v"(pt[3][1]), "+v"(pt[3][2]),
+                       "+v"(X), "+v"(Y), "+v"(Z));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int j0 = i * 32 + 8 * g + 4 * hh;
+            const bf32x4 p0 = pt[g][0], p1 = pt[g][1], p2 = pt[g][2];
             // two points per packed instruction (v_pk_add / v_pk_mul / v_pk_fma_f32: each half bit-identical to dist2())
             const f32x2 bX = {X, X}, bY = {Y, Y}, bZ = {Z, Z};
             const f32x2 ax = f32x2{p0[0], p0[3]} - bX, ay = f32x2{p0[1], p1[0]} - bY, az = f32x2{p0[2], p1[1]} - bZ;
@@ -405,13 +432,13 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
             const f32x2 da = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
             const f32x2 dc = __builtin_elementwise_fma(cz, cz, __builtin_elementwise_fma(cy, cy, cx * cx));
             const float d0 = da[0], d1 = da[1], d2 = dc[0], d3 = dc[1];
-            bool lt = in & (d0 < bb);
+            bool lt = in[g] & (d0 < bb);
             bb = lt ? d0 : bb, bj = lt ? j0 : bj;
-            lt = in & (d1 < bb);
+            lt = in[g] & (d1 < bb);
             bb = lt ? d1 : bb, bj = lt ? j0 + 1 : bj;
-            lt = in & (d2 < bb);
+            lt = in[g] & (d2 < bb);
             bb = lt ? d2 : bb, bj = lt ? j0 + 2 : bj;
-            lt = in & (d3 < bb);
+            lt = in[g] & (d3 < bb);
             bb = lt ? d3 : bb, bj = lt ? j0 + 3 : bj;
         }
     };
@@ -420,10 +447,13 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
             atomicMin(&slot[bl], ((unsigned long long)__builtin_bit_cast(unsigned, bb) << 32) | (unsigned)bj);
     };
     auto tile_of = [](float k) { return (int)(__builtin_bit_cast(unsigned, k) & 127u); };
+    float Xs[NT], Ys[NT], Zs[NT];  // (again from memory: nothing of this lives through the main loop)
+    load_basis(Xs, Ys, Zs);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        float X, Y, Z, bq, S;  // (again from memory: nothing of this lives through the main loop)
-        const bool full = basis_point(t, X, Y, Z, bq, S);
+        const float X = Xs[t], Y = Ys[t], Z = Zs[t];
+        float bq, S;
+        const bool full = basis_point(X, Y, Z, bq, S);
         const int bl = t * 32 + col;
         const float o1 = __shfl_xor(k1[t], 32);
         const float g1 = __builtin_bit_cast(float, __builtin_elementwise_min(__builtin_bit_cast(unsigned, k1[t]),

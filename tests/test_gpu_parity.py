@@ -203,6 +203,56 @@ def test_bps_block_argmin_keeps_lowest_index_rule():
     assert (ids[3] >= 50).all()
 
 
+@pytest.mark.parametrize("B,N,P", [(64, 104, 4096), (40, 2560, 4096), (33, 64, 1500), (200, 1000, 4097), (48, 2048, 130)])
+def test_bps_matrix_path_keeps_the_scan_answer(B, N, P):
+    """The many-clouds path (64 <= N <= 2560, N % 4 == 0, 16-byte aligned clouds): the bf16x3 coarse pass on the matrix
+    cores only SELECTS candidate blocks, the contract's arithmetic decides.  Ties inside a block, across blocks and
+    across the two half-waves of a tile, a cloud of identical points, a cloud whose points sit within 1e-6 of each other
+    (every block a candidate -> the all-points fallback), overflowing coordinates (-> the fallback for the whole cloud),
+    a cloud far from the origin (wide candidate threshold), padded last tiles (N % 32 != 0), ragged basis counts and the
+    largest N must give the oracle's ids and distance bits.  Also: the same clouds at a pointer that is NOT 16-byte
+    aligned take the vector-ALU scan — same bits."""
+    ops, _lib = _ops()
+    from oracle import bps_oracle
+    basis = H.load("bps_real_objects.npz")["basis"]
+    if P > basis.shape[0]:
+        basis = np.concatenate([basis, basis[:P - basis.shape[0]] * np.float32(0.5)])   # (duplicated directions: ties between basis points are harmless)
+    basis = np.ascontiguousarray(basis[:P])
+    clouds = synth.make_clouds(B, N, 7000 + B + N)
+    clouds[0, 5] = clouds[0, 1]            # same block (rows 1 and 5 of tile 0 belong to different half-waves)
+    clouds[0, 9] = clouds[0, 1]            # same half-wave, next row group
+    clouds[0, N - 1] = clouds[0, 1]        # last tile
+    clouds[0, 40] = clouds[0, 2]           # another tile
+    clouds[1, :] = clouds[1, 0]            # every point the same: index 0 everywhere
+    clouds[2] = clouds[2, :1] + 1e-6 * torch.randn((N, 3), generator=torch.Generator().manual_seed(5))
+    clouds[3, : N // 2] = 3e19             # the finite half wins
+    clouds[4] = clouds[4] + 50.0           # far from the origin
+    clouds[5, :] = 3e19                    # nothing is below +inf: index 0, dist +inf
+    clouds[6, 7] = float("nan")            # a NaN point never wins
+    dist, ids = ops.bps_encode(clouds.to(DEV), torch.from_numpy(basis).to(DEV))
+    dist, ids = dist.cpu().numpy(), ids.cpu().numpy()
+    for b in sorted(set(range(8)) | {B // 2, B - 1}):
+        od, oi = bps_oracle.encode_f32(clouds[b].numpy(), basis)
+        assert (ids[b] == oi).all(), (b, int((ids[b] != oi).sum()))
+        assert (dist[b].view(np.int32) == od.view(np.int32)).all(), b
+    assert not np.isin(ids[0], (5, 9, N - 1, 40)).any()
+    assert (ids[1] == 0).all() and (ids[5] == 0).all() and np.isinf(dist[5]).all() and not (ids[6] == 7).any()
+    # distances only (ids = NULL), and the unaligned-pointer route
+    lib = _lib.lib()
+    flat = torch.empty((B * N * 3 + 1,), device=DEV)
+    flat[1:] = clouds.to(DEV).reshape(-1)
+    off = flat[1:]
+    assert _lib.ptr(off).value % 16 == 4
+    bs = torch.from_numpy(basis).to(DEV)
+    d2, i2 = torch.empty((B, P), device=DEV), torch.empty((B, P), device=DEV, dtype=torch.int32)
+    _lib.check(lib.dgg_bps_encode(_lib.ptr(off), B, N, _lib.ptr(bs), P, _lib.ptr(d2), _lib.ptr(i2), _lib.stream_ptr()))
+    assert (d2.cpu().numpy().view(np.int32) == dist.view(np.int32)).all() and (i2.cpu().numpy() == ids).all()
+    d3 = torch.empty((B, P), device=DEV)
+    cl = clouds.to(DEV).contiguous()
+    _lib.check(lib.dgg_bps_encode(_lib.ptr(cl), B, N, _lib.ptr(bs), P, _lib.ptr(d3), None, _lib.stream_ptr()))
+    assert (d3.cpu().numpy().view(np.int32) == dist.view(np.int32)).all()
+
+
 @pytest.mark.parametrize("B,N", [(1, 3001), (2, 20000), (5, 777)])
 def test_bps_few_clouds_ranges_keep_lowest_index_rule(B, N):
     """Few clouds with many points (the robot path) are scanned as ranges that meet in the output arrays through
