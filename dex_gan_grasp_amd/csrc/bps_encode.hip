@@ -494,7 +494,8 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
     {
         const int n = min(s_qn[w], kBpsQueue);
         const int first = (slice * NW + w) * (NT * 32);
-        for (int base = 0; base < n; base += 64) {
+        int base = 0;
+        for (; n - base > 16; base += 64) {
             if (base + lane < n) {
                 const unsigned it = q[base + lane];
                 const int bl = it >> 8;
@@ -506,6 +507,33 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
                 block(it & 127u, (it >> 7) & 1u, X, Y, Z, bb, bj);
                 offer(bl, bb, bj);
             }
+        }
+        // the last <= 16 entries (the usual case: 128 winners fill two passes, a handful of further candidates remain):
+        // four lanes per entry, four rows each — a quarter of a pass
+        if (base + (lane >> 2) < n) {
+            const unsigned it = q[base + (lane >> 2)];
+            const int bl = it >> 8;
+            int i = first + bl;
+            i = i < P ? i : P - 1;
+            float X, Y, Z, bb = __builtin_inff();
+            int bj = 0;
+            load3(basis + 3 * i, X, Y, Z);
+            const int j0 = (int)(it & 127u) * 32 + 8 * (lane & 3) + 4 * (int)((it >> 7) & 1u);
+            const bool in = j0 < N;
+            const bf32x4* pq = reinterpret_cast<const bf32x4*>(c + 3 * (in ? j0 : 0));
+            bf32x4 p0 = pq[0], p1 = pq[1], p2 = pq[2];
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(X), "+v"(Y), "+v"(Z));
+            const float d0 = dist2(p0[0], p0[1], p0[2], X, Y, Z), d1 = dist2(p0[3], p1[0], p1[1], X, Y, Z);
+            const float d2 = dist2(p1[2], p1[3], p2[0], X, Y, Z), d3 = dist2(p2[1], p2[2], p2[3], X, Y, Z);
+            bool lt = in & (d0 < bb);
+            bb = lt ? d0 : bb, bj = lt ? j0 : bj;
+            lt = in & (d1 < bb);
+            bb = lt ? d1 : bb, bj = lt ? j0 + 1 : bj;
+            lt = in & (d2 < bb);
+            bb = lt ? d2 : bb, bj = lt ? j0 + 2 : bj;
+            lt = in & (d3 < bb);
+            bb = lt ? d3 : bb, bj = lt ? j0 + 3 : bj;
+            offer(bl, bb, bj);
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll

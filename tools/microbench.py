@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmarks used for the rocprofv3 runs under profiles/ (GEMM roofline shape, BPS encode).
     python tools/microbench.py gemm [--iters N]     # the 128x128 NT GEMM kernel (bf16x3 by default, DGG_GEMM_ALGO=f32 for the f32 MFMA) M=1024 N=768 K=4613
-    python tools/microbench.py bps  [--iters N]     # bps_batched_kernel: 1024 clouds x 2048 points x 4096 basis
+    python tools/microbench.py bps  [--iters N]     # bps_mfma_kernel: 1024 clouds x 2048 points x 4096 basis (DGG_BPS=valu: the scan)
 """
 import argparse
 import ctypes as C
