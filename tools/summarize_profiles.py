@@ -70,11 +70,12 @@ specs = [
     ("bps_valu", "bps_batched_kernel", "bps_encode_valu", {"B": 1024, "N": 2048, "P": 4096},
      "DGG_BPS=valu python3 tools/microbench.py bps --iters 5", 1024 * 2048 * 4096 * 8.0, 1024 * (2048 * 12 + 4096 * 8) + 4096 * 12),
 ]
-# FETCH_SIZE factor per kernel.  The guide's x2 is for 16-B-per-lane vector loads (the GEMMs' LDS-DMA); other widths have
-# to be calibrated on a known byte count: bps_batched_kernel reads its clouds through the scalar cache only, and with
-# every cloud fetched once per XCD group the raw counter gives 25.4 MB against 25.17 MB of clouds + 48 KB of basis — exact.
-FETCH_FACTOR = {"bps": (1.0, "scalar (s_load) reads: FETCH_SIZE calibrated exact on this kernel's known 25.2 MB of clouds; "
-                              "WRITE_SIZE exact")}
+# FETCH_SIZE factor per kernel.  The guide's x2 is for 16-B-per-lane vector loads (the GEMMs' LDS-DMA; bps_mfma_kernel's
+# staging and exact stage: raw 13.0 MB x 2 = 26 MB against 25.2 MB of clouds + 48 KB of basis).  Other widths have to be
+# calibrated on a known byte count: bps_batched_kernel (the vector-ALU scan, DGG_BPS=valu) reads its clouds through the
+# scalar cache, factor 1.
+FETCH_FACTOR = {"bps_valu": (1.0, "scalar (s_load) reads: FETCH_SIZE taken as is (calibrated in round 2 on this kernel's "
+                                   "known 25.2 MB of clouds); WRITE_SIZE exact")}
 for name, ksub, outname, shape, cmd, flops, alg_bytes in specs:
     c = {}
     n = {}
