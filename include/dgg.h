@@ -92,7 +92,12 @@ int64_t dgg_workspace_bytes(int net, const dgg_cfg* cfg, int batch); /* activati
 
 /* A1 — replaces bps_torch.encode as called at data/bps_encoder.py:33 and
  * dexgangrasp_real_robot.py:139.  clouds (B,N,3), basis (P,3) -> dists (B,P), ids (B,P) (ids may
- * be NULL).  id = argmin_j |b - x_j|^2 with strict '<' (lowest j wins ties); dist = sqrt of it. */
+ * be NULL).  id = argmin_j |b - x_j|^2 with strict '<' (lowest j wins ties); dist = sqrt of it.
+ * Every shape gives the same bits (d2 = fmaf(dz,dz,fmaf(dy,dy,dx*dx))); what differs is the kernel:
+ * many clouds with 64 <= N <= 2560, N % 4 == 0 and `clouds` 16-byte aligned take the matrix-core
+ * path (bf16x3 coarse pass + exact re-evaluation of the candidate blocks); few
+ * clouds with many points are scanned as ranges of the cloud; everything else by the plain scan.
+ * A NaN point never wins; a basis point that nothing is closer to than +inf gets id 0, dist +inf. */
 int dgg_bps_encode(const float* clouds, int B, int N, const float* basis, int P, float* dists,
                    int32_t* ids, void* stream);
 
