@@ -10,6 +10,9 @@ the caller's stream, plus seeded synthetic grasps, delivered with the keys / sha
     [+ label (B,) int64 for the evaluator dataset, dexevaluator_data_set.py:15-175]
 `device_tensors=True` keeps the grasp tensors on the device as float32 (what a pinned-memory prefetching loader would
 hand to update_*); bps_object always stays on the device — it is produced there.
+`prefetch=True`: iteration keeps ONE batch ahead — batch i+1's clouds are encoded on a side stream, enqueued before the
+consumer enqueues step i, so the encode runs beside the step instead of in front of it (same tensors, same bits: the
+encode is deterministic and touches nothing the step reads).
 """
 from __future__ import annotations
 
@@ -24,7 +27,7 @@ class SyntheticGraspBatches:
     disjoint data (rank offset in the seed), a prefetching consumer may call `batch(i + 1)` early."""
 
     def __init__(self, cfg, batch_size, n_batches, basis, n_points=2048, device=None, seed=0, with_label=False,
-                 device_tensors=False):
+                 device_tensors=False, prefetch=False):
         self.cfg = cfg
         self.batch_size, self.n_batches, self.n_points = int(batch_size), int(n_batches), int(n_points)
         if device is None:
@@ -35,6 +38,8 @@ class SyntheticGraspBatches:
         assert self.basis.dim() == 2 and self.basis.shape[1] == 3
         self.seed, self.with_label, self.device_tensors = int(seed), bool(with_label), bool(device_tensors)
         self.last_encode_event = None
+        self.prefetch = bool(prefetch)
+        self._side = None
 
     def __len__(self):
         return self.n_batches
@@ -65,6 +70,33 @@ class SyntheticGraspBatches:
         out["obj_name"] = ["synthetic_%d_%d" % (self._seed(i), j) for j in range(self.batch_size)]
         return out
 
+    def batch_on_side_stream(self, i):
+        """Batch i produced on the loader's side stream -> (batch, event).  The consumer's stream has to wait for the
+        event before it touches the batch (`__iter__` does); the tensors are marked as used by the consumer's stream so
+        that the caching allocator does not hand their memory out early."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            b = self.batch(i)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        for v in b.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)
+        self.last_encode_event = ev
+        return b, ev
+
     def __iter__(self):
+        if not self.prefetch:
+            for i in range(self.n_batches):
+                yield self.batch(i)
+            return
+        nxt = self.batch_on_side_stream(0) if self.n_batches > 0 else None
         for i in range(self.n_batches):
-            yield self.batch(i)
+            b, ev = nxt
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            # enqueued NOW, i.e. before the consumer enqueues step i: the two overlap on the device
+            nxt = self.batch_on_side_stream(i + 1) if i + 1 < self.n_batches else None
+            yield b

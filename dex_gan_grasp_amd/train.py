@@ -122,6 +122,7 @@ def main(argv=None):
     ap.add_argument("--points", type=int, default=2048, help="points per synthetic object cloud")
     ap.add_argument("--mode", choices=["reference", "interleaved"], default="interleaved")
     ap.add_argument("--save-dir", default=None, help="checkpoint directory (default: none written)")
+    ap.add_argument("--prefetch", action="store_true", help="loaders one batch ahead: BPS encode on a side stream beside the step")
     a = ap.parse_args(argv)
     cfg = dict(synth.DEFAULT_CFG)
     cfg.update({"num_epochs": a.epochs, "batch_size": a.batch_size, "train_ffhevaluator": True, "train_ffhgenerator": True,
@@ -131,9 +132,10 @@ def main(argv=None):
     model = DexGanGrasp(cfg)
     g = torch.Generator().manual_seed(0)
     basis = (torch.rand((4096, 3), generator=g) * 0.2 - 0.1).numpy().astype(np.float32)
-    gen = SyntheticGraspBatches(cfg, a.batch_size, a.batches, basis, n_points=a.points, seed=1, device_tensors=True)
+    gen = SyntheticGraspBatches(cfg, a.batch_size, a.batches, basis, n_points=a.points, seed=1, device_tensors=True,
+                                prefetch=a.prefetch)
     eva = SyntheticGraspBatches(cfg, a.batch_size, a.batches, basis, n_points=a.points, seed=2, with_label=True,
-                                device_tensors=True)
+                                device_tensors=True, prefetch=a.prefetch)
     t0 = time.time()
     n = train(model, cfg, gen, eva, mode=a.mode, save=bool(a.save_dir),
               on_train_loss=lambda ep, it, ld: print(ep, it, {k: round(float(v), 5) for k, v in ld.items()}))

@@ -82,7 +82,8 @@ def test_interleaved_mode_ends_with_the_reference_order_parameters(tmp_path):
     """Two epochs of three batches per data set (gen_train_freq 2: steps without a generator update in between), synthetic
     clouds through dgg_bps_encode in front: the interleaved order (update_joint, look-ahead) and the reference order (two
     epoch loops) end with identical parameters, BatchNorm statistics, Adam moments and step counts — bit for bit — and
-    write loadable checkpoints where train.py writes them."""
+    write loadable checkpoints where train.py writes them.  The same with the loaders one batch ahead (BPS encode on a side
+    stream beside the step)."""
     import os
     from dex_gan_grasp_amd.train import train
     from dex_gan_grasp_amd.data.synthetic_data_set import SyntheticGraspBatches
@@ -91,7 +92,7 @@ def test_interleaved_mode_ends_with_the_reference_order_parameters(tmp_path):
     basis = H.load("bps_real_objects.npz")["basis"]
     b = 96
     out = {}
-    for mode in ("reference", "interleaved"):
+    for mode in ("reference", "interleaved", "interleaved+prefetch"):
         cfg = dict(synth.DEFAULT_CFG)
         cfg.update({"num_epochs": 2, "batch_size": b, "train_ffhevaluator": True, "train_ffhgenerator": True,
                     "save_freq": 2, "print_freq": 0, "gen_train_freq": 2, "save_dir": str(tmp_path / mode)})
@@ -99,11 +100,13 @@ def test_interleaved_mode_ends_with_the_reference_order_parameters(tmp_path):
         m = DexGanGrasp(cfg)
         m.DexGANGrasp.load_state_dict(H.gan_sd("wide"))
         m.DexEvaluator.load_state_dict(H.eva_sd("wide"))
-        gen = SyntheticGraspBatches(cfg, b, 3, basis, n_points=300, seed=1, device_tensors=True)
-        eva = SyntheticGraspBatches(cfg, b, 3, basis, n_points=300, seed=2, with_label=True, device_tensors=True)
+        ahead = mode.endswith("+prefetch")   # the loader one batch ahead: encode on a side stream beside the step
+        gen = SyntheticGraspBatches(cfg, b, 3, basis, n_points=300, seed=1, device_tensors=True, prefetch=ahead)
+        eva = SyntheticGraspBatches(cfg, b, 3, basis, n_points=300, seed=2, with_label=True, device_tensors=True,
+                                    prefetch=ahead)
         torch.manual_seed(1234)      # the latent (device generator) and the dropout seeds (host generator)
         evals = []
-        train(m, cfg, gen, eva, mode=mode, eval_fn=lambda mod, ep: evals.append(ep) or {})
+        train(m, cfg, gen, eva, mode=mode.split("+")[0], eval_fn=lambda mod, ep: evals.append(ep) or {})
         torch.cuda.synchronize()
         assert evals == [2]
         eng = m._eng()
@@ -113,5 +116,6 @@ def test_interleaved_mode_ends_with_the_reference_order_parameters(tmp_path):
         files = sorted(os.listdir(cfg["save_dir"]))
         assert any("2" in f for f in files) and len(files) >= 2, files
         assert (eng.G.step, eng.D.step, eng.E.step) == (4, 6, 6)       # gen_train_freq 2: G updates on batches 0 and 2
-    for a, c in zip(out["reference"], out["interleaved"]):
-        assert torch.equal(a, c)
+    for other in ("interleaved", "interleaved+prefetch"):
+        for a, c in zip(out["reference"], out[other]):
+            assert torch.equal(a, c), other
