@@ -413,10 +413,11 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
             pt[g][0] = pq[0], pt[g][1] = pq[1], pt[g][2] = pq[2];
         }
         // Everything this evaluation loaded — the 12 point vectors and the caller's basis point — is waited for HERE,
-        // with vmcnt(0), not by the compiler's counted waits: with the basis point's load (12 B at a 4-byte aligned
-        // address, compiled to global_load_dwordx3 or dwordx2 + dword) among the 16-byte point loads, lanes 32-63
-        // computed distances from registers the load had not written yet, a handful of 4.2 M outputs in one run of
-        // three and only with another workgroup busy on the CU (tools/exp/bps_race.sh; ROCm 7.2, gfx950).
+        // with vmcnt(0), not by the compiler's counted waits.  With those (correct IF loads return in order: the basis
+        // point's 12-byte load third among thirteen 16-byte point loads) lanes 32-63 computed, in one run of three and only
+        // with another workgroup busy on the CU, a handful of the 4.2 M distances from operands that were not the ones
+        // loaded for them; changing only that load or only this wait cures it (profiles/r03_experiments.txt 7: the
+        // elimination, and a probe that does NOT reproduce it in isolation; ROCm 7.2, gfx950).
         asm volatile("s_waitcnt vmcnt(0)"
                      : "+v"(pt[0][0]), "+v"(pt[0][1]), "+v"(pt[0][2]), "+v"(pt[1][0]), "+v"(pt[1][1]), "+v"(pt[1][2]),
                        "+v"(pt[2][0]), "+v"(pt[2][1]), "+v"(pt[2][2]), "+v"(pt[3][0]), "+v"(pt[3][1]), "+v"(pt[3][2]),
