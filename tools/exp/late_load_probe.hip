@@ -8,7 +8,8 @@
 // registers are poisoned (-1) before the round: a round that reads anything else after the counted wait is counted as
 // "early"; the same registers after vmcnt(0) are checked too ("final").
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/late_load_probe tools/exp/late_load_probe.hip && /tmp/late_load_probe [iters] [lds bytes]
-//   -DX3=0: the 12-byte row as dwordx2 + dword.
+//   -DX3=0: the 12-byte row as dwordx2 + dword.   -DCLOBBER=1: the row's address registers are overwritten by a vector
+//   move right after the next load's issue (is the address read protected?).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,14 @@ typedef float f32x3 __attribute__((ext_vector_type(3)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef X3
 #define X3 1
+#endif
+#ifndef CLOBBER   // 1: a vector move overwrites the 12-byte load's ADDRESS registers one load after its issue
+#define CLOBBER 0
+#endif
+#if CLOBBER
+#define CLOBBER_ASM "v_mov_b64 %[cp], %[hp]\n\t"
+#else
+#define CLOBBER_ASM
 #endif
 
 __global__ __launch_bounds__(512) void probe(const float* __restrict__ hot, int hot_rows, const float* __restrict__ cold,
@@ -51,6 +60,7 @@ __global__ __launch_bounds__(512) void probe(const float* __restrict__ hot, int 
             "global_load_dword %[zz], %[cp], off offset:8\n\t"
 #endif
             "global_load_dwordx4 %[p2], %[hp], off offset:32\n\t"
+            CLOBBER_ASM
             "global_load_dwordx4 %[p3], %[hp], off offset:48\n\t"
             "global_load_dwordx4 %[p4], %[hp], off offset:64\n\t"
             "global_load_dwordx4 %[p5], %[hp], off offset:80\n\t"
@@ -68,7 +78,12 @@ __global__ __launch_bounds__(512) void probe(const float* __restrict__ hot, int 
 #else
               [xy] "+&v"(xy), [zz] "+&v"(zz)
 #endif
+#if CLOBBER
+              , [cp] "+&v"(cp)
+            : [hp] "v"(hp)
+#else
             : [hp] "v"(hp), [cp] "v"(cp)
+#endif
             : "memory");
         // after the counted wait: the first three (four) loads have landed IF loads return in order
 #if X3
@@ -126,8 +141,8 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(probe, dim3(4096), dim3(512), lds_bytes, 0, dh, hot_rows, dc, cold_rows, iters, bad, sink);
         unsigned long long nb[3] = {0, 0, 0};
         hipMemcpy(nb, bad, 24, hipMemcpyDeviceToHost);
-        printf("X3=%d rep %d: after vmcnt(10) %llu rounds read a row that had not landed (%llu of them in lanes 32-63), "
-               "after vmcnt(0) %llu, of %.3g rounds\n", X3, rep, nb[0], nb[1], nb[2], 4096.0 * 512 * iters);
+        printf("X3=%d CLOBBER=%d rep %d: after vmcnt(10) %llu rounds read a row that had not landed (%llu of them in lanes 32-63), "
+               "after vmcnt(0) %llu, of %.3g rounds\n", X3, CLOBBER, rep, nb[0], nb[1], nb[2], 4096.0 * 512 * iters);
     }
     return 0;
 }
