@@ -90,7 +90,7 @@ void gemm_set_side_work(int on);
 void gemm_x3_dispatch(int mode, const GemmBatch& batch, hipStream_t st);  // gemm_x3.hip, 128 x 128 tiles
 // gemm_x4.hip: the same products with the split done by loader waves (opt-in: DGG_X4=1)
 void gemm_x4_dispatch(int mode, const GemmBatch& batch, hipStream_t st);
-bool gemm_x4_enabled();
+bool gemm_x4_enabled(long total_blocks);
 // gemm_p4.hip / gemm_p3_block.h: C = A B^T on pre-split bf16 planes (forward, and the wgrad over transposed planes).
 // A weight-gradient (TN) launch of gemm_launch may carry ONE such problem beside its fp32 problems (a_plane != 0: "NT
 // over transposed planes", gemm_p3_block.h inside gemm_x3_kernel): the BPS block's weight gradient and its riders —

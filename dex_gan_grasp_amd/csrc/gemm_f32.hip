@@ -536,7 +536,7 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
     if (mode != GEMM_NT && mode != GEMM_NN && mode != GEMM_TN) return DGG_ERR_INVALID;
     if (gemm_algo() >= 1 && bm == 128 && bn == 128) {
         // (a planes problem rides in gemm_x3_kernel)
-        if (gemm_x4_enabled() && !planes) {
+        if (!planes && gemm_x4_enabled(batch.total_blocks)) {
             gemm_x4_dispatch(mode, batch, st);
             return check_launch("gemm_x4");
         }

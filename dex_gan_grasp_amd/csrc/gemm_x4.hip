@@ -432,13 +432,19 @@ void gemm_x4_dispatch(int mode, const GemmBatch& batch, hipStream_t st) {
     }
 }
 
-bool gemm_x4_enabled() {
-    // Opt-in: 1.09-1.16x as a kernel (forward 61.6 -> 52.9 us, weight gradient 61.7 -> 56.8 us, profiles/r03_experiments.txt),
-    // no faster as cgan_step / eva_step (1.49 / 0.717 vs 1.485 / 0.712 ms) and SLOWER inside joint_step (1.84 vs 1.74 ms):
-    // its 8-wave workgroups hold 384 of a SIMD's 512 registers, so the chain's short kernels of the other streams find
-    // fewer CUs to co-reside on than beside gemm_x3_kernel's 4 waves.
-    static const bool on = [] { const char* e = getenv("DGG_X4"); return e && e[0] == '1'; }();
-    return on;
+bool gemm_x4_enabled(long total_blocks) {
+    // 1.09-1.16x gemm_x3_kernel as a kernel (forward 61.6 -> 52.9 us, weight gradient 61.7 -> 56.8 us,
+    // profiles/r03_experiments.txt), but no faster as cgan_step / eva_step (1.49 / 0.717 vs 1.485 / 0.712 ms) and SLOWER
+    // inside joint_step (1.84 vs 1.74 ms): its 8-wave workgroups hold 384 of a SIMD's 512 registers, so the chain's short
+    // kernels of the other streams find fewer CUs to co-reside on than beside gemm_x3_kernel's 4 waves.  Where ONE stream
+    // runs long launches it does pay: the config-5 inference sweep (1250 objects x 200 grasps, products of 250 000 rows)
+    // 15.15 -> 13.95 ms.  Hence: launches of >= 1024 workgroups (four rounds of the chip; the train step's largest has
+    // 240) take it, everything else gemm_x3_kernel.  DGG_X4=1 / 0 forces it on / off for every launch.
+    static const int mode = [] {
+        const char* e = getenv("DGG_X4");
+        return !e ? -1 : (e[0] == '1' ? 1 : 0);
+    }();
+    return mode < 0 ? total_blocks >= 1024 : mode == 1;
 }
 
 }  // namespace dgg

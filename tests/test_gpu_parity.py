@@ -80,10 +80,13 @@ def _strided(t, ld, off):
 
 @pytest.mark.parametrize("mode,shape", [(0, (300, 768, 2003)), (0, (1024, 768, 701)),      # NT: forward
                                         (1, (2048, 1100, 200)), (1, (1300, 1664, 77)),      # NN: dgrad
-                                        (2, (768, 4101, 300)), (2, (1664, 1300, 129))])     # TN: wgrad
+                                        (2, (768, 4101, 300)), (2, (1664, 1300, 129)),      # TN: wgrad
+                                        # >= 1024 workgroups: the launches gemm_x4_kernel (loader / consumer waves) takes
+                                        (0, (16500, 1000, 203)), (1, (16400, 1100, 77)), (2, (4100, 4100, 129))])
 @pytest.mark.parametrize("align", ["vv", "vu", "uv", "uu"])
 def test_gemm_bf16x3_variants(mode, shape, align):
-    """128 x 128-tile shapes (the ones gemm_x3_kernel serves) in every operand orientation and every combination of
+    """128 x 128-tile shapes (the ones gemm_x3_kernel serves, and — from 1024 workgroups per launch, the inference
+    sweep's sizes — gemm_x4_kernel) in every operand orientation and every combination of
     16-byte / 4-byte aligned operands, ragged M / N / K tails included; against fp64 and next to the native f32-MFMA
     kernel on the same data: exact on integers, and on real data — N(0,1) and 12-decade log-normal scales — within
     1.5x of the error of the k-ordered f32 fma chain (measured: 2.6-3.1e-7 vs 2.9-3.6e-7 of sum|a||b|)."""
@@ -122,7 +125,8 @@ def test_gemm_bf16x3_variants(mode, shape, align):
                     errs[(algo, splits)] = e
                     # relative to sum |a||b|: < 4e-7 on well-scaled data; with 12 decades inside one dot product a
                     # single term carries the sum and either arithmetic sits at a few 2^-24 of it
-                    assert e <= (4e-6 if kind == "wide" else 4e-7), (kind, algo, splits, e)
+                    # (the k-ordered f32 chain's maximum over the 16 M outputs of the largest shapes reaches 4.05e-7)
+                    assert e <= (4e-6 if kind == "wide" else (4e-7 if algo == 1 else 5e-7)), (kind, algo, splits, e)
             if kind != "int":   # the split is an fp32-accurate GEMM: same error level as the k-ordered f32 fma chain
                 assert errs[(1, 0)] <= 1.5 * errs[(0, 0)] + 2e-8, errs
             print("gemm error / sum|a||b|  mode %d %s %s: bf16x3 %.2e  f32 %.2e" % (mode, align, kind, errs[(1, 0)], errs[(0, 0)]))
