@@ -9,7 +9,7 @@ from dex_gan_grasp_amd import _lib, engine, parallel, synth
 parallel.init_from_env()   # DGG_FORCE_DISTRIBUTED=1: host cost of the collective path (one-rank RCCL group)
 dev = torch.device("cuda", 0)
 cfg = dict(synth.DEFAULT_CFG)
-B = 1024
+B = int(os.environ.get("DGG_HOSTTIME_B", "1024"))
 fg, fd, fe = (_lib.FlatNet(k, cfg, dev) for k in (_lib.NET_GEN, _lib.NET_DISC, _lib.NET_EVA))
 sd = synth.make_state_dict("dexgangrasp", 0)
 fg.load_state_dict(sd, "generator."); fd.load_state_dict(sd, "discriminator.")
