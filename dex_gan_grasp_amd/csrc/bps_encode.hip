@@ -189,53 +189,56 @@ __global__ __launch_bounds__(256) void bps_batched_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------------------------
 // Many clouds: a coarse pass on the matrix cores SELECTS, the contract's arithmetic DECIDES (round 3).
 // The scan above spends ~3.7 vector instructions per (basis point, cloud point) pair.  Here one pair costs 1/16 of a
-// vector min3 and 1/1024 of two matrix instructions:
+// vector min3 and 1/1024 of ONE matrix instruction:
 //     v_ij = x_j.(-2 b_i) + |x_j|^2 + c_i  =  |x_j - b_i|^2 + bias_i            (c_i ~ |b_i|^2 + bias_i, any constant does)
-// as a dot product of bf16 values: every fp32 operand is split EXACTLY into three bf16 planes (h + m + l, by truncation)
-// and the six largest of the nine plane products are kept per coordinate (as in gemm_x3.hip).  Two
-// v_mfma_f32_32x32x16_bf16 evaluate 32 points x 32 basis points (64 cycles of the matrix pipe, which runs beside the
-// vector ALU of other waves; the fp32 matrix instruction of the first version does not: it runs at the vector rate and
-// its time ADDED to the vector work, 1.12x only).  Operand rows (k-slots in pairs, one 32-bit word each):
-//     point, lanes 0-31  : (xh,xm) (xl,xh) (yh,ym) (yl,yh)      lanes 32-63: (zh,zm) (zl,zh) (nh,nm) (nl,1)     n = |x|^2
-//     basis, 1st MFMA    : (qh,qh) (qh,ql) per coordinate        ...          (qzh,qzh) (qzh,qzl) (1,1) (1,ch)   q = -2b
-//     basis, 2nd MFMA    : (qm,qm) (0,0)   per coordinate        ...          (qzm,qzm) (0,0) (0,0) (0,cm)
-// — the SAME point registers feed both instructions (hh + mh, lh + hl, then hm + mm per coordinate), so a point costs 32 B
-// of LDS and one ds_read_b128 per lane and tile.  v orders the cloud points of one basis point like the squared distance
-// does, but not bit for bit like the contract's  d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx)),  so:
+// as a K = 14 dot product of fp16 values.  Cloud and basis are scaled by ONE power of two per cloud so that the cloud's
+// largest |x| sits in [32, 64) — exact, and far from both ends of the fp16 range (a basis point may be ~60 cloud radii
+// away before its lane has to take the all-points path); every scaled fp32 operand is split into two fp16 planes,
+// x = h + m + r with |r| <= 2^-23 |x| (round to nearest twice, the residual step exact), and three of the four plane
+// products are kept per coordinate; |x|^2 goes in three planes, c as 256 x two planes of c / 256.  One
+// v_mfma_f32_32x32x16_f16 evaluates 32 points x 32 basis points (32 cycles of the matrix pipe; the instruction keeps fp16
+// denormal inputs, tools/exp/f16_mfma_probe.hip).  Operand rows (k-slots in pairs, one 32-bit word each):
+//     point, lanes 0-31: (xh,xh) (xm,yh) (yh,ym) (zh,zh)      lanes 32-63: (zm,nh) (nm,nl) (256,256) (0,0)   n = |x|^2
+//     basis            : (qxh,qxm) (qxh,qyh) (qym,qyh) (qzh,qzm)            (qzh,1) (1,1) (ch,cm) (0,0)     q = -2b
+// — 32 B of LDS and one ds_read_b128 per point, tile and lane.  (History: the fp32 matrix instruction runs at the vector
+// rate and does NOT overlap vector work, 1.12x only; three bf16 planes need 23 slots = two matrix instructions per tile,
+// 0.53 ms against this version's 0.47: the matrix instructions share the vector issue port, 8 cycles each.)
+// v orders the cloud points of one basis point like the squared distance does, but not bit for bit like the contract's
+// d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx)),  so:
 //   - a lane sees 16 of a tile's 32 points for its basis point (the accumulator rows of its half-wave) = one BLOCK.  The
 //     block minimum (8 v_min3_f32) gets the tile index written over its 7 lowest mantissa bits: one register is value
 //     and index, and the four smallest keys are kept by three v_med3_f32 and a v_min_u32 — no compare / select.
 //     (v > 0 thanks to the bias, so the keys order like the values; the overwritten bits cost 2^-17 v.)
-//   - |v_ij - (c_i - |b_i|^2) - d2_ij| <= eps_i = 35u S_i + 2^-17 v_ij,  S_i = (R + |b_i|)^2, R = the cloud's largest
-//     |x_j|, u = 2^-24: dropped plane products 2.1u S, at most 24 accumulations of terms whose magnitudes sum to <= S:
-//     24u S (worst case, whatever the order inside the instruction), |x|^2 3u S, the contract's own d2 within 5u of the
-//     true squared distance.  Hence every point whose d2 can be the minimum or tie with it lies in a block whose key is
+//   - |v_ij - (c_i - |b_i|^2) - d2_ij| <= eps_i = 35u S_i + 2^-17 v_ij  (all in the scaled units),  S_i = (R + |b_i|)^2,
+//     R = the cloud's largest |x_j|, u = 2^-24: dropped plane products 12u S, 14 accumulations of terms whose magnitudes
+//     sum to <= S: 14u S (worst case, whatever the order inside the instruction), |x|^2 3u S, the contract's own d2
+//     within 5u of the true squared distance (tests/test_bps_coarse_bound.py restates the operands in numpy: 0.1 eps
+//     observed).  Hence every point whose d2 can be the minimum or tie with it lies in a block whose key is
 //     <= k1 + 2 eps =: lim (k1 the smallest key).
 //   - the (at most three) blocks with keys <= lim are re-evaluated with the contract's instructions on the cloud's own
 //     fp32 coordinates (global memory, 3 x 16-byte loads per 4 consecutive points), the answer is the lexicographic
 //     minimum of (d2, j): the sequential scan's lowest-index rule.  A fourth key <= lim, a cloud or basis point with a
 //     coordinate not below 1e3 in magnitude (NaN, inf, the 3e19 cases of the tests) or a degenerate scale send the lane
 //     through ALL its points with the exact formula: always right, never fast.
-// The two half-waves of a basis point meet through one lane exchange at the end.  Ids and distances are bit-identical to
-// the scan's (tests/test_gpu_parity.py, tools/exp/bps_ab.py on 4.2 M outputs).
-// 512-thread workgroups (8 waves x 128 basis points) share one staged cloud; 64 KB at 2048 points: two per CU, so one
-// workgroup's staging / exact stage runs beside the other's matrix work.
+// Ids and distances are bit-identical to the scan's (tests/test_gpu_parity.py, tools/exp/bps_ab.py on 4.2 M outputs,
+// tools/exp/bps_fuzz.py).  512-thread workgroups (8 waves x 128 basis points) share one staged cloud; 64 KB at 2048
+// points: two per CU, so one workgroup's staging / exact stage runs beside the other's matrix work.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float bf32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bbf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned bu32x4 __attribute__((ext_vector_type(4)));
 
-struct Planes3 { unsigned h, m, l; };  // bf16 values in the UPPER halves; x == h + m + l exactly
-__device__ __forceinline__ Planes3 split3(float x) {
-    Planes3 p;
-    p.h = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
-    const float r1 = x - __builtin_bit_cast(float, p.h);   // exact
-    p.m = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
-    const float r2 = r1 - __builtin_bit_cast(float, p.m);  // exact, at most 8 significant bits left
-    p.l = __builtin_bit_cast(unsigned, r2) & 0xffff0000u;
+typedef _Float16 bh16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bh16x2 __attribute__((ext_vector_type(2)));
+struct Planes2 { _Float16 h, m; };  // x = h + m + r,  |r| <= 2^-23 |x|  (round to nearest twice; the residual step is exact)
+__device__ __forceinline__ Planes2 split2(float x) {
+    Planes2 p;
+    p.h = (_Float16)x;
+    p.m = (_Float16)(x - (float)p.h);
     return p;
 }
-__device__ __forceinline__ unsigned pk2(unsigned even, unsigned odd) { return (even >> 16) | odd; }  // k-slots 2n, 2n+1
+__device__ __forceinline__ unsigned pk16(_Float16 even, _Float16 odd) {  // k-slots 2n, 2n+1 of one operand word
+    return __builtin_bit_cast(unsigned, bh16x2{even, odd});
+}
 
 constexpr int kBpsMfmaMaxN = 2560;  // 32 B of LDS per point, tile index in 7 bits
 constexpr int kBpsQueue = 512;      // work-list entries per wave (128 winners + further candidates; the rest in place)
@@ -263,50 +266,11 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
     const float* __restrict__ c = clouds + (size_t)b * N * 3;  // 16-byte aligned, N % 4 == 0 (launcher)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, col = lane & 31, h = lane >> 5;
     const int ntile = (N + 31) >> 5;
-    constexpr unsigned ONE = 0x3f800000u;
     if (tid == 0) {
         s_r2 = 0;
         s_bad = 0;
     }
     __syncthreads();
-    {
-        float r2 = 0.f;
-        bool bad = false;
-        // four points = three 16-byte loads (the cloud is 16-byte aligned and N % 4 == 0: launcher)
-        for (int g = tid; g < ntile * 8; g += NW * 64) {
-            const int j0 = 4 * g;
-            float xs[4] = {0.f, 0.f, 0.f, 0.f}, ys[4] = {0.f, 0.f, 0.f, 0.f}, zs[4] = {0.f, 0.f, 0.f, 0.f};
-            const bool in = j0 < N;
-            if (in) {
-                const bf32x4* pq = reinterpret_cast<const bf32x4*>(c + 3 * j0);
-                const bf32x4 p0 = pq[0], p1 = pq[1], p2 = pq[2];
-                xs[0] = p0[0], ys[0] = p0[1], zs[0] = p0[2];
-                xs[1] = p0[3], ys[1] = p1[0], zs[1] = p1[1];
-                xs[2] = p1[2], ys[2] = p1[3], zs[2] = p2[0];
-                xs[3] = p2[1], ys[3] = p2[2], zs[3] = p2[3];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float x = xs[k], y = ys[k], z = zs[k];
-                float n2 = 1e30f;  // padding: far away, never NaN
-                if (in) {
-                    n2 = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
-                    bad |= !(__builtin_fabsf(x) < 1e3f && __builtin_fabsf(y) < 1e3f && __builtin_fabsf(z) < 1e3f);
-                    r2 = __builtin_fmaxf(r2, n2);
-                }
-                const Planes3 X = split3(x), Y = split3(y), Z = split3(z), Q = split3(n2);
-                planes[2 * (j0 + k)] = bu32x4{pk2(X.h, X.m), pk2(X.l, X.h), pk2(Y.h, Y.m), pk2(Y.l, Y.h)};
-                planes[2 * (j0 + k) + 1] = bu32x4{pk2(Z.h, Z.m), pk2(Z.l, Z.h), pk2(Q.h, Q.m), pk2(Q.l, ONE)};
-            }
-        }
-        if (bad) atomicOr(&s_bad, 1);
-        else atomicMax(&s_r2, __builtin_bit_cast(int, r2));  // non-negative floats order like their bits
-    }
-    __syncthreads();
-    const bool cloud_bad = s_bad != 0;
-    const float R = __builtin_sqrtf(__builtin_bit_cast(float, s_r2));
-
-    // per basis point: coordinates, S = (R + |b|)^2, and whether the coarse pass can be trusted for it at all
     // (the lane's NT basis points are loaded together and waited for with vmcnt(0), see block())
     auto load_basis = [&](float (&X)[NT], float (&Y)[NT], float (&Z)[NT]) {
 #pragma unroll
@@ -320,31 +284,97 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
                      : "+v"(X[0]), "+v"(Y[0]), "+v"(Z[0]), "+v"(X[1]), "+v"(Y[1]), "+v"(Z[1]), "+v"(X[2]), "+v"(Y[2]),
                        "+v"(Z[2]), "+v"(X[3]), "+v"(Y[3]), "+v"(Z[3]));
     };
+    auto sane = [](float x, float y, float z) {
+        return __builtin_fabsf(x) < 1e3f && __builtin_fabsf(y) < 1e3f && __builtin_fabsf(z) < 1e3f;
+    };
+    float bxs[NT], bys[NT], bzs[NT];
+    load_basis(bxs, bys, bzs);
+    {
+        // pass 1: the largest |x|^2 of the cloud -> ONE power-of-two scale
+        float r2 = 0.f;
+        bool bad = false;
+        for (int g = tid; g < ntile * 8; g += NW * 64) {
+            const int j0 = 4 * g;
+            if (j0 < N) {
+                const bf32x4* pq = reinterpret_cast<const bf32x4*>(c + 3 * j0);
+                const bf32x4 p0 = pq[0], p1 = pq[1], p2 = pq[2];
+                const float xs[4] = {p0[0], p0[3], p1[2], p2[1]}, ys[4] = {p0[1], p1[0], p1[3], p2[2]};
+                const float zs[4] = {p0[2], p1[1], p2[0], p2[3]};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    bad |= !sane(xs[k], ys[k], zs[k]);
+                    r2 = __builtin_fmaxf(r2, __builtin_fmaf(zs[k], zs[k], __builtin_fmaf(ys[k], ys[k], xs[k] * xs[k])));
+                }
+            }
+        }
+        if (bad) atomicOr(&s_bad, 1);
+        else atomicMax(&s_r2, __builtin_bit_cast(int, r2));  // non-negative floats order like their bits
+    }
+    __syncthreads();
+    const bool cloud_bad = s_bad != 0;
+    const float R = __builtin_sqrtf(__builtin_bit_cast(float, s_r2));
+    // scale = 2^e with R * scale in [32, 64): the fp16 planes of the scaled cloud stay far from both ends of the fp16 range
+    // (|x'| < 64, |x'|^2 < 4096; a basis point may be up to 4000 / 64 cloud radii away: -2 b' < 8000, |b'|^2 / 256 < 62500),
+    // and a power of two changes no mantissa bit.  Below 2^-14 fp16 values are spaced 2^-24: an absolute error of at most
+    // 2^-25 per plane, 2^-25 (2 sum|b'_c| + sum|x'_c| + 1) on v — under 0.2 % of eps, which is >= 35u 32 (R' + |b'|).
+    float scale = 1.f;
+    {
+        const float m = R;
+        const int k = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 255u) - 126;  // m = f * 2^k, f in [0.5, 1)
+        if (!cloud_bad && m > 1e-30f) scale = __builtin_bit_cast(float, (unsigned)(127 + 6 - k) << 23);
+    }
+    constexpr float kBpsFar = 4000.f;  // |b| * scale beyond this: the lane takes the all-points path
+    {
+        // pass 2: the operand rows.  Four points = three 16-byte loads (16-byte aligned cloud, N % 4 == 0: launcher)
+        const unsigned C256 = pk16((_Float16)256.f, (_Float16)256.f);  // the constant's slots: c enters as 256 * (c / 256)
+        float lx, ly, lz;  // rows past the cloud repeat its LAST point: a copy inside a block changes no block minimum, a
+        load3(c + 3 * (N - 1), lx, ly, lz);  // block of copies only is a candidate at worst, and the exact stage skips j >= N
+        for (int g = tid; g < ntile * 8; g += NW * 64) {
+            const int j0 = 4 * g;
+            float xs[4] = {lx, lx, lx, lx}, ys[4] = {ly, ly, ly, ly}, zs[4] = {lz, lz, lz, lz};
+            if (j0 < N) {
+                const bf32x4* pq = reinterpret_cast<const bf32x4*>(c + 3 * j0);
+                const bf32x4 p0 = pq[0], p1 = pq[1], p2 = pq[2];
+                xs[0] = p0[0], ys[0] = p0[1], zs[0] = p0[2];
+                xs[1] = p0[3], ys[1] = p1[0], zs[1] = p1[1];
+                xs[2] = p1[2], ys[2] = p1[3], zs[2] = p2[0];
+                xs[3] = p2[1], ys[3] = p2[2], zs[3] = p2[3];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float x = xs[k] * scale, y = ys[k] * scale, z = zs[k] * scale;
+                const float n2 = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+                const Planes2 X = split2(x), Y = split2(y), Z = split2(z);
+                const _Float16 nh = (_Float16)n2;
+                const float r1 = n2 - (float)nh;
+                const _Float16 nm = (_Float16)r1, nl = (_Float16)(r1 - (float)nm);
+                planes[2 * (j0 + k)] = bu32x4{pk16(X.h, X.h), pk16(X.m, Y.h), pk16(Y.h, Y.m), pk16(Z.h, Z.h)};
+                planes[2 * (j0 + k) + 1] = bu32x4{pk16(Z.m, nh), pk16(nm, nl), C256, 0u};
+            }
+        }
+    }
+    // per basis point: S = (R + |b|)^2 in the cloud's units, and whether the coarse pass can be trusted for it at all
     auto basis_point = [&](float X, float Y, float Z, float& bb, float& S) {
         bb = __builtin_fmaf(Z, Z, __builtin_fmaf(Y, Y, X * X));
         const float nb = __builtin_sqrtf(bb);
         S = (R + nb) * (R + nb);
-        return cloud_bad || !(__builtin_fabsf(X) < 1e3f && __builtin_fabsf(Y) < 1e3f && __builtin_fabsf(Z) < 1e3f) ||
-               !(S > 1e-20f);
+        return cloud_bad || !sane(X, Y, Z) || !(S > 1e-20f) || !(nb * scale < kBpsFar);
     };
-    bu32x4 B1[NT], B2[NT];
+    bu32x4 B1[NT];
     float k1[NT], k2[NT], k3[NT], k4[NT];
-    {
-    float bxs[NT], bys[NT], bzs[NT];
-    load_basis(bxs, bys, bzs);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const float bx = bxs[t], by = bys[t], bz = bzs[t];
         float bb, S;
         basis_point(bx, by, bz, bb, S);
-        const Planes3 X = split3(-2.f * bx), Y = split3(-2.f * by), Z = split3(-2.f * bz);
-        const Planes3 C = split3(bb + S * 0x1p-14f);  // |b|^2 + bias; two planes of it are used: bias > 2^-16 c + eps
-        B1[t] = h ? bu32x4{pk2(Z.h, Z.h), pk2(Z.h, Z.l), pk2(ONE, ONE), pk2(ONE, C.h)}
-                  : bu32x4{pk2(X.h, X.h), pk2(X.h, X.l), pk2(Y.h, Y.h), pk2(Y.h, Y.l)};
-        B2[t] = h ? bu32x4{pk2(Z.m, Z.m), 0u, 0u, pk2(0u, C.m)} : bu32x4{pk2(X.m, X.m), 0u, pk2(Y.m, Y.m), 0u};
+        const Planes2 X = split2(-2.f * bx * scale), Y = split2(-2.f * by * scale), Z = split2(-2.f * bz * scale);
+        const float cc = (bb + S * 0x1p-14f) * (scale * scale) * 0x1p-8f;  // (|b'|^2 + bias') / 256; bias' > 2^-22 c' + eps'
+        const _Float16 ch = (_Float16)cc, cm = (_Float16)(cc - (float)ch), one = (_Float16)1.f;
+        B1[t] = h ? bu32x4{pk16(Z.h, one), pk16(one, one), pk16(ch, cm), 0u}
+                  : bu32x4{pk16(X.h, X.m), pk16(X.h, Y.h), pk16(Y.m, Y.h), pk16(Z.h, Z.m)};
         k1[t] = k2[t] = k3[t] = k4[t] = __builtin_inff();
     }
-    }
+    __syncthreads();
 #if defined(BPS_ABLATE) && BPS_ABLATE == 7   // staging only (timing build)
     if (N < 0) {
 #else
@@ -359,10 +389,8 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bbf16x8, cur),
-                                                              __builtin_bit_cast(bbf16x8, B1[t]), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bbf16x8, cur),
-                                                              __builtin_bit_cast(bbf16x8, B2[t]), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(bh16x8, cur), __builtin_bit_cast(bh16x8, B1[t]),
+                                                             acc, 0, 0, 0);
                 // (all values are positive and finite: they order like their bit patterns, and v_min_u32 comes without
                 //  the quieting v_max the compiler puts in front of a two-operand v_min_f32)
                 auto min3 = [](float a_, float b_, float c_) { return __builtin_fminf(__builtin_fminf(a_, b_), c_); };
@@ -459,7 +487,8 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
         const float o1 = __shfl_xor(k1[t], 32);
         const float g1 = __builtin_bit_cast(float, __builtin_elementwise_min(__builtin_bit_cast(unsigned, k1[t]),
                                                                              __builtin_bit_cast(unsigned, o1)));
-        const float lim = g1 + (S * 0x1.4p-18f + g1 * 0x1p-16f);  // 2 eps: 2 * 35u S rounded up, + 2 * 2^-17 v
+        // 2 eps: 2 * 35u S (in the keys' units: scaled) rounded up, + 2 * 2^-17 v
+        const float lim = g1 + (S * (scale * scale) * 0x1.41p-18f + g1 * 0x1p-16f);  // (0x1.41: + the fp16 spacing below 2^-14)
 #if defined(BPS_ABLATE)   // timing builds (tools/exp/bps_ablate.sh): no exact stage, results are NOT the answer
         if (k1[t] == g1) slot[bl] = ((unsigned long long)__builtin_bit_cast(unsigned, g1) << 32) | (unsigned)tile_of(g1);
         (void)full;

@@ -1,7 +1,8 @@
 """Random shapes through dgg_bps_encode against the CPU oracle (bit-identical ids and distances expected):
     python3 tools/exp/bps_fuzz.py [configs] [seed]
 Shapes: B 1..300, N 1..2600 (about half of them multiples of 4 -> the matrix-core path when B is large enough), P 1..4200,
-cloud scale 1e-4 .. 1e3, offsets from the origin, duplicated points, sometimes an unaligned cloud pointer."""
+cloud scale 1e-4 .. 1e3, offsets from the origin, basis points 2 .. 3000 cloud scales away, duplicated points, sometimes
+an unaligned cloud pointer."""
 import os
 import sys
 
@@ -32,7 +33,8 @@ def main():
         if N > 8:
             clouds[0, N - 1] = clouds[0, 2]
             clouds[0, 5] = clouds[0, 2]
-        basis = (rng.uniform(-2, 2, size=(P, 3)) * scale + off * rng.choice([0.0, 1.0])).astype(np.float32)
+        span = float(rng.choice([2.0, 2.0, 40.0, 3000.0]))   # basis points up to thousands of cloud radii away (the all-points path)
+        basis = (rng.uniform(-span, span, size=(P, 3)) * scale + off * rng.choice([0.0, 1.0])).astype(np.float32)
         unaligned = rng.random() < 0.2
         flat = torch.empty((B * N * 3 + 1,), device=dev)
         cl = flat[1:] if unaligned else flat[:-1]
@@ -49,7 +51,7 @@ def main():
                 bad += 1
                 print("MISMATCH cfg %d: B %d N %d P %d scale %.3g off %.3g unaligned %s cloud %d: %d ids differ" %
                       (c, B, N, P, scale, off, unaligned, b, int((idn[b] != oi).sum())))
-        print("cfg %2d  B %3d  N %4d  P %4d  scale %8.3g  off %8.3g  %s ok" % (c, B, N, P, scale, off, "unaligned" if unaligned else "aligned  "), flush=True)
+        print("cfg %2d  B %3d  N %4d  P %4d  scale %8.3g  off %8.3g  basis span %6g  %s ok" % (c, B, N, P, scale, off, span, "unaligned" if unaligned else "aligned  "), flush=True)
     print("mismatching clouds: %d" % bad)
     sys.exit(1 if bad else 0)
 
