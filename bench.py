@@ -144,11 +144,13 @@ def planes_roofline(dev, M, N, K, splits, what, pmc_name, iters=20):
 
 def bps_roofline(dev, B=1024, Np=2048, iters=10):
     """bps_mfma_kernel (A1): 4096 * N (basis point, cloud point) pairs per cloud against N*12 + 4096*8 bytes — arithmetic
-    intensity ~1e3 flop/B, HBM cannot bind.  Since round 3 the pairs go through a bf16x3 coarse pass on the
-    matrix cores: two v_mfma_f32_32x32x16_bf16 per 32 x 32 pairs = 64 matrix flop per pair, which is what `achieved`
-    counts against the dense bf16 peak; the exact re-evaluation of the candidate blocks (~1.6 % of the pairs) is the
-    contract's fp32 arithmetic on the vector ALU.  `valu_equiv_*`: the same launch priced as the round-2 scan was (8 fp32
-    flop per pair against the packed-fp32 peak), for comparison across rounds."""
+    intensity ~1e3 flop/B, HBM cannot bind.  Since round 3 the pairs go through a two-plane fp16 coarse pass
+    on the matrix cores: one v_mfma_f32_32x32x16_f16 per 32 x 32 pairs = 32 matrix flop per pair, which is what
+    `achieved` counts against the dense fp16 / bf16 peak; the exact re-evaluation of the candidate blocks (~1.6 % of the
+    pairs) is the contract's fp32 arithmetic on the vector ALU.  The kernel is bound by vector ISSUE (13 vector
+    instructions per 512 pairs of a lane, which the matrix instruction's issue shares), not by the matrix pipe, so `frac`
+    is low by construction; `valu_equiv_*` prices the same launch as the round-2 scan was priced (8 fp32 flop per pair
+    against the packed-fp32 peak), for comparison across rounds."""
     g = torch.Generator().manual_seed(0)
     basis = (torch.rand((4096, 3), generator=g) * 0.2 - 0.1).to(dev)
     clouds = synth.make_clouds(B, Np, 7).to(dev)
@@ -161,7 +163,7 @@ def bps_roofline(dev, B=1024, Np=2048, iters=10):
     ms = _time_stream(fn, iters)
     pairs = B * Np * 4096.0
     byts = B * (Np * 12 + 4096 * 8) + 4096 * 12
-    tf = pairs * 64 / ms / 1e9
+    tf = pairs * 32 / ms / 1e9
     tfv = pairs * 8 / ms / 1e9
     return {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_BF16_MFMA_TFLOPS, 4), "kernel": "bps_mfma_kernel %d clouds x %d points x 4096 basis" % (B, Np),
@@ -169,7 +171,7 @@ def bps_roofline(dev, B=1024, Np=2048, iters=10):
             "valu_equiv_tflops": round(tfv, 2), "valu_equiv_frac": round(tfv / PEAK_F32_VALU_TFLOPS, 4),
             "algorithmic_bytes": byts, "hbm_gb_per_s": round(byts / ms / 1e6, 2),
             "hbm_frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 5),
-            "note": "64 matrix flop per pair (K = 32 bf16 slots, 23 used); vector-issue bound beside the matrix pipe "
+            "note": "32 matrix flop per pair (K = 16 fp16 slots, 14 used); vector-issue bound beside the matrix pipe "
                     "(DESIGN.md 3.4); round 2's scan: 1.07 ms, DGG_BPS=valu"}
 
 
