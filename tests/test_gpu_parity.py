@@ -257,6 +257,29 @@ def test_bps_matrix_path_keeps_the_scan_answer(B, N, P):
     assert (d3.cpu().numpy().view(np.int32) == dist.view(np.int32)).all()
 
 
+def test_bps_matrix_path_on_the_reference_objects():
+    """The reference's own object clouds (object/*.pcd of tests/golden/bps_real_objects.npz), 2048 points of each (every k-th
+    point), batched — the shape of the training front end — through the matrix-core path: ids and distance bits of the
+    oracle, and the nearest-neighbour distances of the full clouds bound them from below."""
+    ops, _ = _ops()
+    from oracle import bps_oracle
+    d = H.load("bps_real_objects.npz")
+    basis = d["basis"]
+    subs = []
+    for name in d["names"]:
+        cloud = d["cloud_" + str(name)]
+        subs.append(np.ascontiguousarray(cloud[:: cloud.shape[0] // 2048][:2048]))
+    clouds = np.stack([subs[i % len(subs)] for i in range(70)])          # 70 clouds x 4 slices: the many-clouds launch
+    dist, ids = ops.bps_encode(torch.from_numpy(clouds).to(DEV), torch.from_numpy(basis).to(DEV))
+    dist, ids = dist.cpu().numpy(), ids.cpu().numpy()
+    for k, name in enumerate(d["names"]):
+        od, oi = bps_oracle.encode_f32(subs[k], basis)
+        for b in (k, k + 63):
+            assert (ids[b] == oi).all(), name
+            assert (dist[b].view(np.int32) == od.view(np.int32)).all(), name
+        assert (dist[k] >= d["dists_" + str(name)].reshape(-1) - 1e-7).all(), name   # a subset cannot be closer
+
+
 @pytest.mark.parametrize("B,N", [(1, 3001), (2, 20000), (5, 777)])
 def test_bps_few_clouds_ranges_keep_lowest_index_rule(B, N):
     """Few clouds with many points (the robot path) are scanned as ranges that meet in the output arrays through
