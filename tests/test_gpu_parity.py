@@ -257,6 +257,24 @@ def test_bps_matrix_path_keeps_the_scan_answer(B, N, P):
     assert (d3.cpu().numpy().view(np.int32) == dist.view(np.int32)).all()
 
 
+def test_bps_matrix_path_basis_far_outside_the_fp16_range():
+    """Basis points hundreds of cloud radii away cannot be scaled into fp16 next to the cloud: their lanes take the
+    all-points path (exact arithmetic over every point), the near ones of the same launch the coarse pass."""
+    ops, _ = _ops()
+    from oracle import bps_oracle
+    basis = H.load("bps_real_objects.npz")["basis"].copy()
+    basis[::3] *= np.float32(400.0)          # every third basis point ~80 m away from 10 cm clouds
+    basis[1::97] = np.float32(3e5)           # and a few beyond |b| = 1e3
+    B, N = 96, 256
+    clouds = synth.make_clouds(B, N, 515)
+    dist, ids = ops.bps_encode(clouds.to(DEV), torch.from_numpy(basis).to(DEV))
+    dist, ids = dist.cpu().numpy(), ids.cpu().numpy()
+    for b in (0, 50, 95):
+        od, oi = bps_oracle.encode_f32(clouds[b].numpy(), basis)
+        assert (ids[b] == oi).all(), b
+        assert (dist[b].view(np.int32) == od.view(np.int32)).all(), b
+
+
 def test_bps_matrix_path_on_the_reference_objects():
     """The reference's own object clouds (object/*.pcd of tests/golden/bps_real_objects.npz), 2048 points of each (every k-th
     point), batched — the shape of the training front end — through the matrix-core path: ids and distance bits of the
