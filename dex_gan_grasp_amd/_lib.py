@@ -63,6 +63,10 @@ SIGNATURES = {
     "dgg_bnstat_floats": (_I64, [_I, _CFG]),
     "dgg_workspace_bytes": (_I64, [_I, _CFG, _I]),
     "dgg_bps_encode": (_I, [_VP, _I, _I, _VP, _I, _VP, _VP, _VP]),
+    "dgg_bps_workspace_bytes": (_I64, [_I, _I, _I]),
+    "dgg_bps_encode_ws": (_I, [_VP, _I, _I, _VP, _I, _VP, _VP, _VP, _SZ, _VP]),
+    "dgg_set_bps_algo": (_I, [_I]),
+    "dgg_get_bps_algo": (_I, []),
     "dgg_gen_forward": (_I, [_CFG, _VP, _VP, _VP, _SZ, _I, _U, _VP, _VP, _VP, _VP]),
     "dgg_gen_backward": (_I, [_CFG, _VP, _VP, _VP, _SZ, _I, _U, _VP, _VP, _VP, _VP, _VP, _VP]),
     "dgg_disc_forward": (_I, [_CFG, _VP, _VP, _VP, _SZ, _I, _U, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -208,13 +208,14 @@ __global__ __launch_bounds__(256) void bps_batched_kernel(const float* __restric
 //   - a lane sees 16 of a tile's 32 points for its basis point (the accumulator rows of its half-wave) = one BLOCK.  The
 //     block minimum (8 v_min3_f32) gets the tile index written over its 7 lowest mantissa bits: one register is value
 //     and index, and the four smallest keys are kept by three v_med3_f32 and a v_min_u32 — no compare / select.
-//     (v > 0 thanks to the bias, so the keys order like the values; the overwritten bits cost 2^-17 v.)
-//   - |v_ij - (c_i - |b_i|^2) - d2_ij| <= eps_i = 35u S_i + 2^-17 v_ij  (all in the scaled units),  S_i = (R + |b_i|)^2,
+//     (v > 0 thanks to the bias, so the keys order like the values; the overwritten bits cost up to 206 ulp between two
+//     keys, budgeted as 2^-15 v in lim.)
+//   - |v_ij - (c_i - |b_i|^2) - d2_ij| <= eps_i = 35u S_i  (all in the scaled units; the keys' index bits are budgeted apart),  S_i = (R + |b_i|)^2,
 //     R = the cloud's largest |x_j|, u = 2^-24: dropped plane products 12u S, 14 accumulations of terms whose magnitudes
 //     sum to <= S: 14u S (worst case, whatever the order inside the instruction), |x|^2 3u S, the contract's own d2
 //     within 5u of the true squared distance (tests/test_bps_coarse_bound.py restates the operands in numpy: 0.1 eps
 //     observed).  Hence every point whose d2 can be the minimum or tie with it lies in a block whose key is
-//     <= k1 + 2 eps =: lim (k1 the smallest key).
+//     <= k1 + 2 eps + 2^-15 k1 =: lim (k1 the smallest key).
 //   - the (at most three) blocks with keys <= lim are re-evaluated with the contract's instructions on the cloud's own
 //     fp32 coordinates (global memory, 3 x 16-byte loads per 4 consecutive points), the answer is the lexicographic
 //     minimum of (d2, j): the sequential scan's lowest-index rule.  A fourth key <= lim, a cloud or basis point with a
@@ -240,30 +241,68 @@ __device__ __forceinline__ unsigned pk16(_Float16 even, _Float16 odd) {  // k-sl
     return __builtin_bit_cast(unsigned, bh16x2{even, odd});
 }
 
-constexpr int kBpsMfmaMaxN = 2560;  // 32 B of LDS per point, tile index in 7 bits
+constexpr int kBpsMfmaMaxN = 2560;  // points per workgroup: 32 B of LDS per point, tile index in 7 bits
+constexpr int kBpsChunkMax = 1792;  // MERGE: points per chunk (44 B of LDS per point -> two workgroups per CU; <= NW * 256)
 constexpr int kBpsQueue = 512;      // work-list entries per wave (128 winners + further candidates; the rest in place)
 #ifndef BPS_NW
 #define BPS_NW 8
 #endif
 
-template <int NT, int NW>  // 32-wide basis tiles per wave, waves per workgroup
-__global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __restrict__ clouds, int N,
+// Four consecutive cloud points as three 16-byte vectors {x0 y0 z0 x1} {y1 z1 x2 y2} {z2 x3 y3 z3}.  AL: the cloud (chunk) is
+// 16-byte aligned and the four points lie inside it -> three global_load_dwordx4; otherwise point by point with the index
+// clamped to the last point (rows past the cloud repeat its LAST point: a copy inside a block changes no block minimum, a
+// block of copies only is a candidate at worst, and the exact stage skips j >= n), 12-byte loads waited for with vmcnt(0):
+// no counted wait ever covers loads of mixed widths (see block()).
+template <bool AL>
+__device__ __forceinline__ void load_quad(const float* __restrict__ c, int j0, int n, bf32x4& p0, bf32x4& p1, bf32x4& p2) {
+    if (AL && j0 + 4 <= n) {
+        const bf32x4* pq = reinterpret_cast<const bf32x4*>(c + 3 * j0);
+        p0 = pq[0], p1 = pq[1], p2 = pq[2];
+    } else {
+        float v[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = min(j0 + k, n - 1);
+            load3(c + 3 * j, v[3 * k], v[3 * k + 1], v[3 * k + 2]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                       "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]));
+        p0 = bf32x4{v[0], v[1], v[2], v[3]}, p1 = bf32x4{v[4], v[5], v[6], v[7]}, p2 = bf32x4{v[8], v[9], v[10], v[11]};
+    }
+}
+
+// MERGE = false: one workgroup = one whole cloud x NW * 128 basis points, results straight into dists / ids (many clouds).
+// MERGE = true (round 4: the reference's own call shape, ONE cloud of 15k-73k points, dexgangrasp_real_robot.py:133-141): the
+// cloud is cut into `nchunk` chunks of CH points (a multiple of 32), a workgroup = one chunk x NW * 128 basis points with a
+// power-of-two scale of the CHUNK's own; it leaves the chunk's answer per basis point — (d2 bits << 32 | global index j),
+// ~0 if nothing was below +inf — in `scratch[cloud][chunk][P]`, and bps_merge_kernel takes the 64-bit minimum over the
+// chunks: the lexicographic minimum of (d2, j), the sequential scan's lowest-index rule over the whole cloud.
+template <int NT, int NW, bool AL, bool MERGE>  // 32-wide basis tiles per wave, waves per workgroup
+__global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __restrict__ clouds, int Ncloud, int CH, int nchunk,
                                                            const float* __restrict__ basis, int P,
-                                                           float* __restrict__ dists, int32_t* __restrict__ ids, int B,
-                                                           int gx) {
+                                                           float* __restrict__ dists, int32_t* __restrict__ ids,
+                                                           unsigned long long* __restrict__ scratch, int B, int gx) {
     extern __shared__ bu32x4 planes[];  // [ntile * 32][2]: the operand words of lanes 0-31 | lanes 32-63
     __shared__ int s_r2, s_bad;
     __shared__ int s_qn[NW];  // entries on each wave's work list
     const int L = blockIdx.x, per = 8 * gx;
-    int b, slice;
-    if (L < (B / 8) * per) {  // the gx slices of a cloud on one XCD (see bps_batched_kernel)
+    int b, slice, chunk = 0;
+    if (MERGE) {  // (cloud, chunk, slice): slices fastest
+        slice = L % gx;
+        const int rest = L / gx;
+        chunk = rest % nchunk;
+        b = rest / nchunk;
+    } else if (L < (B / 8) * per) {  // the gx slices of a cloud on one XCD (see bps_batched_kernel)
         b = (L / per) * 8 + (L & 7);
         slice = (L % per) >> 3;
     } else {
         b = L / gx;
         slice = L % gx;
     }
-    const float* __restrict__ c = clouds + (size_t)b * N * 3;  // 16-byte aligned, N % 4 == 0 (launcher)
+    const int jbase = MERGE ? chunk * CH : 0;
+    const int N = MERGE ? min(CH, Ncloud - jbase) : Ncloud;  // points of this workgroup's (chunk of the) cloud
+    const float* __restrict__ c = clouds + ((size_t)b * Ncloud + jbase) * 3;  // AL: 16-byte aligned (launcher)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, col = lane & 31, h = lane >> 5;
     const int ntile = (N + 31) >> 5;
     if (tid == 0) {
@@ -287,8 +326,27 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
     auto sane = [](float x, float y, float z) {
         return __builtin_fabsf(x) < 1e3f && __builtin_fabsf(y) < 1e3f && __builtin_fabsf(z) < 1e3f;
     };
+    // MERGE: a chunk has at most NW * 256 points, i.e. at most ONE quad of four points per thread: it is requested before the
+    // basis points (one memory round trip for both), stays in registers from pass 1 to pass 2, and goes to LDS next to the
+    // operand planes (`sc`, 12 B per point in the cloud's own layout) — the exact stage gathers its candidate blocks from
+    // there: gathered from global memory, 13 loads x 64 lanes each in a cache line of its own kept the texture path busy
+    // for ~6 us per pass and made a 256-point chunk take 17 us.
+    constexpr int kExactBytes = NW * (NT * 32 + kBpsQueue / 2) * 8;
+    const int coff = max(((CH + 31) >> 5) * 1024, kExactBytes);  // behind the planes AND behind the exact stage's slots / lists
+    bf32x4* const sc = reinterpret_cast<bf32x4*>(reinterpret_cast<char*>(planes) + coff);
+    bf32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0;
+    const bool mine = MERGE && tid < ntile * 8;
+    if (mine) load_quad<AL>(c, 4 * tid, N, q0, q1, q2);
     float bxs[NT], bys[NT], bzs[NT];
     load_basis(bxs, bys, bzs);
+    auto quad = [&](int j0, bf32x4& p0, bf32x4& p1, bf32x4& p2) {  // the exact stage's four points j0 .. j0 + 3
+        if constexpr (MERGE) {
+            const bf32x4* pq = sc + 3 * (j0 >> 2);
+            p0 = pq[0], p1 = pq[1], p2 = pq[2];
+        } else {
+            load_quad<AL>(c, j0, N, p0, p1, p2);
+        }
+    };
     {
         // pass 1: the largest |x|^2 of the cloud -> ONE power-of-two scale
         float r2 = 0.f;
@@ -296,8 +354,8 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
         for (int g = tid; g < ntile * 8; g += NW * 64) {
             const int j0 = 4 * g;
             if (j0 < N) {
-                const bf32x4* pq = reinterpret_cast<const bf32x4*>(c + 3 * j0);
-                const bf32x4 p0 = pq[0], p1 = pq[1], p2 = pq[2];
+                bf32x4 p0 = q0, p1 = q1, p2 = q2;
+                if (!MERGE) load_quad<AL>(c, j0, N, p0, p1, p2);
                 const float xs[4] = {p0[0], p0[3], p1[2], p2[1]}, ys[4] = {p0[1], p1[0], p1[3], p2[2]};
                 const float zs[4] = {p0[2], p1[1], p2[0], p2[3]};
 #pragma unroll
@@ -325,21 +383,15 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
     }
     constexpr float kBpsFar = 4000.f;  // |b| * scale beyond this: the lane takes the all-points path
     {
-        // pass 2: the operand rows.  Four points = three 16-byte loads (16-byte aligned cloud, N % 4 == 0: launcher)
+        // pass 2: the operand rows (rows past the cloud: copies of its last point, load_quad)
         const unsigned C256 = pk16((_Float16)256.f, (_Float16)256.f);  // the constant's slots: c enters as 256 * (c / 256)
-        float lx, ly, lz;  // rows past the cloud repeat its LAST point: a copy inside a block changes no block minimum, a
-        load3(c + 3 * (N - 1), lx, ly, lz);  // block of copies only is a candidate at worst, and the exact stage skips j >= N
         for (int g = tid; g < ntile * 8; g += NW * 64) {
             const int j0 = 4 * g;
-            float xs[4] = {lx, lx, lx, lx}, ys[4] = {ly, ly, ly, ly}, zs[4] = {lz, lz, lz, lz};
-            if (j0 < N) {
-                const bf32x4* pq = reinterpret_cast<const bf32x4*>(c + 3 * j0);
-                const bf32x4 p0 = pq[0], p1 = pq[1], p2 = pq[2];
-                xs[0] = p0[0], ys[0] = p0[1], zs[0] = p0[2];
-                xs[1] = p0[3], ys[1] = p1[0], zs[1] = p1[1];
-                xs[2] = p1[2], ys[2] = p1[3], zs[2] = p2[0];
-                xs[3] = p2[1], ys[3] = p2[2], zs[3] = p2[3];
-            }
+            bf32x4 p0 = q0, p1 = q1, p2 = q2;
+            if (!MERGE) load_quad<AL>(c, j0, N, p0, p1, p2);
+            if (MERGE) sc[3 * g] = p0, sc[3 * g + 1] = p1, sc[3 * g + 2] = p2;
+            const float xs[4] = {p0[0], p0[3], p1[2], p2[1]}, ys[4] = {p0[1], p1[0], p1[3], p2[2]};
+            const float zs[4] = {p0[2], p1[1], p2[0], p2[3]};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float x = xs[k] * scale, y = ys[k] * scale, z = zs[k] * scale;
@@ -432,14 +484,8 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
     auto block = [&](int i, int hh, float X, float Y, float Z, float& bb, int& bj) {
         // 16 rows of point tile i as half-wave hh sees them, the contract's arithmetic; rows ascend: strict '<'
         bf32x4 pt[4][3];
-        bool in[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int j0 = i * 32 + 8 * g + 4 * hh;
-            in[g] = j0 < N;  // N % 4 == 0: four points or none
-            const bf32x4* pq = reinterpret_cast<const bf32x4*>(c + 3 * (in[g] ? j0 : 0));
-            pt[g][0] = pq[0], pt[g][1] = pq[1], pt[g][2] = pq[2];
-        }
+        for (int g = 0; g < 4; ++g) quad(i * 32 + 8 * g + 4 * hh, pt[g][0], pt[g][1], pt[g][2]);
         // Everything this evaluation loaded — the 12 point vectors and the caller's basis point — is waited for HERE,
         // with vmcnt(0), not by the compiler's counted waits.  With those (correct IF loads return in order: the basis
         // point's 12-byte load third among thirteen 16-byte point loads) lanes 32-63 computed, in one run of three and only
@@ -461,13 +507,13 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
             const f32x2 da = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
             const f32x2 dc = __builtin_elementwise_fma(cz, cz, __builtin_elementwise_fma(cy, cy, cx * cx));
             const float d0 = da[0], d1 = da[1], d2 = dc[0], d3 = dc[1];
-            bool lt = in[g] & (d0 < bb);
+            bool lt = (j0 < N) & (d0 < bb);  // rows past the cloud (copies of its last point) never win
             bb = lt ? d0 : bb, bj = lt ? j0 : bj;
-            lt = in[g] & (d1 < bb);
+            lt = (j0 + 1 < N) & (d1 < bb);
             bb = lt ? d1 : bb, bj = lt ? j0 + 1 : bj;
-            lt = in[g] & (d2 < bb);
+            lt = (j0 + 2 < N) & (d2 < bb);
             bb = lt ? d2 : bb, bj = lt ? j0 + 2 : bj;
-            lt = in[g] & (d3 < bb);
+            lt = (j0 + 3 < N) & (d3 < bb);
             bb = lt ? d3 : bb, bj = lt ? j0 + 3 : bj;
         }
     };
@@ -487,8 +533,12 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
         const float o1 = __shfl_xor(k1[t], 32);
         const float g1 = __builtin_bit_cast(float, __builtin_elementwise_min(__builtin_bit_cast(unsigned, k1[t]),
                                                                              __builtin_bit_cast(unsigned, o1)));
-        // 2 eps: 2 * 35u S (in the keys' units: scaled) rounded up, + 2 * 2^-17 v
-        const float lim = g1 + (S * (scale * scale) * 0x1.41p-18f + g1 * 0x1p-16f);  // (0x1.41: + the fp16 spacing below 2^-14)
+        // 2 eps: 2 * 35u S (in the keys' units: scaled) rounded up (0x1.41: + the fp16 spacing below 2^-14), + the keys' own
+        // bits: a key is (m & ~127) | tile, so the smallest key may sit 127 ulp BELOW its block's m while the key of the
+        // block that holds the true minimum sits up to ntile - 1 <= 79 ulp ABOVE its m: 206 ulp, and an ulp is up to
+        // 2^-23 of the value -> 2^-15 g1 (256 ulp just above a power of two, 512 just below the next; 2^-16 was 128: short
+        // when v ~ S sits just above a power of two — tests/test_bps_coarse_bound.py::test_tile_index_bits_in_the_keys)
+        const float lim = g1 + (S * (scale * scale) * 0x1.41p-18f + g1 * 0x1p-15f);
 #if defined(BPS_ABLATE)   // timing builds (tools/exp/bps_ablate.sh): no exact stage, results are NOT the answer
         if (k1[t] == g1) slot[bl] = ((unsigned long long)__builtin_bit_cast(unsigned, g1) << 32) | (unsigned)tile_of(g1);
         (void)full;
@@ -549,19 +599,18 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
             int bj = 0;
             load3(basis + 3 * i, X, Y, Z);
             const int j0 = (int)(it & 127u) * 32 + 8 * (lane & 3) + 4 * (int)((it >> 7) & 1u);
-            const bool in = j0 < N;
-            const bf32x4* pq = reinterpret_cast<const bf32x4*>(c + 3 * (in ? j0 : 0));
-            bf32x4 p0 = pq[0], p1 = pq[1], p2 = pq[2];
+            bf32x4 p0, p1, p2;
+            quad(j0, p0, p1, p2);
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(X), "+v"(Y), "+v"(Z));
             const float d0 = dist2(p0[0], p0[1], p0[2], X, Y, Z), d1 = dist2(p0[3], p1[0], p1[1], X, Y, Z);
             const float d2 = dist2(p1[2], p1[3], p2[0], X, Y, Z), d3 = dist2(p2[1], p2[2], p2[3], X, Y, Z);
-            bool lt = in & (d0 < bb);
+            bool lt = (j0 < N) & (d0 < bb);
             bb = lt ? d0 : bb, bj = lt ? j0 : bj;
-            lt = in & (d1 < bb);
+            lt = (j0 + 1 < N) & (d1 < bb);
             bb = lt ? d1 : bb, bj = lt ? j0 + 1 : bj;
-            lt = in & (d2 < bb);
+            lt = (j0 + 2 < N) & (d2 < bb);
             bb = lt ? d2 : bb, bj = lt ? j0 + 2 : bj;
-            lt = in & (d3 < bb);
+            lt = (j0 + 3 < N) & (d3 < bb);
             bb = lt ? d3 : bb, bj = lt ? j0 + 3 : bj;
             offer(bl, bb, bj);
         }
@@ -572,10 +621,41 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
             const unsigned long long k = slot[bl];
             if (i < P) {
                 const bool none = k == ~0ull;  // nothing was below +inf: the scan's answer
-                dists[(size_t)b * P + i] = none ? __builtin_inff() : __builtin_sqrtf(__builtin_bit_cast(float, (unsigned)(k >> 32)));
-                if (ids) ids[(size_t)b * P + i] = none ? 0 : (int)(unsigned)k;
+                if (MERGE) {
+                    scratch[((size_t)b * nchunk + chunk) * P + i] = none ? ~0ull : k + (unsigned long long)jbase;
+                } else {
+                    dists[(size_t)b * P + i] = none ? __builtin_inff() : __builtin_sqrtf(__builtin_bit_cast(float, (unsigned)(k >> 32)));
+                    if (ids) ids[(size_t)b * P + i] = none ? 0 : (int)(unsigned)k;
+                }
             }
         }
+    }
+}
+
+// The chunks of a cloud meet here: the 64-bit minimum of (d2 bits << 32 | j) over the chunks is the lexicographic minimum.
+// 32 basis points x 8 groups of chunks per workgroup (256-byte rows of the scratch per load instruction).
+__global__ __launch_bounds__(256) void bps_merge_kernel(const unsigned long long* __restrict__ scratch, int nchunk, int P,
+                                                        float* __restrict__ dists, int32_t* __restrict__ ids) {
+    __shared__ unsigned long long s[8][32];
+    const int il = threadIdx.x & 31, cg = threadIdx.x >> 5, tiles = (P + 31) >> 5;
+    const int b = blockIdx.x / tiles, i = (blockIdx.x % tiles) * 32 + il;
+    unsigned long long best = ~0ull;
+    if (i < P) {
+        const unsigned long long* __restrict__ q = scratch + (size_t)b * nchunk * P + i;
+#pragma unroll 8
+        for (int ch = cg; ch < nchunk; ch += 8) {
+            const unsigned long long v = q[(size_t)ch * P];
+            best = v < best ? v : best;
+        }
+    }
+    s[cg][il] = best;
+    __syncthreads();
+    if (cg == 0 && i < P) {
+#pragma unroll
+        for (int g = 1; g < 8; ++g) best = s[g][il] < best ? s[g][il] : best;
+        const bool none = best == ~0ull;
+        dists[(size_t)b * P + i] = none ? __builtin_inff() : __builtin_sqrtf(__builtin_bit_cast(float, (unsigned)(best >> 32)));
+        if (ids) ids[(size_t)b * P + i] = none ? 0 : (int)(unsigned)best;
     }
 }
 
@@ -594,48 +674,112 @@ __global__ void bps_finish_kernel(float* __restrict__ dists, int32_t* __restrict
     }
 }
 
-int bps_encode_launch(const float* clouds, int B, int N, const float* basis, int P, float* dists, int32_t* ids,
-                      hipStream_t st) {
-    if (!clouds || !basis || !dists || B <= 0 || N <= 0 || P <= 0) return DGG_ERR_INVALID;
+// Which arithmetic: 0 (default) = by shape, 1 = the vector-ALU scan for every shape (A/B timing; the regression tests
+// compare the matrix-core path with it output by output).  Process-wide; DGG_BPS=valu selects 1 at start-up.
+static int g_bps_algo = -1;
+int bps_algo() {
+    if (g_bps_algo < 0) {
+        const char* e = getenv("DGG_BPS");
+        g_bps_algo = (e && !strcmp(e, "valu")) ? 1 : 0;
+    }
+    return g_bps_algo;
+}
+void bps_set_algo(int a) { g_bps_algo = a == 1 ? 1 : 0; }
+
+namespace {
+constexpr int kBpsNW = BPS_NW;
+struct BpsPlan {
+    int kind;    // 0: plain scan, 1: scan over ranges (no workspace), 2: matrix cores, whole clouds, 3: matrix cores, chunks + merge
+    int g;       // basis slices per cloud (matrix paths)
+    int ch, nchunk;
+    size_t ws;   // bytes of workspace kind 3 needs
+};
+// ws_avail: bytes the caller can offer (SIZE_MAX: planning for dgg_bps_workspace_bytes)
+BpsPlan bps_plan(int B, int N, int P, size_t ws_avail) {
+    BpsPlan p = {0, (P + kBpsNW * 128 - 1) / (kBpsNW * 128), N, 1, 0};
     const int gx = (P + 1023) / 1024;
-    // few clouds: cut them into ranges until ~768 workgroups exist, ranges of at least 256 points (multiples of 16)
-    int nchunk = 1, chunk_len = N;
-    if ((long long)gx * B < 192 && N >= 512) {
+    const bool few = (long long)gx * B < 192 && N >= 512;
+    if (bps_algo() != 1 && N >= 64) {
+        // chunks: ~512 workgroups (two per CU), 256..1792 points each (planes + coordinates: 77 KB of LDS), multiples of 32
+        if (few || N > kBpsMfmaMaxN) {
+            long long ch = ((long long)N * p.g * B + 511) / 512;
+            ch = (ch + 31) / 32 * 32;
+            ch = ch < 256 ? 256 : ch > kBpsChunkMax ? kBpsChunkMax : ch;
+            const int nchunk = (int)((N + ch - 1) / ch);
+            const size_t ws = (size_t)B * nchunk * P * sizeof(unsigned long long);
+            if (nchunk > 1 && ws <= ws_avail && ws <= ((size_t)256 << 20)) {
+                p.kind = 3, p.ch = (int)ch, p.nchunk = nchunk, p.ws = ws;
+                return p;
+            }
+        }
+        if (N <= kBpsMfmaMaxN) {
+            p.kind = 2;
+            return p;
+        }
+    }
+    if (few) {  // ranges of at least 256 points (multiples of 16) until ~768 workgroups exist
         int want = 768 / (gx * B);
         const int most = N / 256;
         want = want < most ? want : most;
         if (want > 1) {
-            chunk_len = ((N + want - 1) / want + 15) / 16 * 16;
-            nchunk = (N + chunk_len - 1) / chunk_len;
+            p.ch = ((N + want - 1) / want + 15) / 16 * 16;
+            p.nchunk = (N + p.ch - 1) / p.ch;
+            p.kind = 1;
         }
     }
-    static const bool valu_only = [] {  // DGG_BPS=valu: the vector-ALU scan for every shape (A/B timing, tests)
-        const char* e = getenv("DGG_BPS");
-        return e && !strcmp(e, "valu");
-    }();
-    if (nchunk <= 1 && N >= 64 && N <= kBpsMfmaMaxN && N % 4 == 0 && ((uintptr_t)clouds & 15) == 0 && !valu_only) {
-        constexpr int NW = BPS_NW;
-        const int g = (P + NW * 128 - 1) / (NW * 128);
-        size_t lds = (size_t)((N + 31) / 32) * 32 * 32;                      // operand planes, then reused by the exact stage:
-        const size_t lds_exact = (size_t)NW * (4 * 32 + kBpsQueue / 2) * 8;   // per wave 128 slots + the work list
-        lds = lds > lds_exact ? lds : lds_exact;
-        static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&bps_mfma_kernel<4, NW>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
-        (void)big_lds;
-        hipLaunchKernelGGL((bps_mfma_kernel<4, NW>), dim3((unsigned)g * B), dim3(NW * 64), lds, st, clouds, N, basis, P,
-                           dists, ids, B, g);
-    } else if (nchunk <= 1) {
+    return p;
+}
+
+template <bool AL, bool MERGE>
+void bps_mfma_launch(const BpsPlan& pl, const float* clouds, int B, int N, const float* basis, int P, float* dists,
+                     int32_t* ids, unsigned long long* scratch, hipStream_t st) {
+    const int rows = MERGE ? pl.ch : N;
+    size_t lds = (size_t)((rows + 31) / 32) * 32 * 32;                       // operand planes, then reused by the exact stage:
+    const size_t lds_exact = (size_t)kBpsNW * (4 * 32 + kBpsQueue / 2) * 8;   // per wave 128 slots + the work list
+    lds = lds > lds_exact ? lds : lds_exact;
+    if (MERGE) lds += (size_t)((rows + 31) / 32) * 32 * 12;                  // + the chunk's fp32 coordinates (`sc`)
+    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&bps_mfma_kernel<4, kBpsNW, AL, MERGE>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+    (void)big_lds;
+    hipLaunchKernelGGL((bps_mfma_kernel<4, kBpsNW, AL, MERGE>), dim3((unsigned)pl.g * B * (MERGE ? pl.nchunk : 1)),
+                       dim3(kBpsNW * 64), lds, st, clouds, N, pl.ch, pl.nchunk, basis, P, dists, ids, scratch, B, pl.g);
+}
+}  // namespace
+
+long long bps_workspace_bytes(int B, int N, int P) {
+    if (B <= 0 || N <= 0 || P <= 0) return DGG_ERR_INVALID;
+    return (long long)bps_plan(B, N, P, SIZE_MAX).ws;
+}
+
+int bps_encode_launch(const float* clouds, int B, int N, const float* basis, int P, float* dists, int32_t* ids, void* ws,
+                      size_t ws_bytes, hipStream_t st) {
+    if (!clouds || !basis || !dists || B <= 0 || N <= 0 || P <= 0) return DGG_ERR_INVALID;
+    if (ws && ((uintptr_t)ws & 7)) return DGG_ERR_INVALID;
+    const BpsPlan pl = bps_plan(B, N, P, ws ? ws_bytes : 0);
+    const int gx = (P + 1023) / 1024;
+    // 16-byte loads of four points: every cloud (and chunk: ch % 32 == 0) must start on a 16-byte boundary
+    const bool al = ((uintptr_t)clouds & 15) == 0 && (B == 1 || N % 4 == 0);
+    if (pl.kind == 3) {
+        unsigned long long* scratch = static_cast<unsigned long long*>(ws);
+        if (al) bps_mfma_launch<true, true>(pl, clouds, B, N, basis, P, dists, ids, scratch, st);
+        else bps_mfma_launch<false, true>(pl, clouds, B, N, basis, P, dists, ids, scratch, st);
+        hipLaunchKernelGGL(bps_merge_kernel, dim3((unsigned)((P + 31) / 32) * B), dim3(256), 0, st, scratch, pl.nchunk, P,
+                           dists, ids);
+    } else if (pl.kind == 2) {
+        if (al) bps_mfma_launch<true, false>(pl, clouds, B, N, basis, P, dists, ids, nullptr, st);
+        else bps_mfma_launch<false, false>(pl, clouds, B, N, basis, P, dists, ids, nullptr, st);
+    } else if (pl.kind == 0) {
         hipLaunchKernelGGL((bps_batched_kernel<4, 16, 0>), dim3((unsigned)gx * B), dim3(256), 0, st, clouds, N, basis, P,
                            dists, ids, B, gx, 1, N);
     } else {
         const int n = B * P;
-        const dim3 grid((unsigned)gx * B * nchunk);
+        const dim3 grid((unsigned)gx * B * pl.nchunk);
         hipLaunchKernelGGL(bps_preset_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dists, ids, n);
         hipLaunchKernelGGL((bps_batched_kernel<4, 16, 1>), grid, dim3(256), 0, st, clouds, N, basis, P, dists, ids, B, gx,
-                           nchunk, chunk_len);
+                           pl.nchunk, pl.ch);
         if (ids)
             hipLaunchKernelGGL((bps_batched_kernel<4, 16, 2>), grid, dim3(256), 0, st, clouds, N, basis, P, dists, ids, B,
-                               gx, nchunk, chunk_len);
+                               gx, pl.nchunk, pl.ch);
         hipLaunchKernelGGL(bps_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dists, ids, n);
     }
     return check_launch("bps_encode");

@@ -1512,8 +1512,19 @@ int64_t dgg_workspace_bytes(int net, const dgg_cfg* cfg, int batch) {
 
 int dgg_bps_encode(const float* clouds, int B, int N, const float* basis, int P, float* dists, int32_t* ids,
                    void* stream) {
-    return bps_encode_launch(clouds, B, N, basis, P, dists, ids, (hipStream_t)stream);
+    return bps_encode_launch(clouds, B, N, basis, P, dists, ids, nullptr, 0, (hipStream_t)stream);
 }
+int64_t dgg_bps_workspace_bytes(int B, int N, int P) { return bps_workspace_bytes(B, N, P); }
+int dgg_bps_encode_ws(const float* clouds, int B, int N, const float* basis, int P, float* dists, int32_t* ids, void* ws,
+                      size_t ws_bytes, void* stream) {
+    return bps_encode_launch(clouds, B, N, basis, P, dists, ids, ws, ws_bytes, (hipStream_t)stream);
+}
+int dgg_set_bps_algo(int algo) {
+    if (algo != DGG_BPS_AUTO && algo != DGG_BPS_SCAN) return DGG_ERR_INVALID;
+    bps_set_algo(algo);
+    return DGG_OK;
+}
+int dgg_get_bps_algo(void) { return bps_algo(); }
 
 int dgg_gen_forward(const dgg_cfg* cfg, const float* params, float* bnstats, void* ws, size_t ws_bytes, int B,
                     unsigned flags, const float* z, const float* bps, float* out_heads, void* stream) {

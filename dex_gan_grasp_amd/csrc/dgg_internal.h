@@ -160,8 +160,11 @@ int rowdot_run(const RowDotJobs& jobs, hipStream_t st);
 int gemm_x3_occupancy(int mode);
 
 // ---------------------------------------------------------------- BPS encode (bps_encode.hip)
-int bps_encode_launch(const float* clouds, int B, int N, const float* basis, int P, float* dists, int32_t* ids,
-                      hipStream_t st);
+int bps_encode_launch(const float* clouds, int B, int N, const float* basis, int P, float* dists, int32_t* ids, void* ws,
+                      size_t ws_bytes, hipStream_t st);
+long long bps_workspace_bytes(int B, int N, int P);
+int bps_algo();
+void bps_set_algo(int a);
 
 // ---------------------------------------------------------------- element-wise / BN / losses (elementwise.hip)
 struct ColSrc {           // one column block of a concatenated input

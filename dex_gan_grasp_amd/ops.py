@@ -29,7 +29,12 @@ def bps_encode(clouds, basis, return_ids=True):
     P = b.shape[0]
     dists = torch.empty((B, P), dtype=torch.float32, device=dev)
     ids = torch.empty((B, P), dtype=torch.int32, device=dev) if return_ids else None
-    check(lib().dgg_bps_encode(ptr(x), B, N, ptr(b), P, ptr(dists), ptr(ids), stream_ptr(dev)), "dgg_bps_encode")
+    # few clouds of many points (the reference's call shape: one cloud of 15k-73k points) run chunk by chunk on the matrix
+    # cores and meet in a workspace; the many-clouds shapes need none (0 bytes)
+    nws = int(lib().dgg_bps_workspace_bytes(B, N, P))
+    ws = torch.empty((nws,), dtype=torch.uint8, device=dev) if nws > 0 else None
+    check(lib().dgg_bps_encode_ws(ptr(x), B, N, ptr(b), P, ptr(dists), ptr(ids), ptr(ws), nws, stream_ptr(dev)),
+          "dgg_bps_encode_ws")
     return (dists, ids) if return_ids else dists
 
 

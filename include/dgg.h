@@ -93,13 +93,32 @@ int64_t dgg_workspace_bytes(int net, const dgg_cfg* cfg, int batch); /* activati
 /* A1 — replaces bps_torch.encode as called at data/bps_encoder.py:33 and
  * dexgangrasp_real_robot.py:139.  clouds (B,N,3), basis (P,3) -> dists (B,P), ids (B,P) (ids may
  * be NULL).  id = argmin_j |b - x_j|^2 with strict '<' (lowest j wins ties); dist = sqrt of it.
- * Every shape gives the same bits (d2 = fmaf(dz,dz,fmaf(dy,dy,dx*dx))); what differs is the kernel:
- * many clouds with 64 <= N <= 2560, N % 4 == 0 and `clouds` 16-byte aligned take the matrix-core
- * path (bf16x3 coarse pass + exact re-evaluation of the candidate blocks); few
- * clouds with many points are scanned as ranges of the cloud; everything else by the plain scan.
- * A NaN point never wins; a basis point that nothing is closer to than +inf gets id 0, dist +inf. */
+ * Every shape gives the same bits (d2 = fmaf(dz,dz,fmaf(dy,dy,dx*dx))); what differs is the kernel
+ * (csrc/bps_encode.hip):
+ *   - clouds of 64 <= N <= 2560 points: the matrix-core path — a two-plane fp16 coarse pass on
+ *     v_mfma_f32_32x32x16_f16 SELECTS candidate blocks of 16 points, the contract's arithmetic on the candidates
+ *     DECIDES (16-byte aligned clouds with N % 4 == 0 load four points as three 16-byte vectors, others point by point);
+ *   - dgg_bps_encode_ws with a workspace of dgg_bps_workspace_bytes(B, N, P): few clouds of many points (the
+ *     reference's own call shape: ONE cloud of 15k-73k points, dexgangrasp_real_robot.py:133-141) and clouds of more
+ *     than 2560 points take the same path chunk by chunk — a workgroup per (chunk of 256..1792 points, 1024 basis
+ *     points), each with its own power-of-two scale, (d2 bits, index) per chunk and basis point into the workspace,
+ *     a second launch takes the 64-bit minimum over the chunks = the lowest-index rule over the whole cloud;
+ *   - without a workspace such clouds are scanned by the vector ALU as ranges that meet in the output arrays
+ *     (atomicMin, two passes); fewer than 64 points: the plain scan.
+ * A NaN point never wins; a basis point that nothing is closer to than +inf gets id 0, dist +inf.
+ * ws == NULL: exactly dgg_bps_encode.  ws must be 8-byte aligned; a ws smaller than the query falls back to the
+ * workspace-free kernels (never an error: the answer does not depend on the route). */
 int dgg_bps_encode(const float* clouds, int B, int N, const float* basis, int P, float* dists,
                    int32_t* ids, void* stream);
+int64_t dgg_bps_workspace_bytes(int B, int N, int P);   /* 0: this shape needs none */
+int dgg_bps_encode_ws(const float* clouds, int B, int N, const float* basis, int P, float* dists,
+                      int32_t* ids, void* ws, size_t ws_bytes, void* stream);
+/* Process-wide route override (A/B timing and the regression tests that compare the matrix-core path with the scan
+ * output by output): DGG_BPS_SCAN = the vector-ALU scan for every shape.  DGG_BPS=valu in the environment selects it
+ * at start-up. */
+enum { DGG_BPS_AUTO = 0, DGG_BPS_SCAN = 1 };
+int dgg_set_bps_algo(int algo);
+int dgg_get_bps_algo(void);
 
 /* Flags */
 #define DGG_TRAIN 1u            /* BatchNorm batch statistics + running-stat update, dropout on */

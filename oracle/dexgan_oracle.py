@@ -84,10 +84,19 @@ def class_labels_from_logits(p, thresh):
 _SLOPES = None   # None: plain F.leaky_relu;  ("force", list, [pos]) / ("record", list)
 
 
+# The steering is CAPPED: a side may only be handed over where this evaluation's own pre-activation is within rounding
+# distance of zero.  Per context: at most `max_flips` elements may differ (default 8), and at each of them |x| must not
+# exceed `max_ratio` (default 1e-5) times the rms of its tensor — a device bug that put many units, or units far from
+# zero, on the wrong side fails here instead of being adopted.  `flips` / `worst` report what happened.
+MAX_FLIPS, MAX_FLIP_RATIO = 8, 1e-5
+
+
 class forced_slopes:
-    def __init__(self, masks):
+    def __init__(self, masks, max_flips=MAX_FLIPS, max_ratio=MAX_FLIP_RATIO):
         self.masks = list(masks)
+        self.max_flips, self.max_ratio = max_flips, max_ratio   # None: uncapped (only the test that steers on purpose)
         self.flips = 0           # elements where the forced side differs from this evaluation's own
+        self.worst = 0.0         # largest |x| / rms(tensor) over those elements
 
     def __enter__(self):
         global _SLOPES
@@ -101,6 +110,10 @@ class forced_slopes:
         _SLOPES = None
         if exc[0] is None:
             assert used == len(self.masks), "forced_slopes: %d masks given, %d LeakyReLU calls made" % (len(self.masks), used)
+            assert self.max_flips is None or self.flips <= self.max_flips, \
+                "forced_slopes: the oracle was steered at %d LeakyReLU elements (cap %d)" % (self.flips, self.max_flips)
+            assert self.max_ratio is None or self.worst <= self.max_ratio, \
+                "forced_slopes: steered at a pre-activation %.3e of its tensor's rms away from zero (cap %.1e)" % (self.worst, self.max_ratio)
         return False
 
 
@@ -132,7 +145,12 @@ def _lrelu(x):
         return F.leaky_relu(x, LRELU)
     m = m.to(torch.bool)
     assert m.shape == x.shape, (tuple(m.shape), tuple(x.shape))
-    ctx.flips += int((m != (x.detach() > 0)).sum())
+    diff = m != (x.detach() > 0)
+    n = int(diff.sum())
+    if n:
+        xd = x.detach().double()
+        ctx.flips += n
+        ctx.worst = max(ctx.worst, float(xd.abs()[diff].max()) / (float(xd.pow(2).mean().sqrt()) + 1e-300))
     return torch.where(m, x, LRELU * x)
 
 
@@ -342,8 +360,15 @@ def cgan_g_part(sd, ctx, cfg):
     return {k: v.detach() for k, v in dict_g.items()}, g_g
 
 
+def _caps(slopes):
+    """(max_flips, max_ratio) of a step's `slopes` dict: the defaults unless the dict overrides them ("max_flips" /
+    "max_ratio"; None = uncapped — only the test that steers the oracle on purpose does that)."""
+    return slopes.get("max_flips", MAX_FLIPS), slopes.get("max_ratio", MAX_FLIP_RATIO)
+
+
 class _no_ctx:
     flips = 0
+    worst = 0.0
 
     def __enter__(self):
         return self
@@ -356,18 +381,19 @@ def cgan_step(sd, batch, z, adam_g, adam_d, cfg, is_train_gen=True, return_grads
     """dexgangrasp.py:757-823 (BCE branch).  `sd` holds the DexGANGrasp state_dict
     ('generator.*', 'discriminator.*'), modified in place.  z is the injected latent (:770).
     slopes (checker only, see forced_slopes): {"d": masks of G fwd + D(real) + D(fake) (18), "g": masks of the G phase's
-    D pass (6)}; the number of elements where a forced side differed lands in slopes["flips"]."""
-    with (forced_slopes(slopes["d"]) if slopes else _no_ctx()) as fs:
+    D pass (6)}; the number of elements where a forced side differed lands in slopes["flips"], the largest |x| / rms
+    among them in slopes["worst"] (both capped per phase: forced_slopes)."""
+    with (forced_slopes(slopes["d"], *_caps(slopes)) if slopes else _no_ctx()) as fs:
         out, g_d, ctx = cgan_d_part(sd, batch, z, cfg)
-    nflip = fs.flips
+    nflip, worst = fs.flips, fs.worst
     adam_step(sd, g_d, adam_d, lr=cfg["lr_dis"], b1=cfg["beta1"], wd=cfg["weight_decay"])  # :794
     g_g = None
     if is_train_gen:
-        with (forced_slopes(slopes["g"]) if slopes else _no_ctx()) as fs:
+        with (forced_slopes(slopes["g"], *_caps(slopes)) if slopes else _no_ctx()) as fs:
             dict_g, g_g = cgan_g_part(sd, ctx, cfg)
-        nflip += fs.flips
+        nflip, worst = nflip + fs.flips, max(worst, fs.worst)
     if slopes is not None:
-        slopes["flips"] = nflip
+        slopes["flips"], slopes["worst"] = nflip, worst
     if is_train_gen:
         adam_step(sd, g_g, adam_g, lr=cfg["lr_gen"], b1=cfg["beta1"], wd=cfg["weight_decay"])  # :816
         out.update(dict_g)
@@ -529,12 +555,12 @@ def eva_step(sd, batch, adam_e, cfg, drop_masks=None, return_grads=False, slopes
     en = param_names(sd)
     _set_requires_grad(sd, en, True)
     label = batch["label"].float().unsqueeze(-1)  # networks.py:312
-    with (forced_slopes(slopes["e"]) if slopes else _no_ctx()) as fs:
+    with (forced_slopes(slopes["e"], *_caps(slopes)) if slopes else _no_ctx()) as fs:
         p = evaluator_forward(sd, batch["bps_object"], batch["rot_matrix"], batch["transl"], True, drop_masks)
         l_e, dict_e = loss_evaluator(p, label, bw)
         g_e = _grads(l_e, sd, en)
     if slopes is not None:
-        slopes["flips"] = fs.flips
+        slopes["flips"], slopes["worst"] = fs.flips, fs.worst
     adam_step(sd, g_e, adam_e, lr=cfg["lr"], b1=cfg["beta1"], wd=cfg["weight_decay"])
     _set_requires_grad(sd, en, False)
     out = {k: v.detach() for k, v in dict_e.items()}

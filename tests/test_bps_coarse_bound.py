@@ -70,6 +70,25 @@ def coarse(cloud, b, R, scale):
     return acc, ch + cm, np.float64(S) * np.float64(scale) ** 2, bb
 
 
+def block_keys(v):
+    """Keys as bps_mfma_kernel forms them: point j sits in tile j >> 5, half-wave (j >> 2) & 1; a block = the 16 rows one
+    lane sees.  Returns (keys per block as f32, block number of every point)."""
+    n = len(v)
+    j = np.arange(n)
+    blk_of = (j >> 5) * 2 + ((j >> 2) & 1)
+    nblk = ((n + 31) >> 5) * 2
+    m = np.full(nblk, np.inf, dtype=f32)
+    np.minimum.at(m, blk_of, v.astype(f32))
+    keys = ((m.view(np.uint32) & np.uint32(0xFFFFFF80)) | (np.arange(nblk, dtype=np.uint32) >> 1)).view(f32)
+    keys[~np.isfinite(m)] = np.inf                                              # (no such block: padded rows copy a real point)
+    return keys, blk_of
+
+
+def kernel_lim(g1, S_scaled, key_slack=2.0 ** -15):
+    """lim = g1 + (S' * 0x1.41p-18 + g1 * 2^-15), in fp32 like the kernel."""
+    return f32(f32(g1) + f32(f32(f32(S_scaled) * f32(float.fromhex("0x1.41p-18"))) + f32(f32(g1) * f32(key_slack))))
+
+
 def clouds():
     g = np.random.default_rng(11)
     base = (g.normal(size=(2048, 3)) * [0.05, 0.03, 0.08]).astype(f32)
@@ -105,10 +124,56 @@ def test_coarse_value_is_within_its_bound(name, cloud, basis_span):
         err = np.abs(v.astype(np.float64) - bias - d2)
         worst = max(worst, float((err / eps).max()))
         assert (v > 0).all() and np.isfinite(v).all()                          # keys order like values only if positive
-        # the kernel's threshold: 2 eps (rounded up) + the key's overwritten bits; the true minimum must be a candidate
-        k = (v.view(np.uint32) & np.uint32(0xFFFFFF80)).view(f32)
-        lim = np.float64(k.min()) + S * 1.25 * 2.0 ** -18 + np.float64(k.min()) * 2.0 ** -16
+        # the kernel's keys and threshold: a lane's block = 16 rows of a 32-point tile (rows 8g + 4h + 0..3), its key
+        # = (block minimum & ~127) | tile index; lim from the smallest key; the true minimum's block must be a candidate
+        kb, blk_of = block_keys(v)
+        lim = kernel_lim(kb.min(), S)
         winners = np.flatnonzero(d2 == d2.min())
-        assert (k[winners] <= lim).all(), (name, b)
+        assert (kb[blk_of[winners]] <= lim).all(), (name, b)
     print("%-22s basis +-%-4g worst |v - bias - d2| / eps = %.3f   (%d of 64 basis points beyond the fp16 range)" % (name, basis_span, worst, far))
     assert worst < 1.0, (name, worst)
+
+
+def test_tile_index_bits_in_the_keys():
+    """the 7-bit tile index in the keys moves two keys up to 127 + (ntile - 1) ulp apart, on top of 2 eps.
+    Adversarial family: an off-centre cloud whose scaled radius sits just above a power of two (R' = 32.1 -> v ~ S ~ 1030,
+    where an ulp is 2^-23 v), a basis point near the origin, and two nearly tied nearest points, one in the FIRST tile and
+    one in the LAST (tile 79: N = 2560).  Every other block is far away, so a pair of points is a whole trial; the trials
+    are vectorised.  The winner's block must be a candidate with the kernel's slack 2^-15; the same trials defeat the
+    round-3 slack 2^-16 (the test has teeth)."""
+    g = np.random.default_rng(2024)
+    T = 400_000
+    R = f32(32.1 / 64.0)                                                        # scale_for(R) = 64 -> R' = 32.1
+    scale = scale_for(R)
+    assert scale == 64.0
+    u = g.normal(size=(T, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    w = g.normal(size=(T, 3))
+    w /= np.linalg.norm(w, axis=1, keepdims=True)
+    r = np.float64(R) * (1 - 2.0 ** -12 - g.uniform(0, 2.0 ** -11, size=(T, 1)))   # v mod 128 ulp uniform over the trials
+    b = (g.normal(size=3) * 2e-5).astype(f32)                                   # |b| < R 2^-12: every point stays inside R
+    a = (b + u * r).astype(f32)                                                 # both on one sphere AROUND b: nearly tied d2
+    bpts = (b + w * r * (1 + g.integers(-1, 2, size=(T, 1)) * 2.0 ** -25)).astype(f32)   # the rival a few ulp nearer or farther
+    assert (np.linalg.norm(np.concatenate([a, bpts]).astype(np.float64), axis=1) <= R).all()
+    pts = np.concatenate([a, bpts]).astype(f32)
+    v, c, S, bb = coarse(pts, b, R, scale)
+    d2 = contract_d2(pts, b)
+    vA, vB, dA, dB = v[:T], v[T:], d2[:T], d2[T:]
+    assert (v > 0).all()
+    last = np.uint32(79)
+    kA = ((vA.view(np.uint32) & np.uint32(0xFFFFFF80)) | np.uint32(0)).view(f32)
+    kB = ((vB.view(np.uint32) & np.uint32(0xFFFFFF80)) | last).view(f32)
+    g1 = np.minimum(kA, kB)
+    b_wins = dB < dA                                                            # strict: a tie goes to the lower index, point A
+    k_win = np.where(b_wins, kB, kA)
+    lim_new = np.array([kernel_lim(x, S) for x in np.unique(g1)])
+    lim_of = dict(zip(np.unique(g1).tolist(), lim_new.tolist()))
+    lim = np.array([lim_of[x] for x in g1.tolist()], dtype=f32)
+    missed = int((k_win > lim).sum())
+    far = np.flatnonzero(k_win.view(np.int32).astype(np.int64) - g1.view(np.int32).astype(np.int64) > 128)
+    missed_old = sum(1 for t in far if k_win[t] > kernel_lim(g1[t], S, 2.0 ** -16))
+    span = (k_win.view(np.int32).astype(np.int64) - g1.view(np.int32).astype(np.int64)).max()
+    print("tile-index trials: %d, winner above the smallest key by up to %d ulp; missed with 2^-15: %d, with 2^-16: %d"
+          % (T, span, missed, missed_old))
+    assert missed == 0
+    assert span > 128 and missed_old > 0                                        # the family reaches past the old budget (128 ulp) and defeats it

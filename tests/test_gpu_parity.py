@@ -331,6 +331,178 @@ def test_bps_few_clouds_ranges_keep_lowest_index_rule(B, N):
     assert (d2.cpu().numpy().view(np.int32) == dist.view(np.int32)).all()
 
 
+def _encode_raw(lib, _lib, cl, bs, d, ids, ws=None):
+    B, N = cl.shape[0], cl.shape[1]
+    P = bs.shape[0]
+    if ws is None:
+        _lib.check(lib.dgg_bps_encode(_lib.ptr(cl), B, N, _lib.ptr(bs), P, _lib.ptr(d), _lib.ptr(ids), _lib.stream_ptr()))
+    else:
+        _lib.check(lib.dgg_bps_encode_ws(_lib.ptr(cl), B, N, _lib.ptr(bs), P, _lib.ptr(d), _lib.ptr(ids), _lib.ptr(ws),
+                                         ws.numel(), _lib.stream_ptr()))
+
+
+def _scan_answer(lib, _lib, cl, bs):
+    """The vector-ALU scan's ids / distances for the same device tensors (route override of the ABI)."""
+    B, P = cl.shape[0], bs.shape[0]
+    d = torch.empty((B, P), device=DEV)
+    ids = torch.empty((B, P), device=DEV, dtype=torch.int32)
+    assert lib.dgg_set_bps_algo(1) == 0
+    try:
+        _encode_raw(lib, _lib, cl, bs, d, ids)
+    finally:
+        assert lib.dgg_set_bps_algo(0) == 0
+    return d, ids
+
+
+@pytest.mark.parametrize("B,N", [(1024, 1024), (1024, 2048)])
+def test_bps_matrix_path_every_output_under_load_repeated(B, N):
+    """Regression guard for the wrong-operand failure of round 3 (profiles/r03_experiments.txt 7): 1-16 of
+    4.2 M outputs wrong in about one run of three, only with several workgroups resident per CU (1024 x 1024: three per
+    CU, the most failure-prone occupancy; 1024 x 2048: two), never in a quiet single comparison of a few clouds.  So:
+    ALL B x 4096 ids and distance bits, compared on the device with the scan's, 20 launches per shape, with a loop of large
+    GEMMs running on a second stream the whole time.  A compiler or ROCm bump that brings the failure back shows here."""
+    ops, _lib = _ops()
+    lib = _lib.lib()
+    basis = H.load("bps_real_objects.npz")["basis"]
+    clouds = synth.make_clouds(B, N, 31337)
+    clouds[0, 7] = clouds[0, 3]
+    clouds[0, N - 1] = clouds[0, 3]
+    clouds[1, :] = clouds[1, 0]
+    clouds[2] = clouds[2, :1] + 1e-6 * torch.randn((N, 3), generator=torch.Generator().manual_seed(5))
+    clouds[4] = clouds[4] + 50.0
+    cl, bs = clouds.to(DEV).contiguous(), torch.from_numpy(basis).to(DEV)
+    want_d, want_i = _scan_answer(lib, _lib, cl, bs)
+    torch.cuda.synchronize()
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn((2048, 4096), generator=g).to(DEV)
+    W = torch.randn((2048, 4096), generator=g).to(DEV)
+    C = torch.empty((2048, 2048), device=DEV)
+    side = torch.cuda.Stream()
+    P = bs.shape[0]
+    outs = [(torch.empty((B, P), device=DEV), torch.empty((B, P), device=DEV, dtype=torch.int32)) for _ in range(20)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(60):   # ~240 us each: busy well past the 20 encodes
+            ops.gemm(0, A, W, 2048, 2048, 4096, C_out=C)
+    e0.record()
+    for d, i in outs:
+        _encode_raw(lib, _lib, cl, bs, d, i)
+    e1.record()
+    torch.cuda.synchronize()
+    bad = 0
+    for d, i in outs:
+        bad += int((i != want_i).sum().item()) + int((d.view(torch.int32) != want_d.view(torch.int32)).sum().item())
+    print("bps %d x %d: 20 launches beside a GEMM loop, %.3f ms each; outputs differing from the scan: %d of %d"
+          % (B, N, e0.elapsed_time(e1) / 20, bad, 20 * 2 * B * P))
+    assert bad == 0
+
+
+def test_bps_tile_index_bits_adversarial_clouds():
+    """keys carry the tile index in their 7 low mantissa bits, so two keys may sit 127 + (ntile - 1) ulp
+    apart on top of the coarse error.  1024 clouds x 4096 basis points of the adversarial family of
+    tests/test_bps_coarse_bound.py::test_tile_index_bits_in_the_keys: the cloud's scaled radius just above a power of two
+    (R' = 32.1), basis points within 1e-8 of the origin, the two nearest points nearly tied (sub-ulp to a few ulp), one in
+    the FIRST tile and one in the LAST (tile 79: N = 2560), every other point ~1700 ulp farther.  Every output against the
+    scan."""
+    ops, _lib = _ops()
+    lib = _lib.lib()
+    g = np.random.default_rng(77)
+    B, N, P = 1024, 2560, 4096
+    R = np.float32(32.1 / 64.0)
+    u = g.normal(size=(B, N, 3))
+    u /= np.linalg.norm(u, axis=2, keepdims=True)
+    clouds = (u * np.float64(R)).astype(np.float32)
+    r = np.float64(R) * (1 - 2.0 ** -12 - g.uniform(0, 2.0 ** -11, size=(B, 1)))
+    clouds[:, 3] = (u[:, 3] * r).astype(np.float32)
+    clouds[:, N - 5] = (u[:, N - 5] * r * (1 + g.integers(-1, 2, size=(B, 1)) * 2.0 ** -25)).astype(np.float32)
+    basis = (g.normal(size=(P, 3)) * 1e-8).astype(np.float32)
+    cl, bs = torch.from_numpy(clouds).to(DEV), torch.from_numpy(basis).to(DEV)
+    want_d, want_i = _scan_answer(lib, _lib, cl, bs)
+    d, i = torch.empty((B, P), device=DEV), torch.empty((B, P), device=DEV, dtype=torch.int32)
+    _encode_raw(lib, _lib, cl, bs, d, i)
+    torch.cuda.synchronize()
+    wi = want_i.cpu().numpy()
+    assert np.isin(wi, (3, N - 5)).all()                       # the family is what it claims: only the two rivals win
+    share = float((wi == N - 5).mean())
+    assert 0.2 < share < 0.8, share
+    nbad = int((i != want_i).sum().item()) + int((d.view(torch.int32) != want_d.view(torch.int32)).sum().item())
+    print("adversarial tile-index clouds: last-tile rival wins %.1f %% of %d outputs; differing from the scan: %d"
+          % (100 * share, B * P, nbad))
+    assert nbad == 0
+    from oracle import bps_oracle
+    od, oi = bps_oracle.encode_f32(clouds[5], basis)           # and the scan itself against the oracle on one cloud
+    assert (wi[5] == oi).all() and (want_d[5].cpu().numpy().view(np.int32) == od.view(np.int32)).all()
+
+
+@pytest.mark.parametrize("B,N", [(1, 73000), (1, 15009), (1, 2561), (2, 20001), (3, 5000), (5, 777), (40, 4100)])
+def test_bps_chunked_matrix_path_for_large_clouds(B, N):
+    """Round 4: the reference's own call shape — ONE cloud of 15k-73k points (dexgangrasp_real_robot.py:133-141) — and every
+    cloud of more than 2560 points on the matrix cores, chunk by chunk, chunks meeting in the caller's workspace by a 64-bit
+    minimum of (d2 bits, j).  Duplicates of a point in other chunks (lowest index wins), an all-equal cloud, an
+    overflowing one, NaN points, N % 4 != 0 (ragged last quad; for B > 1 clouds that do not start on 16-byte boundaries)
+    against the scan on every output, and against the oracle on one cloud."""
+    ops, _lib = _ops()
+    lib = _lib.lib()
+    from oracle import bps_oracle
+    basis = H.load("bps_real_objects.npz")["basis"]
+    P = basis.shape[0]
+    clouds = synth.make_clouds(B, N, 1900 + B + N)
+    clouds[0, N - 1] = clouds[0, 3]          # the last chunk duplicates a point of the first
+    clouds[0, N // 2] = clouds[0, 3]         # a middle chunk too
+    clouds[0, N // 2 + 1] = clouds[0, N // 3]
+    clouds[0, 300] = float("nan")
+    if B > 1:
+        clouds[1, :] = clouds[1, 7]          # every point the same: index 0 everywhere
+    if B > 2:
+        clouds[2, :] = 3e19                  # nothing is below +inf: index 0, dist +inf
+    if B > 3:
+        clouds[3, : N // 2] = 3e19           # the finite half wins
+        clouds[4] = clouds[4] + 50.0         # far from the origin
+    cl, bs = clouds.to(DEV).contiguous(), torch.from_numpy(basis).to(DEV)
+    nws = int(lib.dgg_bps_workspace_bytes(B, N, P))
+    assert nws > 0, "these shapes are the chunked route's"
+    ws = torch.empty((nws,), dtype=torch.uint8, device=DEV)
+    want_d, want_i = _scan_answer(lib, _lib, cl, bs)
+    d, i = torch.empty((B, P), device=DEV), torch.empty((B, P), device=DEV, dtype=torch.int32)
+    _encode_raw(lib, _lib, cl, bs, d, i, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(i, want_i), int((i != want_i).sum().item())
+    assert torch.equal(d.view(torch.int32), want_d.view(torch.int32))
+    for b in {0, B - 1}:
+        od, oi = bps_oracle.encode_f32(clouds[b].numpy(), basis)
+        assert (i[b].cpu().numpy() == oi).all(), b
+        assert (d[b].cpu().numpy().view(np.int32) == od.view(np.int32)).all(), b
+    assert not np.isin(i[0].cpu().numpy(), (N - 1, N // 2, N // 2 + 1, 300)).any()
+    # distances only (ids = NULL), a workspace that is too small (falls back to the workspace-free kernels), and the
+    # wrapper (allocates the workspace itself): same bits
+    d2 = torch.empty((B, P), device=DEV)
+    _lib.check(lib.dgg_bps_encode_ws(_lib.ptr(cl), B, N, _lib.ptr(bs), P, _lib.ptr(d2), None, _lib.ptr(ws), nws, _lib.stream_ptr()))
+    assert torch.equal(d2.view(torch.int32), want_d.view(torch.int32))
+    d3, i3 = torch.empty((B, P), device=DEV), torch.empty((B, P), device=DEV, dtype=torch.int32)
+    _lib.check(lib.dgg_bps_encode_ws(_lib.ptr(cl), B, N, _lib.ptr(bs), P, _lib.ptr(d3), _lib.ptr(i3), _lib.ptr(ws), 64, _lib.stream_ptr()))
+    assert torch.equal(i3, want_i) and torch.equal(d3.view(torch.int32), want_d.view(torch.int32))
+    d4, i4 = ops.bps_encode(cl, bs)
+    assert torch.equal(i4, want_i) and torch.equal(d4.view(torch.int32), want_d.view(torch.int32))
+    if B == 1:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            _encode_raw(lib, _lib, cl, bs, d, i, ws)
+        e0.record()
+        for _ in range(20):
+            _encode_raw(lib, _lib, cl, bs, d, i, ws)
+        e1.record()
+        torch.cuda.synchronize()
+        t_new = e0.elapsed_time(e1) / 20
+        e0.record()
+        for _ in range(20):
+            _encode_raw(lib, _lib, cl, bs, d, i)
+        e1.record()
+        torch.cuda.synchronize()
+        print("one cloud of %d points: %.1f us on the matrix cores (chunks + merge), %.1f us as vector-ALU ranges"
+              % (N, 1e3 * t_new, 1e3 * e0.elapsed_time(e1) / 20))
+
+
 # ------------------------------------------------------------------ A6 / A7: small ops
 def test_ortho6d_forward_backward():
     ops, _ = _ops()

@@ -271,7 +271,7 @@ def test_forced_slopes_reproduce_and_steer_the_oracle():
     masks = synth.make_dropout_masks(64, 3)
     cfg = dict(synth.DEFAULT_CFG)
 
-    def run(slopes=None, rec=False):
+    def run(slopes=None, rec=False, capped=True):
         sd = {k: v.clone() for k, v in sde.items()}
         st = O.AdamState(O.param_names(sd))
         if rec:
@@ -279,6 +279,8 @@ def test_forced_slopes_reproduce_and_steer_the_oracle():
                 out, g, p = O.eva_step(sd, H.clone_batch(batch), st, cfg, masks, return_grads=True)
             return out, g, p, r.masks
         s = {"e": slopes} if slopes is not None else None
+        if s is not None and not capped:
+            s["max_flips"] = s["max_ratio"] = None
         out, g, p = O.eva_step(sd, H.clone_batch(batch), st, cfg, masks, return_grads=True, slopes=s)
         return out, g, p, (s or {}).get("flips")
 
@@ -290,9 +292,17 @@ def test_forced_slopes_reproduce_and_steer_the_oracle():
         assert torch.equal(g0[n], g1[n]), n
     flipped = [m.clone() for m in sides]
     flipped[1][5, 7] = ~flipped[1][5, 7]          # rb1's bn1 branch, sample 5, unit 7
-    out2, g2, p2, flips = run(flipped)
+    out2, g2, p2, flips = run(flipped, capped=False)
     assert flips >= 1      # (a far-from-zero flip also moves downstream pre-activations across their forced sides)
     assert not torch.equal(g0["rb1.fc1.weight"][7], g2["rb1.fc1.weight"][7])
+    # ... and the steering is capped: the same far-from-zero flip is REFUSED by default (|x| / rms <= 1e-5, <= 8 elements),
+    # so a device that took a wrong side away from a kink fails the comparison instead of being followed
+    with pytest.raises(AssertionError, match="forced_slopes: (steered at a pre-activation|the oracle was steered at)"):
+        run(flipped)
+    many = [m.clone() for m in sides]
+    many[1][:, :] = ~many[1]
+    with pytest.raises(AssertionError, match="forced_slopes: the oracle was steered at"):
+        run(many)
     with pytest.raises(AssertionError):
         with O.forced_slopes(sides[:3]):
             O.evaluator_forward({k: v.clone() for k, v in sde.items()}, batch["bps_object"], batch["rot_matrix"],
