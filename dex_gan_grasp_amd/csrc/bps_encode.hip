@@ -96,11 +96,21 @@ __global__ __launch_bounds__(256) void bps_batched_kernel(const float* __restric
         bx[q >> 1][q & 1] = tx;
         by[q >> 1][q & 1] = ty;
         bz[q >> 1][q & 1] = tz;
-        // MODE 2: `best` is the TARGET, the global minimum pass 1 left in dists (+inf: nothing was smaller, leave ids)
-        best[q] = MODE == 2 ? __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)dists + (size_t)b * P + i,
-                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                            : __builtin_inff();
+        best[q] = __builtin_inff();
         blk[q] = -1;
+    }
+    if (MODE == 2) {
+        // `best` is the TARGET, the global minimum pass 1 left in dists (+inf: nothing was smaller, leave ids).  These dword
+        // loads are issued only once the 12-byte basis loads above have landed: no counted wait over two classes of loads
+        // (tools/vmcnt_audit.py)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < BPT; ++q) {
+            int i = slice * (256 * BPT) + q * 256 + threadIdx.x;
+            i = i < P ? i : P - 1;
+            best[q] = __builtin_bit_cast(float, __hip_atomic_load((const unsigned*)dists + (size_t)b * P + i, __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_AGENT));
+        }
     }
     auto pair_d2 = [&](int h, float x, float y, float z) {
         const f32x2 dx = f32x2{x, x} - bx[h], dy = f32x2{y, y} - by[h], dz = f32x2{z, z} - bz[h];
@@ -242,7 +252,7 @@ __device__ __forceinline__ unsigned pk16(_Float16 even, _Float16 odd) {  // k-sl
 }
 
 constexpr int kBpsMfmaMaxN = 2560;  // points per workgroup: 32 B of LDS per point, tile index in 7 bits
-constexpr int kBpsChunkMax = 1792;  // MERGE: points per chunk (44 B of LDS per point -> two workgroups per CU; <= NW * 256)
+constexpr int kBpsChunkMax = 1536;  // MERGE: points per chunk (44 B of LDS per point + 12 KB of basis -> two workgroups per CU; <= NW * 256)
 constexpr int kBpsQueue = 512;      // work-list entries per wave (128 winners + further candidates; the rest in place)
 #ifndef BPS_NW
 #define BPS_NW 8
@@ -251,24 +261,33 @@ constexpr int kBpsQueue = 512;      // work-list entries per wave (128 winners +
 // Four consecutive cloud points as three 16-byte vectors {x0 y0 z0 x1} {y1 z1 x2 y2} {z2 x3 y3 z3}.  AL: the cloud (chunk) is
 // 16-byte aligned and the four points lie inside it -> three global_load_dwordx4; otherwise point by point with the index
 // clamped to the last point (rows past the cloud repeat its LAST point: a copy inside a block changes no block minimum, a
-// block of copies only is a candidate at worst, and the exact stage skips j >= n), 12-byte loads waited for with vmcnt(0):
-// no counted wait ever covers loads of mixed widths (see block()).
+// block of copies only is a candidate at worst, and the exact stage skips j >= n).  That path is ONE asm statement: twelve
+// naturally aligned dword loads and the `s_waitcnt vmcnt(0)` that covers them — the compiler sees neither 12-byte loads
+// at 4-byte alignment nor loads of a second class among its counted waits, and cannot read a result before the wait
+// (an asm wait behind compiler-visible loads does not bind it: it copies loaded registers under its own counted waits
+// in front of such an asm; DESIGN.md 3.4, tools/vmcnt_audit.py).
 template <bool AL>
 __device__ __forceinline__ void load_quad(const float* __restrict__ c, int j0, int n, bf32x4& p0, bf32x4& p1, bf32x4& p2) {
     if (AL && j0 + 4 <= n) {
         const bf32x4* pq = reinterpret_cast<const bf32x4*>(c + 3 * j0);
         p0 = pq[0], p1 = pq[1], p2 = pq[2];
     } else {
-        float v[12];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = min(j0 + k, n - 1);
-            load3(c + 3 * j, v[3 * k], v[3 * k + 1], v[3 * k + 2]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                       "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]));
-        p0 = bf32x4{v[0], v[1], v[2], v[3]}, p1 = bf32x4{v[4], v[5], v[6], v[7]}, p2 = bf32x4{v[8], v[9], v[10], v[11]};
+        const float* a0 = c + 3 * min(j0, n - 1);
+        const float* a1 = c + 3 * min(j0 + 1, n - 1);
+        const float* a2 = c + 3 * min(j0 + 2, n - 1);
+        const float* a3 = c + 3 * min(j0 + 3, n - 1);
+        float v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11;
+        asm volatile(
+            "global_load_dword %0, %12, off\n\tglobal_load_dword %1, %12, off offset:4\n\tglobal_load_dword %2, %12, off offset:8\n\t"
+            "global_load_dword %3, %13, off\n\tglobal_load_dword %4, %13, off offset:4\n\tglobal_load_dword %5, %13, off offset:8\n\t"
+            "global_load_dword %6, %14, off\n\tglobal_load_dword %7, %14, off offset:4\n\tglobal_load_dword %8, %14, off offset:8\n\t"
+            "global_load_dword %9, %15, off\n\tglobal_load_dword %10, %15, off offset:4\n\tglobal_load_dword %11, %15, off offset:8\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7), "=&v"(v8), "=&v"(v9),
+              "=&v"(v10), "=&v"(v11)
+            : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+            : "memory");
+        p0 = bf32x4{v0, v1, v2, v3}, p1 = bf32x4{v4, v5, v6, v7}, p2 = bf32x4{v8, v9, v10, v11};
     }
 }
 
@@ -309,34 +328,48 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
         s_r2 = 0;
         s_bad = 0;
     }
+    // LDS behind the operand planes AND behind the exact stage's slots / lists (which overlay the planes): the workgroup's
+    // NW * 128 basis points (`sb`), then — MERGE — the chunk's fp32 coordinates (`sc`).
+    constexpr int kExactBytes = NW * (NT * 32 + kBpsQueue / 2) * 8, kBasisFloats = NW * NT * 32 * 3;
+    const int boff = max(((CH + 31) >> 5) * 1024, kExactBytes);
+    float* const sb = reinterpret_cast<float*>(reinterpret_cast<char*>(planes) + boff);
+    bf32x4* const sc = reinterpret_cast<bf32x4*>(sb + kBasisFloats);
+    // MERGE: a chunk has at most NW * 256 points, i.e. at most ONE quad of four points per thread: it is requested together
+    // with the basis points (one memory round trip for both), stays in registers from pass 1 to pass 2, and goes to LDS
+    // (`sc`, 12 B per point in the cloud's own layout) — the exact stage gathers its candidate blocks from there: gathered
+    // from global memory, 13 loads x 64 lanes each in a cache line of its own kept the texture path busy for ~6 us per
+    // pass.
+    bf32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0;
+    const bool mine = MERGE && tid < ntile * 8;
+    {
+        // The basis points reach the lanes through LDS: 16-byte loads of the slice (the same class as the cloud's loads) or,
+        // for a ragged last slice / a basis that is not 16-byte aligned, aligned dwords with the index clamped to P - 1 —
+        // never a 12-byte load at a 4-byte aligned address among other loads (the round-3 wrong-operand failure,
+        // DESIGN.md 3.4), and coalesced instead of one 12-byte piece per lane.
+        const int first = slice * (NW * NT * 32);
+        if (((uintptr_t)basis & 15) == 0 && first + NW * NT * 32 <= P) {
+            if (mine) load_quad<AL>(c, 4 * tid, N, q0, q1, q2);
+            const bf32x4* src = reinterpret_cast<const bf32x4*>(basis + 3 * (size_t)first);
+            for (int e = tid; e < kBasisFloats / 4; e += NW * 64) reinterpret_cast<bf32x4*>(sb)[e] = src[e];
+        } else {
+            for (int e = tid; e < kBasisFloats; e += NW * 64) sb[e] = basis[3 * (size_t)min(first + e / 3, P - 1) + e % 3];
+            if (mine) {  // (behind the dword loads: consumed by their LDS stores before these are waited for)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                load_quad<AL>(c, 4 * tid, N, q0, q1, q2);
+            }
+        }
+    }
     __syncthreads();
-    // (the lane's NT basis points are loaded together and waited for with vmcnt(0), see block())
     auto load_basis = [&](float (&X)[NT], float (&Y)[NT], float (&Z)[NT]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            int i = (slice * NW + w) * (NT * 32) + t * 32 + col;
-            i = i < P ? i : P - 1;
-            load3(basis + 3 * i, X[t], Y[t], Z[t]);
+            const float* q = sb + 3 * (w * (NT * 32) + t * 32 + col);
+            X[t] = q[0], Y[t] = q[1], Z[t] = q[2];
         }
-        static_assert(NT == 4, "the wait below names 4 basis points");
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(X[0]), "+v"(Y[0]), "+v"(Z[0]), "+v"(X[1]), "+v"(Y[1]), "+v"(Z[1]), "+v"(X[2]), "+v"(Y[2]),
-                       "+v"(Z[2]), "+v"(X[3]), "+v"(Y[3]), "+v"(Z[3]));
     };
     auto sane = [](float x, float y, float z) {
         return __builtin_fabsf(x) < 1e3f && __builtin_fabsf(y) < 1e3f && __builtin_fabsf(z) < 1e3f;
     };
-    // MERGE: a chunk has at most NW * 256 points, i.e. at most ONE quad of four points per thread: it is requested before the
-    // basis points (one memory round trip for both), stays in registers from pass 1 to pass 2, and goes to LDS next to the
-    // operand planes (`sc`, 12 B per point in the cloud's own layout) — the exact stage gathers its candidate blocks from
-    // there: gathered from global memory, 13 loads x 64 lanes each in a cache line of its own kept the texture path busy
-    // for ~6 us per pass and made a 256-point chunk take 17 us.
-    constexpr int kExactBytes = NW * (NT * 32 + kBpsQueue / 2) * 8;
-    const int coff = max(((CH + 31) >> 5) * 1024, kExactBytes);  // behind the planes AND behind the exact stage's slots / lists
-    bf32x4* const sc = reinterpret_cast<bf32x4*>(reinterpret_cast<char*>(planes) + coff);
-    bf32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0;
-    const bool mine = MERGE && tid < ntile * 8;
-    if (mine) load_quad<AL>(c, 4 * tid, N, q0, q1, q2);
     float bxs[NT], bys[NT], bzs[NT];
     load_basis(bxs, bys, bzs);
     auto quad = [&](int j0, bf32x4& p0, bf32x4& p1, bf32x4& p2) {  // the exact stage's four points j0 .. j0 + 3
@@ -484,8 +517,20 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
     auto block = [&](int i, int hh, float X, float Y, float Z, float& bb, int& bj) {
         // 16 rows of point tile i as half-wave hh sees them, the contract's arithmetic; rows ascend: strict '<'
         bf32x4 pt[4][3];
+        if (!MERGE && AL && i * 32 + 32 <= N) {  // the whole tile inside the cloud: twelve 16-byte loads, one test
 #pragma unroll
-        for (int g = 0; g < 4; ++g) quad(i * 32 + 8 * g + 4 * hh, pt[g][0], pt[g][1], pt[g][2]);
+            for (int g = 0; g < 4; ++g) {
+                const bf32x4* pq = reinterpret_cast<const bf32x4*>(c + 3 * (i * 32 + 8 * g + 4 * hh));
+                pt[g][0] = pq[0], pt[g][1] = pq[1], pt[g][2] = pq[2];
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) quad(i * 32 + 8 * g + 4 * hh, pt[g][0], pt[g][1], pt[g][2]);
+        }
+        // (No j < N test below.  Rows past the cloud are copies of its LAST point, bit for bit, at larger indices: inside a
+        //  block the strict '<' never prefers a later copy; a block of copies only has a key >= the key of the block that
+        //  holds the original — same value, smaller-or-equal minimum, smaller-or-equal tile — so whenever it is a candidate
+        //  the original's block is one too, in its own lane, and the slots' 64-bit minimum of (d2, j) keeps the original.)
         // Everything this evaluation loaded — the 12 point vectors and the caller's basis point — is waited for HERE,
         // with vmcnt(0), not by the compiler's counted waits.  With those (correct IF loads return in order: the basis
         // point's 12-byte load third among thirteen 16-byte point loads) lanes 32-63 computed, in one run of three and only
@@ -507,13 +552,13 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
             const f32x2 da = __builtin_elementwise_fma(az, az, __builtin_elementwise_fma(ay, ay, ax * ax));
             const f32x2 dc = __builtin_elementwise_fma(cz, cz, __builtin_elementwise_fma(cy, cy, cx * cx));
             const float d0 = da[0], d1 = da[1], d2 = dc[0], d3 = dc[1];
-            bool lt = (j0 < N) & (d0 < bb);  // rows past the cloud (copies of its last point) never win
+            bool lt = d0 < bb;
             bb = lt ? d0 : bb, bj = lt ? j0 : bj;
-            lt = (j0 + 1 < N) & (d1 < bb);
+            lt = d1 < bb;
             bb = lt ? d1 : bb, bj = lt ? j0 + 1 : bj;
-            lt = (j0 + 2 < N) & (d2 < bb);
+            lt = d2 < bb;
             bb = lt ? d2 : bb, bj = lt ? j0 + 2 : bj;
-            lt = (j0 + 3 < N) & (d3 < bb);
+            lt = d3 < bb;
             bb = lt ? d3 : bb, bj = lt ? j0 + 3 : bj;
         }
     };
@@ -579,11 +624,9 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
             if (base + lane < n) {
                 const unsigned it = q[base + lane];
                 const int bl = it >> 8;
-                int i = first + bl;
-                i = i < P ? i : P - 1;
-                float X, Y, Z, bb = __builtin_inff();
+                const float* bq = sb + 3 * (w * (NT * 32) + bl);
+                float X = bq[0], Y = bq[1], Z = bq[2], bb = __builtin_inff();
                 int bj = 0;
-                load3(basis + 3 * i, X, Y, Z);
                 block(it & 127u, (it >> 7) & 1u, X, Y, Z, bb, bj);
                 offer(bl, bb, bj);
             }
@@ -593,24 +636,22 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
         if (base + (lane >> 2) < n) {
             const unsigned it = q[base + (lane >> 2)];
             const int bl = it >> 8;
-            int i = first + bl;
-            i = i < P ? i : P - 1;
-            float X, Y, Z, bb = __builtin_inff();
+            const float* bq = sb + 3 * (w * (NT * 32) + bl);
+            float X = bq[0], Y = bq[1], Z = bq[2], bb = __builtin_inff();
             int bj = 0;
-            load3(basis + 3 * i, X, Y, Z);
             const int j0 = (int)(it & 127u) * 32 + 8 * (lane & 3) + 4 * (int)((it >> 7) & 1u);
             bf32x4 p0, p1, p2;
             quad(j0, p0, p1, p2);
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(X), "+v"(Y), "+v"(Z));
             const float d0 = dist2(p0[0], p0[1], p0[2], X, Y, Z), d1 = dist2(p0[3], p1[0], p1[1], X, Y, Z);
             const float d2 = dist2(p1[2], p1[3], p2[0], X, Y, Z), d3 = dist2(p2[1], p2[2], p2[3], X, Y, Z);
-            bool lt = (j0 < N) & (d0 < bb);
+            bool lt = d0 < bb;
             bb = lt ? d0 : bb, bj = lt ? j0 : bj;
-            lt = (j0 + 1 < N) & (d1 < bb);
+            lt = d1 < bb;
             bb = lt ? d1 : bb, bj = lt ? j0 + 1 : bj;
-            lt = (j0 + 2 < N) & (d2 < bb);
+            lt = d2 < bb;
             bb = lt ? d2 : bb, bj = lt ? j0 + 2 : bj;
-            lt = (j0 + 3 < N) & (d3 < bb);
+            lt = d3 < bb;
             bb = lt ? d3 : bb, bj = lt ? j0 + 3 : bj;
             offer(bl, bb, bj);
         }
@@ -700,7 +741,7 @@ BpsPlan bps_plan(int B, int N, int P, size_t ws_avail) {
     const int gx = (P + 1023) / 1024;
     const bool few = (long long)gx * B < 192 && N >= 512;
     if (bps_algo() != 1 && N >= 64) {
-        // chunks: ~512 workgroups (two per CU), 256..1792 points each (planes + coordinates: 77 KB of LDS), multiples of 32
+        // chunks: ~512 workgroups (two per CU), 256..1536 points each (planes + coordinates + basis: 78 KB of LDS), multiples of 32
         if (few || N > kBpsMfmaMaxN) {
             long long ch = ((long long)N * p.g * B + 511) / 512;
             ch = (ch + 31) / 32 * 32;
@@ -737,6 +778,7 @@ void bps_mfma_launch(const BpsPlan& pl, const float* clouds, int B, int N, const
     size_t lds = (size_t)((rows + 31) / 32) * 32 * 32;                       // operand planes, then reused by the exact stage:
     const size_t lds_exact = (size_t)kBpsNW * (4 * 32 + kBpsQueue / 2) * 8;   // per wave 128 slots + the work list
     lds = lds > lds_exact ? lds : lds_exact;
+    lds += (size_t)kBpsNW * 128 * 12;                                        // + the workgroup's basis points (`sb`)
     if (MERGE) lds += (size_t)((rows + 31) / 32) * 32 * 12;                  // + the chunk's fp32 coordinates (`sc`)
     static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void*>(&bps_mfma_kernel<4, kBpsNW, AL, MERGE>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;

@@ -1115,7 +1115,34 @@ struct Rot {
     float b[3];
 };
 
-__device__ __forceinline__ void ortho6d(const float* o, Rot& R) {
+// Rows of 6 / 9 floats at a 4-byte aligned address (pitches of 6, 9, 21 floats): the compiler merges their loads into
+// dwordx4 + dwordx2 (+ dword) pieces at addresses that are not aligned to the piece and waits for them with counted
+// vmcnt(N) among each other — the shape of load the round-3 wrong-operand failure of the BPS kernel went away without
+// (tools/vmcnt_audit.py lists every such wait of the library).  These helpers are ONE asm statement each:
+// naturally aligned dword loads and the s_waitcnt vmcnt(0) that covers them.
+__device__ __forceinline__ void gld6(const float* p, float (&v)[6]) {
+    asm volatile(
+        "global_load_dword %0, %6, off\n\tglobal_load_dword %1, %6, off offset:4\n\tglobal_load_dword %2, %6, off offset:8\n\t"
+        "global_load_dword %3, %6, off offset:12\n\tglobal_load_dword %4, %6, off offset:16\n\t"
+        "global_load_dword %5, %6, off offset:20\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5])
+        : "v"(p)
+        : "memory");
+}
+__device__ __forceinline__ void gld9(const float* p, float (&v)[9]) {
+    asm volatile(
+        "global_load_dword %0, %9, off\n\tglobal_load_dword %1, %9, off offset:4\n\tglobal_load_dword %2, %9, off offset:8\n\t"
+        "global_load_dword %3, %9, off offset:12\n\tglobal_load_dword %4, %9, off offset:16\n\t"
+        "global_load_dword %5, %9, off offset:20\n\tglobal_load_dword %6, %9, off offset:24\n\t"
+        "global_load_dword %7, %9, off offset:28\n\tglobal_load_dword %8, %9, off offset:32\n\ts_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8])
+        : "v"(p)
+        : "memory");
+}
+
+__device__ __forceinline__ void ortho6d(const float* op, Rot& R) {
+    float o[6];
+    gld6(op, o);
     const float a0 = o[0], a1 = o[1], a2 = o[2];
     R.b[0] = o[3]; R.b[1] = o[4]; R.b[2] = o[5];
     R.na = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
@@ -1212,8 +1239,9 @@ __global__ __launch_bounds__(256) void ortho6d_bwd_kernel(const float* __restric
     if (i >= B) return;
     Rot R;
     ortho6d(o6 + (size_t)i * ld, R);
-    float go[6];
-    ortho6d_bwd(R, d_rot9 + (size_t)i * 9, go);
+    float go[6], gR[9];
+    gld9(d_rot9 + (size_t)i * 9, gR);
+    ortho6d_bwd(R, gR, go);
 #pragma unroll
     for (int k = 0; k < 6; ++k) d_o6[(size_t)i * ldd + k] = go[k];
 }

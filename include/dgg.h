@@ -100,7 +100,7 @@ int64_t dgg_workspace_bytes(int net, const dgg_cfg* cfg, int batch); /* activati
  *     DECIDES (16-byte aligned clouds with N % 4 == 0 load four points as three 16-byte vectors, others point by point);
  *   - dgg_bps_encode_ws with a workspace of dgg_bps_workspace_bytes(B, N, P): few clouds of many points (the
  *     reference's own call shape: ONE cloud of 15k-73k points, dexgangrasp_real_robot.py:133-141) and clouds of more
- *     than 2560 points take the same path chunk by chunk — a workgroup per (chunk of 256..1792 points, 1024 basis
+ *     than 2560 points take the same path chunk by chunk — a workgroup per (chunk of 256..1536 points, 1024 basis
  *     points), each with its own power-of-two scale, (d2 bits, index) per chunk and basis point into the workspace,
  *     a second launch takes the 64-bit minimum over the chunks = the lowest-index rule over the whole cloud;
  *   - without a workspace such clouds are scanned by the vector ALU as ranges that meet in the output arrays

@@ -193,7 +193,7 @@ def test_benched_joint_step_with_prefetch_and_philox_vs_oracle(b, variant, front
         ebs = [synth.make_batch(b, 2 + 10 * i, with_label=True) for i in range(3)]
     g_ins = [_dev_inputs(x) for x in gbs]
     steps = 3
-    store, flips = {}, 0
+    store, flips, worst = {}, 0, 0.0
     eng.after_d_phase = _sides_hook(store)
     for i in range(steps):
         eb = ebs[i]
@@ -212,7 +212,12 @@ def test_benched_joint_step_with_prefetch_and_philox_vs_oracle(b, variant, front
         ref, g_d, g_g, _ = O.cgan_step(sd, H.clone_batch(gbs[i % 2]), z, ag, ad, CFG, True, return_grads=True,
                                        slopes=sl["gan"])
         refe, g_e, _ = O.eva_step(sde, H.clone_batch(eb), ae, CFG, masks, return_grads=True, slopes=sl["eva"])
-        flips += sl["gan"]["flips"] + sl["eva"]["flips"]
+        # the steering is capped inside the oracle (forced_slopes: <= 8 elements per phase, each within 1e-5 of its tensor's
+        # rms of zero); per STEP, stated here as well:
+        step_flips = sl["gan"]["flips"] + sl["eva"]["flips"]
+        step_worst = max(sl["gan"]["worst"], sl["eva"]["worst"])
+        assert step_flips <= O.MAX_FLIPS and step_worst <= O.MAX_FLIP_RATIO, (i, step_flips, step_worst)
+        flips, worst = flips + step_flips, max(worst, step_worst)
         for k, n in enumerate(LOSS_NAMES):
             np.testing.assert_allclose(got[k], float(ref[n]), rtol=1e-4, atol=1e-6, err_msg="step %d %s" % (i, n))
         np.testing.assert_allclose(got[L.L_TOTAL_EVA], float(refe["total_loss_eva"]), rtol=1e-4, atol=1e-6)
@@ -237,8 +242,8 @@ def test_benched_joint_step_with_prefetch_and_philox_vs_oracle(b, variant, front
         _adopt(eng.G, sd, ag, "generator.")
         _adopt(eng.D, sd, ad, "discriminator.")
         _adopt(eng.E, sde, ae, "")
-    print("B=%d %s %s: the oracle took the HIP path's side at %d LeakyReLU kink crossing(s) over %d steps"
-          % (b, variant, front, flips, steps))
+    print("B=%d %s %s: the oracle took the HIP path's side at %d LeakyReLU kink crossing(s) over %d steps, the farthest "
+          "%.2e of its tensor's rms from zero (caps: %d per step, %.0e)" % (b, variant, front, flips, steps, worst, O.MAX_FLIPS, O.MAX_FLIP_RATIO))
     # running statistics integrate three steps of batch statistics (real, fake, fake for D)
     for flat, s, pre in ((eng.G, sd, "generator."), (eng.D, sd, "discriminator."), (eng.E, sde, "")):
         for n, t in flat.state_dict().items():
