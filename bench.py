@@ -63,7 +63,7 @@ def _time_stream(fn, iters, warm=3):
 def _pmc_traffic(name, shape):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction +
     WRITE_SIZE; separate passes, see profiles/): PMC counters cannot be read from inside a run."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, name))))
             if pmc.get("shape") == shape:
@@ -100,14 +100,15 @@ def gemm_roofline(dev, mode, M, N, K, lda, ldb, splits, what, pmc_name, iters=20
     ms = _time_stream(launch, iters)
     flops = 2.0 * M * N * K
     achieved = flops / (ms * 1e-3) / 1e12
-    peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if algo == 1 else PEAK_F32_MFMA_TFLOPS
+    peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if algo in (1, 2) else PEAK_BF16_MFMA_TFLOPS if algo == 3 else PEAK_F32_MFMA_TFLOPS
     shape = {"M": M, "N": N, "K": K, "splits": splits}
     traffic, src = _pmc_traffic(pmc_name, shape)
     alg_bytes = 4 * (M * K + N * K + max(splits, 1) * M * N)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": src,
             "algorithmic_bytes": alg_bytes, "kernel": what, "shape": shape,
-            "peak_basis": "dense bf16 MFMA 2500 TFLOP/s / 6 products" if algo == 1 else "dense f32 MFMA",
+            "peak_basis": ("dense bf16 MFMA 2500 TFLOP/s / 6 products" if algo in (1, 2) else
+                           "dense bf16 MFMA 2500 TFLOP/s (plain bf16: one product)" if algo == 3 else "dense f32 MFMA"),
             "f32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "ms_per_launch": round(ms, 4)}
 
@@ -149,8 +150,9 @@ def bps_roofline(dev, B=1024, Np=2048, iters=10):
     `achieved` counts against the dense fp16 / bf16 peak; the exact re-evaluation of the candidate blocks (~1.6 % of the
     pairs) is the contract's fp32 arithmetic on the vector ALU.  The kernel is bound by vector ISSUE (13 vector
     instructions per 512 pairs of a lane, which the matrix instruction's issue shares), not by the matrix pipe, so `frac`
-    is low by construction; `valu_equiv_*` prices the same launch as the round-2 scan was priced (8 fp32 flop per pair
-    against the packed-fp32 peak), for comparison across rounds."""
+    is low by construction (the measured port occupancy is in profiles/r04_bps_encode_pmc.json: vector_issue_port_busy_frac);
+    `scan_equiv_tflops_cross_round_ruler` prices the same launch as the round-2 scan was priced (8 fp32 flop per pair) —
+    a ruler across rounds, not a fraction of anything this kernel executes."""
     g = torch.Generator().manual_seed(0)
     basis = (torch.rand((4096, 3), generator=g) * 0.2 - 0.1).to(dev)
     clouds = synth.make_clouds(B, Np, 7).to(dev)
@@ -168,31 +170,67 @@ def bps_roofline(dev, B=1024, Np=2048, iters=10):
     return {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_BF16_MFMA_TFLOPS, 4), "kernel": "bps_mfma_kernel %d clouds x %d points x 4096 basis" % (B, Np),
             "ms_per_launch": round(ms, 4), "pairs_per_s": round(pairs / ms * 1e3, 1), "clouds_per_s": round(B / ms * 1e3, 1),
-            "valu_equiv_tflops": round(tfv, 2), "valu_equiv_frac": round(tfv / PEAK_F32_VALU_TFLOPS, 4),
+            "scan_equiv_tflops_cross_round_ruler": round(tfv, 2),
             "algorithmic_bytes": byts, "hbm_gb_per_s": round(byts / ms / 1e6, 2),
             "hbm_frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 5),
             "note": "32 matrix flop per pair (K = 16 fp16 slots, 14 used); vector-issue bound beside the matrix pipe "
                     "(DESIGN.md 3.4); round 2's scan: 1.07 ms, DGG_BPS=valu"}
 
 
-def adam_roofline(dev, n=10661657, iters=20):
-    """adam_kernel (A12) on the evaluator's flat buffer: 16 B read + 12 B written per parameter, pure HBM streaming."""
-    p, g, m, v = (torch.randn(n, device=dev) * 0.01 for _ in range(4))
-    v.abs_()
+def bps_one_cloud(dev, sizes=(73000, 15009), iters=30):
+    """The reference's own call shape (dexgangrasp_real_robot.py:133-141, data/bps_encoder.py:28-55): ONE cloud of 15k-73k
+    points.  Round 4: chunk by chunk on the matrix cores (dgg_bps_encode_ws), chunks meeting in a workspace; round 3: ranges
+    of the vector-ALU scan meeting in the output arrays (dgg_bps_encode without a workspace), timed next to it.  A launch
+    of ~10 us of arithmetic: latency-bound (two dependent launches), reported in us."""
+    g = torch.Generator().manual_seed(0)
+    basis = (torch.rand((4096, 3), generator=g) * 0.2 - 0.1).to(dev)
     lib = _lib.lib()
     st = torch.cuda.current_stream()
-    k = [0]
+    out = {}
+    for n in sizes:
+        cl = synth.make_clouds(1, n, 5).to(dev).contiguous()
+        d = torch.empty((1, 4096), device=dev)
+        ids = torch.empty((1, 4096), dtype=torch.int32, device=dev)
+        nws = int(lib.dgg_bps_workspace_bytes(1, n, 4096))
+        ws = torch.empty((max(nws, 8),), dtype=torch.uint8, device=dev)
+        new = lambda: _lib.check(lib.dgg_bps_encode_ws(_lib.ptr(cl), 1, n, _lib.ptr(basis), 4096, _lib.ptr(d), _lib.ptr(ids),
+                                                       _lib.ptr(ws), nws, C.c_void_p(st.cuda_stream)))
+        old = lambda: _lib.check(lib.dgg_bps_encode(_lib.ptr(cl), 1, n, _lib.ptr(basis), 4096, _lib.ptr(d), _lib.ptr(ids),
+                                                    C.c_void_p(st.cuda_stream)))
+        t_new, t_old = _time_stream(new, iters) * 1e3, _time_stream(old, iters) * 1e3
+        out["%d_points" % n] = {"us_matrix_cores_chunked": round(t_new, 1), "us_vector_alu_ranges": round(t_old, 1),
+                                "pairs_per_s": round(n * 4096.0 / t_new * 1e6, 1), "workspace_bytes": nws}
+    return out
 
-    def fn():
-        k[0] += 1
-        _lib.check(lib.dgg_adam_l2(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n, k[0], 1e-4, 0.9, 0.999,
-                                   1e-8, 5e-4, 1.0, C.c_void_p(st.cuda_stream)))
-    ms = _time_stream(fn, iters)
-    byts = 28.0 * n
-    gbs = byts / ms / 1e6
+
+def adam_roofline(dev, n_small=10661657, n_big=32 * 1024 * 1024, iters=20):
+    """adam_kernel (A12): 16 B read + 12 B written per parameter.  The entry streams a working set LARGER than the 256 MB
+    Infinity Cache (4 x 32 M floats = 512 MB), so that `achieved` is HBM bandwidth; the evaluator's own flat buffer
+    (4 x 42.6 MB = 170 MB, launches back to back: served partly from the Infinity Cache) is reported next to it as
+    `cache_assisted` — round 3 quoted that figure (6.8 TB/s) as a fraction of the HBM peak, which it is not."""
+    lib = _lib.lib()
+    st = torch.cuda.current_stream()
+
+    def run(n):
+        p, g, m, v = (torch.randn(n, device=dev) * 0.01 for _ in range(4))
+        v.abs_()
+        k = [0]
+
+        def fn():
+            k[0] += 1
+            _lib.check(lib.dgg_adam_l2(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n, k[0], 1e-4, 0.9, 0.999,
+                                       1e-8, 5e-4, 1.0, C.c_void_p(st.cuda_stream)))
+        ms = _time_stream(fn, iters)
+        return ms, 28.0 * n / ms / 1e6
+    ms, gbs = run(n_big)
+    ms_s, gbs_s = run(n_small)
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(gbs / PEAK_HBM_GBS, 4), "kernel": "adam_kernel, %d parameters (28 B each)" % n,
-            "algorithmic_bytes": int(byts), "ms_per_launch": round(ms, 4)}
+            "frac": round(gbs / PEAK_HBM_GBS, 4), "kernel": "adam_kernel, %d parameters (28 B each; 4 arrays = %d MB)"
+                                                            % (n_big, 16 * n_big // 2 ** 20),
+            "algorithmic_bytes": int(28.0 * n_big), "ms_per_launch": round(ms, 4),
+            "cache_assisted": {"gb_per_s": round(gbs_s, 1), "ms_per_launch": round(ms_s, 4),
+                               "kernel": "adam_kernel, %d parameters (the evaluator's flat buffer: 170 MB)" % n_small,
+                               "note": "working set < 256 MB Infinity Cache, launches back to back: not an HBM figure"}}
 
 
 def usable_cores():
@@ -300,6 +338,23 @@ def sub_results(cfg, dev, eng):
     dt = wall(eva, 40)
     out["config3_eva_step_b1024"] = {"ms_per_step": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1),
                                      "workload": "update_dexevaluator only, batch 1024, in-kernel dropout"}
+    # config 3 as BASELINE words it ("bf16 MFMA fc stacks"): the same update with the large products in plain bf16
+    # (DGG_GEMM_BF16: one product, fp32 accumulate, fp32 master weights; tolerance vs fp32 stated in
+    # tests/test_gpu_steps.py::test_bf16_mode_evaluator_step_tolerance_vs_fp32).  Never the default, never the headline dtype.
+    lib_ = _lib.lib()
+    algo0 = int(lib_.dgg_get_gemm_algo())
+    try:
+        _lib.check(lib_.dgg_set_gemm_algo(3))
+        dt16 = wall(eva, 40)
+        nt16 = gemm_roofline(dev, 0, b, 768, 4120, 4120, 4632, 4, "forward of fc1||fc3 (NT), plain bf16: a13[%d,768] = "
+                             "X0[%d,4120] W13[768,4120]^T, split-K 4 (DGG_GEMM_BF16)" % (b, b), "gemm_x3_bf16")
+    finally:
+        _lib.check(lib_.dgg_set_gemm_algo(algo0))
+    out["config3_eva_step_b1024_bf16"] = {"ms_per_step": round(dt16 * 1e3, 4), "grasps_per_s": round(b / dt16, 1),
+                                          "dtype": "bf16 (large products; fp32 master weights, fp32 accumulate)",
+                                          "roofline_forward_gemm": nt16,
+                                          "workload": "update_dexevaluator only, batch 1024, DGG_GEMM_BF16 (BASELINE config 3 as "
+                                                      "worded); tolerance vs fp32: scores 2e-2, see the test"}
     # the cGAN update alone at the headline batch, serial entry with intra-step side streams
     gb = synth.make_batch(b, 1)
     g_in = (f(gb["bps_object"]), f(gb["rot_matrix"]).reshape(b, 9), f(gb["transl"]), f(gb["joint_conf"]))
@@ -471,25 +526,40 @@ def main():
     losses = eng.losses.cpu().numpy()
     assert all(map(lambda x: x == x, losses[:10])), "NaN in losses"
 
-    # where a step spends its time: timed events at the phase boundaries (engine.trace), outside the timed region
-    phase_us = None
-    if world == 1:
-        eng.trace = []
-        n_tr = 12
-        for _ in range(n_tr):
-            step()
-        torch.cuda.synchronize()
-        tr, eng.trace = eng.trace, None
-        per = len(tr) // n_tr
-        acc = {}
-        for s_ in range(2, n_tr - 1):
-            ev, nxt = dict(tr[s_ * per:(s_ + 1) * per]), dict(tr[(s_ + 1) * per:(s_ + 2) * per])
-            for name in ("d_phase_end", "adam_d_end", "g_phase_end", "adam_g_end", "e_phase_end", "adam_e_end",
-                         "prefetch_begin", "prefetch_end"):
-                if name in ev:
-                    acc.setdefault(name, []).append(ev["step_begin"].elapsed_time(ev[name]) * 1e3)
-            acc.setdefault("next_step_begin", []).append(ev["step_begin"].elapsed_time(nxt["step_begin"]) * 1e3)
-        phase_us = {k: round(statistics.median(v), 1) for k, v in acc.items()}
+    # where a step spends its time: timed events at the phase boundaries (engine.trace), outside the timed region — every
+    # rank runs the same extra steps (their collectives match).  Data parallel this is also what makes the first N > 1 run
+    # falsifiable: per-bucket all-reduce durations and, per network, the time its optimiser step
+    # waited for the all-reduce after its backward had finished ("exposed": nothing else runs on that stream in between).
+    eng.trace = []
+    eng.trace_buckets = [] if parallel.is_distributed() else None
+    n_tr = 12
+    for _ in range(n_tr):
+        step()
+    torch.cuda.synchronize()
+    tr, eng.trace = eng.trace, None
+    tb, eng.trace_buckets = eng.trace_buckets, None
+    per = len(tr) // n_tr
+    acc = {}
+    for s_ in range(2, n_tr - 1):
+        ev, nxt = dict(tr[s_ * per:(s_ + 1) * per]), dict(tr[(s_ + 1) * per:(s_ + 2) * per])
+        for name in ("d_phase_end", "adam_d_end", "g_phase_end", "adam_g_end", "e_phase_end", "adam_e_end",
+                     "prefetch_begin", "prefetch_end", "ar_d_waited", "ar_g_waited", "ar_e_waited"):
+            if name in ev:
+                acc.setdefault(name, []).append(ev["step_begin"].elapsed_time(ev[name]) * 1e3)
+        for net, a, b_ in (("D", "d_phase_end", "ar_d_waited"), ("G", "g_phase_end", "ar_g_waited"),
+                           ("E", "e_phase_end", "ar_e_waited")):
+            if a in ev and b_ in ev:
+                acc.setdefault("exposed_" + net, []).append(ev[a].elapsed_time(ev[b_]) * 1e3)
+        acc.setdefault("next_step_begin", []).append(ev["step_begin"].elapsed_time(nxt["step_begin"]) * 1e3)
+    phase_us = {k: round(statistics.median(v), 1) for k, v in acc.items() if not k.startswith("exposed_")}
+    exposed_us = {k[len("exposed_"):]: round(statistics.median(v), 1) for k, v in acc.items() if k.startswith("exposed_")}
+    bucket_us = {}
+    if tb:
+        by = {}
+        for tag, i, nbytes, e0, e1 in tb:
+            by.setdefault((tag, i, nbytes), []).append(e0.elapsed_time(e1) * 1e3)
+        for (tag, i, nbytes), v in sorted(by.items()):
+            bucket_us.setdefault(tag, []).append({"bucket": i, "bytes": nbytes, "us": round(statistics.median(v[2:] or v), 1)})
 
     if rank == 0:
         value = B * world * args.steps / dt
@@ -526,6 +596,7 @@ def main():
                            "gemm_x3")
         res["roofline"] = tn
         res["roofline_kernels"] = {"gemm_wgrad_tn": tn, "gemm_forward_nt": nt, "bps_encode": bps_roofline(dev),
+                                   "bps_encode_one_cloud": bps_one_cloud(dev),
                                    "adam": adam_roofline(dev),
                                    "optional_planes_batched_forward": planes_roofline(
                                        dev, B, 3072, 4096, 4, "gemm_p4_kernel: [G | D] BPS products of all ResBlocks, "
@@ -539,7 +610,15 @@ def main():
                              "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
                              "allreduce_bytes_per_step_per_rank": nbytes if world > 1 else 0,
                              "buckets": "per ResBlock, behind in-backward events (parallel.BucketReducer)" if world > 1 else None,
-                             "evaluator_group": os.environ.get("DGG_EVA_GROUP", "0") == "1"}
+                             "evaluator_group": os.environ.get("DGG_EVA_GROUP", "0") == "1",
+                             # measured on rank 0 in the untimed trace steps (events; DESIGN.md 6 holds the predictions
+                             # these numbers are to be compared with):
+                             "exposed_us": exposed_us or None,     # per network: optimiser step waited this long for the all-reduce
+                             "bucket_allreduce_us": bucket_us or None,   # per bucket, in issue order, queueing included
+                             "rccl_env": {k: os.environ.get(k) for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS",
+                                                                         "NCCL_MAX_NCHANNELS", "RCCL_MSCCL_ENABLE",
+                                                                         "DGG_BUCKETED_AR", "DGG_EVA_GROUP")
+                                          if os.environ.get(k) is not None}}
         if world == 1 and not args.no_sub:
             res["sub_results"] = sub_results(cfg, dev, eng)
             sr = res["sub_results"]

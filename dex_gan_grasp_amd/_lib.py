@@ -192,8 +192,10 @@ def kink_sides(net, ccfg, ws, B, base=0):
     """Which side of every LeakyReLU kink (networks.py:41) the last train-mode pass of network `net` took, read back from
     the activations it left in its workspace `ws` (uint8 tensor; `base`: byte offset of the network workspace inside it,
     dgg_cgan_ws_offset): per ResBlock three bool tensors [fc3 branch (B,512), bn1 branch (B,256), block output (B,512)],
-    True = positive side, in the order a CPU evaluation of the same pass meets its LeakyReLUs.  Dropped units (evaluator)
-    read False: their gradient is zero either way."""
+    True = positive side, in the order a CPU evaluation of the same pass meets its LeakyReLUs.  The evaluator's block
+    outputs are int8 instead: 1 / 0 = positive / negative side, -1 = the unit was DROPPED (the workspace holds 0 there and
+    the sign is gone; its gradient is zero either way) — a checker that follows these sides must leave such elements alone
+    (oracle.dexgan_oracle.forced_slopes does, and does not count them as steering)."""
     nrb = 3 if net == NET_EVA else 2
     out = []
     for r in range(nrb):
@@ -201,7 +203,14 @@ def kink_sides(net, ccfg, ws, B, base=0):
         if base < 0 or min(offs) < 0:
             raise DggError("dgg_ws_offset / dgg_cgan_ws_offset: bad arguments")
         f = lambda off, n: ws[base + off: base + off + 4 * B * n].view(torch.float32).view(B, n)
-        out += [f(offs[0], 768)[:, 256:] > 0, f(offs[1], 256) > 0, f(offs[2], 512) > 0]
+        y = f(offs[2], 512) > 0
+        if net == NET_EVA:
+            ko = int(lib().dgg_eva_keep_offset(C.byref(ccfg), B, r))
+            if ko < 0:
+                raise DggError("dgg_eva_keep_offset: %d" % ko)
+            keep = ws[base + ko: base + ko + B * 512].view(B, 512)
+            y = torch.where(keep != 0, y.to(torch.int8), torch.full_like(keep, -1, dtype=torch.int8))
+        out += [f(offs[0], 768)[:, 256:] > 0, f(offs[1], 256) > 0, y]
     return out
 
 

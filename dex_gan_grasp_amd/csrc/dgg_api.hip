@@ -2395,7 +2395,7 @@ int dgg_gemm_occupancy(int mode, int bm, int bn) {
 }
 
 int dgg_set_gemm_algo(int algo) {
-    if (algo != DGG_GEMM_F32 && algo != DGG_GEMM_BF16X3 && algo != DGG_GEMM_PLANES) return DGG_ERR_INVALID;
+    if (algo != DGG_GEMM_F32 && algo != DGG_GEMM_BF16X3 && algo != DGG_GEMM_PLANES && algo != DGG_GEMM_BF16) return DGG_ERR_INVALID;
     gemm_set_algo(algo);
     return DGG_OK;
 }

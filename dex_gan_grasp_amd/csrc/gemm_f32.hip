@@ -481,16 +481,18 @@ static void launch_shape(int bm, int bn, const GemmBatch& b, hipStream_t st) {
 // DGG_X4=1: by loader waves, gemm_x4.hip); 2 = the BPS block of a train pass — the K = 4096 part of every fused fc1 || fc3 product and of its weight
 // gradient — on operands pre-split into bf16 planes by their producers (gemm_p4.hip: one batched launch per pass forward;
 // backward one planes problem inside the block's weight-gradient launch), everything else as 1; 0 = native f32 MFMA
-// (this file).  Process-wide; DGG_GEMM_ALGO=f32 / planes select 0 / 2 at start-up.
+// (this file); 3 = plain bf16 (the hi plane only: one product, fp32 accumulate — BASELINE config 3, never the default).
+// Process-wide; DGG_GEMM_ALGO=f32 / planes / bf16 select 0 / 2 / 3 at start-up.
 static int g_algo = -1;
 int gemm_algo() {
     if (g_algo < 0) {
         const char* e = getenv("DGG_GEMM_ALGO");
-        g_algo = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : (e && (e[0] == 'p' || e[0] == '2')) ? 2 : 1;
+        g_algo = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : (e && (e[0] == 'p' || e[0] == '2')) ? 2
+                 : (e && (e[0] == 'b' || e[0] == '3')) ? 3 : 1;
     }
     return g_algo;
 }
-void gemm_set_algo(int a) { g_algo = a < 0 ? 0 : a > 2 ? 2 : a; }
+void gemm_set_algo(int a) { g_algo = a < 0 ? 0 : a > 3 ? 3 : a; }
 
 // "Side work" (dgg_set_side_work, per calling thread): the launches that follow run beside a latency-critical chain on
 // another stream — their large forward products take half the chip for twice as long (the bf16x3 kernel walks two work
@@ -536,7 +538,17 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
     if (mode != GEMM_NT && mode != GEMM_NN && mode != GEMM_TN) return DGG_ERR_INVALID;
     if (gemm_algo() >= 1 && bm == 128 && bn == 128) {
         // (a planes problem rides in gemm_x3_kernel)
-        if (!planes && gemm_x4_enabled(batch.total_blocks)) {
+        // gemm_x4_kernel fetches a k-strided operand ([K][rows]: B of NN, A and B of TN) in quads of 4 rows: with
+        // rows % 4 != 0 the last quad of EVERY k-row reads up to 12 bytes past the row — past the operand itself on its last
+        // k-row when the pitch is the row count.  Such problems stay on gemm_x3_kernel, whose padding rule is
+        // in include/dgg.h (dgg_gemm_f32); inside the library every pitch covers the quad.
+        bool quads_ok = true;
+        for (int i = 0; i < batch.nprob; ++i) {
+            const GemmProb& p = batch.p[i];
+            if (mode == GEMM_TN && p.lda < ((p.M + 3) & ~3)) quads_ok = false;
+            if (mode != GEMM_NT && p.ldb < ((p.N + 3) & ~3)) quads_ok = false;
+        }
+        if (!planes && quads_ok && gemm_algo() != 3 && gemm_x4_enabled(batch.total_blocks)) {
             gemm_x4_dispatch(mode, batch, st);
             return check_launch("gemm_x4");
         }

@@ -225,7 +225,7 @@ __device__ __forceinline__ FragAddr<KC> frag_setup(int lane, int w0) {
 // vector instruction at a time at ~4-5 cycles per plain VALU op whatever the number of waves (a two-waves-per-SIMD
 // variant with half the VALU per wave ran at 2900), so 380 VALU + 48 MFMA (8 issue cycles each) + 8 DMA pieces (~60
 // each) per k-tile fill the issue port.  Next lever: operands arriving pre-split (producers emit the bf16 planes).
-template <bool A_KC, bool B_KC, bool AFF>
+template <bool A_KC, bool B_KC, bool AFF, bool X1 = false>
 __device__ __forceinline__ void gemm_x3_block(const GemmBatch& batch, const int bid, char* smem);
 
 // One workgroup per (problem, split, tile) work item — or, launched with fewer workgroups than items ("side work",
@@ -234,7 +234,9 @@ __device__ __forceinline__ void gemm_x3_block(const GemmBatch& batch, const int 
 // is a multiple of 8 so that an item's XCD (bid & 7) does not depend on which round of the loop takes it.
 // PL (weight-gradient launches only): the launch carries a problem on pre-split planes (GemmProb::a_plane != 0, "NT over
 // transposed planes": the BPS block's weight gradient) beside its fp32 riders; its work items run gemm_p3_block.
-template <bool A_KC, bool B_KC, bool AFF, bool PL = false>
+// X1 (DGG_GEMM_BF16, BASELINE config 3 "bf16 MFMA fc stacks"; never the default): plain bf16 — only the hi plane, ONE
+// product per fragment pair, fp32 accumulate, fp32 master operands converted while they are staged.
+template <bool A_KC, bool B_KC, bool AFF, bool PL = false, bool X1 = false>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmBatch batch) {
     constexpr int kSmem = (PL && PS * PSTAGE > XS * XSTAGE) ? PS * PSTAGE : XS * XSTAGE;
     __shared__ __attribute__((aligned(16))) char smem[kSmem];
@@ -246,12 +248,12 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmBatch batch) {
                 if (q < batch.nprob && bid >= batch.p[q].blk_begin) planes = batch.p[q].a_plane != 0;
         }
         if (planes) gemm_p3_block<true>(batch, bid, smem);
-        else gemm_x3_block<A_KC, B_KC, AFF>(batch, bid, smem);
+        else gemm_x3_block<A_KC, B_KC, AFF, X1>(batch, bid, smem);
         if (bid + (int)gridDim.x < batch.total_blocks) __syncthreads();  // the epilogue's LDS scratch is done with
     }
 }
 
-template <bool A_KC, bool B_KC, bool AFF>
+template <bool A_KC, bool B_KC, bool AFF, bool X1>
 __device__ __forceinline__ void gemm_x3_block(const GemmBatch& batch, const int bid, char* smem) {
 
     // ---- work assignment: identical to gemm_f32_kernel (problem select, XCD-contiguous remap, split-K range)
@@ -404,6 +406,24 @@ __device__ __forceinline__ void gemm_x3_block(const GemmBatch& batch, const int 
             if (sl == 5) out.p[0] = out.p[1] = out.p[2] = __builtin_bit_cast(bf16x8, (f32x4){x[0], x[1], x[2], x[3]});
             return;
         }
+        if constexpr (X1) {   // plain bf16: affine / tail mask, one conversion, nothing else
+            if (sl != 0) return;
+            if (f < 2) {
+                if constexpr (AFF) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = __builtin_fmaf(x[j], q[0][j], q[1][j]);
+                }
+                if constexpr (TAIL) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = j < kvalid ? x[j] : 0.f;
+                }
+            }
+            unsigned hh[4];
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) hh[p2] = pack_bf16(x[2 * p2], x[2 * p2 + 1]);
+            out.p[0] = __builtin_bit_cast(bf16x8, (u32x4){hh[0], hh[1], hh[2], hh[3]});
+            return;
+        }
         if (sl == 0) {
             if (f < 2) {
                 if constexpr (AFF) {
@@ -457,6 +477,9 @@ __device__ __forceinline__ void gemm_x3_block(const GemmBatch& batch, const int 
     auto mfma_one = [&](int g, const Frag (&P4)[4]) {
         if constexpr (DGG_X3_ABLATE == 3) return;
         const int ta = g / 12, tb = (g / 6) & 1, pr = g % 6;
+        if constexpr (X1) {
+            if (pr != 5) return;   // hi * hi only
+        }
         const Frag& a = P4[ta];
         const Frag& b = P4[2 + tb];
         // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi  (small terms first)
@@ -591,7 +614,7 @@ __device__ __forceinline__ void gemm_x3_block(const GemmBatch& batch, const int 
 #endif
 }
 
-template <bool A_KC, bool B_KC, bool AFF, bool PL = false>
+template <bool A_KC, bool B_KC, bool AFF, bool PL = false, bool X1 = false>
 static void launch_x3(const GemmBatch& b, hipStream_t st) {
     int grid = b.total_blocks;
     // side work (dgg_set_side_work): the forward products walk two work items per workgroup — same items, same sums,
@@ -600,7 +623,7 @@ static void launch_x3(const GemmBatch& b, hipStream_t st) {
     // 1850, 4 -> 1923 / 1893, 6 -> 1928 / 1924)
     static const int kdiv = [] { const char* e = getenv("DGG_SIDE_DIV"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
     if (gemm_side_work() && A_KC && B_KC && grid > 64) grid = ((grid + kdiv - 1) / kdiv + 7) / 8 * 8;
-    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, AFF, PL>), dim3(grid), dim3(256), 0, st, b);
+    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC, AFF, PL, X1>), dim3(grid), dim3(256), 0, st, b);
 }
 
 // 128 x 128 tiles only.  Operand bases and pitches need 4-byte alignment only (the DMA fetches 16-byte chunks from any
@@ -608,6 +631,19 @@ static void launch_x3(const GemmBatch& b, hipStream_t st) {
 // chunk may extend up to 12 bytes past an operand row's last element: operands live inside larger buffers (flat
 // parameter buffers, workspaces), the bytes are fetched and never used.
 void gemm_x3_dispatch(int mode, const GemmBatch& batch, hipStream_t st) {
+    if (gemm_algo() == 3) {   // DGG_GEMM_BF16: the same kernel, hi plane only
+        if (mode == GEMM_NT) {
+            bool any = false;
+            for (int i = 0; i < batch.nprob; ++i) any = any || batch.p[i].a_scale != nullptr;
+            if (any) launch_x3<true, true, true, false, true>(batch, st);
+            else launch_x3<true, true, false, false, true>(batch, st);
+        } else if (mode == GEMM_NN) {
+            launch_x3<true, false, false, false, true>(batch, st);
+        } else {
+            launch_x3<false, false, false, false, true>(batch, st);
+        }
+        return;
+    }
     if (mode == GEMM_NT) {
         bool any = false;
         for (int i = 0; i < batch.nprob; ++i) any = any || batch.p[i].a_scale != nullptr;

@@ -113,7 +113,7 @@ class TrainEngine:
         if os.environ.get("DGG_BUCKETED_AR", "1") == "0" or not self._reducers:
             w = parallel.allreduce_sum_(net.grads, async_op=async_op)
             return [w] if async_op else None
-        works = self._reducers[which].reduce_async(feeder)
+        works = self._reducers[which].reduce_async(feeder, timing=getattr(self, "trace_buckets", None), tag=which)
         if async_op:
             return works
         parallel.wait_all(works)
@@ -299,7 +299,7 @@ class TrainEngine:
         ResBlock, True = positive side — the order a CPU evaluation of the same pass meets them.  which: "G", "Dreal",
         "Dfake" (cGAN step workspace of batch B; "Dfake" holds the D phase's fake pass until the G phase's pass through
         the updated discriminator overwrites it) or "E".  ws: a snapshot (clone) of the workspace taken earlier.
-        Dropped units of the evaluator read False (their gradient is zero either way).  Parity tests hand these to the
+        Dropped units of the evaluator read -1 in its (int8) block-output masks: no side to follow.  Parity tests hand these to the
         oracle (oracle.dexgan_oracle.forced_slopes) so that gradient comparisons are strict on every data set."""
         net = {"G": _lib.NET_GEN, "Dreal": _lib.NET_DISC, "Dfake": _lib.NET_DISC, "E": _lib.NET_EVA}[which]
         if which == "E":
@@ -495,6 +495,8 @@ class TrainEngine:
             # the evaluator's optimiser step follows on its own stream at once (it blocks nothing else there; enqueued
             # after the G phase it would reach the GPU only when the host gets that far — behind the generator's)
             parallel.wait_all(w_e)
+            if w_e:
+                self._mark("ar_e_waited", side)     # (trace: e_phase_end -> here = the evaluator's exposed all-reduce time)
             adam(E, hp.lr_eva)
             self._mark("adam_e_end", side)
         # (data parallel: one optimiser launch per network — the stream that would run the early half is the one feeding
@@ -505,6 +507,8 @@ class TrainEngine:
             self._adam_split("D", hp.lr_dis, hp, w_d, self._side2)
         else:
             parallel.wait_all(w_d)
+            if w_d:
+                self._mark("ar_d_waited")           # (trace: d_phase_end -> here = D's exposed all-reduce time)
             adam(D, hp.lr_dis)
         self._mark("adam_d_end")
         w_g = None
@@ -534,6 +538,8 @@ class TrainEngine:
                 self._adam_split("G", hp.lr_gen, hp, w_g, side)
             else:
                 parallel.wait_all(w_g)
+                if w_g:
+                    self._mark("ar_g_waited")       # (trace: g_phase_end -> here = G's exposed all-reduce time)
                 adam(G, hp.lr_gen)
             self._mark("adam_g_end")
         if two_streams:

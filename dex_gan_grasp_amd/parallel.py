@@ -149,9 +149,14 @@ class BucketReducer:
 
     _shared_feeder = None   # one per process: every additional HIP stream risks sharing a hardware queue (see below)
 
-    def reduce_async(self, feeder=None):
+    def reduce_async(self, feeder=None, timing=None, tag=""):
         """After the phase call: enqueue the bucket collectives behind their events.  Returns the work handles; wait()
         on each (a stream-level dependency for RCCL) before the optimiser step.
+
+        timing (diagnostics, bench.py's untimed trace steps): a list that receives one (tag, bucket, bytes, begin, end)
+        per collective — timed events on the feeding stream, `begin` once the bucket's gradients are ready, `end` once
+        the collective has completed (the feeder waits for it: in this mode the buckets of one feeder go out one after
+        the other, which is also the order RCCL runs them in).
 
         `feeder` is the stream that waits for the bucket events and hands each collective to RCCL's own stream.  The HIP
         runtime multiplexes a process's streams onto 4 hardware queues, in order within a queue: with the step's three
@@ -162,18 +167,32 @@ class BucketReducer:
         feeder="current": no event waits at all — the collectives follow the current stream's tail (a phase that is not
         on the critical path and whose stream has nothing else to do)."""
         works = []
+
+        def one(i, lo, hi, stream):
+            e0 = None
+            if timing is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            w = dist.all_reduce(self.flat.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True, group=self.group)
+            works.append(w)
+            if timing is not None:
+                w.wait()
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(stream)
+                timing.append((tag, i, 4 * (hi - lo), e0, e1))
         if feeder == "current":
-            for lo, hi in self.bounds:
-                works.append(dist.all_reduce(self.flat.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True, group=self.group))
+            cur = torch.cuda.current_stream(self.flat.grads.device)
+            for i, (lo, hi) in enumerate(self.bounds):
+                one(i, lo, hi, cur)
             return works
         if feeder is None:       # the serial entry points: the (idle) first side stream, on a queue of its own
             if BucketReducer._shared_feeder is None:
                 BucketReducer._shared_feeder = side_streams_or_plain(self.flat.grads.device, 2)[0]
             feeder = BucketReducer._shared_feeder
-        for (lo, hi), ev in zip(self.bounds, self.events):
+        for i, ((lo, hi), ev) in enumerate(zip(self.bounds, self.events)):
             feeder.wait_event(ev)
             with torch.cuda.stream(feeder):
-                works.append(dist.all_reduce(self.flat.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True, group=self.group))
+                one(i, lo, hi, feeder)
         return works
 
 

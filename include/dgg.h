@@ -403,8 +403,13 @@ int dgg_translate_along_axis(float* transl, const float* rot9, int B, int axis, 
  *                     forms the BPS products of all ResBlocks (csrc/gemm_p4.hip), the weight gradient is one planes
  *                     problem inside the block's weight-gradient launch (csrc/gemm_p3_block.h).  Everything else runs as
  *                     under DGG_GEMM_BF16X3.  Faster kernels (0.38-0.46 of the bf16x3 bound against 0.27), slower step
- *                     (1.93 vs 1.74 ms: DESIGN.md 3.1): optional. */
-enum { DGG_GEMM_F32 = 0, DGG_GEMM_BF16X3 = 1, DGG_GEMM_PLANES = 2 };
+ *                     (1.93 vs 1.74 ms: DESIGN.md 3.1): optional.
+ *   DGG_GEMM_BF16   : plain bf16 (BASELINE config 3, "bf16 MFMA fc stacks"; never the default, never the headline dtype):
+ *                     the large (128 x 128-tile) products take only the hi plane — fp32 master operands rounded to bf16
+ *                     while they are staged, ONE product, fp32 accumulate; the K = 256 products, BatchNorm, losses and
+ *                     Adam stay fp32.  Measured against the fp32 goldens: tests/test_gpu_steps.py::test_bf16_mode_* state the
+ *                     tolerances (scores ~1e-2, losses ~1e-2 relative) — outside the 1e-4 contract by construction. */
+enum { DGG_GEMM_F32 = 0, DGG_GEMM_BF16X3 = 1, DGG_GEMM_PLANES = 2, DGG_GEMM_BF16 = 3 };
 int dgg_set_gemm_algo(int algo);
 int dgg_get_gemm_algo(void);
 /* Diagnostic: workgroups of the GEMM variant (mode, tile) resident per CU according to the HIP occupancy API. */

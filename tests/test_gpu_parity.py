@@ -614,7 +614,7 @@ def _oracle_grads(net, sd, batch, z, train, masks, seed, slopes=None):
             res = _oracle_grads(net, sd, batch, z, train, masks, seed)
         if fs.flips:
             print("oracle took the HIP path's side at %d LeakyReLU kink crossing(s), the farthest %.2e of its tensor's rms "
-                  "from zero (capped in forced_slopes: %d, %.0e)" % (fs.flips, fs.worst, O.MAX_FLIPS, O.MAX_FLIP_RATIO))
+                  "from zero (capped in forced_slopes: %d, %.0e)" % (fs.flips, fs.worst, fs.cap(), O.MAX_FLIP_RATIO))
         return res
     names = O.param_names(sd)
     for n in names:

@@ -4,7 +4,7 @@
 #   launches, the BPS encode and Adam.  Summaries land in gpurun_out/prof_<tag>/; tools/summarize_profiles.py turns
 #   them into the committed files under profiles/.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.environ.get("PROFILES_DST") or os.path.join(ROOT, "profiles")   # PROFILES_DST: scratch summaries of an experiment
 os.makedirs(dst, exist_ok=True)
@@ -103,5 +103,17 @@ for name, ksub, outname, shape, cmd, flops, alg_bytes in specs:
         out["derived"] = {"shader_clock_ghz_from_GRBM_GUI_ACTIVE": round(clk, 3),
                           "mfma_pipe_busy_frac": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0) / (256 * 4), 4),
                           "tflops_algorithmic": round(flops / (dur * 1e-9) / 1e12, 2)}
+        # The vector-issue port, measured: SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD issues
+        # vector-ALU instructions (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* are in quad-cycles), a matrix instruction holds the
+        # same port for 8 of its cycles; denominator = the launch's shader cycles x 1024 SIMDs.
+        simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * (256 * 4)
+        if "SQ_ACTIVE_INST_VALU" in c:
+            va = 4.0 * c["SQ_ACTIVE_INST_VALU"] / simd_cycles
+            mi = 8.0 * c.get("SQ_INSTS_MFMA", 0.0) / simd_cycles
+            out["derived"].update({"valu_issue_active_frac": round(va, 4), "mfma_issue_frac": round(mi, 4),
+                                   "vector_issue_port_busy_frac": round(va + mi, 4)})
+        if "SQ_WAVE_CYCLES" in c and "SQ_WAIT_ANY" in c:
+            out["derived"].update({"wave_wait_any_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4),
+                                   "wave_wait_inst_any_frac": round(c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)})
     json.dump(out, open(os.path.join(dst, "%s_%s_pmc.json" % (tag, outname)), "w"), indent=1)
     print(outname, json.dumps(out.get("derived")), "traffic MB %.1f alg MB %.1f dur us %.1f" % ((fetch + write) / 1e6, alg_bytes / 1e6, dur / 1e3))
