@@ -23,42 +23,68 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProb& P, f32x16 (&acc)[B
     const int li = lane & 31, lh = lane >> 5;
     float* Cb = P.C + (P.splits > 0 ? (size_t)split * (size_t)P.slab_stride : (size_t)0);
     const bool accum = (P.splits == 0) && P.accumulate;
+    // Every global LOAD below is unconditional, on indices clamped into the matrix, and all loads of a phase are issued
+    // before the first is used; only the STORES are predicated.  (Round 4: with `if (row < M && col < N) { load; fma; store }`
+    // per element the compiler could not move a load across its branch — 64 dependent L2 round trips per lane, 27 us of an
+    // 86 us weight-gradient launch; profiles/r04_experiments.txt 9.)  Values and their order of accumulation are unchanged.
     if constexpr (WGRAD) {
         if (P.ep_gamma) {  // BatchNorm-aware wgrad epilogue (see GemmProb); wave-uniform branch
             float* red = smem;  // [WM m-slots][2][BN], free after the last barrier of the k loop
             float csn[TM][16];
+            {
+                const int split = P.ep_split;
+                float c0[TM][16], c1[TM][16], c1b[TM][16];
 #pragma unroll
-            for (int ta = 0; ta < TM; ++ta)
+                for (int ta = 0; ta < TM; ++ta)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    float v = 0.f;
-                    if (row < M)
-                        v = row < P.ep_split ? (P.ep_cs0 ? P.ep_cs0[row] : 0.f)
-                                             : P.ep_cs1[row - P.ep_split] + (P.ep_cs1b ? P.ep_cs1b[row - P.ep_split] : 0.f);
-                    csn[ta][r] = v;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        row = row < M ? row : M - 1;
+                        const int r0 = row < split ? row : (split > 0 ? split - 1 : 0);
+                        const int r1 = row >= split ? row - split : 0;
+                        c0[ta][r] = P.ep_cs0 ? P.ep_cs0[r0] : 0.f;      // (pointer tests: wave-uniform)
+                        c1[ta][r] = P.ep_cs1[r1];
+                        c1b[ta][r] = P.ep_cs1b ? P.ep_cs1b[r1] : 0.f;
+                    }
+#pragma unroll
+                for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float v1 = P.ep_cs1b ? c1[ta][r] + c1b[ta][r] : c1[ta][r];
+                        csn[ta][r] = row < M ? (row < split ? c0[ta][r] : v1) : 0.f;
+                    }
+            }
 #pragma unroll
             for (int tb = 0; tb < TN; ++tb) {
                 const int col = n0 + wn0 + tb * 32 + li;
                 const bool colok = col < N;
-                const float ga = colok ? P.ep_gamma[col] : 0.f, be = colok ? P.ep_beta[col] : 0.f;
+                const int colc = colok ? col : N - 1;
+                const float ga = P.ep_gamma[colc], be = P.ep_beta[colc];
+                float w[TM][16], old[TM][16];
+#pragma unroll
+                for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        row = row < M ? row : M - 1;
+                        w[ta][r] = P.ep_w[(size_t)row * P.ep_ldw + colc];
+                        old[ta][r] = accum ? Cb[(size_t)row * P.ldc + colc] : 0.f;
+                    }
                 float pg = 0.f, pb = 0.f;
 #pragma unroll
                 for (int ta = 0; ta < TM; ++ta)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (row < M && colok) {
-                            const float t = acc[ta][tb][r];
-                            const float w = P.ep_w[(size_t)row * P.ep_ldw + col];
-                            pg = __builtin_fmaf(w, t, pg);
-                            pb = __builtin_fmaf(w, csn[ta][r], pb);
-                            float* p = Cb + (size_t)row * P.ldc + col;
-                            float v = __builtin_fmaf(ga, t, be * csn[ta][r]);
-                            if (accum) v += *p;
-                            *p = v;
-                        }
+                        const bool ok = row < M && colok;
+                        const float t = acc[ta][tb][r];
+                        const float pg1 = __builtin_fmaf(w[ta][r], t, pg), pb1 = __builtin_fmaf(w[ta][r], csn[ta][r], pb);
+                        pg = ok ? pg1 : pg;
+                        pb = ok ? pb1 : pb;
+                        float v = __builtin_fmaf(ga, t, be * csn[ta][r]);
+                        if (accum) v += old[ta][r];
+                        if (ok) Cb[(size_t)row * P.ldc + col] = v;
                     }
                 pg += __shfl_xor(pg, 32);
                 pb += __shfl_xor(pb, 32);
@@ -81,6 +107,30 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProb& P, f32x16 (&acc)[B
             return;
         }
     }
+    if (accum) {   // wave-uniform: read-modify-write — all the old values first
+#pragma unroll
+        for (int tb = 0; tb < TN; ++tb) {
+            const int col = n0 + wn0 + tb * 32 + li;
+            const int colc = col < N ? col : N - 1;
+            float old[TM][16];
+#pragma unroll
+            for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    row = row < M ? row : M - 1;
+                    old[ta][r] = Cb[(size_t)row * P.ldc + colc];
+                }
+#pragma unroll
+            for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row < M && col < N) Cb[(size_t)row * P.ldc + col] = acc[ta][tb][r] + old[ta][r];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int ta = 0; ta < TM; ++ta)
 #pragma unroll
@@ -89,12 +139,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProb& P, f32x16 (&acc)[B
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < M && col < N) {
-                    float* p = Cb + (size_t)row * P.ldc + col;
-                    float v = acc[ta][tb][r];
-                    if (accum) v += *p;
-                    *p = v;
-                }
+                if (row < M && col < N) Cb[(size_t)row * P.ldc + col] = acc[ta][tb][r];
             }
         }
 }

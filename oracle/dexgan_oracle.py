@@ -118,7 +118,7 @@ class forced_slopes:
         if exc[0] is None:
             assert used == len(self.masks), "forced_slopes: %d masks given, %d LeakyReLU calls made" % (len(self.masks), used)
             assert self.max_flips is None or self.flips <= self.cap(), \
-                "forced_slopes: the oracle was steered at %d LeakyReLU elements (cap %d)" % (self.flips, self.cap())
+                "forced_slopes: the oracle was steered at %d LeakyReLU elements (cap %d; the farthest %.2e of its tensor's rms from zero)" % (self.flips, self.cap(), self.worst)
             assert self.max_ratio is None or self.worst <= self.max_ratio, \
                 "forced_slopes: steered at a pre-activation %.3e of its tensor's rms away from zero (cap %.1e)" % (self.worst, self.max_ratio)
         return False
@@ -390,7 +390,7 @@ class _no_ctx:
         return False
 
 
-def cgan_step(sd, batch, z, adam_g, adam_d, cfg, is_train_gen=True, return_grads=False, slopes=None):
+def cgan_step(sd, batch, z, adam_g, adam_d, cfg, is_train_gen=True, return_grads=False, slopes=None, after_adam_d=None):
     """dexgangrasp.py:757-823 (BCE branch).  `sd` holds the DexGANGrasp state_dict
     ('generator.*', 'discriminator.*'), modified in place.  z is the injected latent (:770).
     slopes (checker only, see forced_slopes): {"d": masks of G fwd + D(real) + D(fake) (18), "g": masks of the G phase's
@@ -400,6 +400,12 @@ def cgan_step(sd, batch, z, adam_g, adam_d, cfg, is_train_gen=True, return_grads
         out, g_d, ctx = cgan_d_part(sd, batch, z, cfg)
     nflip, worst, cap = fs.flips, fs.worst, fs.cap() or 0
     adam_step(sd, g_d, adam_d, lr=cfg["lr_dis"], b1=cfg["beta1"], wd=cfg["weight_decay"])  # :794
+    if after_adam_d is not None:
+        # checker only: the G phase passes through the UPDATED discriminator, and parameters after Adam cannot be pinned
+        # element-wise between two evaluations (Adam's early update lr * g / (|g| + eps) turns gradient noise of 1e-9 into
+        # steps of +-lr): a test that compares the G phase strictly hands in the other evaluation's post-Adam discriminator
+        # here (after_adam_d(sd) overwrites sd's 'discriminator.*' parameters) and checks the Adam step itself apart
+        after_adam_d(sd)
     g_g = None
     if is_train_gen:
         with (forced_slopes(slopes["g"], *_caps(slopes)) if slopes else _no_ctx()) as fs:

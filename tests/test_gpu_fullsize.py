@@ -209,8 +209,18 @@ def test_benched_joint_step_with_prefetch_and_philox_vs_oracle(b, variant, front
         masks = keep.float().cpu()
         prev, preve = {k: v.clone() for k, v in sd.items()}, {k: v.clone() for k, v in sde.items()}
         sl = _slopes_after(eng, store, b, b)
+        # the G phase runs through the discriminator AFTER its Adam step: the oracle takes the engine's post-Adam D there
+        # (Adam amplifies 1e-9 gradient noise to +-lr per element — with the reference-init weights, |w| ~ 4e-4, that moved
+        # pre-activations by up to 8e-5 of their rms and 12 LeakyReLU sides per G phase); the Adam step itself is checked
+        # exactly below (_cmp_adam_of_own_grads) and the oracle adopts the engine's parameters at the end of the step anyway
+        d_post = {k: v.cpu().clone() for k, v in eng.D.views("params").items()}
+
+        def take_engine_d(sd_):
+            with torch.no_grad():
+                for k, v in d_post.items():
+                    sd_["discriminator." + k].copy_(v)
         ref, g_d, g_g, _ = O.cgan_step(sd, H.clone_batch(gbs[i % 2]), z, ag, ad, CFG, True, return_grads=True,
-                                       slopes=sl["gan"])
+                                       slopes=sl["gan"], after_adam_d=take_engine_d)
         refe, g_e, _ = O.eva_step(sde, H.clone_batch(eb), ae, CFG, masks, return_grads=True, slopes=sl["eva"])
         # the steering is capped inside the oracle (forced_slopes: per phase at most max(8, 4 per million pre-activations)
         # elements, each within 1e-5 of its tensor's rms of zero); per STEP, stated here as well:
