@@ -28,6 +28,29 @@ static_assert(RS == 8, "the transposed plane stores pack exactly 8 rows into 16 
 // a valid address) and are masked out of stores and sums, which keep their row order (same bits as the plain loop).
 __device__ __forceinline__ int row_clamp(int r, int n) { return r < n ? r : n - 1; }
 
+// The (mean, rstd) of every row of a wave — from the fused finalize's LDS copy or from the finalized arrays — fetched
+// BEFORE the per-row arithmetic and stores: a `fused ? lds : global` select inside the row loop is a global load behind
+// the previous row's store, and the compiler waits for that store, once per row.
+template <typename Res>
+__device__ __forceinline__ void row_stats(bool fused, const Res& res, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                          int stride, int c, int lane, int r0, int n, int rpg, float (&mu)[RS], float (&rs)[RS]) {
+    if (fused) {
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const int g = (r0 + row_clamp(r, n > 0 ? n : 1)) / rpg;
+            mu[r] = res[g][0][lane];
+            rs[r] = res[g][1][lane];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const int g = (r0 + row_clamp(r, n > 0 ? n : 1)) / rpg;
+            mu[r] = mean[g * stride + c];
+            rs[r] = rstd[g * stride + c];
+        }
+    }
+}
+
 // ---- bf16 planes beside the fp32 outputs (PlaneOut): the split of gemm_x3.hip / gemm_p3.hip, one element at a time
 typedef __bf16 ew_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float ew_f32x2 __attribute__((ext_vector_type(2)));
@@ -171,11 +194,13 @@ __global__ __launch_bounds__(256) void ibn_stats_kernel(ColSrcs S, int rpg, int 
     const int n = min(RB, rpg - r0);
     const int ns = min(RS, max(0, n - sub * RS));
     int ld = 0;
-    const float* p = cok ? src_col(S, c, ld) : nullptr;
+    const float* p = src_col(S, cok ? c : S.total - 1, ld);
     float v[RS];
+    // (unconditional loads on clamped indices, all in flight; the select comes afterwards)
 #pragma unroll
-    for (int r = 0; r < RS; ++r)
-        v[r] = (cok && r < ns) ? p[(size_t)(g * rpg + r0 + sub * RS + r) * ld] : 0.f;
+    for (int r = 0; r < RS; ++r) v[r] = p[(size_t)(g * rpg + r0 + (ns > 0 ? sub * RS + row_clamp(r, ns) : 0)) * ld];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) v[r] = (cok && r < ns) ? v[r] : 0.f;
     float mean, m2, om, oq;
     sub_stats(v, ns, mean, m2);
     merge_sub_stats(mean, m2, ns, lane, sub, sh, n, om, oq);
@@ -332,7 +357,8 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
 #pragma unroll
             for (int r = 0; r < RS; ++r) {
                 const size_t row = (size_t)(n > 0 ? r0 + row_clamp(r, n) : 0);
-                xv[k][r] = bnc ? p[row * ld] : prefix[row * nprefix + oc];
+                const float* src = bnc ? p + row * ld : prefix + row * nprefix + oc;   // ONE load (a value select would merge two)
+                xv[k][r] = *src;
             }
         }
     }
@@ -369,12 +395,12 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
             if (PL.pT && pin) planes_store_cols(PL, pc, r0, n, xv[k], last_block);
             continue;
         }
+        float mu_[RS], rs_[RS];
+        row_stats(fused, res, mean, rstd, S.total, c, lane, r0, n, rpg, mu_, rs_);
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
             const int row = r0 + row_clamp(r, n);
-            const int g = row / rpg;
-            const float mu = fused ? res[g][0][lane] : mean[g * S.total + c];
-            const float rs = fused ? res[g][1][lane] : rstd[g * S.total + c];
+            const float mu = mu_[r], rs = rs_[r];
             const float sc = rs * ga;
             const float shf = be - mu * sc;
             xv[k][r] = fmaf(xv[k][r], sc, shf);
@@ -422,37 +448,47 @@ __global__ __launch_bounds__(256) void reduce_bias_kernel(const float* __restric
             return i < nslab ? slabs + (size_t)i * slab_stride + row0 * ld_slab + c
                              : slabs2 + (size_t)(i - nslab) * stride2 + row0 * ld2 + c;
         };
-        int s = 0;
-        for (; s + 4 <= ntot; s += 4) {
+        // (the last group may hold 1-3 slabs: the same batch of loads, not one slab — one round trip per ROW — at a time;
+        //  round 4: five or six slabs are the common case, [x_hat | previous block] pieces of a ResBlock input)
+        for (int s = 0; s < ntot; s += 4) {
+            const int nu = min(4, ntot - s);   // uniform
             float t[4][RS];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 int ld;
-                const float* p = slab(s + u, ld);
+                const float* p = slab(s + min(u, nu - 1), ld);
 #pragma unroll
-                for (int r = 0; r < RS; ++r) t[u][r] = (r < ns) ? p[(size_t)r * ld] : 0.f;
+                for (int r = 0; r < RS; ++r) t[u][r] = (r < ns && u < nu) ? p[(size_t)r * ld] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int r = 0; r < RS; ++r) v[r] += t[u][r];
+                for (int r = 0; r < RS; ++r)
+                    if (u < nu) v[r] += t[u][r];
         }
-        for (; s < ntot; ++s) {
-            int ld;
-            const float* p = slab(s, ld);
+        // (old values — accumulate — all at once, then the sums, then the stores: a load or a store per row behind the
+        //  previous row's store makes the compiler wait for that store, 8 times in a row)
+        float oldv[RS];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) oldv[r] = 0.f;
+        if (accumulate) {
 #pragma unroll
             for (int r = 0; r < RS; ++r)
-                if (r < ns) v[r] += p[(size_t)r * ld];
+                if (r < ns) oldv[r] = out[(row0 + r) * ld_out + c];
         }
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
             if (r < ns) {
                 v[r] += b;
-                float* o = out + (row0 + r) * ld_out + c;
-                if (accumulate) v[r] += *o;
-                *o = act ? lrelu(v[r]) : v[r];
+                if (accumulate) v[r] += oldv[r];
             }
         }
+        float ov[RS];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) ov[r] = act ? lrelu(v[r]) : v[r];
+#pragma unroll
+        for (int r = 0; r < RS; ++r)
+            if (r < ns) out[(row0 + r) * ld_out + c] = ov[r];
     }
     const bool any_stat = stat_hi > stat_lo;  // uniform
     if (any_stat) {
@@ -489,15 +525,14 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ a
     float av[RS];
 #pragma unroll
     for (int r = 0; r < RS; ++r) av[r] = a[(size_t)(r0 + row_clamp(r, n)) * lda + c];
+    float mu_[RS], rs_[RS];
+    row_stats(fused, res, mean, rstd, N, c, lane, r0, n, rpg, mu_, rs_);
 #pragma unroll
     for (int r = 0; r < RS; ++r) {
         if (r < n) {
             const int row = r0 + r;
-            const int g = row / rpg;
-            const float mu = fused ? res[g][0][lane] : mean[g * N + c];
-            const float rs = fused ? res[g][1][lane] : rstd[g * N + c];
-            const float sc = rs * ga;
-            const float shf = be - mu * sc;
+            const float sc = rs_[r] * ga;
+            const float shf = be - mu_[r] * sc;
             h[(size_t)row * ldh + c] = lrelu(fmaf(av[r], sc, shf));
         }
     }
@@ -570,17 +605,20 @@ __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ 
         const size_t row = (size_t)(r0 + row_clamp(r, n));
         sv[r] = s[row * lds + c];
         av[r] = a2[row * lda2 + c] + ab;
-        kv[r] = drop_mode == 1 ? keep_in[row * N + c] : 1.f;
+        kv[r] = 1.f;
     }
+    if (drop_mode == 1) {   // (one uniform branch around the loop, not a load-or-constant per row)
+#pragma unroll
+        for (int r = 0; r < RS; ++r) kv[r] = keep_in[(size_t)(r0 + row_clamp(r, n)) * N + c];
+    }
+    float mu_[RS], rs_[RS];
+    row_stats(fused, res, mean, rstd, N, c, lane, r0, n, rpg, mu_, rs_);
 #pragma unroll
     for (int r = 0; r < RS; ++r) {
         if (r < n) {
             const int row = r0 + r;
-            const int g = row / rpg;
-            const float mu = fused ? res[g][0][lane] : mean[g * N + c];
-            const float rs = fused ? res[g][1][lane] : rstd[g * N + c];
-            const float sc = rs * ga;
-            const float shf = be - mu * sc;
+            const float sc = rs_[r] * ga;
+            const float shf = be - mu_[r] * sc;
             float v = lrelu(sv[r] + fmaf(av[r], sc, shf));
             if (drop_mode) {
                 const size_t e = (size_t)row * N + c;
@@ -667,16 +705,28 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
     for (int r = 0; r < RS; ++r) d3v[r] = 0.f;
     if (n > 0) {
         float yv_[RS], dv_[RS], av_[RS], sv_[RS], ov_[RS];
-        uint8_t kp_[RS];
+        unsigned kp_[RS];   // (a register each: bytes packed into one register made every row's loads wait for the previous row's)
+        // (one load per value, optional operands under ONE uniform branch around their loop: `p ? load_a : load_b` per
+        //  element merges two registers at a join, and the compiler waits for both loads there — once per row)
+        const float* dbase = hd_dout ? hd_dout : dy + c;
+        const size_t dstr = hd_dout ? (size_t)1 : (size_t)lddy;
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
             const size_t row = (size_t)(g * rpg + r0 + row_clamp(r, n));
             yv_[r] = y[row * ldy + c];
-            dv_[r] = hd_dout ? hd_dout[row] : dy[row * lddy + c];
-            kp_[r] = keep ? keep[row * N + c] : (uint8_t)1;
+            dv_[r] = dbase[row * dstr];
             av_[r] = a2[row * lda2 + c];
             sv_[r] = s[row * lds + c];
-            ov_[r] = SO.other ? SO.other[row * SO.ld + c] : 0.f;
+            kp_[r] = 1u;
+            ov_[r] = 0.f;
+        }
+        if (keep) {
+#pragma unroll
+            for (int r = 0; r < RS; ++r) kp_[r] = (unsigned)keep[(size_t)(g * rpg + r0 + row_clamp(r, n)) * N + c];
+        }
+        if (SO.other) {
+#pragma unroll
+            for (int r = 0; r < RS; ++r) ov_[r] = SO.other[(size_t)(g * rpg + r0 + row_clamp(r, n)) * SO.ld + c];
         }
         for (int q = 1; q < nslab; ++q) {
             float t[RS];
@@ -803,7 +853,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             const size_t row = (size_t)(g * rpg + r0 + row_clamp(r, n));
             dv_[r] = dz[row * lddz + c];
             av_[r] = a[row * lda + c];
-            ov_[r] = SO.other ? SO.other[row * SO.ld + c] : 0.f;
+            ov_[r] = 0.f;
+        }
+        if (SO.other) {
+#pragma unroll
+            for (int r = 0; r < RS; ++r) ov_[r] = SO.other[(size_t)(g * rpg + r0 + row_clamp(r, n)) * SO.ld + c];
         }
 #pragma unroll
         for (int r = 0; r < RS; ++r) {

@@ -121,12 +121,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProb& P, f32x16 (&acc)[B
                     row = row < M ? row : M - 1;
                     old[ta][r] = Cb[(size_t)row * P.ldc + colc];
                 }
+            // (sums into registers of their own first: a store whose data register the next sum overwrites makes the
+            //  compiler wait for that store — vmcnt(0) after every one of them)
+#pragma unroll
+            for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[ta][r] = acc[ta][tb][r] + old[ta][r];
 #pragma unroll
             for (int ta = 0; ta < TM; ++ta)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (row < M && col < N) Cb[(size_t)row * P.ldc + col] = acc[ta][tb][r] + old[ta][r];
+                    if (row < M && col < N) Cb[(size_t)row * P.ldc + col] = old[ta][r];
                 }
         }
         return;
