@@ -841,8 +841,6 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
         // the BatchNorm-aware epilogue of a problem over the columns [lo, ..) of the [prefix | x_hat] segment
         auto ep_x0 = [&](GemmProb& q, int wcol, int lo, const float* cs1b) {
             has_x0 = true;
-            static const bool plain = [] { const char* e = getenv("DGG_EP_PLAIN"); return e && e[0] == '1'; }();
-            if (plain) return;   // TIMING ONLY (wrong gradients): the weight-gradient launch without its BatchNorm-aware epilogue
             q.ep_gamma = c.W.aff_scale + lo;
             q.ep_beta = c.W.aff_shift + lo;
             q.ep_cs0 = c.train ? nullptr : cs13;
