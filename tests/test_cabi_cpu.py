@@ -141,3 +141,31 @@ def test_grad_buckets_partition_the_flat_buffer():
         for name, off, rows, cols, kind in fn.entries:
             if kind == 0:
                 assert sum(lo <= off and off + rows * cols <= hi for lo, hi in b) == 1, name
+
+
+def test_bps_workspace_plan_and_route_switch():
+    """Host-side logic of the round-4 BPS entry points (no GPU): the workspace query follows the chunk plan — 0 bytes for the
+    many-clouds shapes, B * nchunk * P * 8 for few clouds of many points (chunks of 256..1536 points, ~512 workgroups) —,
+    bad arguments are refused, the route override takes only its two values."""
+    from dex_gan_grasp_amd import _lib
+    lib = _lib.lib()
+    P = 4096
+    assert lib.dgg_bps_workspace_bytes(1024, 2048, P) == 0          # the training front end: one workgroup per cloud slice
+    assert lib.dgg_bps_workspace_bytes(512, 2048, P) == 0
+    assert lib.dgg_bps_workspace_bytes(1, 32, P) == 0               # fewer than 64 points: the scan
+    w73 = lib.dgg_bps_workspace_bytes(1, 73000, P)                  # the robot path's largest cloud: chunks of 576 points
+    assert w73 == 127 * P * 8, w73
+    w15 = lib.dgg_bps_workspace_bytes(1, 15009, P)                  # chunks of 256 points
+    assert w15 == 59 * P * 8, w15
+    assert lib.dgg_bps_workspace_bytes(3, 5000, P) % (3 * P * 8) == 0 and lib.dgg_bps_workspace_bytes(3, 5000, P) > 0
+    assert lib.dgg_bps_workspace_bytes(40, 4100, P) > 0             # more than 2560 points per cloud: always chunks
+    for bad in ((0, 100, P), (1, 0, P), (1, 100, 0)):
+        assert lib.dgg_bps_workspace_bytes(*bad) == -1
+    assert lib.dgg_get_bps_algo() == 0
+    assert lib.dgg_set_bps_algo(1) == 0 and lib.dgg_get_bps_algo() == 1
+    assert lib.dgg_bps_workspace_bytes(1, 73000, P) == 0            # the scan needs no workspace
+    assert lib.dgg_set_bps_algo(2) == -1 and lib.dgg_get_bps_algo() == 1
+    assert lib.dgg_set_bps_algo(0) == 0
+    assert lib.dgg_bps_encode_ws(None, 1, 10, None, P, None, None, None, 0, None) == -1
+    assert lib.dgg_set_gemm_algo(3) == 0 and lib.dgg_get_gemm_algo() == 3 and lib.dgg_set_gemm_algo(1) == 0   # DGG_GEMM_BF16
+    assert lib.dgg_set_gemm_algo(4) == -1

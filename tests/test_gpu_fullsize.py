@@ -470,6 +470,15 @@ def test_bench_py_runs_its_multi_rank_branches_in_rehearsal():
     assert d["rccl_ranks"]["allreduce_bytes_per_step_per_rank"] == 4 * (6979096 + 6998068 + 10661660) or \
         d["rccl_ranks"]["allreduce_bytes_per_step_per_rank"] > 9e7
     assert d["value"] > 0 and "roofline" in d and d["side_streams"]["mode"] in ("probed", "plain")
+    # round 4: what makes the first N > 1 run falsifiable — per-bucket all-reduce durations (with their bytes, in issue
+    # order) and the time each network's optimiser step waited for its all-reduce after its backward had finished
+    rr = d["rccl_ranks"]
+    assert set(rr["exposed_us"]) == {"D", "G", "E"} and all(v >= 0 for v in rr["exposed_us"].values()), rr
+    assert set(rr["bucket_allreduce_us"]) == {"D", "G", "E"}, rr
+    assert [len(rr["bucket_allreduce_us"][k]) for k in "DGE"] == [2, 2, 3]
+    for k in "DGE":
+        assert all(b["bytes"] > 1e7 and b["us"] > 0 for b in rr["bucket_allreduce_us"][k]), rr["bucket_allreduce_us"][k]
+    assert sum(b["bytes"] for k in "DGE" for b in rr["bucket_allreduce_us"][k]) == rr["allreduce_bytes_per_step_per_rank"]
 
 
 def test_one_rank_rccl_process_group_runs_the_collective_path():
