@@ -4,14 +4,18 @@
 // Arithmetic contract (identical to oracle/bps_oracle.c, so ids are bit-exact against it):
 //   dx = x - bx ...;  d2 = fmaf(dz, dz, fmaf(dy, dy, dx*dx));  dist = sqrtf(d2) correctly rounded.
 //
-// This kernel is fp32-VALU bound (arithmetic intensity ~1e3 flop/B: 4096*N pair evaluations against
-// 12*N + 32 KiB bytes per cloud), not HBM bound.  Mapping for CDNA4:
-//  - a lane owns basis points (registers: bx,by,bz,best,id per point); the cloud point index j is
-//    wave-uniform, so x_j,y_j,z_j arrive through the SCALAR cache (s_load) and are broadcast as SGPR
-//    operands — no LDS traffic, no per-lane loads in the inner loop;
-//  - 256-thread workgroups, 4 basis points per lane (two packed pairs), P/1024 basis slices per cloud;
-//  - few clouds (robot path, one 15k..73k-point cloud): the same kernel over RANGES of the cloud, merged through the
-//    output arrays with atomicMin in two passes (see the kernel) -> the whole chip works on one cloud.
+// Arithmetic intensity ~1e3 flop/B (4096*N pair evaluations against 12*N + 32 KiB bytes per cloud): never HBM bound.
+// Two kernels, one answer (ids and distance bits are identical on every route):
+//  - bps_mfma_kernel (below, rounds 3-4): clouds of >= 64 points.  A two-plane fp16 coarse pass on the matrix cores SELECTS
+//    candidate blocks of 16 points, the contract's arithmetic on the candidates DECIDES.  One workgroup per (cloud, 1024 basis
+//    points) for many clouds; for few clouds of many points — the reference's own call: ONE cloud of 15k-73k points — one
+//    workgroup per (chunk of the cloud, 1024 basis points), chunks meeting by a 64-bit minimum in a caller-owned workspace
+//    (dgg_bps_encode_ws, bps_merge_kernel);
+//  - bps_batched_kernel (round 2), the vector-ALU scan: a lane owns basis points in registers, the cloud point index is
+//    wave-uniform, so x_j, y_j, z_j arrive through the SCALAR cache and are broadcast as SGPR operands; 256-thread
+//    workgroups, 4 basis points per lane (two packed pairs).  Serves clouds of fewer than 64 points, large clouds when no
+//    workspace is given (RANGES of the cloud merged through the output arrays with atomicMin in two passes) and
+//    dgg_set_bps_algo(DGG_BPS_SCAN): the second opinion the regression tests compare every output with.
 #include "dgg_internal.h"
 #include <cstdlib>
 #include <cstring>
@@ -25,8 +29,9 @@ __device__ __forceinline__ float dist2(float x, float y, float z, float bx, floa
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Three consecutive floats (a basis point, a cloud point).  The compiler makes one global_load_dwordx3 of it; where such a
-// load is in flight TOGETHER with 16-byte loads its consumer must wait with vmcnt(0) — see block() in bps_mfma_kernel.
+// Three consecutive floats (a basis point, a cloud point) of the SCAN: the compiler makes one global_load_dwordx3 of it.  The
+// matrix-core kernel has no such load (round 4: basis points through LDS, ragged point loads as one asm statement — see
+// "Operands that were not there yet" in DESIGN.md 3.4 and tools/vmcnt_audit.py).
 __device__ __forceinline__ void load3(const float* p, float& x, float& y, float& z) {
     x = p[0];
     y = p[1];
