@@ -1892,10 +1892,11 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
     share.mode = 2;
     DGG_TRY(net_forward(Ld, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN,
                         srcs_pose(cfg, bps, S.rfake, S.f_transl, S.f_joint), nullptr, nullptr, 0, S.p_fake, st, &share));
-    DGG_TRY(bce_launch(S.p_fake, nullptr, 0.f, B, (float)hp->bce_weight, 0.5f, losses + DGG_L_BCE_FAKE, S.dl_fake, st));
-    // :792-793 the fake pass accumulates onto the real pass' gradients
+    // :792-793 the fake pass accumulates onto the real pass' gradients (and the loss terms meet: the BCE kernel of the fake
+    // pass also forms the total — one launch less on the chain than a combine kernel of its own)
     if (fork && hipStreamWaitEvent(st, ev[2], 0) != hipSuccess) return DGG_ERR_LAUNCH;
-    DGG_TRY(disc_loss_combine_launch(losses, st, real_slot));
+    DGG_TRY(bce_launch(S.p_fake, nullptr, 0.f, B, (float)hp->bce_weight, 0.5f, losses + DGG_L_BCE_FAKE, S.dl_fake, st, losses,
+                       real_slot));
     // the real pass (bwd_mode 1) kept dY13 / cs13 of every block in its workspace: the BPS columns' weight gradient is
     // formed here on dY_real + dY_fake
     if (share.bwd_mode == 1) {

@@ -296,7 +296,7 @@ int ibn_bwd_apply_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col
 
 // losses -------------------------------------------------------------------------------------
 int bce_launch(const float* p, const float* labels, float target_const, int B, float weight, float loss_scale,
-               float* loss_out, float* d_logit, hipStream_t st);
+               float* loss_out, float* d_logit, hipStream_t st, float* combine = nullptr, int real_slot = DGG_L_BCE_REAL);
 int ortho6d_fwd_launch(const float* o6, int ld, int B, float* rot9, hipStream_t st);
 int fake_pose_launch(const float* heads, int ld, int nj, int B, float* rot9, float* transl, float* joint, hipStream_t st);
 int ortho6d_bwd_launch(const float* o6, int ld, int B, const float* d_rot9, float* d_o6, int ldd, hipStream_t st);
@@ -304,7 +304,6 @@ int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const floa
                     const float* gt_transl, const float* gt_joint, const float* fake_score, const float* d_pose,
                     float* losses, float* d_heads, hipStream_t st, float* scratch = nullptr /* >= 4*ceil(B/64) floats */,
                     int wass = 0 /* 1: gen_loss_fake = -mean(fake_score) (dexgangrasp.py:258) instead of BCE(., 1) */);
-int disc_loss_combine_launch(float* losses, hipStream_t st, int real_slot = DGG_L_BCE_REAL);
 
 // ---------------------------------------------------------------- WGAN-GP second-order pass (second_order.hip)
 int gp_interp_launch(const float* alphas, const float* r_rot, const float* r_tr, const float* r_jt, const float* f_rot,

@@ -1146,7 +1146,8 @@ __device__ __forceinline__ float block_sum_1024(float v, float* sh) {
 // (binary_cross_entropy_backward: (p - t) / max((1-p) p, 1e-12)) chained through the sigmoid.
 __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ p, const float* __restrict__ labels,
                                                    float target_const, int B, float weight, float loss_scale,
-                                                   float* __restrict__ loss_out, float* __restrict__ d_logit) {
+                                                   float* __restrict__ loss_out, float* __restrict__ d_logit,
+                                                   float* __restrict__ combine, int real_slot) {
     __shared__ float sh[16];
     float acc = 0.f;
     for (int i = threadIdx.x; i < B; i += blockDim.x) {
@@ -1160,7 +1161,18 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ p, 
         }
     }
     const float tot = block_sum_1024(acc, sh);
-    if (threadIdx.x == 0) loss_out[0] = weight * (tot / (float)B);
+    if (threadIdx.x == 0) {
+        const float l = weight * (tot / (float)B);
+        loss_out[0] = l;
+        // combine (the D phase's fake-pass term; dexgangrasp.py:229-231): total = (real + fake) / 2 with the real pass' term
+        // taken from `real_slot` (a prefetched real pass leaves it in a spare slot) — what a one-thread kernel of its own did
+        // before round 4
+        if (combine) {
+            const float r = combine[real_slot];
+            combine[DGG_L_BCE_REAL] = r;
+            combine[DGG_L_TOTAL_DISC] = (r + l) / 2.f;
+        }
+    }
 }
 
 struct Rot {
@@ -1391,12 +1403,6 @@ __global__ void gen_loss_final_kernel(int nj, float bce_w, float c_tr, float c_r
     losses[DGG_L_ROT] = lrot;
     losses[DGG_L_CONF] = lcf;
     losses[DGG_L_TOTAL_GEN] = lf + (ltr + lrot + lcf);
-}
-
-__global__ void disc_loss_combine_kernel(float* losses, int real_slot) {
-    const float r = losses[real_slot];   // a prefetched real pass leaves its term in a spare slot
-    losses[DGG_L_BCE_REAL] = r;
-    losses[DGG_L_TOTAL_DISC] = (r + losses[DGG_L_BCE_FAKE]) / 2.f;
 }
 
 // Graph replay: the optimiser's step number lives in device memory.  step[0] += 1; dyn = {lr / (1 - b1^t), sqrt(1 - b2^t)}
@@ -1884,9 +1890,9 @@ int ibn_bwd_apply_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col
 }
 
 int bce_launch(const float* p, const float* labels, float target_const, int B, float weight, float loss_scale,
-               float* loss_out, float* d_logit, hipStream_t st) {
+               float* loss_out, float* d_logit, hipStream_t st, float* combine, int real_slot) {
     hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, st, p, labels, target_const, B, weight, loss_scale,
-                       loss_out, d_logit);
+                       loss_out, d_logit, combine, real_slot);
     return check_launch("bce");
 }
 
@@ -1922,11 +1928,6 @@ int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const floa
     hipLaunchKernelGGL(gen_loss_final_kernel, dim3(1), dim3(1), 0, st, cfg->n_hand_joints, bw, ct, cr, cc, B, nblk,
                        scratch, losses);
     return check_launch("gen_loss");
-}
-
-int disc_loss_combine_launch(float* losses, hipStream_t st, int real_slot) {
-    hipLaunchKernelGGL(disc_loss_combine_kernel, dim3(1), dim3(1), 0, st, losses, real_slot);
-    return check_launch("disc_loss_combine");
 }
 
 int adam_launch(float* params, const float* grads, float* m, float* v, int64_t n, int step, double lr, double b1,
