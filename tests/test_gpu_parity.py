@@ -915,3 +915,32 @@ def test_train_step_on_planes_matches_in_register_split():
     print("planes vs in-register split: %d LeakyReLU sides differ in step 1" % flips)
     for p1, p2 in zip(out[1][2], out[2][2]):
         assert float((p1 - p2).abs().max()) <= 2.5 * 1e-4 * 2   # hard Adam bound: 2 steps of at most ~lr each
+
+
+def test_integration_md_ctypes_stub_for_bps_encode_runs_as_written():
+    """INTEGRATION.md section B shows the ctypes stub a maintainer of the reference adds for `bps.encode(...)`
+    (data/bps_encoder.py:33, dexgangrasp_real_robot.py:139).  The block is executed here AS WRITTEN (from the repository
+    root, where its relative library path resolves) on one of the reference's own object clouds at full size, and its answer
+    is compared with the oracle: documentation that runs."""
+    import os
+    import re
+    from oracle import bps_oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "def bps_encode" in b]
+    assert len(blocks) == 1
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        exec(compile(blocks[0], "INTEGRATION.md", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    d = H.load("bps_real_objects.npz")
+    name = str(d["names"][0])
+    cloud, basis = d["cloud_" + name], d["basis"]
+    out = ns["bps_encode"](torch.from_numpy(cloud).to(DEV), torch.from_numpy(basis).to(DEV))
+    od, oi = bps_oracle.encode_f32(cloud, basis)
+    assert (out["ids"].cpu().numpy()[0] == oi).all()
+    assert (out["dists"].cpu().numpy()[0].view(np.int32) == od.view(np.int32)).all()
+    assert int(ns["lib"].dgg_bps_workspace_bytes(1, cloud.shape[0], basis.shape[0])) > 0   # the chunked matrix-core route
