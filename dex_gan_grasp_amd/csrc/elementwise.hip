@@ -723,6 +723,9 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
         if (keep) {
 #pragma unroll
             for (int r = 0; r < RS; ++r) kp_[r] = (unsigned)keep[(size_t)(g * rpg + r0 + row_clamp(r, n)) * N + c];
+            // byte loads among the dword loads above: everything in flight is waited for at once, no counted wait over the
+            // two widths (tools/vmcnt_audit.py)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (SO.other) {
 #pragma unroll

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
             }
         }
     } else {
-        gemm_epilogue<BM, BN, 2, 2, !A_KC && !B_KC>(P, acc, smem, split, tm_i, m0, n0, tid);
+        gemm_epilogue<BM, BN, 2, 2, !A_KC && !B_KC, 1>(P, acc, smem, split, tm_i, m0, n0, tid);
     }
 }
 
@@ -529,6 +529,9 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
     for (int i = 0; i < batch.nprob; ++i) {
         GemmProb& p = batch.p[i];
         if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.A || !p.B || !p.C) return DGG_ERR_INVALID;
+        // the epilogue addresses C (one slab of it) and ep_w through 32-bit byte offsets (gemm_epilogue.h)
+        if ((long long)p.M * p.ldc * 4 >= (1ll << 31) || (p.ep_gamma && (long long)p.M * p.ep_ldw * 4 >= (1ll << 31)))
+            return DGG_ERR_INVALID;
         p.tiles_m = (p.M + bm - 1) / bm;
         p.tiles_n = (p.N + bn - 1) / bn;
         p.blk_begin = blocks;

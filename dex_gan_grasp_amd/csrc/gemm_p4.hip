@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512) void gemm_p4_kernel(const GemmBatch batch) {
     if (t < nkt) ktile(No{});
 
     p4_barrier();  // every consumer has read its last fragments (the loaders are gone): the epilogue reuses the ring's LDS
-    gemm_epilogue<QT, QT, 2, 2, WGRAD>(P, acc, reinterpret_cast<float*>(smem), split, tm_i, m0, n0, (int)threadIdx.x);
+    gemm_epilogue<QT, QT, 2, 2, WGRAD, 1>(P, acc, reinterpret_cast<float*>(smem), split, tm_i, m0, n0, (int)threadIdx.x);
 }
 
 // Operands: planes (a_plane / b_plane != 0), 16-byte aligned bases, pitches and plane distances multiples of 8 elements,
@@ -234,6 +234,8 @@ int gemm_p4_launch(GemmBatch& batch, bool wgrad, hipStream_t st) {
         if ((p.K & 31) || (p.lda & 7) || (p.ldb & 7) || (p.a_plane & 7) || (p.b_plane & 7) || p.lda < p.K || p.ldb < p.K ||
             (((uintptr_t)p.A | (uintptr_t)p.B) & 15) || (p.splits > 0 && (p.kchunk & 31)))
             return DGG_ERR_INVALID;
+        if ((long long)p.M * p.ldc * 4 >= (1ll << 31) || (p.ep_gamma && (long long)p.M * p.ep_ldw * 4 >= (1ll << 31)))
+            return DGG_ERR_INVALID;   // 32-bit byte offsets in the epilogue (gemm_epilogue.h)
         p.tiles_m = (p.M + QT - 1) / QT;
         p.tiles_n = (p.N + QT - 1) / QT;
         p.blk_begin = blocks;

@@ -396,7 +396,7 @@ __device__ __forceinline__ void gemm_x4_block(const GemmBatch& batch, const int 
     // this barrier unless they have left, may stage the next item
     x4_barrier();
     (void)last;
-    gemm_epilogue<YT, YT, 2, 2, !A_KC && !B_KC>(P, acc, reinterpret_cast<float*>(smem), split, tm_i, m0, n0, (int)threadIdx.x);
+    gemm_epilogue<YT, YT, 2, 2, !A_KC && !B_KC, 1>(P, acc, reinterpret_cast<float*>(smem), split, tm_i, m0, n0, (int)threadIdx.x);
 }
 
 // One workgroup per work item — or, launched with fewer workgroups than items ("side work", forward products only: their

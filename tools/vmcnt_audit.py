@@ -11,8 +11,9 @@ the pattern itself is what this script looks for, in EVERY kernel of the library
     order), and at every `s_waitcnt vmcnt(N)` with N > 0 that retires at least one LOAD report the wait if the loads
     outstanding at that point are not all of one class (class = width x address form x to-LDS).
 
-Loops are walked twice (the body once more with the queue its back edge carries), other control flow linearly — an
-approximation that over-reports rather than under-reports.  Output: one line per kernel with the mixes found; exit code 1
+The queue is followed over the kernel's control-flow graph (basic blocks split at labels and branches) to a fixed point:
+queues that meet at a block are joined entry by entry, counted from the newest operation, so every path is covered — the
+join over-approximates (it can report a mix that no single path has, never the reverse).  Output: one line per kernel with the mixes found; exit code 1
 if a kernel NOT on the justified list below has one.  `python3 tools/vmcnt_audit.py > profiles/r04_vmcnt_audit.txt`.
 """
 import os
@@ -34,20 +35,30 @@ EXTRA = {  # as in csrc/build.sh
 
 # Kernels whose mixed counted waits were read by hand and are accepted, with the reason (substring of the demangled name).
 JUSTIFIED = {
-    "gemm_f32_kernel<64, 64, true, true, true>":
-        "dword/saddr + dword/vaddr64: same width, naturally aligned; the two address forms are instruction encodings of the "
-        "same request (SGPR base + VGPR offset vs 64-bit VGPR address)",
-    "gemm_x3_kernel<true, true, true, false>":
+    "gemm_x4_kernel<false, false, false>":
+        "compiler spill reloads (scratch_load_dword, private segment; 9 registers) among the loader waves' dwordx4 loads.  The TN "
+        "instantiation of the >= 1024-workgroup kernel is reached by no launch of any BASELINE config (weight-gradient launches "
+        "have <= 240 workgroups); it is compared with fp64 in test_gemm_bf16x3_variants[*-2-shape8] on the GPU",
+    "gemm_x3_kernel<true, true, true, false, ":
         "LDS-DMA pieces of 4 B (operand whose row pitch is not a multiple of 16 B: the checkpoint's 4101 / 4613 / ... columns) "
         "and 16 B, both naturally aligned, nothing returns to registers; the ring's counted vmcnt is the kernel's design "
         "(DESIGN.md 3.1) and every product of every train step is compared with the oracle at ~1e-6 "
         "(tests/test_gpu_fullsize.py, three streams busy) and with fp64 on unaligned operands (test_gemm_bf16x3_variants[*-uv|vu|uu])",
 }
 
+# Accepted as a class: loads of ONE width, all returning to registers (or all to LDS), that differ only in how the
+# instruction encodes the address.  Listed in the output, not counted as open.
+FORM_ONLY = ("address form only: one width, one destination kind; `v, s[a:b]` (SGPR base + 32-bit VGPR offset) and `v[a:b], off` "
+             "(64-bit VGPR address) are two encodings of the same naturally aligned request")
+
+
+def form_only(loads):
+    return len({(c.split("/")[0], c.endswith("/lds")) for c in loads}) == 1
+
+
 VMEM = re.compile(r"^\s+((?:global|buffer|flat|scratch)_(?:load|store|atomic)\S*)\s+(.*)$")
 WAIT = re.compile(r"^\s+s_waitcnt\s+(.*)$")
 LABEL = re.compile(r"^(\.LBB\d+_\d+):")
-BRANCH = re.compile(r"^\s+s_c?branch\S*\s+(\.LBB\d+_\d+)")
 FUNC = re.compile(r"^(_Z\w+):\s*; @")
 
 
@@ -56,7 +67,9 @@ def classify(mn, ops):
     w = re.search(r"(dwordx[234]|dword|ubyte|sbyte|ushort|sshort|short_d16\w*|b\d+)", mn)
     width = w.group(1) if w else mn
     to_lds = "_lds_" in mn or ops.rstrip().endswith(" lds") or " lds " in ops
-    if mn.startswith("flat"):
+    if mn.startswith("scratch"):
+        form = "scratch"   # private segment: the compiler's spill reloads
+    elif mn.startswith("flat"):
         form = "flat"
     elif mn.startswith("buffer"):
         form = "buffer"
@@ -79,38 +92,93 @@ def vmcnt_of(text):
     return None
 
 
-def walk(lines, lo, hi, queue, labels, found, replayed, depth=0):
-    i = lo
-    while i < hi:
-        ln = lines[i]
-        m = VMEM.match(ln)
+TERM = re.compile(r"^\s+(s_endpgm|s_setpc_b64|s_branch|s_cbranch\S*)\b\s*(\.LBB\d+_\d+)?")
+
+
+def blocks_of(lines, lo, hi):
+    """Basic blocks [start, end) of one function and their successors."""
+    starts = {lo}
+    for i in range(lo, hi):
+        if LABEL.match(lines[i]):
+            starts.add(i)
+        elif TERM.match(lines[i]):
+            starts.add(i + 1)
+    order = sorted(x for x in starts if x < hi)
+    label_at = {}
+    for i in range(lo, hi):
+        m = LABEL.match(lines[i])
         if m:
-            kind, cls = classify(m.group(1), m.group(2))
-            queue.append((kind, cls, i))
-        else:
+            label_at[m.group(1)] = i
+    blocks = {}
+    for k, st in enumerate(order):
+        en = order[k + 1] if k + 1 < len(order) else hi
+        succ = [en] if en < hi else []
+        m = TERM.match(lines[en - 1]) if en - 1 >= st else None
+        if m:
+            op, tgt = m.group(1), m.group(2)
+            if op in ("s_endpgm", "s_setpc_b64"):
+                succ = []
+            elif op == "s_branch":
+                succ = [label_at[tgt]] if tgt in label_at else []
+            elif tgt in label_at:
+                succ = succ + [label_at[tgt]]
+        blocks[st] = (en, succ)
+    return blocks
+
+
+def join(a, b):
+    """Elementwise union of two abstract queues, aligned at their NEWEST entry (what vmcnt(N) counts from)."""
+    if len(a) < len(b):
+        a, b = b, a
+    pad = len(a) - len(b)
+    return tuple(a[i] | (b[i - pad] if i >= pad else frozenset()) for i in range(len(a)))
+
+
+def walk(lines, lo, hi, found):
+    """Fixed point over the control-flow graph.  The abstract state at a program point is the queue of outstanding
+    vector-memory operations, oldest first, each entry the SET of (kind, class) that some path puts at that distance from
+    the newest operation; states that meet at a block are joined entry by entry.  An over-approximation of every path
+    (it never misses a mix a real path has; it may report one no single path has)."""
+    blocks = blocks_of(lines, lo, hi)
+    state = {lo: ()}
+    work = [lo]
+    reported = set()
+    while work:
+        st = work.pop()
+        en, succ = blocks[st]
+        queue = list(state[st])
+        for i in range(st, en):
+            ln = lines[i]
+            m = VMEM.match(ln)
+            if m:
+                queue.append(frozenset([classify(m.group(1), m.group(2))]))
+                continue
             m = WAIT.match(ln)
             if m:
                 n = vmcnt_of(m.group(1))
                 if n is not None:
                     if n > 0 and len(queue) > n:
                         retired = queue[:len(queue) - n]
-                        loads = sorted({c for k, c, _ in queue if k == "load"})
-                        if any(k == "load" for k, _, _ in retired) and len(loads) > 1:
-                            found.append((i, n, tuple(loads)))
+                        loads = tuple(sorted({c for e in queue for k, c in e if k == "load"}))
+                        if any(k == "load" for e in retired for k, _ in e) and len(loads) > 1 and (i, n, loads) not in reported:
+                            reported.add((i, n, loads))
+                            found.append((i, n, loads))
                     del queue[:max(0, len(queue) - n)]
-            else:
-                m = BRANCH.match(ln)
-                if m and depth < 2:
-                    tgt = labels.get(m.group(1))
-                    if tgt is not None and lo <= tgt < i and (tgt, i) not in replayed:
-                        replayed.add((tgt, i))
-                        walk(lines, tgt, i, queue, labels, found, replayed, depth + 1)
-        i += 1
+        out = tuple(queue[-63:])   # vmcnt is a 6-bit counter: a wait never counts further back
+        for nx in succ:
+            old = state.get(nx)
+            new = out if old is None else join(old, out)
+            if new != old:
+                state[nx] = new
+                work.append(nx)
+    return False
 
 
 def demangle(names):
+    if not names:
+        return []
     try:
-        out = subprocess.run([CXXFILT] + names, capture_output=True, text=True, check=True).stdout
+        out = subprocess.run([CXXFILT] + names, capture_output=True, text=True, check=True, stdin=subprocess.DEVNULL).stdout
         return out.strip().split("\n")
     except Exception:
         return names
@@ -132,17 +200,12 @@ def audit_file(src):
     res = []
     for name, lo, hi in funcs:
         hi = hi or len(lines)
-        labels = {}
-        for i in range(lo, hi):
-            m = LABEL.match(lines[i])
-            if m:
-                labels[m.group(1)] = i
         found = []
-        walk(lines, lo, hi, [], labels, found, set())
+        capped = walk(lines, lo, hi, found)
         n_counted = sum(1 for i in range(lo, hi) if WAIT.match(lines[i]) and (vmcnt_of(WAIT.match(lines[i]).group(1)) or 0) > 0)
         n_x3 = sum(1 for i in range(lo, hi) if re.match(r"^\s+global_load_dwordx3", lines[i]))
         n_flat = sum(1 for i in range(lo, hi) if re.match(r"^\s+flat_(load|store|atomic)", lines[i]))
-        res.append((name, n_counted, n_x3, n_flat, found))
+        res.append((name, n_counted, n_x3, n_flat, found, capped))
     return res
 
 
@@ -154,12 +217,14 @@ def main():
     for f in srcs:
         res = audit_file(os.path.join(CSRC, f))
         names = demangle([r[0] for r in res])
-        for (name, n_counted, n_x3, n_flat, found), dn in zip(res, names):
+        for (name, n_counted, n_x3, n_flat, found, capped), dn in zip(res, names):
             short = re.sub(r"^void ", "", re.sub(r"\(.*", "", dn))
             mixes = {}
             for _, n, loads in found:
                 mixes[loads] = mixes.get(loads, 0) + 1
             why = next((v for k, v in JUSTIFIED.items() if k in dn), None)
+            if found and not why and all(form_only(loads) for loads in mixes):
+                why = FORM_ONLY
             status = "clean" if not found else ("JUSTIFIED: " + why if why else "MIXED")
             if found and not why:
                 bad += 1
