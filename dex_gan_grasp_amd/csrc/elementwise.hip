@@ -333,7 +333,6 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
     const int c = bnc ? oc - nprefix : 0;
     const int groups = B / rpg;
     const bool fused = fin.mean_out != nullptr;
-    if (fused) bn_block_stats(fin, rpg, groups, S.total, c, bnc, blockIdx.y == 0, sh, res);
     // planes window (PlaneOut::win_n): only the BPS block of X0 goes out as planes, at column oc - win_lo
     const bool pwin = PL.win_n > 0;
     const bool pin = !pwin || (oc >= PL.win_lo && oc < PL.win_lo + PL.win_n);
@@ -362,6 +361,8 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
             }
         }
     }
+    // (the statistics merge — two barriers, a chain of dependent partial loads — runs while the 32 loads above are in flight)
+    if (fused) bn_block_stats(fin, rpg, groups, S.total, c, bnc, blockIdx.y == 0, sh, res);
 #pragma unroll
     for (int k = 0; k < kIbnBlocks; ++k) {
         const int rbk = blockIdx.y * kIbnBlocks + k;
@@ -580,10 +581,20 @@ __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ 
     const bool cok = c0 < N;
     const int c = cok ? c0 : N - 1;
     const bool fused = fin.mean_out != nullptr;
-    if (fused) bn_block_stats(fin, rpg, B / rpg, N, c, cok, blockIdx.y == 0, sh, res);
-    if (!cok) return;
     const int r0 = blockIdx.y * RB + sub * RS;
     const int n = min(RS, B - r0);
+    // (the two operand tiles are requested before the statistics merge — two barriers and a chain of dependent partial
+    //  loads — so that one memory latency covers both; clamped indices, every lane)
+    float sv[RS], av[RS], kv[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        const size_t row = (size_t)(n > 0 ? r0 + row_clamp(r, n) : 0);
+        sv[r] = s[row * lds + c];
+        av[r] = a2[row * lda2 + c];
+        kv[r] = 1.f;
+    }
+    if (fused) bn_block_stats(fin, rpg, B / rpg, N, c, cok, blockIdx.y == 0, sh, res);
+    if (!cok) return;
     const bool last_block = blockIdx.y == gridDim.y - 1;
     float yv[RS];
     if (n <= 0) {
@@ -599,14 +610,8 @@ __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ 
     const float inv_keep = 1.0f / (1.0f - kDropP);
     // drop_mode 3: `seed` carries a device pointer to the seed (graph replay: the seed lives in device memory)
     const uint64_t sd = drop_mode == 3 ? *reinterpret_cast<const uint64_t*>(seed) : seed;
-    float sv[RS], av[RS], kv[RS];
 #pragma unroll
-    for (int r = 0; r < RS; ++r) {
-        const size_t row = (size_t)(r0 + row_clamp(r, n));
-        sv[r] = s[row * lds + c];
-        av[r] = a2[row * lda2 + c] + ab;
-        kv[r] = 1.f;
-    }
+    for (int r = 0; r < RS; ++r) av[r] += ab;
     if (drop_mode == 1) {   // (one uniform branch around the loop, not a load-or-constant per row)
 #pragma unroll
         for (int r = 0; r < RS; ++r) kv[r] = keep_in[(size_t)(r0 + row_clamp(r, n)) * N + c];
@@ -790,7 +795,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ sums, int train, int rpg,
                                                            int nrb, int N, float* __restrict__ dx, int lddx,
                                                            float* __restrict__ part, ColFin fin, PlaneOut PL, SumOut SO) {
+    constexpr int kFinQ = 5;   // quantities a ColFin finalizes at most (fin.nq)
     __shared__ float sh[SUB][1][64];
+    __shared__ float shq[SUB][kFinQ][64];
     __shared__ float tq[2][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 64 + lane;
@@ -803,6 +810,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float k = gamma[c] * rs;
     const float inv_n = 1.0f / (float)rpg;
     float m0 = 0.f, m1 = 0.f;
+    // the rows this thread transforms: requested before the finalize prologue below, one memory latency for both
+    float dv_[RS], av_[RS], ov_[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        const size_t row = (size_t)(g * rpg + (n > 0 ? r0 + row_clamp(r, n) : 0));
+        dv_[r] = dz[row * lddz + c];
+        av_[r] = a[row * lda + c];
+        ov_[r] = 0.f;
+    }
+    if (SO.other) {
+#pragma unroll
+        for (int r = 0; r < RS; ++r) ov_[r] = SO.other[(size_t)(g * rpg + (n > 0 ? r0 + row_clamp(r, n) : 0)) * SO.ld + c];
+    }
     if (fin.part) {  // one group: column totals from the row-block partials (see ColFin)
         const bool writer = blockIdx.y == 0;
         if (writer && blockIdx.x == 0) {
@@ -812,26 +832,44 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const int per = (nrb + SUB - 1) / SUB;
         const int rb_lo = min(nrb, sub * per), rb_hi = min(nrb, rb_lo + per);
         const int nqq = writer ? fin.nq : (train ? 2 : 0);  // workgroup-uniform
-        for (int q = 0; q < nqq; ++q) {
-            float sg = 0.f;
-            for (int b8 = rb_lo; b8 < rb_hi; b8 += 8) {
-                float t[8];
+        // all quantities' partials in ONE round of loads and one pair of barriers (they were a round and a pair each);
+        // per quantity the same sums in the same order
+        float sg[kFinQ];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) t[j] = fin.part[((size_t)min(b8 + j, rb_hi - 1) * fin.nq + q) * N + c];
+        for (int q = 0; q < kFinQ; ++q) sg[q] = 0.f;
+        for (int b8 = rb_lo; b8 < rb_hi; b8 += 8) {
+            float t[kFinQ][8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (b8 + j < rb_hi) sg += t[j];
+            for (int q = 0; q < kFinQ; ++q) {
+                if (q < nqq) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t[q][j] = fin.part[((size_t)min(b8 + j, rb_hi - 1) * fin.nq + q) * N + c];
+                }
             }
-            __syncthreads();
-            sh[sub][0][lane] = sg;
-            __syncthreads();
-            if (sub == 0) {
-                const float tot = ((sh[0][0][lane] + sh[1][0][lane]) + sh[2][0][lane]) + sh[3][0][lane];
-                if (q < 2) tq[q][lane] = tot;
-                if (writer && cok) {
-                    float* d = q < 4 ? fin.d[q] : (c == 0 ? fin.d[4] : nullptr);  // q 4: one scalar
-                    if (d) d[c] = fin.accumulate ? d[c] + tot : tot;
-                    if (q == 2 && fin.copy2) fin.copy2[c] = tot;
+#pragma unroll
+            for (int q = 0; q < kFinQ; ++q) {
+                if (q < nqq) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (b8 + j < rb_hi) sg[q] += t[q][j];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kFinQ; ++q)
+            if (q < nqq) shq[sub][q][lane] = sg[q];
+        __syncthreads();
+        if (sub == 0) {
+#pragma unroll
+            for (int q = 0; q < kFinQ; ++q) {
+                if (q < nqq) {
+                    const float tot = ((shq[0][q][lane] + shq[1][q][lane]) + shq[2][q][lane]) + shq[3][q][lane];
+                    if (q < 2) tq[q][lane] = tot;
+                    if (writer && cok) {
+                        float* d = q < 4 ? fin.d[q] : (c == 0 ? fin.d[4] : nullptr);  // q 4: one scalar
+                        if (d) d[c] = fin.accumulate ? d[c] + tot : tot;
+                        if (q == 2 && fin.copy2) fin.copy2[c] = tot;
+                    }
                 }
             }
         }
@@ -840,7 +878,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             m0 = tq[0][lane] * inv_n;
             m1 = tq[1][lane] * inv_n;
         }
-        __syncthreads();  // sh is reused below
     } else if (train) {
         m0 = sums[(size_t)(g * 2 + 0) * N + c] * inv_n;
         m1 = sums[(size_t)(g * 2 + 1) * N + c] * inv_n;
@@ -850,18 +887,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < RS; ++r) xo[r] = 0.f;
     if (n > 0) {
-        float dv_[RS], av_[RS], ov_[RS];
-#pragma unroll
-        for (int r = 0; r < RS; ++r) {
-            const size_t row = (size_t)(g * rpg + r0 + row_clamp(r, n));
-            dv_[r] = dz[row * lddz + c];
-            av_[r] = a[row * lda + c];
-            ov_[r] = 0.f;
-        }
-        if (SO.other) {
-#pragma unroll
-            for (int r = 0; r < RS; ++r) ov_[r] = SO.other[(size_t)(g * rpg + r0 + row_clamp(r, n)) * SO.ld + c];
-        }
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
             if (r < n) {
