@@ -2142,6 +2142,7 @@ namespace dgg {
 struct GpW {
     void* ws_di;
     float *xi_rot, *xi_tr, *xi_jt, *p_i, *dl_i, *g, *v, *xhd0, *tu0, *tu0bar, *c1, *c2, *cs;
+    float* gp_part;   // per-workgroup partial sums of the penalty (gp_value_launch -> wgan_combine_launch)
     float *ta13[2], *th[2], *ta2[2], *ty[2];
     float *A13bar, *A13dbar, *a2bar, *a2dbar, *hbar, *hdbar, *pbar, *pdbar, *ybar, *ydbar;
     size_t bytes;
@@ -2169,6 +2170,7 @@ static int carve_wgan(const dgg_cfg* cfg, int B, void* base, StepW& S, GpW& W) {
     W.c1 = b.take<float>(Bz);
     W.c2 = b.take<float>(Bz);
     W.cs = b.take<float>((size_t)Ld.n13);
+    W.gp_part = b.take<float>((size_t)gp_value_parts(B));
     for (int r = 0; r < 2; ++r) {
         W.ta13[r] = b.take<float>(Bz * Ld.n13);
         W.th[r] = b.take<float>(Bz * Ld.hid);
@@ -2199,10 +2201,11 @@ static int gemm1(int mode, const float* A, int lda, const float* Bm, int ldb, fl
     return gemm_launch(mode, g, st);
 }
 
-// The gradient-penalty term: adds gain * dGP/dtheta to d_grads, writes GP to losses[DGG_L_GRAD_PENALTY].
+// The gradient-penalty term: adds gain * dGP/dtheta to d_grads; the penalty's per-workgroup partial sums go to Q.gp_part
+// (wgan_combine_launch forms GP in losses[DGG_L_GRAD_PENALTY] from them).
 static int gradient_penalty(const dgg_cfg* cfg, const dgg_gan_state* s, const StepW& S, GpW& Q, int B, const float* bps,
                             const float* rot9, const float* transl, const float* joint, const float* alphas, float gain,
-                            float* losses, hipStream_t st) {
+                            float* losses, hipStream_t st, Share* share) {
     NetL L;
     DGG_TRY(build_layout(DGG_NET_DISC, cfg, L));
     const int nj = cfg->n_hand_joints, np = 12 + nj, ib = cfg->in_bps;
@@ -2212,13 +2215,21 @@ static int gradient_penalty(const dgg_cfg* cfg, const dgg_gan_state* s, const St
     //     g = d sum(score) / d(rot, transl, joint)  (:160-172)
     DGG_TRY(gp_interp_launch(alphas, rot9, transl, joint, S.rfake, S.f_transl, S.f_joint, B, nj, Q.xi_rot, Q.xi_tr,
                              Q.xi_jt, st));
-    DGG_TRY(dgg_disc_forward(cfg, P, s->d_bn, Q.ws_di, S.d_bytes, B, DGG_TRAIN, bps, Q.xi_rot, Q.xi_tr, Q.xi_jt, Q.p_i,
-                             st));
+    // (share: the interpolates sit on the same BPS batch as the real / fake passes — that part of the fc1 || fc3 products is
+    //  read from the real pass' slabs, mode 2, as the fake pass does)
+    if (share) {
+        share->mode = 2;
+        DGG_TRY(net_forward(L, P, s->d_bn, Q.ws_di, S.d_bytes, B, DGG_TRAIN, srcs_pose(cfg, bps, Q.xi_rot, Q.xi_tr, Q.xi_jt),
+                            nullptr, nullptr, 0, Q.p_i, st, share));
+    } else {
+        DGG_TRY(dgg_disc_forward(cfg, P, s->d_bn, Q.ws_di, S.d_bytes, B, DGG_TRAIN, bps, Q.xi_rot, Q.xi_tr, Q.xi_jt, Q.p_i,
+                                 st));
+    }
     DGG_TRY(sig_grad_launch(Q.p_i, B, Q.dl_i, st));
     DGG_TRY(dgg_disc_backward(cfg, P, nullptr, Q.ws_di, S.d_bytes, B,
                               DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_NEED_INPUT_GRADS, bps, Q.xi_rot, Q.xi_tr, Q.xi_jt,
                               Q.dl_i, Q.g, st));
-    DGG_TRY(gp_value_launch(Q.g, B, nj, gain, losses + DGG_L_GRAD_PENALTY, Q.v, st));
+    DGG_TRY(gp_value_launch(Q.g, B, nj, gain, Q.gp_part, Q.v, st));
     // (2) tangent forward of v next to the stored activations of that forward
     NetW W;
     carve(L, B, Q.ws_di, W);
@@ -2250,11 +2261,18 @@ static int gradient_penalty(const dgg_cfg* cfg, const dgg_gan_state* s, const St
                                 L.nn, Q.A13bar + L.hid, Q.A13dbar + L.hid, L.n13, st));
         DGG_TRY(bn_second_bwd_launch(A.a2, L.nn, Q.ta2[r], L.nn, A.mean2, A.rstd2, P + R.bn2w, Q.pbar, Q.pdbar, L.nn, nullptr,
                                      0, B, L.nn, Q.a2bar, Q.a2dbar, L.nn, G + R.bn2w, G + R.bn2b, st));
-        // fc2: a2 = h W2^T + b2, a2dot = hdot W2^T  (b2 feeds a train-mode BatchNorm: its gradient is exactly zero)
-        DGG_TRY(gemm1(GEMM_NN, Q.a2bar, L.nn, P + R.w2, L.hid, Q.hbar, L.hid, B, L.hid, L.nn, 0, st));
-        DGG_TRY(gemm1(GEMM_NN, Q.a2dbar, L.nn, P + R.w2, L.hid, Q.hdbar, L.hid, B, L.hid, L.nn, 0, st));
-        DGG_TRY(gemm1(GEMM_TN, Q.a2bar, L.nn, A.h, L.hid, G + R.w2, L.hid, L.nn, L.hid, B, 1, st));
-        DGG_TRY(gemm1(GEMM_TN, Q.a2dbar, L.nn, Q.th[r], L.hid, G + R.w2, L.hid, L.nn, L.hid, B, 1, st));
+        // fc2: a2 = h W2^T + b2, a2dot = hdot W2^T  (b2 feeds a train-mode BatchNorm: its gradient is exactly zero).
+        // Both adjoint streams through W2 in one launch; the two weight-gradient products dW2 += a2bar^T h and
+        // dW2 += a2dbar^T hdot ride in the block's primal / tangent weight-gradient launches below (alone they were 32
+        // workgroups for 33 us each).
+        {
+            GemmBatch g;
+            memset(&g, 0, sizeof(g));
+            g.nprob = 2;
+            prob_init(g.p[0], Q.a2bar, L.nn, P + R.w2, L.hid, Q.hbar, L.hid, B, L.hid, L.nn);
+            prob_init(g.p[1], Q.a2dbar, L.nn, P + R.w2, L.hid, Q.hdbar, L.hid, B, L.hid, L.nn);
+            DGG_TRY(gemm_launch(GEMM_NN, g, st));
+        }
         DGG_TRY(bn_second_bwd_launch(A.a13, L.n13, Q.ta13[r], L.n13, A.mean1, A.rstd1, P + R.bn1w, Q.hbar, Q.hdbar, L.hid, A.h,
                                      L.hid, B, L.hid, Q.A13bar, Q.A13dbar, L.n13, G + R.bn1w, G + R.bn1b, st));
         // fc3.bias (the fc1.bias part is exactly zero) and the column sums the BatchNorm-aware wgrad epilogue needs
@@ -2278,18 +2296,42 @@ static int gradient_penalty(const dgg_cfg* cfg, const dgg_gan_state* s, const St
                 prob_init(g.p[1], Q.A13bar, L.n13, W.rb[r - 1].y, L.nn, G + R.w13 + L.k0, R.fin, L.n13, L.nn, B);
                 g.p[1].accumulate = 1;
             }
+            {   // rider: dW2 += a2bar^T h
+                GemmProb& q = g.p[g.nprob++];
+                prob_init(q, Q.a2bar, L.nn, A.h, L.hid, G + R.w2, L.hid, L.nn, L.hid, B);
+                q.accumulate = 1;
+            }
             int bm, bn;
             gemm_tile_shape(GEMM_TN, g.p[0].M, g.p[0].N, bm, bn, g.p[0].K);
             ibn_tiles[r] = (L.n13 + bm - 1) / bm;
             if (ibn_tiles[r] > 12) return DGG_ERR_INVALID;
             DGG_TRY(gemm_launch(GEMM_TN, g, st));
         }
-        // tangent stream: only the pose columns of x_hat (and the previous block) carry a tangent
-        DGG_TRY(gemm1(GEMM_TN, Q.A13dbar, L.n13, Q.tu0, np, G + R.w13 + ib, R.fin, L.n13, np, B, 1, st));
-        if (r > 0) {
-            DGG_TRY(gemm1(GEMM_TN, Q.A13dbar, L.n13, Q.ty[r - 1], L.nn, G + R.w13 + L.k0, R.fin, L.n13, L.nn, B, 1, st));
-            DGG_TRY(gemm1(GEMM_NN, Q.A13bar, L.n13, P + R.w13 + L.k0, R.fin, Q.ybar, L.nn, B, L.nn, L.n13, 0, st));
-            DGG_TRY(gemm1(GEMM_NN, Q.A13dbar, L.n13, P + R.w13 + L.k0, R.fin, Q.ydbar, L.nn, B, L.nn, L.n13, 0, st));
+        // tangent stream: only the pose columns of x_hat (and the previous block) carry a tangent.  One launch, after the
+        // primal one (both accumulate into the same entries): dW13[:, pose] += A13dbar^T u0dot, dW13[:, previous block] +=
+        // A13dbar^T ydot, dW2 += a2dbar^T hdot
+        {
+            GemmBatch g;
+            memset(&g, 0, sizeof(g));
+            int nq = 0;
+            prob_init(g.p[nq], Q.A13dbar, L.n13, Q.tu0, np, G + R.w13 + ib, R.fin, L.n13, np, B);
+            g.p[nq++].accumulate = 1;
+            if (r > 0) {
+                prob_init(g.p[nq], Q.A13dbar, L.n13, Q.ty[r - 1], L.nn, G + R.w13 + L.k0, R.fin, L.n13, L.nn, B);
+                g.p[nq++].accumulate = 1;
+            }
+            prob_init(g.p[nq], Q.a2dbar, L.nn, Q.th[r], L.hid, G + R.w2, L.hid, L.nn, L.hid, B);
+            g.p[nq++].accumulate = 1;
+            g.nprob = nq;
+            DGG_TRY(gemm_launch(GEMM_TN, g, st));
+        }
+        if (r > 0) {   // both adjoint streams into the previous block's output, one launch
+            GemmBatch g;
+            memset(&g, 0, sizeof(g));
+            g.nprob = 2;
+            prob_init(g.p[0], Q.A13bar, L.n13, P + R.w13 + L.k0, R.fin, Q.ybar, L.nn, B, L.nn, L.n13);
+            prob_init(g.p[1], Q.A13dbar, L.n13, P + R.w13 + L.k0, R.fin, Q.ydbar, L.nn, B, L.nn, L.n13);
+            DGG_TRY(gemm_launch(GEMM_NN, g, st));
         }
         DGG_TRY(gemm1(GEMM_NN, Q.A13dbar, L.n13, P + R.w13 + ib, R.fin, Q.tu0bar, np, B, np, L.n13, last ? 0 : 1, st));
     }
@@ -2323,20 +2365,46 @@ int dgg_wgan_d_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
     // :772-776 generator forward (train, activations kept for the G phase), R = ortho6d(rot_6D)
     DGG_TRY(dgg_gen_forward(cfg, s->g_params, s->g_bn, S.ws_g, S.g_bytes, B, DGG_TRAIN, z, bps, S.heads, stream));
     DGG_TRY(fake_pose_launch(S.heads, nh, nj, B, S.rfake, S.f_transl, S.f_joint, st));
-    // :788-789 D(real), D(fake.detach()); :199-205 -mean(real) + mean(fake)
-    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint, S.p_real,
-                             stream));
-    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN, bps, S.rfake, S.f_transl, S.f_joint,
-                             S.p_fake, stream));
-    DGG_TRY(wass_launch(S.p_real, B, -1.f, losses + DGG_L_BCE_REAL, S.dl_real, st));
-    DGG_TRY(wass_launch(S.p_fake, B, 1.f, losses + DGG_L_BCE_FAKE, S.dl_fake, st));
-    DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_dr, S.d_bytes, B, DGG_TRAIN, bps, rot9, transl, joint,
-                              S.dl_real, nullptr, stream));
-    DGG_TRY(dgg_disc_backward(cfg, s->d_params, s->d_grads, S.ws_df, S.d_bytes, B, DGG_TRAIN | DGG_ACCUM_GRADS, bps, S.rfake,
-                              S.f_transl, S.f_joint, S.dl_fake, nullptr, stream));
+    // :788-789 D(real), D(fake.detach()); :199-205 -mean(real) + mean(fake).  The two passes share what the cGAN D phase
+    // shares (dgg_cgan_d_phase2, one stream): the BPS columns are the same batch in both, so their part of every fc1 || fc3
+    // product is formed once, by the real pass, and their weight gradient once, by the fake pass, on dY_real + dY_fake.
+    // (The order of the forwards — real, then fake — is the reference's: D's running statistics see the same sequence.)
+    Share share;
+    {
+        NetL Ld;
+        DGG_TRY(build_layout(DGG_NET_DISC, cfg, Ld));
+        memset(&share, 0, sizeof(share));
+        share.ncols = cfg->in_bps;
+        share.events = false;
+        for (int r = 0; r < S.d_nrb; ++r) share.slabs[r] = S.dshare[r];
+        share.mode = 1;
+        DGG_TRY(net_forward(Ld, s->d_params, s->d_bn, S.ws_dr, S.d_bytes, B, DGG_TRAIN, srcs_pose(cfg, bps, rot9, transl, joint),
+                            nullptr, nullptr, 0, S.p_real, st, &share));
+        DGG_TRY(wass_launch(S.p_real, B, -1.f, losses + DGG_L_BCE_REAL, S.dl_real, st));
+        share.bwd_mode = share_wgrad() ? 1 : 0;
+        DGG_TRY(net_backward(Ld, s->d_params, s->d_grads, S.ws_dr, S.d_bytes, B, DGG_TRAIN,
+                             srcs_pose(cfg, bps, rot9, transl, joint), S.dl_real, nullptr, 0, 0, nullptr, st, &share));
+        share.mode = 2;
+        DGG_TRY(net_forward(Ld, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN,
+                            srcs_pose(cfg, bps, S.rfake, S.f_transl, S.f_joint), nullptr, nullptr, 0, S.p_fake, st, &share));
+        DGG_TRY(wass_launch(S.p_fake, B, 1.f, losses + DGG_L_BCE_FAKE, S.dl_fake, st));
+        if (share.bwd_mode == 1) {
+            NetW Wr;
+            carve(Ld, B, S.ws_dr, Wr);
+            for (int r = 0; r < Ld.nrb; ++r) {
+                share.dY13_other[r] = Wr.dY13[r];
+                share.cs13_other[r] = Wr.cs13[r];
+            }
+            share.bwd_mode = 2;
+        } else {
+            share.bwd_mode = 0;
+        }
+        DGG_TRY(net_backward(Ld, s->d_params, s->d_grads, S.ws_df, S.d_bytes, B, DGG_TRAIN | DGG_ACCUM_GRADS,
+                             srcs_pose(cfg, bps, S.rfake, S.f_transl, S.f_joint), S.dl_fake, nullptr, 0, 0, nullptr, st, &share));
+    }
     // :174-197 gradient penalty and its parameter gradient
-    DGG_TRY(gradient_penalty(cfg, s, S, Q, B, bps, rot9, transl, joint, alphas, (float)penalty_gain, losses, st));
-    return wgan_combine_launch(losses, (float)penalty_gain, DGG_L_GRAD_PENALTY, st);
+    DGG_TRY(gradient_penalty(cfg, s, S, Q, B, bps, rot9, transl, joint, alphas, (float)penalty_gain, losses, st, &share));
+    return wgan_combine_launch(losses, (float)penalty_gain, DGG_L_GRAD_PENALTY, Q.gp_part, B, st);
 }
 
 int dgg_wgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, void* ws, size_t ws_bytes, int B,

@@ -311,8 +311,9 @@ int gp_interp_launch(const float* alphas, const float* r_rot, const float* r_tr,
                      hipStream_t st);
 int wass_launch(const float* p, int B, float sign, float* loss_out, float* d_logit, hipStream_t st);
 int sig_grad_launch(const float* p, int B, float* d_logit, hipStream_t st);
-int gp_value_launch(const float* g, int B, int nj, float gain, float* gp_out, float* v, hipStream_t st);
-int wgan_combine_launch(float* losses, float gain, int gp_slot, hipStream_t st);
+int gp_value_parts(int B);   // floats of gp_part
+int gp_value_launch(const float* g, int B, int nj, float gain, float* gp_part, float* v, hipStream_t st);
+int wgan_combine_launch(float* losses, float gain, int gp_slot, const float* gp_part, int B, hipStream_t st);
 int bn_jvp_launch(const float* a, int lda, const float* adot, int ldad, const float* mean, const float* rstd,
                   const float* gamma, const float* addend, int ldadd, const float* mask_ref, int ldm, int B, int N,
                   float* out, int ldo, float* xhd_out, int ldx, int a_is_xhat, hipStream_t st);

@@ -32,9 +32,9 @@ __device__ __forceinline__ size_t srow(int b0, int u, int B) {
 
 __device__ __forceinline__ float lrelu_d(float post) { return post > 0.f ? 1.f : kLrelu; }
 
-// sums over the 16 row-lanes of a column, NQ quantities at once; every thread of the column gets the totals
-template <int NQ>
-__device__ __forceinline__ void col_reduce(float (&q)[NQ], float (*sh)[SR][SC]) {
+// sums over the NR row-lanes of a column, NQ quantities at once; every thread of the column gets the totals
+template <int NQ, int NR = SR>
+__device__ __forceinline__ void col_reduce(float (&q)[NQ], float (*sh)[NR][SC]) {
     const int cl = threadIdx.x & (SC - 1), rl = threadIdx.x / SC;
     __syncthreads();
 #pragma unroll
@@ -44,9 +44,55 @@ __device__ __forceinline__ void col_reduce(float (&q)[NQ], float (*sh)[SR][SC]) 
     for (int i = 0; i < NQ; ++i) {
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < SR; ++r) t += sh[i][r][cl];
+        for (int r = 0; r < NR; ++r) t += sh[i][r][cl];
         q[i] = t;
     }
+}
+
+// "Resident" variants (round 4) of the two BatchNorm kernels below, for B <= SRF * 16 = 1024 rows: 1024 threads = 16
+// columns x 64 row-lanes, every thread keeps its RT = ceil(B / 64) rows of every operand in registers — ONE round of loads
+// (up to 80 in flight per thread) instead of one per 8-row batch and sweep (24 dependent round trips in the second-order
+// backward: 44 us at B = 1024, N = 512; 32 us in the tangent).  Same formulas; the row sums run over 64 lanes instead of 16.
+constexpr int SRF = 64;
+__device__ __forceinline__ unsigned frow(int rl, int u, int B, int nrl = SRF) {
+    const int b = rl + u * nrl;
+    return (unsigned)(b < B ? b : B - 1);
+}
+// Column totals for the resident variants (CW columns x 1024 / CW row-lanes): the 64 / CW row-lanes of a column inside a
+// wave meet through xor-shuffles (both partners form the same sum), the 16 waves through LDS in wave order — 16 LDS reads per
+// quantity and thread.
+template <int NQ, int CW>
+__device__ __forceinline__ void col_reduce_res(float (&q)[NQ], float (*sh)[16][SC], float (*tot)[SC]) {
+    const int cl = threadIdx.x & (CW - 1), wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+#pragma unroll
+        for (int d = CW; d < 64; d <<= 1) q[i] += __shfl_xor(q[i], d);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) < CW) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) sh[i][wv][cl] = q[i];
+    }
+    __syncthreads();
+    // NQ * CW threads add the 16 waves' sums of one (quantity, column) each — in wave order —, everybody reads the totals
+    // (each thread summing all NQ * 16 values itself kept ~100 registers busy with LDS reads in flight)
+    if ((int)threadIdx.x < NQ * CW) {
+        const int i = threadIdx.x / CW, c = threadIdx.x - i * CW;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += sh[i][w][c];
+        tot[i][c] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) q[i] = tot[i][cl];
+}
+
+// base[i] through a 32-bit byte offset from the uniform base (SGPR pair + one VGPR per load in flight: B <= 1024 rows of at
+// most a few thousand floats)
+__device__ __forceinline__ float ldf(const float* __restrict__ base, unsigned i) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + i * 4u);
 }
 
 // x_i = alpha * real + (1 - alpha) * fake for the 12 + nj pose columns; alphas (B,3) = [rot | transl | joint]
@@ -96,38 +142,56 @@ __global__ void sig_grad_kernel(const float* __restrict__ p, int B, float* __res
     if (b < B) d_logit[b] = p[b] * (1.f - p[b]);
 }
 
-// GP value and v = gain * dGP/dg from the input gradient g (B, 12 + nj): parts rot (9), transl (3), joint (nj)
+// GP value and v = gain * dGP/dg from the input gradient g (B, 12 + nj): parts rot (9), transl (3), joint (nj).
+// One thread per row, all of the row's values requested at once (single dwords: rows of 12 + nj floats have no 16-byte
+// alignment to offer); gp_part[workgroup] = the workgroup's sum of (|g_part| - 1)^2 — wgan_combine_kernel adds them up
+// in workgroup order.  (Round 3: one workgroup walked all rows, four per thread, value by value: 47 us at B = 1024.)
+constexpr int kGpMaxCols = 48;
 __global__ __launch_bounds__(256) void gp_value_kernel(const float* __restrict__ g, int B, int nj, float gain,
-                                                       float* __restrict__ gp_out, float* __restrict__ v) {
+                                                       float* __restrict__ gp_part, float* __restrict__ v) {
     __shared__ float sh[256];
     const int np = 12 + nj;
-    const int lo[3] = {0, 9, 12}, hi[3] = {9, 12, 12 + nj};
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const bool bok = b < B;
+    const float* gr = g + (size_t)(bok ? b : B - 1) * np;
+    float x[kGpMaxCols];
+#pragma unroll
+    for (int j = 0; j < kGpMaxCols; ++j) x[j] = gr[j < np ? j : np - 1];
     float pen = 0.f;
-    for (int b = threadIdx.x; b < B; b += 256) {
-        // (volatile: single-dword loads only — the 3-float translation part would become a global_load_dwordx3 among
-        //  dwordx4 loads, the pattern that returned late in bps_encode.hip, see load3() there)
-        const volatile float* gr = g + (size_t)b * np;
-        for (int part = 0; part < 3; ++part) {
-            float s = 0.f;
-            for (int j = lo[part]; j < hi[part]; ++j) s = fmaf(gr[j], gr[j], s);
-            const float n = sqrtf(s);
-            pen += (n - 1.f) * (n - 1.f);
-            // d/dg of mean_parts mean_b (n - 1)^2 = 2 (n - 1) g / n / (3 B)
-            const float k = n > 0.f ? gain * 2.f * (n - 1.f) / (n * 3.f * (float)B) : 0.f;
-            for (int j = lo[part]; j < hi[part]; ++j) v[(size_t)b * np + j] = k * gr[j];
-        }
+    float k[3];
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+        const int lo = part == 0 ? 0 : part == 1 ? 9 : 12, hi = part == 0 ? 9 : part == 1 ? 12 : np;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < kGpMaxCols; ++j)
+            if (j >= lo && j < hi) s = fmaf(x[j], x[j], s);
+        const float n = sqrtf(s);
+        pen += (n - 1.f) * (n - 1.f);
+        // d/dg of mean_parts mean_b (n - 1)^2 = 2 (n - 1) g / n / (3 B)
+        k[part] = n > 0.f ? gain * 2.f * (n - 1.f) / (n * 3.f * (float)B) : 0.f;
     }
-    sh[threadIdx.x] = pen;
+    if (bok) {
+#pragma unroll
+        for (int j = 0; j < kGpMaxCols; ++j)
+            if (j < np) v[(size_t)b * np + j] = (j < 9 ? k[0] : j < 12 ? k[1] : k[2]) * x[j];
+    }
+    sh[threadIdx.x] = bok ? pen : 0.f;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) gp_out[0] = sh[0] / (3.f * (float)B);
+    if (threadIdx.x == 0) gp_part[blockIdx.x] = sh[0];
 }
 
-__global__ void wgan_combine_kernel(float* losses, float gain, int gp_slot) {
-    losses[DGG_L_TOTAL_DISC] = -losses[DGG_L_BCE_REAL] + losses[DGG_L_BCE_FAKE] + gain * losses[gp_slot];
+__global__ void wgan_combine_kernel(float* losses, float gain, int gp_slot, const float* __restrict__ gp_part, int npart,
+                                    int B) {
+    float s = 0.f;
+    for (int i = 0; i < npart; ++i) s += gp_part[i];
+    const float gp = s / (3.f * (float)B);
+    losses[gp_slot] = gp;
+    losses[DGG_L_TOTAL_DISC] = -losses[DGG_L_BCE_REAL] + losses[DGG_L_BCE_FAKE] + gain * gp;
 }
 
 // Tangent of a train-mode BatchNorm1d (+ optional addend, + optional LeakyReLU mask):
@@ -389,6 +453,152 @@ __global__ __launch_bounds__(256) void bn_second_bwd_kernel(
     }
 }
 
+// ---- resident variants (see frow): B <= 64 * RT rows
+template <int RT>
+__global__ __launch_bounds__(1024) void bn_jvp_res_kernel(const float* __restrict__ a, int lda, const float* __restrict__ adot,
+                                                          int ldad, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ addend, int ldadd,
+                                                          const float* __restrict__ mask_ref, int ldm, int B, int N,
+                                                          float* __restrict__ out, int ldo, float* __restrict__ xhd_out,
+                                                          int ldx, int a_is_xhat) {
+    __shared__ float sh[2][16][SC];
+    __shared__ float tot[2][SC];
+    const int cl = threadIdx.x & (SC - 1), rl = threadIdx.x / SC;
+    const int c0 = blockIdx.x * SC + cl;
+    const bool ok = c0 < N;
+    const int c = ok ? c0 : N - 1;
+    const float mu = a_is_xhat ? 0.f : mean[c], rs = rstd[c];
+    const float ga = gamma ? gamma[c] : 1.f;
+    float xh[RT], dv[RT], ev[RT], mv[RT];
+#pragma unroll
+    for (int u = 0; u < RT; ++u) {
+        xh[u] = ldf(a, frow(rl, u, B) * (unsigned)lda + (unsigned)c);
+        dv[u] = ldf(adot, frow(rl, u, B) * (unsigned)ldad + (unsigned)c);
+        ev[u] = 0.f;
+        mv[u] = 1.f;
+    }
+    if (addend) {
+#pragma unroll
+        for (int u = 0; u < RT; ++u) ev[u] = ldf(addend, frow(rl, u, B) * (unsigned)ldadd + (unsigned)c);
+    }
+    if (mask_ref) {
+#pragma unroll
+        for (int u = 0; u < RT; ++u) mv[u] = lrelu_d(ldf(mask_ref, frow(rl, u, B) * (unsigned)ldm + (unsigned)c));
+    }
+    float q[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < RT; ++u) {
+        if (!a_is_xhat) xh[u] = (xh[u] - mu) * rs;
+        if (rl + u * SRF < B) {
+            q[0] += dv[u];
+            q[1] = fmaf(xh[u], dv[u], q[1]);
+        }
+    }
+    col_reduce_res<2, SC>(q, sh, tot);
+    const float mad = q[0] / (float)B, m = q[1] / (float)B;
+    if (!ok) return;
+#pragma unroll
+    for (int u = 0; u < RT; ++u) {
+        const int b = rl + u * SRF;
+        if (b < B) {
+            const float xhd = rs * (dv[u] - mad - xh[u] * m);
+            if (xhd_out) xhd_out[(size_t)b * ldx + c] = xhd;
+            out[(size_t)b * ldo + c] = (ga * xhd + ev[u]) * mv[u];
+        }
+    }
+}
+
+template <int RT, int CW>
+__global__ __launch_bounds__(1024) void bn_second_bwd_res_kernel(
+    const float* __restrict__ a, int lda, const float* __restrict__ adot, int ldad, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ zbar,
+    const float* __restrict__ zdbar, int ldz, const float* __restrict__ mask_ref, int ldm, int B, int N,
+    float* __restrict__ abar, float* __restrict__ adbar, int ldo, float* __restrict__ g_gamma, float* __restrict__ g_beta) {
+    __shared__ float sh[6][16][SC];
+    __shared__ float tot[6][SC];
+    constexpr int NRL = 1024 / CW;   // row-lanes
+    const int cl = threadIdx.x & (CW - 1), rl = threadIdx.x / CW;
+    const int c0 = blockIdx.x * CW + cl;
+    const bool ok = c0 < N;
+    const int c = ok ? c0 : N - 1;
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c];
+    const float invB = 1.f / (float)B;
+    float xh[RT], ad[RT], zb[RT], zdb[RT];
+    {
+        float mv[RT];
+#pragma unroll
+        for (int u = 0; u < RT; ++u) {
+            xh[u] = ldf(a, frow(rl, u, B, NRL) * (unsigned)lda + (unsigned)c);
+            ad[u] = ldf(adot, frow(rl, u, B, NRL) * (unsigned)ldad + (unsigned)c);
+            zb[u] = ldf(zbar, frow(rl, u, B, NRL) * (unsigned)ldz + (unsigned)c);
+            zdb[u] = ldf(zdbar, frow(rl, u, B, NRL) * (unsigned)ldz + (unsigned)c);
+            mv[u] = 1.f;
+        }
+        if (mask_ref) {
+#pragma unroll
+            for (int u = 0; u < RT; ++u) mv[u] = lrelu_d(ldf(mask_ref, frow(rl, u, B, NRL) * (unsigned)ldm + (unsigned)c));
+        }
+#pragma unroll
+        for (int u = 0; u < RT; ++u) {
+            xh[u] = (xh[u] - mu) * rs;
+            zb[u] *= mv[u];
+            zdb[u] *= mv[u];
+        }
+    }
+    // sweep 1
+    float q[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // sum adot, sum xh adot, sum w, sum w xh, sum zbar, sum zbar xh
+#pragma unroll
+    for (int u = 0; u < RT; ++u) {
+        if (rl + u * NRL < B) {
+            const float w = ga * zdb[u];
+            q[0] += ad[u];
+            q[1] = fmaf(xh[u], ad[u], q[1]);
+            q[2] += w;
+            q[3] = fmaf(w, xh[u], q[3]);
+            q[4] += zb[u];
+            q[5] = fmaf(zb[u], xh[u], q[5]);
+        }
+    }
+    col_reduce_res<6, CW>(q, sh, tot);
+    const float mad = q[0] * invB, m = q[1] * invB, mw = q[2] * invB, mwx = q[3] * invB;
+    const float s_zb = q[4], s_zbx = q[5];
+    // sweep 2
+    float r2[4] = {0.f, 0.f, 0.f, 0.f};  // sum w xhd, sum X, sum X xh, sum zdbar xhd
+#pragma unroll
+    for (int u = 0; u < RT; ++u) {
+        if (rl + u * NRL < B) {
+            const float adc = ad[u] - mad;
+            const float w = ga * zdb[u];
+            const float xhd = rs * (adc - xh[u] * m);
+            const float X = ga * zb[u] - rs * (w * m + adc * mwx);
+            r2[0] = fmaf(w, xhd, r2[0]);
+            r2[1] += X;
+            r2[2] = fmaf(X, xh[u], r2[2]);
+            r2[3] = fmaf(zdb[u], xhd, r2[3]);
+        }
+    }
+    col_reduce_res<4, CW>(r2, reinterpret_cast<float(*)[16][SC]>(sh), tot);
+    const float s_wxd = r2[0], mX = r2[1] * invB, mXx = r2[2] * invB;
+    if (!ok) return;
+    // sweep 3
+#pragma unroll
+    for (int u = 0; u < RT; ++u) {
+        const int b = rl + u * NRL;
+        if (b < B) {
+            const float adc = ad[u] - mad;
+            const float w = ga * zdb[u];
+            const float X = ga * zb[u] - rs * (w * m + adc * mwx);
+            abar[(size_t)b * ldo + c] = rs * (X - mX - xh[u] * mXx) - rs * xh[u] * (s_wxd * invB);
+            adbar[(size_t)b * ldo + c] = rs * (w - mw - xh[u] * mwx);
+        }
+    }
+    if (rl == 0) {
+        g_gamma[c] += s_zbx + r2[3];
+        g_beta[c] += s_zb;
+    }
+}
+
 // dst[c] (+)= sum_b x[b][c] * (y ? y[b][c] : 1).   grid: ceil(N / 16)
 __global__ __launch_bounds__(256) void colsum_prod_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ y,
                                                           int ldy, int B, int N, float* __restrict__ dst, int accumulate) {
@@ -430,19 +640,30 @@ int sig_grad_launch(const float* p, int B, float* d_logit, hipStream_t st) {
     hipLaunchKernelGGL(sig_grad_kernel, dim3(cdiv2(B, 256)), dim3(256), 0, st, p, B, d_logit);
     return check_launch("sig_grad");
 }
-int gp_value_launch(const float* g, int B, int nj, float gain, float* gp_out, float* v, hipStream_t st) {
-    hipLaunchKernelGGL(gp_value_kernel, dim3(1), dim3(256), 0, st, g, B, nj, gain, gp_out, v);
+int gp_value_parts(int B) { return cdiv2(B, 256); }
+int gp_value_launch(const float* g, int B, int nj, float gain, float* gp_part, float* v, hipStream_t st) {
+    if (12 + nj > kGpMaxCols) return DGG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gp_value_kernel, dim3(gp_value_parts(B)), dim3(256), 0, st, g, B, nj, gain, gp_part, v);
     return check_launch("gp_value");
 }
-int wgan_combine_launch(float* losses, float gain, int gp_slot, hipStream_t st) {
-    hipLaunchKernelGGL(wgan_combine_kernel, dim3(1), dim3(1), 0, st, losses, gain, gp_slot);
+int wgan_combine_launch(float* losses, float gain, int gp_slot, const float* gp_part, int B, hipStream_t st) {
+    hipLaunchKernelGGL(wgan_combine_kernel, dim3(1), dim3(1), 0, st, losses, gain, gp_slot, gp_part, gp_value_parts(B), B);
     return check_launch("wgan_combine");
 }
 int bn_jvp_launch(const float* a, int lda, const float* adot, int ldad, const float* mean, const float* rstd,
                   const float* gamma, const float* addend, int ldadd, const float* mask_ref, int ldm, int B, int N,
                   float* out, int ldo, float* xhd_out, int ldx, int a_is_xhat, hipStream_t st) {
-    hipLaunchKernelGGL(bn_jvp_kernel, dim3(cdiv2(N, SC)), dim3(256), 0, st, a, lda, adot, ldad, mean, rstd, gamma, addend,
-                       ldadd, mask_ref, ldm, B, N, out, ldo, xhd_out, ldx, a_is_xhat);
+    const dim3 grid(cdiv2(N, SC));
+#define DGG_JVP_RES(RT)                                                                                                    \
+    hipLaunchKernelGGL((bn_jvp_res_kernel<RT>), grid, dim3(1024), 0, st, a, lda, adot, ldad, mean, rstd, gamma, addend, ldadd, \
+                       mask_ref, ldm, B, N, out, ldo, xhd_out, ldx, a_is_xhat)
+    if (B <= 4 * SRF) DGG_JVP_RES(4);
+    else if (B <= 8 * SRF) DGG_JVP_RES(8);
+    else if (B <= 16 * SRF) DGG_JVP_RES(16);
+    else
+        hipLaunchKernelGGL(bn_jvp_kernel, grid, dim3(256), 0, st, a, lda, adot, ldad, mean, rstd, gamma, addend, ldadd,
+                           mask_ref, ldm, B, N, out, ldo, xhd_out, ldx, a_is_xhat);
+#undef DGG_JVP_RES
     return check_launch("bn_jvp");
 }
 int mask_inplace_launch(float* x, int ldx, const float* ref, int ldr, int B, int N, hipStream_t st) {
@@ -469,8 +690,17 @@ int out2_bwd_launch(const float* ybar, const float* ydbar, int ldyb, const float
 int bn_second_bwd_launch(const float* a, int lda, const float* adot, int ldad, const float* mean, const float* rstd,
                          const float* gamma, const float* zbar, const float* zdbar, int ldz, const float* mask_ref, int ldm,
                          int B, int N, float* abar, float* adbar, int ldo, float* g_gamma, float* g_beta, hipStream_t st) {
-    hipLaunchKernelGGL(bn_second_bwd_kernel, dim3(cdiv2(N, SC)), dim3(256), 0, st, a, lda, adot, ldad, mean, rstd, gamma,
-                       zbar, zdbar, ldz, mask_ref, ldm, B, N, abar, adbar, ldo, g_gamma, g_beta);
+#define DGG_BN2_RES(RT, CW)                                                                                                \
+    hipLaunchKernelGGL((bn_second_bwd_res_kernel<RT, CW>), dim3(cdiv2(N, CW)), dim3(1024), 0, st, a, lda, adot, ldad, mean,  \
+                       rstd, gamma, zbar, zdbar, ldz, mask_ref, ldm, B, N, abar, adbar, ldo, g_gamma, g_beta)
+    // (8 rows of five operands per thread at most: 16 would not fit the 128 registers of a 1024-thread workgroup)
+    if (B <= 4 * 64) DGG_BN2_RES(4, 16);
+    else if (B <= 8 * 64) DGG_BN2_RES(8, 16);
+    else if (B <= 8 * 128) DGG_BN2_RES(8, 8);
+    else
+        hipLaunchKernelGGL(bn_second_bwd_kernel, dim3(cdiv2(N, SC)), dim3(256), 0, st, a, lda, adot, ldad, mean, rstd, gamma, zbar,
+                           zdbar, ldz, mask_ref, ldm, B, N, abar, adbar, ldo, g_gamma, g_beta);
+#undef DGG_BN2_RES
     return check_launch("bn_second_bwd");
 }
 int colsum_prod_launch(const float* x, int ldx, const float* y, int ldy, int B, int N, float* dst, int accumulate,
