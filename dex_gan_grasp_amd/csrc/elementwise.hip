@@ -1634,6 +1634,16 @@ __global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restric
         }
         smx[rl][j] = x;
     }
+    // the 64 columns' weights of the small inputs, staged the same way: 16 consecutive floats per column lie 64 bytes
+    // apart from the next column's — fetched per thread (lane = column) every one of the 16 loads touched 64 cache lines
+    // (1024 line requests per wave against 32 for the rows themselves: 112 us per launch of the config-5 sweep, now see
+    // profiles/r04_experiments.txt 21); staged, 16 lanes read one column's 64 bytes
+    __shared__ float wl[64][17];
+    for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
+        const int cc = idx >> 4, j = idx & 15;
+        const int col = blockIdx.x * 64 + cc;
+        wl[cc][j] = (j < ns && col < N) ? wsm[(size_t)col * ldw + j] : 0.f;
+    }
     __syncthreads();
     const int c = blockIdx.x * 64 + lane;
     if (c >= N) return;
@@ -1647,7 +1657,7 @@ __global__ __launch_bounds__(256) void expand_rows_kernel(const float* __restric
     }
     float w[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) w[j] = j < ns ? wsm[(size_t)c * ldw + j] : 0.f;
+    for (int j = 0; j < 16; ++j) w[j] = wl[lane][j];
     const bool act = c >= act_lo && c < act_hi;
     const int r0 = blockIdx.y * RB + sub * RS;
     const int n = min(RS, B - r0);
