@@ -468,8 +468,8 @@ __global__ __launch_bounds__(1024) void bn_jvp_res_kernel(const float* __restric
     const int c0 = blockIdx.x * SC + cl;
     const bool ok = c0 < N;
     const int c = ok ? c0 : N - 1;
-    const float mu = a_is_xhat ? 0.f : mean[c], rs = rstd[c];
-    const float ga = gamma ? gamma[c] : 1.f;
+    const float mu = a_is_xhat ? 0.f : ldf(mean, (unsigned)c), rs = ldf(rstd, (unsigned)c);
+    const float ga = gamma ? ldf(gamma, (unsigned)c) : 1.f;
     float xh[RT], dv[RT], ev[RT], mv[RT];
 #pragma unroll
     for (int u = 0; u < RT; ++u) {
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(1024) void bn_second_bwd_res_kernel(
     const int c0 = blockIdx.x * CW + cl;
     const bool ok = c0 < N;
     const int c = ok ? c0 : N - 1;
-    const float mu = mean[c], rs = rstd[c], ga = gamma[c];
+    const float mu = ldf(mean, (unsigned)c), rs = ldf(rstd, (unsigned)c), ga = ldf(gamma, (unsigned)c);
     const float invB = 1.f / (float)B;
     float xh[RT], ad[RT], zb[RT], zdb[RT];
     {
