@@ -423,7 +423,8 @@ int dgg_gemm_occupancy(int mode, int bm, int bn);
  * operand lies in a larger buffer (flat parameter buffers, workspaces); a caller-owned A / B whose last row ends exactly
  * at the end of its allocation with K % 4 != 0 (or, k-strided, a row count % 4 != 0) must be padded by 12 bytes — or run
  * with DGG_X4=1 / DGG_GEMM_ALGO=f32, whose k-tails are fetched element by element (launches of >= 1024 workgroups take
- * the DGG_X4 kernel by themselves). */
+ * the DGG_X4 kernel by themselves).  SIZE: the epilogues address C through 32-bit byte offsets — M * ldc * 4 must stay below
+ * 2 GiB (DGG_ERR_INVALID otherwise; the library's own products are 50 000 x 768 at most, callers chunk their rows). */
 int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C,
                  int ldc, int splits, float* slabs, int accumulate, void* stream);
 /* Diagnostic / test entry of the pre-split GEMM of the optional planes path (csrc/gemm_p4.hip): C[M,N] = sum_k A(m,k) B(n,k) with both fp32 operands first split into their three bf16 planes in `ws`

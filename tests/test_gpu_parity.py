@@ -134,6 +134,20 @@ def test_gemm_bf16x3_variants(mode, shape, align):
         lib.dgg_set_gemm_algo(default_algo)
 
 
+def test_gemm_refuses_an_output_beyond_32_bit_byte_offsets():
+    """include/dgg.h dgg_gemm_f32 SIZE: the epilogues address C through 32-bit byte offsets; M * ldc * 4 >= 2 GiB is
+    refused before anything is launched (the buffers behind the pointers are never touched)."""
+    ops, _lib = _ops()
+    lib = _lib.lib()
+    a = torch.zeros(64, device=DEV)
+    for mode in (0, 1, 2):
+        rc = lib.dgg_gemm_f32(mode, 1 << 20, 512, 32, _lib.ptr(a), 32, _lib.ptr(a), 32, _lib.ptr(a), 512, 0, None, 0,
+                              _lib.stream_ptr(torch.device(DEV)))
+        assert rc == -1, (mode, rc)   # DGG_ERR_INVALID
+    # one row less than the limit of this pitch is a size question only (not run: 2 GiB of output)
+    assert (1 << 20) * 512 * 4 == 1 << 31
+
+
 # ------------------------------------------------------------------ A1: BPS encode
 def _ulp(a, b):
     return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
