@@ -468,9 +468,12 @@ def sub_results(cfg, dev, eng):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--repeats", type=int, default=25, help="timed blocks of --steps steps; the median is reported")
+    # (defaults: blocks long enough that the pipeline's fill and drain at the two synchronisation points of a block — the first
+    #  step has no prefetched real pass to pick up, the last one's prefetch is wasted — stay under half a percent; with 20
+    #  steps per block they were ~2 %)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=11, help="timed blocks of --steps steps; the median is reported")
     ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch (BASELINE: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub", action="store_true")
