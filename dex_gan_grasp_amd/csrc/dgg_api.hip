@@ -1179,8 +1179,9 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
         const bool share_ok = share && share->bwd_mode && L.nprefix == 0 && share->ncols > 0 && share->ncols < L.k0;
         // part layout per block: [tiles][2][k0], blocks 12 * 2 * k0 apart; q0 -> d gamma, q1 -> d beta.  One launch sums
         // the blocks (groups) of a column range when they all used the same tile count — they do within one pass.
-        // fin(c_lo, ncols, tiles, noacc): BatchNorm columns [c_lo, c_lo + ncols); noacc: overwrite even when accumulating
-        auto fin = [&](int c_lo, int ncols, const int* tiles, bool noacc) -> int {
+        // fin(c_lo, ncols, tiles, noacc): BatchNorm columns [c_lo, c_lo + ncols); the first `noacc` of them are overwritten
+        // even when accumulating
+        auto fin = [&](int c_lo, int ncols, const int* tiles, int noacc) -> int {
             if (ncols <= 0) return DGG_OK;
             bool same = true;
             for (int r = 1; r < L.nrb; ++r) same = same && tiles[r] == tiles[0];
@@ -1189,23 +1190,22 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
                 return colsum_finalize_launch(c.W.ibn_part, L.nrb, tiles[0], 2, ncols, nullptr, grads + L.ibnw + c_lo,
                                               grads + L.ibnb + c_lo, nullptr, accum ? 1 : 0, st, L.k0, L.nprefix + c_lo,
                                               nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr,
-                                              noacc ? ncols : 0, (long long)12 * 2 * L.k0);
+                                              noacc, (long long)12 * 2 * L.k0);
             }
             for (int r = 0; r < L.nrb; ++r) {
                 if (tiles[r] <= 0) return DGG_ERR_INVALID;
                 DGG_TRY(colsum_finalize_launch(c.W.ibn_part + (size_t)r * 12 * 2 * L.k0, 1, tiles[r], 2, ncols, nullptr,
                                                grads + L.ibnw + c_lo, grads + L.ibnb + c_lo, nullptr,
                                                (accum || r > 0) ? 1 : 0, st, L.k0, L.nprefix + c_lo, nullptr, nullptr,
-                                               nullptr, 0, nullptr, 0, nullptr, nullptr, (r == 0 && noacc) ? ncols : 0));
+                                               nullptr, 0, nullptr, 0, nullptr, nullptr, r == 0 ? noacc : 0));
             }
             return DGG_OK;
         };
         const int c_first = (share_ok && share->bwd_mode == 1) ? share->ncols : 0;
-        if (share_ok && share->bwd_mode == 2) {
-            DGG_TRY(fin(0, share->ncols, ibn_tiles, true));
-            DGG_TRY(fin(share->ncols, L.k_in - share->ncols, ibn_tiles, false));
+        if (share_ok && share->bwd_mode == 2) {   // one launch: the BPS columns overwritten, the pose columns accumulated
+            DGG_TRY(fin(0, L.k_in, ibn_tiles, share->ncols));
         } else {
-            DGG_TRY(fin(c_first, L.k_in - c_first, ibn_tiles, false));
+            DGG_TRY(fin(c_first, L.k_in - c_first, ibn_tiles, 0));
         }
     }
     // everything else — block 0 and the input BatchNorm — is complete here
