@@ -568,6 +568,8 @@ def test_bf16_mode_evaluator_step_tolerance_vs_fp32(variant):
     masks = synth.make_dropout_masks(b, 4).to(DEV)
     f = lambda t: t.float().to(DEV).contiguous()
     ins = (f(batch["bps_object"]), f(batch["rot_matrix"]).reshape(b, 9), f(batch["transl"]), f(batch["label"]))
+    if os.environ.get("DGG_GEMM_ALGO"):
+        pytest.skip("DGG_GEMM_ALGO overrides the default GEMM arithmetic this test compares with")
     assert lib.dgg_get_gemm_algo() == 1
     res = {}
     try:
