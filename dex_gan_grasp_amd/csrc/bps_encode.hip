@@ -542,16 +542,13 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
         // with another workgroup busy on the CU, a handful of the 4.2 M distances from operands that were not the ones
         // loaded for them; changing only that load or only this wait cures it (profiles/r03_experiments.txt 7: the
         // elimination, and a probe that does NOT reproduce it in isolation; ROCm 7.2, gfx950).
-        // -DBPS_R3_HAZARD (tools/exp/bps_hazard.sh; never shipped): the failing form of round 3 — the basis point as a
-        // 12-byte global load per lane among the thirteen loads of an evaluation, waited for by the compiler's counted
-        // vmcnt only — kept so that the regression test (tests/test_gpu_parity.py::
-        // test_bps_matrix_path_every_output_under_load_repeated) can be shown to catch it.
-#if !defined(BPS_R3_HAZARD)
+        // (Round 4 rebuilt the failing load form behind a macro to show that the regression test — tests/test_gpu_parity.py::
+        // test_bps_matrix_path_every_output_under_load_repeated — catches it: that build did not fail, profiles/
+        // r04_experiments.txt 4; the variant is gone from the source since round 5.)
         asm volatile("s_waitcnt vmcnt(0)"
                      : "+v"(pt[0][0]), "+v"(pt[0][1]), "+v"(pt[0][2]), "+v"(pt[1][0]), "+v"(pt[1][1]), "+v"(pt[1][2]),
                        "+v"(pt[2][0]), "+v"(pt[2][1]), "+v"(pt[2][2]), "+v"(pt[3][0]), "+v"(pt[3][1]), "+v"(pt[3][2]),
                        "+v"(X), "+v"(Y), "+v"(Z));
-#endif
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int j0 = i * 32 + 8 * g + 4 * hh;
@@ -629,16 +626,12 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
     __builtin_amdgcn_wave_barrier();
     {
         const int n = min(s_qn[w], kBpsQueue);
-        const int first = (slice * NW + w) * (NT * 32);
         int base = 0;
         for (; n - base > 16; base += 64) {
             if (base + lane < n) {
                 const unsigned it = q[base + lane];
                 const int bl = it >> 8;
                 const float* bq = sb + 3 * (w * (NT * 32) + bl);
-#if defined(BPS_R3_HAZARD)   // diagnostic build only (see block()): the round-3 form of this load
-                bq = basis + 3 * (size_t)min(first + bl, P - 1);
-#endif
                 float X = bq[0], Y = bq[1], Z = bq[2], bb = __builtin_inff();
                 int bj = 0;
                 block(it & 127u, (it >> 7) & 1u, X, Y, Z, bb, bj);
@@ -651,17 +644,12 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
             const unsigned it = q[base + (lane >> 2)];
             const int bl = it >> 8;
             const float* bq = sb + 3 * (w * (NT * 32) + bl);
-#if defined(BPS_R3_HAZARD)
-            bq = basis + 3 * (size_t)min(first + bl, P - 1);
-#endif
             float X = bq[0], Y = bq[1], Z = bq[2], bb = __builtin_inff();
             int bj = 0;
             const int j0 = (int)(it & 127u) * 32 + 8 * (lane & 3) + 4 * (int)((it >> 7) & 1u);
             bf32x4 p0, p1, p2;
             quad(j0, p0, p1, p2);
-#if !defined(BPS_R3_HAZARD)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(X), "+v"(Y), "+v"(Z));
-#endif
             const float d0 = dist2(p0[0], p0[1], p0[2], X, Y, Z), d1 = dist2(p0[3], p1[0], p1[1], X, Y, Z);
             const float d2 = dist2(p1[2], p1[3], p2[0], X, Y, Z), d3 = dist2(p2[1], p2[2], p2[3], X, Y, Z);
             bool lt = d0 < bb;

@@ -11,6 +11,7 @@ $HIPCC $COMMON $X3FLAGS -c gemm_x3.hip -o _obj/gemm_x3.o &
 $HIPCC $COMMON -c gemm_p3.hip -o _obj/gemm_p3.o &
 $HIPCC $COMMON -c gemm_p4.hip -o _obj/gemm_p4.o &
 $HIPCC $COMMON $X3FLAGS -c gemm_x4.hip -o _obj/gemm_x4.o &
+$HIPCC $COMMON $X3FLAGS -c gemm_x5.hip -o _obj/gemm_x5.o &
 $HIPCC $COMMON -c elementwise.hip -o _obj/elementwise.o &
 $HIPCC $COMMON -c second_order.hip -o _obj/second_order.o &
 # fixed contraction: only the explicit fmaf() calls of the distance formula fuse (parity contract)
@@ -18,5 +19,5 @@ $HIPCC $COMMON -c second_order.hip -o _obj/second_order.o &
 $HIPCC $COMMON -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -c bps_encode.hip -o _obj/bps_encode.o &
 $HIPCC $COMMON -c dgg_api.hip -o _obj/dgg_api.o &
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libdgg.so _obj/gemm_f32.o _obj/gemm_x3.o _obj/gemm_p3.o _obj/gemm_p4.o _obj/gemm_x4.o _obj/elementwise.o _obj/second_order.o _obj/bps_encode.o _obj/dgg_api.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libdgg.so _obj/gemm_f32.o _obj/gemm_x3.o _obj/gemm_p3.o _obj/gemm_p4.o _obj/gemm_x4.o _obj/gemm_x5.o _obj/elementwise.o _obj/second_order.o _obj/bps_encode.o _obj/dgg_api.o
 echo "built $(cd .. && pwd)/libdgg.so"

@@ -9,12 +9,21 @@
 #include <math.h>
 #include "dgg_internal.h"
 
+#include <stdarg.h>
+
 namespace dgg {
 
 static thread_local char g_err[512] = "";
 
 void set_error(const char* what, hipError_t e) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+}
+
+void set_error_text(const char* fmt, ...) {   // a reason for a DGG_ERR_INVALID that the caller could not guess
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
 }
 
 int check_launch(const char* what) {

@@ -14,6 +14,7 @@ constexpr float kDropP = 0.3f;   // networks.py:294
 constexpr int kRowBlock = 32;    // rows per partial-statistics block
 
 void set_error(const char* what, hipError_t e);
+void set_error_text(const char* fmt, ...);   // dgg_last_error() text for an error without a HIP status
 int check_launch(const char* what);
 
 // ---------------------------------------------------------------- GEMM (gemm_f32.hip)
@@ -91,6 +92,10 @@ void gemm_x3_dispatch(int mode, const GemmBatch& batch, hipStream_t st);  // gem
 // gemm_x4.hip: the same products with the split done by loader waves (opt-in: DGG_X4=1)
 void gemm_x4_dispatch(int mode, const GemmBatch& batch, hipStream_t st);
 bool gemm_x4_enabled(long total_blocks);
+// gemm_x5.hip: the same products with ONE wave per 128 x 128 accumulator block (the workgroup's waves split K); default
+// for every launch it can take (DGG_X5=0 switches it off)
+void gemm_x5_dispatch(int mode, const GemmBatch& batch, hipStream_t st);
+bool gemm_x5_usable(const GemmBatch& batch);
 // gemm_p4.hip / gemm_p3_block.h: C = A B^T on pre-split bf16 planes (forward, and the wgrad over transposed planes).
 // A weight-gradient (TN) launch of gemm_launch may carry ONE such problem beside its fp32 problems (a_plane != 0: "NT
 // over transposed planes", gemm_p3_block.h inside gemm_x3_kernel): the BPS block's weight gradient and its riders —

@@ -185,6 +185,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProb& P, f32x16 (&acc)[B
         }
         return;
     }
+    if (m0 + BM <= M && n0 + BN <= N) {   // a tile inside the matrix (workgroup-uniform): 64 stores, no exec masks, no branches
+#pragma unroll
+        for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < TN; ++tb) {
+                const int col = n0 + wn0 + tb * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *c_at(m0 + wm0 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, col) = acc[ta][tb][r];
+            }
+        return;
+    }
 #pragma unroll
     for (int ta = 0; ta < TM; ++ta)
 #pragma unroll

@@ -530,8 +530,12 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
         GemmProb& p = batch.p[i];
         if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.A || !p.B || !p.C) return DGG_ERR_INVALID;
         // the epilogue addresses C (one slab of it) and ep_w through 32-bit byte offsets (gemm_epilogue.h)
-        if ((long long)p.M * p.ldc * 4 >= (1ll << 31) || (p.ep_gamma && (long long)p.M * p.ep_ldw * 4 >= (1ll << 31)))
+        if ((long long)p.M * p.ldc * 4 >= (1ll << 31) || (p.ep_gamma && (long long)p.M * p.ep_ldw * 4 >= (1ll << 31))) {
+            set_error_text("GEMM output of %d rows x pitch %d floats: the epilogues address C through 32-bit byte offsets, "
+                           "rows * pitch * 4 must stay below 2 GiB (chunk the batch: at most %lld rows at this pitch)",
+                           p.M, p.ldc, ((1ll << 31) - 1) / (4ll * (p.ldc > 0 ? p.ldc : 1)));
             return DGG_ERR_INVALID;
+        }
         p.tiles_m = (p.M + bm - 1) / bm;
         p.tiles_n = (p.N + bn - 1) / bn;
         p.blk_begin = blocks;
@@ -554,6 +558,10 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
         if (!planes && quads_ok && gemm_algo() != 3 && gemm_x4_enabled(batch.total_blocks)) {
             gemm_x4_dispatch(mode, batch, st);
             return check_launch("gemm_x4");
+        }
+        if (!planes && gemm_algo() == 1 && gemm_x5_usable(batch)) {
+            gemm_x5_dispatch(mode, batch, st);
+            return check_launch("gemm_x5");
         }
         gemm_x3_dispatch(mode, batch, st);
         return check_launch("gemm_x3");

@@ -234,8 +234,12 @@ int gemm_p4_launch(GemmBatch& batch, bool wgrad, hipStream_t st) {
         if ((p.K & 31) || (p.lda & 7) || (p.ldb & 7) || (p.a_plane & 7) || (p.b_plane & 7) || p.lda < p.K || p.ldb < p.K ||
             (((uintptr_t)p.A | (uintptr_t)p.B) & 15) || (p.splits > 0 && (p.kchunk & 31)))
             return DGG_ERR_INVALID;
-        if ((long long)p.M * p.ldc * 4 >= (1ll << 31) || (p.ep_gamma && (long long)p.M * p.ep_ldw * 4 >= (1ll << 31)))
-            return DGG_ERR_INVALID;   // 32-bit byte offsets in the epilogue (gemm_epilogue.h)
+        if ((long long)p.M * p.ldc * 4 >= (1ll << 31) || (p.ep_gamma && (long long)p.M * p.ep_ldw * 4 >= (1ll << 31))) {
+            set_error_text("GEMM output of %d rows x pitch %d floats: the epilogues address C through 32-bit byte offsets, "
+                           "rows * pitch * 4 must stay below 2 GiB (chunk the batch: at most %lld rows at this pitch)",
+                           p.M, p.ldc, ((1ll << 31) - 1) / (4ll * (p.ldc > 0 ? p.ldc : 1)));
+            return DGG_ERR_INVALID;
+        }   // 32-bit byte offsets in the epilogue (gemm_epilogue.h)
         p.tiles_m = (p.M + QT - 1) / QT;
         p.tiles_n = (p.N + QT - 1) / QT;
         p.blk_begin = blocks;

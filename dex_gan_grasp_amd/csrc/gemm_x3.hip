@@ -269,16 +269,8 @@ __device__ __forceinline__ void gemm_x3_block(const GemmBatch& batch, const int 
         local = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
     }
     const int ntile = P.tiles_m * P.tiles_n;
-    int split = local / ntile;
-    int tile = local - split * ntile;
-#ifdef DGG_X3_TILEMAJOR   // experiment 24: all splits of an output tile on ONE XCD (what a reduce inside the launch would need)
-    if (P.splits > 1 && ntile % 8 == 0) {
-        const int l0 = bid - P.blk_begin;
-        const int xcd = l0 & 7, pos = l0 >> 3;
-        tile = xcd * (ntile / 8) + pos / P.splits;
-        split = pos % P.splits;
-    }
-#endif
+    const int split = local / ntile;
+    const int tile = local - split * ntile;
     const int tn_i = tile / P.tiles_m;
     const int tm_i = tile - tn_i * P.tiles_m;
     const int m0 = tm_i * XT, n0 = tn_i * XT;

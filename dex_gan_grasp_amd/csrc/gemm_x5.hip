@@ -1,0 +1,578 @@
+// bf16x3 GEMM, round 5: ONE wave owns the whole 128 x 128 accumulator block.
+//
+// Same arithmetic as gemm_x3.hip (fp32 operands split exactly into three bf16 pieces, six partial products per
+// product on v_mfma_f32_32x32x16_bf16, fp32 accumulate), same problem descriptors, work assignment and epilogues.  What
+// changes is who computes what.  gemm_x3_kernel gives each of its four waves a 64 x 64 quarter of the output tile: per
+// 16-deep k-step a wave splits 4 fragments for 24 MFMAs — 7.3 vector instructions per MFMA, where an MFMA's 32 cycles
+// hide about five (MI355X_MICROARCH.md, cycle constants) — and every element is split by two waves; measured 57
+// cycles per MFMA.  Here the four waves of a workgroup split the K range instead: wave w takes the k-steps w, w + 4,
+// w + 8, ... of the tile and accumulates the FULL 128 x 128 block (16 MFMA tiles, 256 accumulator registers) over them:
+// 8 fragments per 96 MFMAs = 3.7 vector instructions per MFMA, every element split once, every staged byte read from
+// LDS once.  The four partial blocks meet in LDS at the end (fixed order w0 + w1 + w2 + w3: deterministic), each wave
+// keeps one 64 x 64 quadrant and runs the shared epilogue on it (gemm_epilogue.h, unchanged).
+// tools/exp/x5_probe.hip is the timing probe of the two instruction mixes (42 against 66 cycles per MFMA).
+//
+// No wave shares staged data with another, so nothing in the k loop needs a workgroup barrier: each wave has a
+// PRIVATE two-stage LDS ring (2 x 16 KB + the affine vectors), fills it by LDS-DMA (global_load_lds_dwordx4, 17 pieces
+// per k-step) and waits for it with its own vmcnt.
+//
+// Software pipeline of one wave (local k-steps i = 0, 1, ...; stage = i & 1).  The planes of k-step i feed 96 MFMAs; the
+// 8 fragment splits issued between them produce what the NEXT MFMAs need.  Two planes sets would not fit beside 256
+// accumulators, so consecutive k-steps alternate the loop order of the 4 x 4 MFMA tiles:
+//   even steps ("AO"): A block outermost — the B planes persist, the A planes rotate: A[a] is dead after its 24 MFMAs;
+//   odd steps  ("BO"): B block outermost — the A planes persist, the B planes rotate.
+// An AO step splits, in windows of 12 MFMAs: its own A[1], A[2], A[3] (each ready before its group of MFMAs starts),
+// then the next step's four A fragments (persistent there) and B[0]; a BO step mirrors that.  At most 10 fragments'
+// planes (120 registers) are live.  Raw fp32 fragments travel LDS -> registers one window ahead (two 8-register
+// buffers); the stage a step reads for itself is free after its third window, and the DMA of k-step i + 2 goes there
+// during MFMAs 24 .. 88 of step i.
+//
+// K tail: a partial last k-step is moved BACK to end exactly at the split's last k (k0 = kend - 16) and the A elements
+// the previous step already covered are zeroed while they are staged — every DMA address lies inside the operand's k
+// range, no clamped variants of the loop.
+#include <stdint.h>
+#include <type_traits>
+#include <utility>
+#include "dgg_internal.h"
+#include "gemm_epilogue.h"
+
+#ifndef DGG_X5_STAMP
+#define DGG_X5_STAMP 0  // diagnostics only: per-wave s_memtime / s_memrealtime stamps (never in the shipped build)
+#endif
+
+namespace dgg {
+
+#if DGG_X5_STAMP
+__device__ unsigned long long g_x5_stamp[2048][4][8];
+#endif
+
+namespace x5 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+
+constexpr int YT = 128;                 // tile rows / columns
+constexpr int YK = 16;                  // k-step
+constexpr int YOP = YT * YK * 4;        // bytes of one operand's k-step (8 KB)
+constexpr int YAFF = 2 * YOP;           // affine vectors inside a stage: [scale 16 | shift 16 | unused]
+constexpr int YSTAGE = 2 * YOP + 256;
+constexpr int YWAVE = 2 * YSTAGE;       // a wave's private ring
+constexpr int YSMEM = 4 * YWAVE;        // 133120 B; the reduction at the end reuses it (128 KB + 2 KB of epilogue scratch)
+constexpr int YNP = YOP / 1024;         // DMA pieces per operand and k-step (8)
+constexpr int YMINK = 64;               // shorter problems stay on gemm_x3_kernel
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {   // f(integral_constant<int, 0>) ... : unrolled by construction
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (RNE): low half = a
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+struct Frag {
+    bf16x8 p[3];  // hi, mid, lo
+};
+
+__device__ float g_aff_identity[2][YK] = {{1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}, {0}};
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Which fragment a window of 12 MFMAs splits.  op: 0 = A, 1 = B; par: parity of the k-step the planes belong to (= the
+// stage its raw values lie in); blk: 32-row block.
+struct FD {
+    int op, par, blk;
+};
+// TY: 0 = AO step (parity 0), 1 = BO step (parity 1).  Windows 0..7, and 8 = window 0 of the step that follows.
+__host__ __device__ constexpr FD frag_of(int TY, int n) {
+    const int own = TY;        // rotating operand of this step: A in AO, B in BO
+    const int cur = TY, nxt = TY ^ 1;
+    if (n < 3) return FD{own, cur, n + 1};
+    if (n < 7) return FD{own, nxt, n - 3};    // persistent operand of the next step
+    if (n == 7) return FD{own ^ 1, nxt, 0};   // first block of the next step's rotating operand
+    return FD{own ^ 1, nxt, 1};               // n == 8: the next step's window 0
+}
+
+__host__ __device__ constexpr int fcode(FD f) { return f.op * 16 + f.par * 8 + f.blk; }   // C++17: no class-type template arguments
+__host__ __device__ constexpr FD fdec(int c) { return FD{c >> 4, (c >> 3) & 1, c & 7}; }
+template <int C>
+using FC = std::integral_constant<int, C>;
+
+template <bool A_KC, bool B_KC, bool AFF>
+__device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int bid, char* smem) {
+    // ---- work assignment: identical to gemm_x3_kernel (problem select, XCD-contiguous remap, split-K range)
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < kMaxProb; ++q)
+        if (q < batch.nprob && bid >= batch.p[q].blk_begin) pi = q;
+    const GemmProb& P = batch.p[pi];   // left in the kernel-argument segment: the epilogue's fields are fetched when it runs
+    int local = bid - P.blk_begin;
+    {
+        const int nb = P.tiles_m * P.tiles_n * (P.splits > 0 ? P.splits : 1);
+        const int q = nb >> 3, r = nb & 7;
+        const int xcd = local & 7, pos = local >> 3;
+        local = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    }
+    const int ntile = P.tiles_m * P.tiles_n;
+    const int split = local / ntile;
+    const int tile = local - split * ntile;
+    const int tn_i = tile / P.tiles_m;
+    const int tm_i = tile - tn_i * P.tiles_m;
+    const int m0 = tm_i * YT, n0 = tn_i * YT;
+    const int M = P.M, N = P.N;
+    int kbeg = 0, kend = P.K;
+    if (P.splits > 0) {
+        kbeg = split * P.kchunk;
+        kend = min(P.K, kbeg + P.kchunk);
+    }
+    const int nks = (kend - kbeg + YK - 1) / YK;   // k-steps of this work item (kend - kbeg >= 16: gemm_x5_usable)
+
+    unsigned lds0 = (unsigned)(size_t)(lds_char*)smem;
+    asm volatile("" : "+s"(lds0));   // the compiler does not model the DMA's LDS writes (see gemm_x3.hip)
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5, r32 = lane & 31;
+    const unsigned wl = lds0 + (unsigned)wave * YWAVE;
+    const int nw = nks > wave ? (nks - wave + 3) >> 2 : 0;    // this wave's k-steps: wave, wave + 4, ...
+    auto k0_of = [&](int i) {   // first k of local step i (the partial last step of the work item ends at kend)
+        const int k = kbeg + YK * (wave + 4 * i);
+        return k + YK <= kend ? k : kend - YK;
+    };
+
+    // ---- DMA addressing.  KC operand ([row][k]): piece j = rows 16 j .. 16 j + 15 of the k-step, 64 B each; lane -> (row,
+    // 16-byte chunk); the LDS image is lane-linear, so the swizzle — physical chunk = logical chunk ^ ((row >> 2) & 3), which
+    // makes the ds_read_b128 fragment fetches bank-conflict-free — is applied on the source side.  !KC ([k][col]): piece
+    // j = k-rows 2 j, 2 j + 1, lane -> (k-row, column quad).  Rows / columns are clamped into the matrix.
+    unsigned va[A_KC ? YNP : 1], vb[B_KC ? YNP : 1];
+    if constexpr (A_KC) {
+#pragma unroll
+        for (int j = 0; j < YNP; ++j) {
+            int gr = m0 + 16 * j + (lane >> 2);
+            gr = gr < M ? gr : M - 1;
+            va[j] = ((unsigned)gr * (unsigned)P.lda + 4u * (unsigned)((lane & 3) ^ ((lane >> 4) & 3))) * 4u;
+        }
+    } else {
+        int gc = m0 + 4 * r32;
+        const int last = (M - 1) & ~3;
+        gc = gc < last ? gc : last;
+        va[0] = ((unsigned)h * (unsigned)P.lda + (unsigned)gc) * 4u;
+    }
+    if constexpr (B_KC) {
+#pragma unroll
+        for (int j = 0; j < YNP; ++j) {
+            int gr = n0 + 16 * j + (lane >> 2);
+            gr = gr < N ? gr : N - 1;
+            vb[j] = ((unsigned)gr * (unsigned)P.ldb + 4u * (unsigned)((lane & 3) ^ ((lane >> 4) & 3))) * 4u;
+        }
+    } else {
+        int gc = n0 + 4 * r32;
+        const int last = (N - 1) & ~3;
+        gc = gc < last ? gc : last;
+        vb[0] = ((unsigned)h * (unsigned)P.ldb + (unsigned)gc) * 4u;
+    }
+    // the affine's source per lane (a problem without one stages the identity, which does not move with k)
+    const float* aff_src = nullptr;
+    int aff_step = 0;
+    if constexpr (AFF) {
+        const int l = lane & 31;
+        const bool has = P.a_scale != nullptr;
+        aff_src = has ? (l < 16 ? P.a_scale : P.a_shift) + (l & 15) : &g_aff_identity[l >> 4][l & 15];
+        aff_step = has ? 1 : 0;
+    }
+    // piece t (0..16: A pieces, B pieces, affine) of the k-step starting at k0, into stage st.  rowA / rowB: first byte of
+    // k-row k0 of a k-strided operand (dma_rows), advanced here by two rows per piece.
+    const size_t strideA2 = (size_t)P.lda * 8u, strideB2 = (size_t)P.ldb * 8u;
+    auto dma_piece = [&](auto tc, int k0, int st, const char* rowA, const char* rowB) {
+        constexpr int t = decltype(tc)::value;
+        const unsigned dst = wl + (unsigned)st * YSTAGE;
+        if constexpr (t < YNP) {
+            const char* base;
+            unsigned v;
+            if constexpr (A_KC) { base = reinterpret_cast<const char*>(P.A + (size_t)k0); v = va[t]; }
+            else { base = rowA + (size_t)t * strideA2; v = va[0]; }
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(base + v), (lds_f32*)(size_t)(dst + (unsigned)t * 1024u), 16, 0, 0);
+        } else if constexpr (t < 2 * YNP) {
+            constexpr int u = t - YNP;
+            const char* base;
+            unsigned v;
+            if constexpr (B_KC) { base = reinterpret_cast<const char*>(P.B + (size_t)k0); v = vb[u]; }
+            else { base = rowB + (size_t)u * strideB2; v = vb[0]; }
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(base + v), (lds_f32*)(size_t)(dst + YOP + (unsigned)u * 1024u), 16, 0, 0);
+        } else if constexpr (AFF) {   // lanes 0-15: scale[k0 + lane], 16-31: shift[k0 + lane - 16]; lanes 32-63 repeat
+            __builtin_amdgcn_global_load_lds(aff_src + (size_t)(k0 * aff_step), (lds_f32*)(size_t)(dst + YAFF), 4, 0, 0);
+        }
+    };
+    auto row_a = [&](int k0) { return reinterpret_cast<const char*>(P.A) + (A_KC ? (size_t)0 : (size_t)k0 * (size_t)P.lda * 4u); };
+    auto row_b = [&](int k0) { return reinterpret_cast<const char*>(P.B) + (B_KC ? (size_t)0 : (size_t)k0 * (size_t)P.ldb * 4u); };
+    constexpr int NDMA = 2 * YNP + (AFF ? 1 : 0);
+
+    // ---- fragment reads: 8 consecutive k of one row of a 32-row block, lane = (row, k half)
+    unsigned rk[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) rk[e] = (unsigned)r32 * 64u + (unsigned)(((2 * h + e) ^ ((r32 >> 2) & 3)) * 16);
+    const unsigned rs = (unsigned)h * (8u * 512u) + (unsigned)r32 * 4u;
+    auto read_frag = [&](auto fc, float (&dst)[8]) {
+        constexpr FD f = fdec(decltype(fc)::value);
+        constexpr bool KC = f.op == 0 ? A_KC : B_KC;
+        const unsigned base = wl + (unsigned)f.par * YSTAGE + (unsigned)f.op * YOP;
+        if constexpr (KC) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const f32x4 v = *(lds_f32x4*)(size_t)(base + (unsigned)f.blk * 2048u + rk[e]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[4 * e + j] = v[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[j] = *(lds_f32*)(size_t)(base + (unsigned)f.blk * 128u + (unsigned)j * 512u + rs);
+        }
+    };
+    float aq[2][2][8];   // [parity of the k-step][scale / shift][this lane's 8 k]
+    auto read_aff = [&](int par) {
+        if constexpr (AFF) {
+            const unsigned p = wl + (unsigned)par * YSTAGE + YAFF + (unsigned)h * 32u;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const f32x4 v0 = *(lds_f32x4*)(size_t)(p + (unsigned)e * 64u), v1 = *(lds_f32x4*)(size_t)(p + (unsigned)e * 64u + 16u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    aq[par][e][j] = v0[j];
+                    aq[par][e][4 + j] = v1[j];
+                }
+            }
+        }
+    };
+
+#if DGG_X5_STAMP
+    unsigned long long stamp[8];
+    stamp[0] = __builtin_amdgcn_s_memtime();
+    stamp[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    f32x16 acc[4][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    };
+    Frag PA[2][4], PB[2][4];   // [parity of the k-step][32-row block]
+    float rawb[2][8];          // raw fragments, one window ahead of the split
+    unsigned sh_[4], sm_[4];
+    float sr_[8], se_[4];
+
+    // A fragment as staged -> what the split sees: the folded BatchNorm affine, and (MASK: only where a wave's LAST k-step
+    // is being prepared) zeros for the k a moved-back last step shares with its predecessor
+    auto prep = [&](auto fc, float (&x)[8], int mlo, auto mask_tag) {
+        constexpr FD f = fdec(decltype(fc)::value);
+        if constexpr (f.op == 0) {
+            if constexpr (AFF) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = __builtin_fmaf(x[j], aq[f.par][0][j], aq[f.par][1][j]);
+            }
+            if constexpr (decltype(mask_tag)::value) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = j < mlo ? 0.f : x[j];
+            }
+        }
+    };
+    // the split in 11 slices of 4 vector instructions, one per MFMA of the window
+    auto slice = [&](auto qc, const float (&x)[8], Frag& out) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (q == 0) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) sh_[p] = pack_bf16(x[2 * p], x[2 * p + 1]);
+        } else if constexpr (q == 1 || q == 3) {
+            constexpr int o = q == 1 ? 0 : 2;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                se_[2 * p] = __builtin_bit_cast(float, sh_[o + p] << 16);
+                se_[2 * p + 1] = __builtin_bit_cast(float, sh_[o + p] & 0xffff0000u);
+            }
+        } else if constexpr (q == 2 || q == 4) {
+            constexpr int o = q == 2 ? 0 : 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sr_[o + j] = x[o + j] - se_[j];
+        } else if constexpr (q == 5) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) sm_[p] = pack_bf16(sr_[2 * p], sr_[2 * p + 1]);
+        } else if constexpr (q == 6 || q == 8) {
+            constexpr int o = q == 6 ? 0 : 2;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                se_[2 * p] = __builtin_bit_cast(float, sm_[o + p] << 16);
+                se_[2 * p + 1] = __builtin_bit_cast(float, sm_[o + p] & 0xffff0000u);
+            }
+        } else if constexpr (q == 7 || q == 9) {
+            constexpr int o = q == 7 ? 0 : 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sr_[o + j] -= se_[j];
+        } else if constexpr (q == 10) {
+            unsigned l[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) l[p] = pack_bf16(sr_[2 * p], sr_[2 * p + 1]);
+            out.p[0] = __builtin_bit_cast(bf16x8, (u32x4){sh_[0], sh_[1], sh_[2], sh_[3]});
+            out.p[1] = __builtin_bit_cast(bf16x8, (u32x4){sm_[0], sm_[1], sm_[2], sm_[3]});
+            out.p[2] = __builtin_bit_cast(bf16x8, (u32x4){l[0], l[1], l[2], l[3]});
+        }
+    };
+    auto planes_of = [&](auto fc) -> Frag& {
+        constexpr FD f = fdec(decltype(fc)::value);
+        if constexpr (f.op == 0) return PA[f.par][f.blk];
+        else return PB[f.par][f.blk];
+    };
+
+    // One k-step: 96 MFMAs in 8 windows of 12; slot g = {MFMA g, slice g % 12 of window g / 12's fragment, [the LDS reads
+    // of the next window's fragment], [its prep], [one DMA piece of step i + 2]}, issue order pinned.
+    // DMA: stage k-step i + 2 (k0_dma).  MASK: the NEXT step is this wave's last: its A fragments get the cover mask.
+    // NEXT: a next step exists (else no fragment of it is read or split).
+    auto step = [&](auto ty_tag, auto dma_tag, auto mask_tag, auto next_tag, int k0_dma, int mlo) {
+        constexpr int TY = decltype(ty_tag)::value;
+        constexpr bool DMA = decltype(dma_tag)::value, MASK = decltype(mask_tag)::value, NEXT = decltype(next_tag)::value;
+        constexpr int cur = TY;
+        const char* const rowA = row_a(k0_dma);
+        const char* const rowB = row_b(k0_dma);
+        static_for<96>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int n = g / 12, q = g % 12;
+            {   // the MFMA: small terms first (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi)
+                constexpr int grp = g / 24, inner = (g / 6) % 4, pr = g % 6;
+                constexpr int a = TY == 0 ? grp : inner, b = TY == 0 ? inner : grp;
+                constexpr int ia = pr == 0 ? 2 : pr == 2 || pr == 3 ? 1 : 0;
+                constexpr int ib = pr == 1 ? 2 : pr == 2 || pr == 4 ? 1 : 0;
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[cur][a].p[ia], PB[cur][b].p[ib], acc[a][b], 0, 0, 0);
+            }
+            constexpr FD f = frag_of(TY, n);
+            constexpr bool have = NEXT || f.par == cur;
+            if constexpr (have && q <= 10) slice(std::integral_constant<int, q>{}, rawb[n & 1], planes_of(FC<fcode(f)>{}));
+            constexpr FD f1 = frag_of(TY, n + 1);
+            constexpr bool have1 = NEXT || (f1.par == cur && n + 1 < 8);
+            if constexpr (g == 24 && NEXT) {
+                wait_vm<0>();   // the next step's stage has landed (issued during the previous step); nothing else is in flight
+                read_aff(cur ^ 1);
+            }
+            if constexpr (have1 && q == 0) read_frag(FC<fcode(f1)>{}, rawb[(n + 1) & 1]);
+            if constexpr (have1 && q == 11)
+                prep(FC<fcode(f1)>{}, rawb[(n + 1) & 1], mlo, std::integral_constant<bool, MASK && f1.par != cur>{});
+            if constexpr (DMA && g >= 25 && (g - 25) % 4 == 0 && (g - 25) / 4 < NDMA)
+                dma_piece(std::integral_constant<int, (g - 25) / 4>{}, k0_dma, cur, rowA, rowB);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    if (nw > 0) {
+        // A wave's last step is always a BO step: with an odd number of steps the first one is a BO step (stage 1), run from a
+        // body of its own in front of the pair loop.  Step j has type (j + odd) & 1; stage = type.
+        using AO = std::integral_constant<int, 0>;
+        using BO = std::integral_constant<int, 1>;
+        using Yes = std::true_type;
+        using No = std::false_type;
+        const bool odd = nw & 1;
+        const int cover_last = kbeg + YK * (wave + 4 * (nw - 1)) - k0_of(nw - 1);   // > 0 only for a moved-back last step
+        const int mlo_last = cover_last - 8 * h;
+        const int mlo0 = nw == 1 ? mlo_last : -64;
+        // ---- prologue: stage k-steps 0 and 1, split what step 0 needs at its first MFMA and prepare its window 0
+        if (odd) {
+            const int k0 = k0_of(0), k1 = k0_of(nw > 1 ? 1 : 0);   // (a single step is staged twice: the count in flight is fixed)
+            static_for<NDMA>([&](auto tc) { dma_piece(tc, k0, 1, row_a(k0), row_b(k0)); });
+            static_for<NDMA>([&](auto tc) { dma_piece(tc, k1, 0, row_a(k1), row_b(k1)); });
+            __builtin_amdgcn_sched_barrier(0);
+            zero_acc();   // while the first stage lands
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vm<NDMA>();
+            read_aff(1);
+            static_for<4>([&](auto ac) {
+                constexpr int a = decltype(ac)::value;
+                constexpr FD f{0, 1, a};
+                read_frag(FC<fcode(f)>{}, rawb[0]);
+                prep(FC<fcode(f)>{}, rawb[0], mlo0, Yes{});
+                static_for<11>([&](auto qc) { slice(qc, rawb[0], PA[1][a]); });
+            });
+            {
+                constexpr FD f{1, 1, 0};
+                read_frag(FC<fcode(f)>{}, rawb[0]);
+                static_for<11>([&](auto qc) { slice(qc, rawb[0], PB[1][0]); });
+            }
+            {
+                constexpr FD f{1, 1, 1};
+                read_frag(FC<fcode(f)>{}, rawb[0]);
+            }
+            // the odd step in front: BO, step 0
+            if (nw > 1) step(BO{}, Yes{}, No{}, Yes{}, k0_of(nw > 2 ? 2 : 1), 0);
+            else step(BO{}, No{}, No{}, No{}, 0, 0);
+        } else {
+            const int k0 = k0_of(0), k1 = k0_of(1);
+            static_for<NDMA>([&](auto tc) { dma_piece(tc, k0, 0, row_a(k0), row_b(k0)); });
+            static_for<NDMA>([&](auto tc) { dma_piece(tc, k1, 1, row_a(k1), row_b(k1)); });
+            __builtin_amdgcn_sched_barrier(0);
+            zero_acc();   // while the first stage lands
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vm<NDMA>();
+            read_aff(0);
+            static_for<4>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                constexpr FD f{1, 0, b};
+                read_frag(FC<fcode(f)>{}, rawb[0]);
+                static_for<11>([&](auto qc) { slice(qc, rawb[0], PB[0][b]); });
+            });
+            {
+                constexpr FD f{0, 0, 0};
+                read_frag(FC<fcode(f)>{}, rawb[0]);
+                prep(FC<fcode(f)>{}, rawb[0], 0, No{});
+                static_for<11>([&](auto qc) { slice(qc, rawb[0], PA[0][0]); });
+            }
+            {
+                constexpr FD f{0, 0, 1};
+                read_frag(FC<fcode(f)>{}, rawb[0]);
+                prep(FC<fcode(f)>{}, rawb[0], 0, No{});
+            }
+        }
+#if DGG_X5_STAMP
+        stamp[2] = __builtin_amdgcn_s_memtime();
+#endif
+        // ---- pairs (AO, BO): all but the last one stage two steps ahead; the last pair masks the last step's A fragments
+        int i = odd ? 1 : 0;
+        for (; i + 2 < nw; i += 2) {
+            step(AO{}, Yes{}, No{}, Yes{}, k0_of(i + 2), 0);
+            step(BO{}, Yes{}, No{}, Yes{}, k0_of(i + 3), 0);
+        }
+        if (i < nw) {
+            step(AO{}, No{}, Yes{}, Yes{}, 0, mlo_last);
+            step(BO{}, No{}, No{}, No{}, 0, 0);
+        }
+        wait_vm<0>();   // nothing of this wave is in flight: the ring's LDS is reused below
+    } else {
+        zero_acc();
+    }
+
+    // ---- the four partial blocks meet in LDS: two rounds (tile rows 0-1, then 2-3); in each, every wave parks its 8 tiles of
+    // those rows and the two waves that own the round's quadrants add up the four contributions in wave order.
+    f32x16 res[2][2];
+#if DGG_X5_STAMP
+    stamp[3] = __builtin_amdgcn_s_memtime();
+#endif
+    __syncthreads();   // every wave's ring is idle
+#if DGG_X5_STAMP
+    stamp[4] = __builtin_amdgcn_s_memtime();
+#endif
+    static_for<2>([&](auto rc) {
+        constexpr int R = decltype(rc)::value;
+        static_for<8>([&](auto tc) {
+            constexpr int t8 = decltype(tc)::value;
+            constexpr int ta = t8 >> 2, b = t8 & 3;
+            constexpr int ql = b >> 1, t = ta * 2 + (b & 1);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const unsigned off = lds0 + (unsigned)((((wave * 2 + ql) * 4 + t) * 4 + q4) * 1024) + (unsigned)lane * 16u;
+                const f32x16& s = acc[2 * R + ta][b];
+                *(lds_f32x4*)(size_t)off = (f32x4){s[4 * q4], s[4 * q4 + 1], s[4 * q4 + 2], s[4 * q4 + 3]};
+            }
+        });
+        __syncthreads();
+        if ((wave >> 1) == R) {
+            const int ql = wave & 1;
+            static_for<4>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                f32x4 v[4][4];   // all 16 reads of a tile in flight, then the sums (wave order: deterministic)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        v[q4][w] = *(lds_f32x4*)(size_t)(lds0 + (unsigned)((((w * 2 + ql) * 4 + t) * 4 + q4) * 1024) + (unsigned)lane * 16u);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 sm = ((v[q4][0] + v[q4][1]) + v[q4][2]) + v[q4][3];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) res[t >> 1][t & 1][4 * q4 + j] = sm[j];
+                }
+            });
+        }
+        __syncthreads();
+    });
+#if DGG_X5_STAMP
+    stamp[5] = __builtin_amdgcn_s_memtime();
+#endif
+    gemm_epilogue<YT, YT, 2, 2, !A_KC && !B_KC>(P, res, reinterpret_cast<float*>(smem + 128 * 1024), split, tm_i, m0, n0, (int)threadIdx.x);
+#if DGG_X5_STAMP
+    stamp[6] = __builtin_amdgcn_s_memtime();
+    stamp[7] = __builtin_amdgcn_s_memrealtime();
+    if (nw == 0) stamp[2] = stamp[0];
+    if (lane == 0 && bid < 2048)
+        for (int q = 0; q < 8; ++q) g_x5_stamp[bid][wave][q] = stamp[q];
+#endif
+}
+
+template <bool A_KC, bool B_KC, bool AFF>
+__global__ __launch_bounds__(256) void gemm_x5_kernel(const GemmBatch batch) {
+    __shared__ __attribute__((aligned(16))) char smem[YSMEM];
+    for (int bid = (int)blockIdx.x; bid < batch.total_blocks; bid += (int)gridDim.x) {
+        gemm_x5_block<A_KC, B_KC, AFF>(batch, bid, smem);
+        if (bid + (int)gridDim.x < batch.total_blocks) __syncthreads();  // the epilogue's LDS scratch is done with
+    }
+}
+
+template <bool A_KC, bool B_KC, bool AFF>
+static void launch_x5(const GemmBatch& b, hipStream_t st) {
+    int grid = b.total_blocks;
+    // side work (dgg_set_side_work): as launch_x3 — the forward products walk two work items per workgroup
+    static const int kdiv = [] { const char* e = getenv("DGG_SIDE_DIV"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
+    if (gemm_side_work() && A_KC && B_KC && grid > 64) grid = ((grid + kdiv - 1) / kdiv + 7) / 8 * 8;
+    hipLaunchKernelGGL((gemm_x5_kernel<A_KC, B_KC, AFF>), dim3(grid), dim3(256), 0, st, b);
+}
+
+}  // namespace x5
+
+#if DGG_X5_STAMP
+extern "C" int dgg_x5_debug_stamps(unsigned long long* host_out, int nblocks) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_x5_stamp), (size_t)nblocks * 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
+
+// Every problem of the launch needs at least YMINK of K inside each split (a k-step moved back to the split's end must
+// stay inside the split) and fp32 operands.
+bool gemm_x5_usable(const GemmBatch& batch) {
+    static const int on = [] { const char* e = getenv("DGG_X5"); return e ? atoi(e) : 1; }();
+    if (!on) return false;
+    for (int i = 0; i < batch.nprob; ++i) {
+        const GemmProb& p = batch.p[i];
+        if (p.a_plane || p.b_plane) return false;
+        if (p.K < x5::YMINK) return false;
+        if (p.splits > 0) {
+            if (p.kchunk < x5::YMINK) return false;
+            const int lastk = p.K - (p.splits - 1) * p.kchunk;   // the last split's share
+            if (lastk < x5::YK) return false;
+        }
+    }
+    return true;
+}
+
+void gemm_x5_dispatch(int mode, const GemmBatch& batch, hipStream_t st) {
+    if (mode == GEMM_NT) {
+        bool any = false;
+        for (int i = 0; i < batch.nprob; ++i) any = any || batch.p[i].a_scale != nullptr;
+        if (any) x5::launch_x5<true, true, true>(batch, st);
+        else x5::launch_x5<true, true, false>(batch, st);
+    } else if (mode == GEMM_NN) {
+        x5::launch_x5<true, false, false>(batch, st);
+    } else {
+        x5::launch_x5<false, false, false>(batch, st);
+    }
+}
+
+}  // namespace dgg

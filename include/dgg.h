@@ -17,7 +17,11 @@
  *    null stream); nothing synchronises with the host;
  *  - return value: DGG_OK (0) or a negative dgg_status; no exceptions cross the boundary;
  *  - re-entrant across streams with distinct workspaces; not thread-safe on one workspace.
- *  - all tensors fp32 row-major contiguous unless a leading dimension is given.
+ *  - all tensors fp32 row-major contiguous unless a leading dimension is given;
+ *  - batch limit of every forward / backward / phase / step entry: the GEMM epilogues address their outputs through 32-bit
+ *    byte offsets, so rows * pitch * 4 of every product stays below 2 GiB — B <= 699 050 rows per call at the widest pitch
+ *    (768 floats; the per-object inference entries: O * n rows).  A larger batch returns DGG_ERR_INVALID and
+ *    dgg_last_error() says which product; callers chunk their rows (the reference's own batches are 32 .. 5012).
  *
  * Hidden state (everything else is stateless).  The library keeps, PER CALLING THREAD:
  *  (a) a pool of 64 timing-disabled HIP events used for its internal fork/join between streams;

@@ -177,3 +177,43 @@ def test_tile_index_bits_in_the_keys():
           % (T, span, missed, missed_old))
     assert missed == 0
     assert span > 128 and missed_old > 0                                        # the family reaches past the old budget (128 ulp) and defeats it
+
+
+@pytest.mark.parametrize("n", [33, 104, 777, 2561 - 1, 1000])
+def test_padded_rows_never_beat_the_last_point(n):
+    """the exact stage of bps_mfma_kernel has no j < N test — rows past a ragged cloud (N % 32 != 0) are bit-exact
+    copies of its LAST point at larger indices.  The invariant that makes this safe, restated in numpy on the kernel's own
+    keys, with the last point as the true nearest neighbour: (i) a block made of copies only has a key >= the key of the
+    block that holds the original (same values, smaller-or-equal minimum, smaller-or-equal tile index), so whenever such a
+    block is a candidate the original's block is one too; (ii) inside a block the strict '<' and across blocks the 64-bit
+    minimum of (d2 bits, j) prefer the original: the id that comes out is N - 1, never >= N."""
+    g = np.random.default_rng(100 + n)
+    cloud = (g.normal(size=(n, 3)) * [0.05, 0.03, 0.08] + 0.3).astype(f32)      # off the origin ...
+    b = (g.normal(size=3) * 0.01).astype(f32)                                  # ... a basis point near the origin
+    cloud[n - 1] = (b + f32(1e-4)).astype(f32)                                 # the LAST point is by far the nearest
+    npad = (n + 31) // 32 * 32
+    if npad == n:
+        npad += 32                                                              # (full tiles: a whole tile of copies)
+    padded = np.concatenate([cloud, np.repeat(cloud[n - 1:n], npad - n, axis=0)])
+    n2 = (padded[:, 2].astype(np.float64) * padded[:, 2] + (padded[:, 1].astype(np.float64) * padded[:, 1]
+          + (padded[:, 0] * padded[:, 0]).astype(f32)).astype(f32)).astype(f32)
+    R = f32(np.sqrt(n2.max()))
+    scale = scale_for(R)
+    v, c, S, bb = coarse(padded, b, R, scale)
+    d2 = contract_d2(padded, b)
+    assert d2[n - 1] == d2.min() and (d2[:n - 1] > d2[n - 1]).all()
+    assert np.array_equal(v[n:], np.full(npad - n, v[n - 1], dtype=f32))       # copies: the same coarse value, bit for bit
+    keys, blk_of = block_keys(v)
+    orig = blk_of[n - 1]
+    # (a block = the 16 rows of a tile with the same (j >> 2) & 1: copies-only blocks exist where the last tile holds at most
+    #  4 real points — n = 33 — or is a whole tile of copies; elsewhere copies share a block with real points)
+    copies_only = [k for k in range(len(keys)) if (np.flatnonzero(blk_of == k) >= n).all()]
+    assert copies_only or n % 32 > 4
+    for k in copies_only:
+        assert keys[k].view(np.uint32) >= keys[orig].view(np.uint32), (k, orig)   # positive floats order like their bits
+    lim = kernel_lim(keys.min(), S)
+    assert keys[orig] <= lim
+    # the exact stage over every candidate block: 64-bit minimum of (d2 bits << 32 | j)
+    cand = np.flatnonzero(keys <= lim)
+    best = min((int(d2[j].view(np.uint32)) << 32) | int(j) for k in cand for j in np.flatnonzero(blk_of == k))
+    assert (best & 0xFFFFFFFF) == n - 1

@@ -251,8 +251,12 @@ def test_bps_matrix_path_keeps_the_scan_answer(B, N, P):
     clouds[4] = clouds[4] + 50.0           # far from the origin
     clouds[5, :] = 3e19                    # nothing is below +inf: index 0, dist +inf
     clouds[6, 7] = float("nan")            # a NaN point never wins
+    clouds[7] = clouds[7] + 50.0           # a far cloud whose LAST point sits among the basis points: every id is N - 1 —
+    clouds[7, N - 1] = 0.0                 # the rows that pad a ragged last tile are copies of it at indices >= N
     dist, ids = ops.bps_encode(clouds.to(DEV), torch.from_numpy(basis).to(DEV))
     dist, ids = dist.cpu().numpy(), ids.cpu().numpy()
+    assert ids.min() >= 0 and ids.max() < N, (int(ids.min()), int(ids.max()))   # no padded row ever comes out
+    assert (ids[7] == N - 1).all()
     for b in sorted(set(range(8)) | {B // 2, B - 1}):
         od, oi = bps_oracle.encode_f32(clouds[b].numpy(), basis)
         assert (ids[b] == oi).all(), (b, int((ids[b] != oi).sum()))
@@ -487,6 +491,7 @@ def test_bps_chunked_matrix_path_for_large_clouds(B, N):
     torch.cuda.synchronize()
     assert torch.equal(i, want_i), int((i != want_i).sum().item())
     assert torch.equal(d.view(torch.int32), want_d.view(torch.int32))
+    assert int(i.min()) >= 0 and int(i.max()) < N   # the rows that pad a ragged last quad / tile never come out
     for b in {0, B - 1}:
         od, oi = bps_oracle.encode_f32(clouds[b].numpy(), basis)
         assert (i[b].cpu().numpy() == oi).all(), b

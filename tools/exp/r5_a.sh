@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT
+timeout -k 10 500 python -m pytest tests/test_gpu_parity.py -x -q -k "gemm" 2>&1 | tail -3
+for v in 1 2; do
+DGG_X5=0 timeout -k 10 120 python3 tools/exp/step_prof.py joint 1024 200
+DGG_X5=1 timeout -k 10 120 python3 tools/exp/step_prof.py joint 1024 200
+done
+DGG_X5=0 timeout -k 10 120 python3 tools/exp/step_prof.py cgan 1024 200
+DGG_X5=1 timeout -k 10 120 python3 tools/exp/step_prof.py cgan 1024 200
+DGG_X5=0 timeout -k 10 120 python3 tools/exp/step_prof.py eva 1024 200
+DGG_X5=1 timeout -k 10 120 python3 tools/exp/step_prof.py eva 1024 200

@@ -1,0 +1,196 @@
+// Round 5 probe: what does a k-step cost when ONE wave owns a 128 x 128 accumulator block (16 MFMA tiles, 256 accumulator
+// registers) and splits its 8 fp32 fragments itself?  (gfx950)
+//   hipcc --offload-arch=gfx950 -O3 -w -fno-slp-vectorize tools/exp/x5_probe.hip -o tools/exp/x5_probe && tools/exp/x5_probe
+// gemm_x3_kernel gives every wave a 64 x 64 block: 4 fragments split per 24 MFMAs (7.3 vector instructions per MFMA) and
+// measures 57 cycles per MFMA against the pipe's 32.  With a 128 x 128 block per wave — the workgroup's four waves take
+// different k-steps of the same output tile and add up at the end — it is 8 fragments per 96 MFMAs: 3.7 per MFMA, under the
+// ~5 single-issue instructions an MFMA gap hides (MI355X_MICROARCH.md, cycle constants).  This probe runs that instruction
+// mix per k-step and wave: 96 MFMAs, 8 fragment splits (44 vector instructions each) cut into 88 slices of 4, 16
+// ds_read_b128, 16 LDS-DMA pieces of 1 KiB, one barrier; timing only (the operands are not a real GEMM's).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <utility>
+#include <type_traits>
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) f4v lds_f4;
+
+__device__ __forceinline__ unsigned pack(float a, float b) {
+    f2v v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+}
+
+struct Split {   // one fragment in flight: 8 raw values -> 12 packed registers, 11 slices of 4 vector instructions
+    float x[8], r[8], e[4];
+    unsigned h[4], m[4], l[4];
+};
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {   // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): no unroll pragma, no size threshold
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int k>
+__device__ __forceinline__ void slice(Split& s) {
+    switch (k) {
+    case 0: for (int p = 0; p < 4; ++p) s.h[p] = pack(s.x[2 * p], s.x[2 * p + 1]); break;
+    case 1: for (int p = 0; p < 2; ++p) { s.e[2 * p] = __builtin_bit_cast(float, s.h[p] << 16); s.e[2 * p + 1] = __builtin_bit_cast(float, s.h[p] & 0xffff0000u); } break;
+    case 2: for (int j = 0; j < 4; ++j) s.r[j] = s.x[j] - s.e[j]; break;
+    case 3: for (int p = 2; p < 4; ++p) { s.e[2 * p - 4] = __builtin_bit_cast(float, s.h[p] << 16); s.e[2 * p - 3] = __builtin_bit_cast(float, s.h[p] & 0xffff0000u); } break;
+    case 4: for (int j = 0; j < 4; ++j) s.r[4 + j] = s.x[4 + j] - s.e[j]; break;
+    case 5: for (int p = 0; p < 4; ++p) s.m[p] = pack(s.r[2 * p], s.r[2 * p + 1]); break;
+    case 6: for (int p = 0; p < 2; ++p) { s.e[2 * p] = __builtin_bit_cast(float, s.m[p] << 16); s.e[2 * p + 1] = __builtin_bit_cast(float, s.m[p] & 0xffff0000u); } break;
+    case 7: for (int j = 0; j < 4; ++j) s.r[j] -= s.e[j]; break;
+    case 8: for (int p = 2; p < 4; ++p) { s.e[2 * p - 4] = __builtin_bit_cast(float, s.m[p] << 16); s.e[2 * p - 3] = __builtin_bit_cast(float, s.m[p] & 0xffff0000u); } break;
+    case 9: for (int j = 0; j < 4; ++j) s.r[4 + j] -= s.e[j]; break;
+    case 10: for (int p = 0; p < 4; ++p) s.l[p] = pack(s.r[2 * p], s.r[2 * p + 1]); break;
+    default: break;
+    }
+}
+
+constexpr int STAGE = 64 * 1024;
+
+// MF: MFMAs, SP: splits, RD: LDS fragment reads, DM: LDS-DMA staging (+ counted wait and barrier)
+template <int T, bool MF, bool SP, bool RD, bool DM>
+__global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* out, long long* cyc, int iters, size_t wg_bytes) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    asm volatile("" : "+s"(lds0));
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const char* base = reinterpret_cast<const char*>(src) + (size_t)blockIdx.x * wg_bytes;
+    const unsigned nst = (unsigned)(wg_bytes / STAGE);
+
+    constexpr int NM = T * T * 6;          // MFMAs per k-step
+    constexpr int PF = NM / (2 * T);       // MFMAs per fragment split (12 or 6)
+    constexpr int NP = 4 * T;              // DMA pieces per wave and k-step
+    f16v acc[T * T];
+    for (int t = 0; t < T * T; ++t)
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    bf8 pl[2 * T][3];   // planes of the 2 T fragments (A blocks, B blocks)
+    for (int f = 0; f < 2 * T; ++f)
+        for (int p = 0; p < 3; ++p)
+            for (int i = 0; i < 8; ++i) pl[f][p][i] = (__bf16)(float)((lane * 7 + i + f + p) % 13 - 6);
+    Split s;
+    for (int i = 0; i < 8; ++i) { s.x[i] = lane * 0.37f + i * 1.7f; s.r[i] = 0.f; }
+    for (int i = 0; i < 4; ++i) { s.e[i] = 0.f; s.h[i] = s.m[i] = s.l[i] = 0u; }
+    f4v raw[2];
+    raw[0] = raw[1] = (f4v){1.f, 2.f, 3.f, 4.f};
+
+    auto dma = [&](int it, int q) {   // piece q (0..NP-1) of this wave for stage it
+        const unsigned st = lds0 + (unsigned)(it & 1) * STAGE + (unsigned)(wave * NP + q) * 1024u;
+        const char* g = base + (size_t)((unsigned)it % nst) * STAGE + (size_t)(wave * NP + q) * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(g), (lds_f32*)(size_t)st, 16, 0, 0);
+    };
+    if (DM) {
+        for (int q = 0; q < NP; ++q) dma(0, q);
+        for (int q = 0; q < NP; ++q) dma(1, q);
+    }
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        if (DM) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");   // this stage landed, the next one stays in flight
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        const unsigned st = lds0 + (unsigned)(it & 1) * STAGE + (unsigned)wave * 16384u;
+        static_for<NM>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int ta = g / (6 * T), tb = (g / 6) % T, pr = g % 6;
+            if (MF) {
+                constexpr int ia = pr == 0 ? 2 : pr == 2 || pr == 3 ? 1 : 0;
+                constexpr int ib = pr == 1 ? 2 : pr == 2 || pr == 4 ? 1 : 0;
+                acc[ta * T + tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl[ta][ia], pl[T + tb][ib], acc[ta * T + tb], 0, 0, 0);
+            }
+            constexpr int f = g / PF, q = g % PF;   // fragment f is split during MFMAs PF f .. PF f + PF - 1
+            constexpr int SPM = 12 / PF;             // slices per MFMA (1 or 2)
+            if (RD && q == PF - 1) {                 // its successor's two 16-byte reads
+                const unsigned a = st + (unsigned)((f + 1) % (2 * T)) * 2048u + (unsigned)lane * 16u;
+                raw[0] = *(lds_f4*)(size_t)a;
+                raw[1] = *(lds_f4*)(size_t)(a + 1024u);
+            }
+            if (SP) {
+                if (q == 0) {
+                    for (int j = 0; j < 4; ++j) { s.x[j] = raw[0][j]; s.x[4 + j] = raw[1][j]; }
+                }
+                slice<SPM * q>(s);
+                if (SPM == 2) slice<SPM * q + 1>(s);
+                if (q == PF - 1) {
+                    pl[f][0] = __builtin_bit_cast(bf8, (u4v){s.h[0], s.h[1], s.h[2], s.h[3]});
+                    pl[f][1] = __builtin_bit_cast(bf8, (u4v){s.m[0], s.m[1], s.m[2], s.m[3]});
+                    pl[f][2] = __builtin_bit_cast(bf8, (u4v){s.l[0], s.l[1], s.l[2], s.l[3]});
+                }
+            }
+            if (DM && g >= 4 && (g - 4) % (T == 4 ? 5 : 4) == 0 && (g - 4) / (T == 4 ? 5 : 4) < NP) dma(it + 2, (g - 4) / (T == 4 ? 5 : 4));   // NP pieces, spread
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float a = 0.f;
+    for (int t = 0; t < T * T; ++t)
+        for (int i = 0; i < 16; ++i) a += acc[t][i];
+    for (int f = 0; f < 2 * T; ++f)
+        for (int p = 0; p < 3; ++p)
+            for (int i = 0; i < 8; ++i) a += (float)pl[f][p][i];
+    for (int i = 0; i < 8; ++i) a += s.r[i] + s.x[i];
+    a += raw[0][0] + raw[1][3];
+    out[blockIdx.x * 256 + threadIdx.x] = a;
+    if (lane == 0) cyc[blockIdx.x * 4 + wave] = t1 - t0;
+}
+
+template <int T, bool MF, bool SP, bool RD, bool DM>
+void run(const char* name, const float* src, size_t wg_bytes) {
+    const int nb = 256, iters = T == 4 ? 800 : 3200;   // the same number of MFMAs either way
+    float* out; long long* cyc;
+    hipMalloc(&out, nb * 256 * 4); hipMalloc(&cyc, nb * 4 * 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<T, MF, SP, RD, DM><<<nb, 256>>>(src, out, cyc, 50, wg_bytes);
+    hipEventRecord(e0); k<T, MF, SP, RD, DM><<<nb, 256>>>(src, out, cyc, iters, wg_bytes); hipEventRecord(e1);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed\n", name); exit(1); }
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    static long long h[256 * 4];
+    hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    double c = 0;
+    for (int i = 0; i < nb * 4; ++i) c += (double)h[i];
+    c /= nb * 4.0 * iters;
+    const int nm = T * T * 6;
+    printf("%-62s %8.1f us | %6.0f cycles per k-step and wave (%d MFMA = %d) = %.1f per MFMA | %.2f GHz | %.2f ns per MFMA\n", name, ms * 1e3, c,
+           nm, nm * 32, c / nm, c * iters / (ms * 1e3) * 1e-3, ms * 1e6 / ((double)iters * nm));
+    hipFree(out); hipFree(cyc);
+}
+
+int main() {
+    const size_t wg_bytes = 4 * STAGE;   // 256 KB per workgroup, 64 MB in all: L2 / Infinity Cache resident like a GEMM's operands
+    float* src;
+    hipMalloc(&src, 256 * wg_bytes);
+    {
+        float* h = (float*)malloc(256 * wg_bytes);
+        for (size_t i = 0; i < 256 * wg_bytes / 4; ++i) h[i] = (float)((i * 2654435761u) % 2001) * 1e-3f - 1.f;
+        hipMemcpy(src, h, 256 * wg_bytes, hipMemcpyHostToDevice);
+        free(h);
+    }
+    for (int rep = 0; rep < 2; ++rep) {
+        run<4, true, false, false, false>("4x4 tiles/wave: MFMA only", src, wg_bytes);
+        run<4, true, true, true, false>("4x4: MFMA + splits + LDS reads", src, wg_bytes);
+        run<4, true, false, true, true>("4x4: MFMA + LDS reads + DMA, barrier", src, wg_bytes);
+        run<4, true, true, true, true>("4x4: all (MFMA + splits + LDS reads + DMA, barrier)", src, wg_bytes);
+        run<4, false, true, true, true>("4x4: no MFMA (splits + LDS reads + DMA, barrier)", src, wg_bytes);
+        run<2, true, false, false, false>("2x2 tiles/wave (gemm_x3's mix): MFMA only", src, wg_bytes);
+        run<2, true, true, true, false>("2x2: MFMA + splits + LDS reads", src, wg_bytes);
+        run<2, true, false, true, true>("2x2: MFMA + LDS reads + DMA, barrier", src, wg_bytes);
+        run<2, true, true, true, true>("2x2: all", src, wg_bytes);
+        run<2, false, true, true, true>("2x2: no MFMA", src, wg_bytes);
+    }
+    return 0;
+}
