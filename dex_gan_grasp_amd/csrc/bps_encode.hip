@@ -626,6 +626,7 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
     __builtin_amdgcn_wave_barrier();
     {
         const int n = min(s_qn[w], kBpsQueue);
+        const int first = (slice * NW + w) * (NT * 32);
         int base = 0;
         for (; n - base > 16; base += 64) {
             if (base + lane < n) {

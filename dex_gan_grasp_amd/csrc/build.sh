@@ -6,18 +6,19 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 X3FLAGS="-fno-slp-vectorize"  # packed-f32 VALU beside MFMAs costs more than two scalar ops (MI355X_MICROARCH.md)
 mkdir -p _obj
-$HIPCC $COMMON -c gemm_f32.hip -o _obj/gemm_f32.o &
-$HIPCC $COMMON $X3FLAGS -c gemm_x3.hip -o _obj/gemm_x3.o &
-$HIPCC $COMMON -c gemm_p3.hip -o _obj/gemm_p3.o &
-$HIPCC $COMMON -c gemm_p4.hip -o _obj/gemm_p4.o &
-$HIPCC $COMMON $X3FLAGS -c gemm_x4.hip -o _obj/gemm_x4.o &
-$HIPCC $COMMON $X3FLAGS -c gemm_x5.hip -o _obj/gemm_x5.o &
-$HIPCC $COMMON -c elementwise.hip -o _obj/elementwise.o &
-$HIPCC $COMMON -c second_order.hip -o _obj/second_order.o &
+pids=""
+$HIPCC $COMMON -c gemm_f32.hip -o _obj/gemm_f32.o & pids="$pids $!"
+$HIPCC $COMMON $X3FLAGS -c gemm_x3.hip -o _obj/gemm_x3.o & pids="$pids $!"
+$HIPCC $COMMON -c gemm_p3.hip -o _obj/gemm_p3.o & pids="$pids $!"
+$HIPCC $COMMON -c gemm_p4.hip -o _obj/gemm_p4.o & pids="$pids $!"
+$HIPCC $COMMON $X3FLAGS -c gemm_x4.hip -o _obj/gemm_x4.o & pids="$pids $!"
+$HIPCC $COMMON $X3FLAGS -c gemm_x5.hip -o _obj/gemm_x5.o & pids="$pids $!"
+$HIPCC $COMMON -c elementwise.hip -o _obj/elementwise.o & pids="$pids $!"
+$HIPCC $COMMON -c second_order.hip -o _obj/second_order.o & pids="$pids $!"
 # fixed contraction: only the explicit fmaf() calls of the distance formula fuse (parity contract)
 # (-amdgpu-mfma-vgpr-form: the coarse pass reads its accumulators with vector instructions right away — no AGPR copies)
-$HIPCC $COMMON -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -c bps_encode.hip -o _obj/bps_encode.o &
-$HIPCC $COMMON -c dgg_api.hip -o _obj/dgg_api.o &
-wait
+$HIPCC $COMMON -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -c bps_encode.hip -o _obj/bps_encode.o & pids="$pids $!"
+$HIPCC $COMMON -c dgg_api.hip -o _obj/dgg_api.o & pids="$pids $!"
+for p in $pids; do wait $p || { echo "build.sh: a compile failed" >&2; exit 1; }; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libdgg.so _obj/gemm_f32.o _obj/gemm_x3.o _obj/gemm_p3.o _obj/gemm_p4.o _obj/gemm_x4.o _obj/gemm_x5.o _obj/elementwise.o _obj/second_order.o _obj/bps_encode.o _obj/dgg_api.o
 echo "built $(cd .. && pwd)/libdgg.so"
