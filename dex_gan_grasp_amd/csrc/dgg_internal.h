@@ -96,6 +96,8 @@ bool gemm_x4_enabled(long total_blocks);
 // for every launch it can take (DGG_X5=0 switches it off)
 void gemm_x5_dispatch(int mode, const GemmBatch& batch, hipStream_t st);
 bool gemm_x5_usable(const GemmBatch& batch);
+bool gemm_x5_enabled();
+bool gemm_x5_prob_ok(const GemmProb& p);
 // gemm_p4.hip / gemm_p3_block.h: C = A B^T on pre-split bf16 planes (forward, and the wgrad over transposed planes).
 // A weight-gradient (TN) launch of gemm_launch may carry ONE such problem beside its fp32 problems (a_plane != 0: "NT
 // over transposed planes", gemm_p3_block.h inside gemm_x3_kernel): the BPS block's weight gradient and its riders —

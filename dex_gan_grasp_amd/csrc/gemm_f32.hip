@@ -503,6 +503,7 @@ void gemm_set_side_work(int on) { g_side_work = on ? 1 : 0; }
 
 // All problems of one grouped launch must use the same tile shape: the launcher derives it from
 // problem 0 and re-plans the others with it.
+#define DGG_TRY_RC(expr) do { const int rc__ = (expr); if (rc__ != DGG_OK) return rc__; } while (0)
 int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
     if (batch.nprob < 1 || batch.nprob > kMaxProb) return DGG_ERR_INVALID;
     int bm, bn;
@@ -559,10 +560,31 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
             gemm_x4_dispatch(mode, batch, st);
             return check_launch("gemm_x4");
         }
-        if (!planes && gemm_algo() == 1 && gemm_x5_usable(batch)) {
-            gemm_x5_dispatch(mode, batch, st);
-            return check_launch("gemm_x5");
+        if (!planes && gemm_algo() == 1 && gemm_x5_enabled()) {
+            // gemm_x5_kernel takes every problem with at least 64 of K; a grouped launch that also carries short ones (the
+            // 24 pose columns beside the shared BPS block of a discriminator pass) is cut in two: the short problems are a
+            // handful of tiles on gemm_x3_kernel
+            static const bool cut = [] { const char* e = getenv("DGG_X5_CUT"); return !e || atoi(e) != 0; }();   // diagnostics
+            if (!cut && !gemm_x5_usable(batch)) goto x3_path;
+            GemmBatch big, small;
+            big.nprob = small.nprob = 0;
+            big.total_blocks = small.total_blocks = 0;
+            for (int i = 0; i < batch.nprob; ++i) {
+                GemmBatch& dst = gemm_x5_prob_ok(batch.p[i]) ? big : small;
+                GemmProb& q = dst.p[dst.nprob++];
+                q = batch.p[i];
+                q.blk_begin = dst.total_blocks;
+                dst.total_blocks += q.tiles_m * q.tiles_n * (q.splits > 0 ? q.splits : 1);
+            }
+            if (big.nprob > 0) {
+                gemm_x5_dispatch(mode, big, st);
+                DGG_TRY_RC(check_launch("gemm_x5"));
+                if (small.nprob == 0) return DGG_OK;
+                gemm_x3_dispatch(mode, small, st);
+                return check_launch("gemm_x3");
+            }
         }
+    x3_path:
         gemm_x3_dispatch(mode, batch, st);
         return check_launch("gemm_x3");
     }

@@ -205,6 +205,8 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
             unsigned v;
             if constexpr (A_KC) { base = reinterpret_cast<const char*>(P.A + (size_t)k0); v = va[t]; }
             else { base = rowA + (size_t)t * strideA2; v = va[0]; }
+            asm volatile("" : "+v"(v));   // keeps the offset 32 bits wide: `uniform base + VGPR offset` is one address form of the
+                                          // load; hoisted out of the loop the compiler widens it to a 64-bit pair and adds per piece
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(base + v), (lds_f32*)(size_t)(dst + (unsigned)t * 1024u), 16, 0, 0);
         } else if constexpr (t < 2 * YNP) {
             constexpr int u = t - YNP;
@@ -212,6 +214,7 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
             unsigned v;
             if constexpr (B_KC) { base = reinterpret_cast<const char*>(P.B + (size_t)k0); v = vb[u]; }
             else { base = rowB + (size_t)u * strideB2; v = vb[0]; }
+            asm volatile("" : "+v"(v));
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(base + v), (lds_f32*)(size_t)(dst + YOP + (unsigned)u * 1024u), 16, 0, 0);
         } else if constexpr (AFF) {   // lanes 0-15: scale[k0 + lane], 16-31: shift[k0 + lane - 16]; lanes 32-63 repeat
             __builtin_amdgcn_global_load_lds(aff_src + (size_t)(k0 * aff_step), (lds_f32*)(size_t)(dst + YAFF), 4, 0, 0);
@@ -221,25 +224,39 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
     auto row_b = [&](int k0) { return reinterpret_cast<const char*>(P.B) + (B_KC ? (size_t)0 : (size_t)k0 * (size_t)P.ldb * 4u); };
     constexpr int NDMA = 2 * YNP + (AFF ? 1 : 0);
 
-    // ---- fragment reads: 8 consecutive k of one row of a 32-row block, lane = (row, k half)
-    unsigned rk[2];
+    // ---- fragment reads: 8 consecutive k of one row of a 32-row block, lane = (row, k half).
+    // Wave W owns quadrant (qa, qb) = (W >> 1, W & 1) of the output tile at the end.  So that its OWN quadrant always sits in
+    // the accumulators acc[0..1][0..1] — register names are compile-time, the wave number is not — it reads A block
+    // blk ^ 2 qa and B block blk ^ 2 qb where the schedule says blk: acc[a][b] holds output tile (a ^ 2 qa, b ^ 2 qb).
+    // The remap lives in the per-lane base addresses ("lo" serves the schedule's blocks 0, 1, "hi" the blocks 2, 3), the
+    // stage / operand / block offsets stay instruction immediates.
+    const int qa = wave >> 1, qb = wave & 1;
+    constexpr unsigned A_BLK = A_KC ? 2048u : 128u, B_BLK = B_KC ? 2048u : 128u;   // bytes from one 32-row block to the next
+    unsigned ra[2][2], rb[2][2];   // [lo / hi][16-byte half (k-contiguous operands only)]
 #pragma unroll
-    for (int e = 0; e < 2; ++e) rk[e] = (unsigned)r32 * 64u + (unsigned)(((2 * h + e) ^ ((r32 >> 2) & 3)) * 16);
-    const unsigned rs = (unsigned)h * (8u * 512u) + (unsigned)r32 * 4u;
+    for (int e = 0; e < 2; ++e) {
+        const unsigned lane_a = A_KC ? (unsigned)r32 * 64u + (unsigned)(((2 * h + e) ^ ((r32 >> 2) & 3)) * 16) : (unsigned)h * (8u * 512u) + (unsigned)r32 * 4u;
+        const unsigned lane_b = B_KC ? (unsigned)r32 * 64u + (unsigned)(((2 * h + e) ^ ((r32 >> 2) & 3)) * 16) : (unsigned)h * (8u * 512u) + (unsigned)r32 * 4u;
+        ra[0][e] = wl + lane_a + 2u * A_BLK * (unsigned)qa;
+        ra[1][e] = wl + lane_a + 2u * A_BLK * (unsigned)(1 - qa);
+        rb[0][e] = wl + YOP + lane_b + 2u * B_BLK * (unsigned)qb;
+        rb[1][e] = wl + YOP + lane_b + 2u * B_BLK * (unsigned)(1 - qb);
+    }
     auto read_frag = [&](auto fc, float (&dst)[8]) {
         constexpr FD f = fdec(decltype(fc)::value);
         constexpr bool KC = f.op == 0 ? A_KC : B_KC;
-        const unsigned base = wl + (unsigned)f.par * YSTAGE + (unsigned)f.op * YOP;
+        constexpr int hi = f.blk >> 1;
+        constexpr unsigned imm = (unsigned)f.par * YSTAGE + (unsigned)(f.blk & 1) * (KC ? 2048u : 128u);
         if constexpr (KC) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const f32x4 v = *(lds_f32x4*)(size_t)(base + (unsigned)f.blk * 2048u + rk[e]);
+                const f32x4 v = *(lds_f32x4*)(size_t)((f.op == 0 ? ra[hi][e] : rb[hi][e]) + imm);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) dst[4 * e + j] = v[j];
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dst[j] = *(lds_f32*)(size_t)(base + (unsigned)f.blk * 128u + (unsigned)j * 512u + rs);
+            for (int j = 0; j < 8; ++j) dst[j] = *(lds_f32*)(size_t)((f.op == 0 ? ra[hi][0] : rb[hi][0]) + imm + (unsigned)j * 512u);
         }
     };
     float aq[2][2][8];   // [parity of the k-step][scale / shift][this lane's 8 k]
@@ -461,8 +478,12 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
         zero_acc();
     }
 
-    // ---- the four partial blocks meet in LDS: two rounds (tile rows 0-1, then 2-3); in each, every wave parks its 8 tiles of
-    // those rows and the two waves that own the round's quadrants add up the four contributions in wave order.
+    // ---- the four partial blocks meet in LDS.  Wave W keeps its quadrant — acc[0..1][0..1], see read_frag — and needs the other
+    // three waves' partial sums of it; its accumulators acc[0..1][2..3], acc[2..3][0..1] and acc[2..3][2..3] are the
+    // quadrants of the waves W ^ 1, W ^ 2 and W ^ 3.  Round 1: the quadrants of W ^ 1 and W ^ 2 (8 tiles, 32 KB per wave:
+    // 128 KB), round 2: the quadrant of W ^ 3 (64 KB) — 192 KB through the LDS store path instead of the 256 KB of
+    // "everybody parks everything", and all four waves add in both rounds.  Order of the sum: ((own + W^1) + W^2) + W^3 —
+    // fixed per element: deterministic.
     f32x16 res[2][2];
 #if DGG_X5_STAMP
     stamp[3] = __builtin_amdgcn_s_memtime();
@@ -471,40 +492,51 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
 #if DGG_X5_STAMP
     stamp[4] = __builtin_amdgcn_s_memtime();
 #endif
-    static_for<2>([&](auto rc) {
-        constexpr int R = decltype(rc)::value;
-        static_for<8>([&](auto tc) {
-            constexpr int t8 = decltype(tc)::value;
-            constexpr int ta = t8 >> 2, b = t8 & 3;
-            constexpr int ql = b >> 1, t = ta * 2 + (b & 1);
+    auto slot = [&](int owner, int s, int t, int q4) {   // [owner][source slot][tile of the quadrant][register quad], lane-linear
+        return lds0 + (unsigned)((((owner * 2 + s) * 4 + t) * 4 + q4) * 1024) + (unsigned)lane * 16u;
+    };
+    auto send = [&](auto ac, auto bc, int owner, int s) {   // accumulators acc[A0 + 0..1][B0 + 0..1] to `owner`'s slot s
+        constexpr int A0 = decltype(ac)::value, B0 = decltype(bc)::value;
+        static_for<4>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const f32x16& v = acc[A0 + (t >> 1)][B0 + (t & 1)];
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const unsigned off = lds0 + (unsigned)((((wave * 2 + ql) * 4 + t) * 4 + q4) * 1024) + (unsigned)lane * 16u;
-                const f32x16& s = acc[2 * R + ta][b];
-                *(lds_f32x4*)(size_t)off = (f32x4){s[4 * q4], s[4 * q4 + 1], s[4 * q4 + 2], s[4 * q4 + 3]};
-            }
+            for (int q4 = 0; q4 < 4; ++q4)
+                *(lds_f32x4*)(size_t)slot(owner, s, t, q4) = (f32x4){v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]};
         });
-        __syncthreads();
-        if ((wave >> 1) == R) {
-            const int ql = wave & 1;
-            static_for<4>([&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                f32x4 v[4][4];   // all 16 reads of a tile in flight, then the sums (wave order: deterministic)
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I2 = std::integral_constant<int, 2>;
+    send(I0{}, I2{}, wave ^ 1, 0);   // the owner W ^ 1 finds its partner (W ^ 1) ^ 1 = W in slot 0 ...
+    send(I2{}, I0{}, wave ^ 2, 1);   // ... and the owner W ^ 2 its partner (W ^ 2) ^ 2 = W in slot 1
+    __syncthreads();
+    static_for<4>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        f32x4 v[2][4];
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4)
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int w = 0; w < 4; ++w)
-                        v[q4][w] = *(lds_f32x4*)(size_t)(lds0 + (unsigned)((((w * 2 + ql) * 4 + t) * 4 + q4) * 1024) + (unsigned)lane * 16u);
+            for (int q4 = 0; q4 < 4; ++q4) v[s2][q4] = *(lds_f32x4*)(size_t)slot(wave, s2, t, q4);
+        const f32x16& own = acc[t >> 1][t & 1];
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const f32x4 sm = ((v[q4][0] + v[q4][1]) + v[q4][2]) + v[q4][3];
+        for (int q4 = 0; q4 < 4; ++q4)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) res[t >> 1][t & 1][4 * q4 + j] = sm[j];
-                }
-            });
-        }
-        __syncthreads();
+            for (int j = 0; j < 4; ++j) res[t >> 1][t & 1][4 * q4 + j] = (own[4 * q4 + j] + v[0][q4][j]) + v[1][q4][j];
     });
+    __syncthreads();
+    send(I2{}, I2{}, wave ^ 3, 0);
+    __syncthreads();
+    static_for<4>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        f32x4 v[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) v[q4] = *(lds_f32x4*)(size_t)slot(wave, 0, t, q4);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) res[t >> 1][t & 1][4 * q4 + j] += v[q4][j];
+    });
+    __syncthreads();   // (the epilogue's scratch lies behind the slots; the next work item's ring does not)
 #if DGG_X5_STAMP
     stamp[5] = __builtin_amdgcn_s_memtime();
 #endif
@@ -544,21 +576,26 @@ extern "C" int dgg_x5_debug_stamps(unsigned long long* host_out, int nblocks) {
 }
 #endif
 
-// Every problem of the launch needs at least YMINK of K inside each split (a k-step moved back to the split's end must
-// stay inside the split) and fp32 operands.
-bool gemm_x5_usable(const GemmBatch& batch) {
+// A problem needs at least YMINK of K inside each split (a k-step moved back to the split's end must stay inside the
+// split) and fp32 operands.
+bool gemm_x5_enabled() {
     static const int on = [] { const char* e = getenv("DGG_X5"); return e ? atoi(e) : 1; }();
-    if (!on) return false;
-    for (int i = 0; i < batch.nprob; ++i) {
-        const GemmProb& p = batch.p[i];
-        if (p.a_plane || p.b_plane) return false;
-        if (p.K < x5::YMINK) return false;
-        if (p.splits > 0) {
-            if (p.kchunk < x5::YMINK) return false;
-            const int lastk = p.K - (p.splits - 1) * p.kchunk;   // the last split's share
-            if (lastk < x5::YK) return false;
-        }
+    return on != 0;
+}
+bool gemm_x5_prob_ok(const GemmProb& p) {
+    if (p.a_plane || p.b_plane) return false;
+    if (p.K < x5::YMINK) return false;
+    if (p.splits > 0) {
+        if (p.kchunk < x5::YMINK) return false;
+        const int lastk = p.K - (p.splits - 1) * p.kchunk;   // the last split's share
+        if (lastk < x5::YK) return false;
     }
+    return true;
+}
+bool gemm_x5_usable(const GemmBatch& batch) {
+    if (!gemm_x5_enabled()) return false;
+    for (int i = 0; i < batch.nprob; ++i)
+        if (!gemm_x5_prob_ok(batch.p[i])) return false;
     return true;
 }
 
