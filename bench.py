@@ -63,7 +63,7 @@ def _time_stream(fn, iters, warm=3):
 def _pmc_traffic(name, shape):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction +
     WRITE_SIZE; separate passes, see profiles/): PMC counters cannot be read from inside a run."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05",):   # (rounds 1-4 profiled other kernels: gemm_x3_kernel, deleted in round 5)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, name))))
             if pmc.get("shape") == shape:
@@ -100,47 +100,17 @@ def gemm_roofline(dev, mode, M, N, K, lda, ldb, splits, what, pmc_name, iters=20
     ms = _time_stream(launch, iters)
     flops = 2.0 * M * N * K
     achieved = flops / (ms * 1e-3) / 1e12
-    peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if algo in (1, 2) else PEAK_BF16_MFMA_TFLOPS if algo == 3 else PEAK_F32_MFMA_TFLOPS
+    peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if algo == 1 else PEAK_BF16_MFMA_TFLOPS if algo == 3 else PEAK_F32_MFMA_TFLOPS
     shape = {"M": M, "N": N, "K": K, "splits": splits}
     traffic, src = _pmc_traffic(pmc_name, shape)
     alg_bytes = 4 * (M * K + N * K + max(splits, 1) * M * N)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": src,
             "algorithmic_bytes": alg_bytes, "kernel": what, "shape": shape,
-            "peak_basis": ("dense bf16 MFMA 2500 TFLOP/s / 6 products" if algo in (1, 2) else
+            "peak_basis": ("dense bf16 MFMA 2500 TFLOP/s / 6 products" if algo == 1 else
                            "dense bf16 MFMA 2500 TFLOP/s (plain bf16: one product)" if algo == 3 else "dense f32 MFMA"),
             "f32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "ms_per_launch": round(ms, 4)}
-
-
-def planes_roofline(dev, M, N, K, splits, what, pmc_name, iters=20):
-    """The batched BPS product of the OPTIONAL planes path (DGG_GEMM_ALGO=planes, csrc/gemm_p4.hip): all ResBlocks' fused
-    fc1 || fc3 products over the shared x_hat block in one launch, operands pre-split into bf16 planes by their producers
-    — the GEMM kernel alone (the planes are made once, outside the timed launches)."""
-    g = torch.Generator().manual_seed(0)
-    A = torch.randn((M, K), generator=g).to(dev)
-    W = torch.randn((N, K), generator=g).to(dev)
-    lib = _lib.lib()
-    nws = int(lib.dgg_gemm_planes_workspace_bytes(M, N, K))
-    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-    slabs = torch.empty((splits * M * N,), device=dev)
-    st = torch.cuda.current_stream()
-    sp = C.c_void_p(st.cuda_stream)
-    _lib.check(lib.dgg_gemm_planes(0, 0, M, N, K, _lib.ptr(A), K, _lib.ptr(W), K, None, N, splits, _lib.ptr(slabs), 0,
-                                   _lib.ptr(ws), nws, sp))
-    fn = lambda: _lib.check(lib.dgg_gemm_planes(0, 0, M, N, K, None, K, None, K, None, N, splits, _lib.ptr(slabs), 0,
-                                                _lib.ptr(ws), nws, sp))
-    ms = _time_stream(fn, iters)
-    achieved = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-    peak = PEAK_BF16_MFMA_TFLOPS / 6.0
-    shape = {"M": M, "N": N, "K": K, "splits": splits}
-    traffic, src = _pmc_traffic(pmc_name, shape)
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": src,
-            "algorithmic_bytes": 6 * (M * K + N * K) + 4 * splits * M * N, "kernel": what, "shape": shape,
-            "peak_basis": "dense bf16 MFMA 2500 TFLOP/s / 6 products", "ms_per_launch": round(ms, 4),
-            "in_default_step": False,
-            "note": "optional path: faster kernel, slower step (1.93 vs 1.74 ms) — DESIGN.md 3.1"}
 
 
 def bps_roofline(dev, B=1024, Np=2048, iters=10):
@@ -349,7 +319,7 @@ def sub_results(cfg, dev, eng):
         _lib.check(lib_.dgg_set_gemm_algo(3))
         dt16 = wall(eva, 40)
         nt16 = gemm_roofline(dev, 0, b, 768, 4120, 4120, 4632, 4, "forward of fc1||fc3 (NT), plain bf16: a13[%d,768] = "
-                             "X0[%d,4120] W13[768,4120]^T, split-K 4 (DGG_GEMM_BF16)" % (b, b), "gemm_x3_bf16")
+                             "X0[%d,4120] W13[768,4120]^T, split-K 4 (DGG_GEMM_BF16)" % (b, b), "gemm_x5_bf16")
     finally:
         _lib.check(lib_.dgg_set_gemm_algo(algo0))
     out["config3_eva_step_b1024_bf16"] = {"ms_per_step": round(dt16 * 1e3, 4), "grasps_per_s": round(b / dt16, 1),
@@ -594,19 +564,15 @@ def main():
         # dominant kernel of the step: the weight gradient of a ResBlock's fused fc1||fc3 layer,
         # dW13[768, 4120] = dY13[1024, 768]^T X0[1024, 4120] (TN); the forward of the same layer (NT, split-K 4) next
         tn = gemm_roofline(dev, 2, 768, 4120, B, 768, 4120, 0,
-                           "weight gradient of fc1||fc3 (TN): dW13[768,4120] = dY13[%d,768]^T X0[%d,4120]" % (B, B),
-                           "gemm_x3_tn")
+                           "gemm_x5_kernel, weight gradient of fc1||fc3 (TN): dW13[768,4120] = dY13[%d,768]^T X0[%d,4120]" % (B, B),
+                           "gemm_x5_tn")
         nt = gemm_roofline(dev, 0, B, 768, 4120, 4120, 4632, 4,
-                           "forward of fc1||fc3 (NT): a13[%d,768] = X0[%d,4120] W13[768,4120]^T, split-K 4" % (B, B),
-                           "gemm_x3")
+                           "gemm_x5_kernel, forward of fc1||fc3 (NT): a13[%d,768] = X0[%d,4120] W13[768,4120]^T, split-K 4" % (B, B),
+                           "gemm_x5")
         res["roofline"] = tn
         res["roofline_kernels"] = {"gemm_wgrad_tn": tn, "gemm_forward_nt": nt, "bps_encode": bps_roofline(dev),
                                    "bps_encode_one_cloud": bps_one_cloud(dev),
-                                   "adam": adam_roofline(dev),
-                                   "optional_planes_batched_forward": planes_roofline(
-                                       dev, B, 3072, 4096, 4, "gemm_p4_kernel: [G | D] BPS products of all ResBlocks, "
-                                       "x_hat[%d,4096] x W'[3072,4096]^T, split-K 4 (DGG_GEMM_ALGO=planes)" % B,
-                                       "gemm_p4_batched_gd")}
+                                   "adam": adam_roofline(dev)}
         # what the hardware-queue probe behind the engine's side streams found (parallel.pick_side_streams): a fallback to
         # plain streams costs 15-20 % and would otherwise go unnoticed
         res["side_streams"] = dict(parallel.pick_report) if parallel.pick_report else {"mode": "not created"}

@@ -123,8 +123,6 @@ SIGNATURES = {
     "dgg_gemm_f32": (_I, [_I, _I, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _VP, _I, _VP]),
     "dgg_set_grad_events": (_I, [_VP, _VP, _I, _I]),
     "dgg_set_side_work": (_I, [_I]),
-    "dgg_gemm_planes_workspace_bytes": (_SZ, [_I, _I, _I]),
-    "dgg_gemm_planes": (_I, [_I, _I, _I, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _VP, _I, _VP, _SZ, _VP]),
 }
 
 

@@ -8,9 +8,6 @@ X3FLAGS="-fno-slp-vectorize"  # packed-f32 VALU beside MFMAs costs more than two
 mkdir -p _obj
 pids=""
 $HIPCC $COMMON -c gemm_f32.hip -o _obj/gemm_f32.o & pids="$pids $!"
-$HIPCC $COMMON $X3FLAGS -c gemm_x3.hip -o _obj/gemm_x3.o & pids="$pids $!"
-$HIPCC $COMMON -c gemm_p3.hip -o _obj/gemm_p3.o & pids="$pids $!"
-$HIPCC $COMMON -c gemm_p4.hip -o _obj/gemm_p4.o & pids="$pids $!"
 $HIPCC $COMMON $X3FLAGS -c gemm_x4.hip -o _obj/gemm_x4.o & pids="$pids $!"
 $HIPCC $COMMON $X3FLAGS -c gemm_x5.hip -o _obj/gemm_x5.o & pids="$pids $!"
 $HIPCC $COMMON -c elementwise.hip -o _obj/elementwise.o & pids="$pids $!"
@@ -20,5 +17,5 @@ $HIPCC $COMMON -c second_order.hip -o _obj/second_order.o & pids="$pids $!"
 $HIPCC $COMMON -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -c bps_encode.hip -o _obj/bps_encode.o & pids="$pids $!"
 $HIPCC $COMMON -c dgg_api.hip -o _obj/dgg_api.o & pids="$pids $!"
 for p in $pids; do wait $p || { echo "build.sh: a compile failed" >&2; exit 1; }; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libdgg.so _obj/gemm_f32.o _obj/gemm_x3.o _obj/gemm_p3.o _obj/gemm_p4.o _obj/gemm_x4.o _obj/gemm_x5.o _obj/elementwise.o _obj/second_order.o _obj/bps_encode.o _obj/dgg_api.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libdgg.so _obj/gemm_f32.o _obj/gemm_x4.o _obj/gemm_x5.o _obj/elementwise.o _obj/second_order.o _obj/bps_encode.o _obj/dgg_api.o
 echo "built $(cd .. && pwd)/libdgg.so"

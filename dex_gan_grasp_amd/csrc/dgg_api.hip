@@ -267,19 +267,8 @@ struct NetW {
     float* dYs[3];               // dY13 of this pass + dY13 of the discriminator's other pass (Share::bwd_mode 2)
     float *slabs_w;              // split-K slabs of the fc2 weight gradient
     int64_t slab_floats;
-    // bf16 planes of the large GEMMs' operands (gemm_p4.hip), carved for train-sized batches only (p3).  Only the BPS
-    // block of the input — in_bps of the k0 columns, the same for every ResBlock of the net — runs on planes:
-    bool p3;
-    int ldB;                     // round64(B): pitch of the transposed planes
-    __bf16 *Xb, *Xbt;            // x_hat of the BPS block: [3][B][in_bps] (forward), [3][in_bps][ldB] transposed (wgrad)
-    __bf16 *Wb;                  // [3][n13 * nrb][in_bps]: gamma[k] * W13[n][BPS column k] of all ResBlocks, stacked
-    float* cbias;                // [n13 * nrb]: b13[n] + sum_k beta[k] W13[n][BPS column k] (what the folded affine adds)
-    float* xslabs;               // [xsplits][B][n13 * nrb]: the BPS products of all ResBlocks, ONE launch per pass
-    int xsplits;
-    __bf16 *dYt[3];              // dY13 transposed: [3][n13][ldB]
     size_t bytes;
 };
-static const int kP3MaxB = 8192;   // larger batches (inference sweeps) never train: no planes carved for them
 static bool share_wgrad() {  // diagnostics: DGG_SHARE_WGRAD=0: both passes of D form their own BPS weight gradient
     static const bool v = [] { const char* e = getenv("DGG_SHARE_WGRAD"); return !(e && e[0] == '0'); }();
     return v;
@@ -292,25 +281,6 @@ static bool fuse_fc2() {  // diagnostics: DGG_FUSE_FC2=0 keeps bn_act / fc2 GEMM
     static const bool v = [] { const char* e = getenv("DGG_FUSE_FC2"); return !(e && e[0] == '0'); }();
     return v;
 }
-// Split-K of the batched BPS product (M = B, N = n13 * nrb, K = in_bps; 128 x 128 tiles, one workgroup per CU): the
-// fewest splits that fill >= 90 % of the last round of 256 workgroups with at least 8 k-tiles each
-static int plan_xsplits(int B, int N, int K) {
-    const long tiles = (long)((B + 127) / 128) * ((N + 127) / 128);
-    const int kt = (K + 31) / 32;
-    int best = 1;
-    double best_eff = 0.0;
-    for (int s = 1; s <= 16 && kt / s >= 8; ++s) {
-        const int per = (kt + s - 1) / s;
-        const int used = (kt + per - 1) / per;
-        if (used != s) continue;
-        const long wg = tiles * s;
-        const double eff = (double)wg / (double)(((wg + 255) / 256) * 256);
-        if (eff > best_eff + 0.03) { best_eff = eff; best = s; }
-        if (best_eff >= 0.9) break;
-    }
-    return best;
-}
-
 struct Bump {
     char* base;
     size_t off;
@@ -427,19 +397,6 @@ static void carve(const NetL& L, int B, void* base, NetW& W) {
     W.dX0 = b.take<float>(Bz * L.ldx0);
     W.dXa = b.take<float>(Bz * L.nn);
     W.dXb = b.take<float>(Bz * L.nn);
-    W.p3 = B <= kP3MaxB && B >= 2 && L.net != kNetResBlock && L.in_bps >= 1024 && (L.in_bps % 64) == 0;
-    W.ldB = (int)round64(B);
-    W.xsplits = 0;
-    if (W.p3) {
-        const size_t nall = (size_t)L.n13 * L.nrb;
-        W.Xb = b.take<__bf16>(3 * Bz * L.in_bps);
-        W.Xbt = b.take<__bf16>(3 * (size_t)L.in_bps * W.ldB);
-        W.Wb = b.take<__bf16>(3 * nall * L.in_bps);
-        W.cbias = b.take<float>(nall);
-        W.xsplits = plan_xsplits(B, (int)nall, L.in_bps);
-        W.xslabs = b.take<float>((size_t)W.xsplits * Bz * nall);
-        for (int r = 0; r < L.nrb; ++r) W.dYt[r] = b.take<__bf16>(3 * (size_t)L.n13 * W.ldB);
-    }
     W.bytes = (b.off + 255) & ~(size_t)255;
 }
 
@@ -531,14 +488,6 @@ struct Share {
     int bwd_mode;
     const float* dY13_other[3];
     const float* cs13_other[3];
-    // Planes mode (NetW::p3): the producer's ONE batched BPS product of all ResBlocks [xnslab][B][n13 * nrb] and its
-    // combined bias (the folded BatchNorm shift), `xready` recorded behind the launch; and, for the fake pass' shared
-    // weight gradient, the producer's transposed x_hat planes
-    const float* xslabs;
-    const float* xcbias;
-    int xnslab;
-    hipEvent_t xready;
-    const __bf16* xbt;
 };
 static const int kShareSlabs = 16;  // plan13 never gives one piece more
 
@@ -557,16 +506,6 @@ struct Ctx {
     // the next rb_backward's first stage instead of the `dy` it is given)
     int dy_nslab = 0;
     long long dy_stride = 0;
-    bool p3 = false;      // this pass runs the BPS block's GEMMs on pre-split planes (train pass, planes carved, algorithm 2)
-    bool p3_fwd = false;  // forward: ... and forms the batched BPS product itself (a D fake pass consumes the real pass')
-    bool p3_t = false;    // forward: a weight-gradient pass follows — emit the transposed planes of x_hat
-    // forward, planes mode: the batched BPS products to add to every block's pre-activations, and the bias that goes
-    // with them (NetW::cbias of this pass or of the Share's producer)
-    const float* xs = nullptr;
-    const float* xcbias = nullptr;
-    int xs_n = 0;
-    // backward, planes mode: transposed x_hat planes of the BPS block (this pass' or the Share producer's)
-    const __bf16* xbt = nullptr;
 };
 
 static int rb_tail(Ctx& c, int r, int drop_mode, const float* keep_in, uint64_t seed, uint64_t seed_off);
@@ -584,14 +523,8 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
     Piece pc[4];
     int np = 0;
     Share* sh = c.share;
-    const bool planes = c.xs != nullptr;   // the BPS block's product of this block comes out of the pass' batched launch
     for (int i = 0; i < nseg; ++i) {
-        if (planes && segs[i].is_x0) {      // only what lies around the BPS block: the prefix / the pose columns
-            const int lo = L.nprefix, hi = L.nprefix + L.in_bps;
-            if (lo > 0) pc[np++] = Piece{segs[i].p, segs[i].ld, lo, segs[i].wcol, 0, true, false};
-            if (hi < segs[i].width)
-                pc[np++] = Piece{segs[i].p + hi, segs[i].ld, segs[i].width - hi, segs[i].wcol + hi, hi, true, false};
-        } else if (sh && segs[i].is_x0 && L.nprefix == 0 && sh->ncols > 0 && sh->ncols < segs[i].width) {
+        if (sh && segs[i].is_x0 && L.nprefix == 0 && sh->ncols > 0 && sh->ncols < segs[i].width) {
             pc[np++] = Piece{segs[i].p, segs[i].ld, sh->ncols, segs[i].wcol, 0, true, true};
             pc[np++] = Piece{segs[i].p + sh->ncols, segs[i].ld, segs[i].width - sh->ncols, segs[i].wcol + sh->ncols,
                              sh->ncols, true, false};
@@ -629,18 +562,10 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
     gb.nprob = nq;
     if ((int64_t)nslab * slab > c.W.slab_floats) return DGG_ERR_WORKSPACE;
     if (nq > 0) DGG_TRY(gemm_launch(GEMM_NT, gb, c.st));
-    const bool shared_here = sh && !planes && np > nseg;
+    const bool shared_here = sh && np > nseg;
     if (shared_here && sh->events) {
         if (sh->mode == 1 && hipEventRecord(sh->ready[r], c.st) != hipSuccess) return DGG_ERR_LAUNCH;
         if (sh->mode == 2 && hipStreamWaitEvent(c.st, sh->ready[r], 0) != hipSuccess) return DGG_ERR_LAUNCH;
-    }
-    if (planes) {
-        // 2. batched BPS slabs (pitch n13 * nrb, this block's columns) + the pieces above + the combined bias
-        const int nall = L.n13 * L.nrb;
-        DGG_TRY(reduce_bias_launch(c.xs + (size_t)r * L.n13, c.xs_n, (long long)B * nall, nall, c.xcbias + (size_t)r * L.n13,
-                                   A.a13, L.n13, B, B, 1, L.n13, 0, L.hid, L.hid, L.n13, c.W.part, c.st, 0,
-                                   nslab > 0 ? c.W.slabs : nullptr, nslab, slab, L.n13));
-        return rb_tail(c, r, drop_mode, keep_in, seed, seed_off);
     }
     // 2. sum slabs (k order: shared BPS chunks first) + bias; a1 -> statistics, a3 -> s = lrelu(a3)
     if (shared_here)
@@ -750,23 +675,16 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     const Share* sh = c.share;
     const bool share_ok = sh && sh->bwd_mode && !skip_param && L.nprefix == 0 && sh->ncols > 0 && sh->ncols < L.k0;
     const bool share_r = share_ok && sh->bwd_mode == 1, share_f = share_ok && sh->bwd_mode == 2;
-    // planes GEMM for the BPS block's weight gradient: dY13 goes out transposed as well ([n13][B]: rows 0 .. hid-1 from
-    // stage 4, the rest from stage 1) — as the SUM with the other pass' dY13 in the fake pass of a shared gradient; the
-    // real pass of one forms no BPS weight gradient and needs no planes
-    const bool use_p3 = c.p3 && !skip_param && L.net != kNetResBlock;
-    const bool dyt = use_p3 && !share_r;
-    const PlaneOut plt1 = {nullptr, 0, 0, 0, dyt ? c.W.dYt[r] : nullptr, c.W.ldB, 0, (long long)L.n13 * c.W.ldB, 0, 0};
-    const PlaneOut plt3 = {nullptr, 0, 0, 0, dyt ? c.W.dYt[r] : nullptr, c.W.ldB, L.hid, (long long)L.n13 * c.W.ldB, 0, 0};
-    // (x3 mode keeps the fp32 sum dYs for the in-register-split kernel; planes mode only the planes of the sum)
-    const SumOut so1 = {share_f ? sh->dY13_other[r] : nullptr, (share_f && !use_p3) ? c.W.dYs[r] : nullptr, L.n13};
-    const SumOut so3 = {share_f ? sh->dY13_other[r] + L.hid : nullptr, (share_f && !use_p3) ? c.W.dYs[r] + L.hid : nullptr,
+    // the fake pass of a shared gradient also writes dY13 + the other pass' dY13 (the shared weight gradient's operand)
+    const SumOut so1 = {share_f ? sh->dY13_other[r] : nullptr, share_f ? c.W.dYs[r] : nullptr, L.n13};
+    const SumOut so3 = {share_f ? sh->dY13_other[r] + L.hid : nullptr, share_f ? c.W.dYs[r] + L.hid : nullptr,
                         L.n13};
     const bool dy_slabs = !hb && c.dy_nslab > 1;
     DGG_TRY(res_out_bwd_launch(hb ? nullptr : (dy_slabs ? c.W.slabs : dy), L.nn, A.y, L.nn,
                                had_dropout ? A.keep : nullptr, A.a13 + L.hid, L.n13, A.a2, L.nn, A.mean2, A.rstd2, B, B,
                                L.nn, c.W.dpre, dY13 + L.hid, L.n13, c.W.part, c.st, hb ? hb->d_score : nullptr,
                                hb ? hb->w : nullptr, nq1, dy_slabs ? c.dy_nslab : 0, c.dy_stride,
-                               dyt ? &plt3 : nullptr, share_f ? &so3 : nullptr));
+                               share_f ? &so3 : nullptr));
     c.dy_nslab = 0;
     // fc1.bias / fc2.bias feed a train-mode BatchNorm: their gradient is EXACTLY zero (the batch-mean subtraction
     // removes any per-column constant; the reference stores fp32 rounding noise there) — cleared by this launch
@@ -804,8 +722,7 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     {
         ColFin fin = {c.W.part, 2, {gp(R.bn1b), gp(R.bn1w), nullptr, nullptr, nullptr}, acc, nullptr, nullptr, nullptr, 0, 0};
         DGG_TRY(bn_bwd_apply_launch(c.W.dh, L.hid, A.a13, L.n13, A.mean1, A.rstd1, c.P + R.bn1w, nullptr, c.train, B, B,
-                                    L.hid, dY13, L.n13, c.W.part2, c.st, &fin, dyt ? &plt1 : nullptr,
-                                    share_f ? &so1 : nullptr));
+                                    L.hid, dY13, L.n13, c.W.part2, c.st, &fin, share_f ? &so1 : nullptr));
     }
     // fc1.bias: same argument as fc2.bias above; in eval mode the real column sum is also kept in cs13[0:hid]
     // for the BatchNorm-aware wgrad epilogue (train mode: exactly zero -> ep_cs0 = NULL)
@@ -826,10 +743,7 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     }
     // fc2: dW2 = da2^T h (512 x 256, K = B).  It rides along as one more problem of the [fc1;fc3] weight-gradient launch
     // below — 8 tiles beside ~200, written (or accumulated) in place — unless that launch is full.
-    const int bps_lo = L.nprefix, bps_hi = L.nprefix + L.in_bps;   // the BPS block inside the [prefix | x_hat] segment
     int nx0 = share_f ? 2 : 1;           // problems the [prefix | x_hat] segment takes in the fp32 launch
-    if (use_p3) nx0 = (bps_lo > 0 ? 1 : 0) + (bps_hi < L.k0 ? 1 : 0);
-    if (use_p3 && !share_r) ++nx0;      // ... plus the BPS block's own problem on planes
     const bool fc2_rides = !skip_param && (nseg - 1 + nx0) + (hr ? 1 : 0) < kMaxProb;
     if (!skip_param && !fc2_rides) {  // separate: split-K slabs + reduce
         GemmBatch g;
@@ -869,24 +783,7 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
             if (sg.is_x0) ep_x0(q, sg.wcol, lo, cs1b);
         };
         for (int i = 0; i < nseg; ++i) {
-            if (segs[i].is_x0 && use_p3) {
-                // planes mode: the BPS block as one problem on planes — dW13[n][k] = sum_b dY13[b][n] x_hat[b][k] over the
-                // transposed planes dY13^T [n13][B], x_hat^T [in_bps][B] ("NT"), BatchNorm-aware epilogue; the fake pass of a
-                // shared gradient multiplies dY_real + dY_fake and OVERWRITES (the real pass wrote nothing there) —, what
-                // lies around it as fp32 riders of the same launch
-                if (!share_r) {
-                    if (!c.xbt) return DGG_ERR_INVALID;
-                    GemmProb& q = g.p[np++];
-                    prob_init(q, reinterpret_cast<const float*>(c.W.dYt[r]), c.W.ldB, reinterpret_cast<const float*>(c.xbt),
-                              c.W.ldB, G + R.w13 + segs[i].wcol + bps_lo, R.fin, L.n13, L.in_bps, (B + 31) / 32 * 32);
-                    q.a_plane = (long long)L.n13 * c.W.ldB;
-                    q.b_plane = (long long)L.in_bps * c.W.ldB;
-                    q.accumulate = share_f ? 0 : acc;
-                    ep_x0(q, segs[i].wcol, bps_lo, share_f ? sh->cs13_other[r] + L.hid : nullptr);
-                }
-                if (bps_lo > 0) add(segs[i], 0, bps_lo, dY13, acc, nullptr);
-                if (bps_hi < segs[i].width) add(segs[i], bps_hi, segs[i].width, dY13, acc, nullptr);
-            } else if (segs[i].is_x0 && share_r) {     // real pass: the pose columns only
+            if (segs[i].is_x0 && share_r) {     // real pass: the pose columns only
                 add(segs[i], sh->ncols, segs[i].width, dY13, acc, nullptr);
             } else if (segs[i].is_x0 && share_f) {     // fake pass: BPS columns on dY_real + dY_fake, pose columns on its own
                 add(segs[i], 0, sh->ncols, c.W.dYs[r], 0, sh->cs13_other[r] + L.hid);
@@ -908,16 +805,13 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
         }
         g.nprob = np;
         if (np > 0) {
-            // the tile shape gemm_launch will pick (the problem with the most work decides; 128 x 128 with a planes
-            // problem): the row-tile count of the epilogue's per-tile partials
+            // the tile shape gemm_launch will pick (the problem with the most work decides): the row-tile count of the
+            // epilogue's per-tile partials
             int big = 0;
-            bool planes = false;
-            for (int i = 0; i < np; ++i) planes = planes || g.p[i].a_plane != 0;
             for (int i = 1; i < np; ++i)
                 if ((double)g.p[i].M * g.p[i].N * g.p[i].K > (double)g.p[big].M * g.p[big].N * g.p[big].K) big = i;
             int bm, bn;
             gemm_tile_shape(GEMM_TN, g.p[big].M, g.p[big].N, bm, bn, g.p[big].K);
-            if (planes) bm = 128;
             ibn_tiles[r] = (L.n13 + bm - 1) / bm;
             if (ibn_tiles[r] > 12 || (!has_x0 && L.net != kNetResBlock)) return DGG_ERR_INVALID;
             DGG_TRY(gemm_launch(GEMM_TN, g, sw));
@@ -987,18 +881,7 @@ static int net_forward(const NetL& L, const float* params, float* bn, void* ws, 
     carve(L, B, ws, c.W);
     if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
     if (!bn) return DGG_ERR_INVALID;
-    // Train pass on the planes GEMM (gemm_p4.hip): the BPS block of the input — in_bps of the k0 columns, the same
-    // operand for every ResBlock — is split into bf16 planes where it is produced (ibn_apply: x_hat row-major for the
-    // forward, transposed for the weight gradient), the matching columns of every block's W13 go out as planes with the
-    // BatchNorm scale folded in (gamma[k] W[n][k]; the shift becomes a bias, NetW::cbias), and ONE launch forms the BPS
-    // products of all ResBlocks of the pass ahead of the block chain.  A fake-batch pass of a D phase (share mode 2)
-    // takes the real pass' products instead: same BPS rows, same batch statistics, same parameters.
-    c.p3 = c.train && c.W.p3 && gemm_algo() == 2;
-    const bool consumer = share && share->mode == 2;
-    c.p3_fwd = c.p3 && !consumer;
-    c.p3_t = c.p3 && !consumer && !(flags & DGG_SKIP_PARAM_GRADS);
-    // (input-norm reuse needs this workspace's planes: a consumer pass left none)
-    const bool reuse_norm = c.train && (flags & DGG_REUSE_INPUT_NORM) != 0 && !c.p3;
+    const bool reuse_norm = c.train && (flags & DGG_REUSE_INPUT_NORM) != 0;
     if (c.train && !reuse_norm) DGG_TRY(ibn_stats_launch(srcs, B, 1, c.W.part, st));
     if (reuse_norm) {
         // x_hat, mean and rstd of this workspace are those of the previous train forward over these inputs
@@ -1006,61 +889,8 @@ static int net_forward(const NetL& L, const float* params, float* bn, void* ws, 
                                    c.W.aff_scale, c.W.aff_shift, L.nprefix, L.k_in, st));
     } else {
         BnFused fz{c.W.part, c.train ? 1 : 0, bn + L.irm, bn + L.irv, c.W.imean, c.W.irstd, c.W.ivaru};
-        PlaneOut pl = {c.p3_fwd ? c.W.Xb : nullptr, L.in_bps, 0, (long long)B * L.in_bps,
-                       c.p3_t ? c.W.Xbt : nullptr, c.W.ldB, 0, (long long)L.in_bps * c.W.ldB, L.nprefix, L.in_bps};
         DGG_TRY(ibn_apply_launch(srcs, B, B, c.W.imean, c.W.irstd, nullptr, nullptr, prefix, L.nprefix, c.W.X0, L.ldx0,
-                                 params + L.ibnw, params + L.ibnb, c.W.aff_scale, c.W.aff_shift, st, &fz,
-                                 (c.p3_fwd || c.p3_t) ? &pl : nullptr));
-    }
-    if (c.p3_fwd) {
-        const int nall = L.n13 * L.nrb;
-        PlanesJobs jobs;
-        jobs.n = 0;
-        RowDotJobs rd;
-        rd.n = 0;
-        for (int r = 0; r < L.nrb; ++r) {
-            Seg segs[2];
-            int nseg;
-            make_segs(L, c.W, r, segs, nseg);
-            for (int i = 0; i < nseg; ++i) {
-                if (!segs[i].is_x0) continue;
-                const float* wb = params + L.rb[r].w13 + segs[i].wcol + L.nprefix;   // W13[:, first BPS column]
-                // (the BatchNorm's BPS columns are its first in_bps: the concat starts with bps in every network)
-                DGG_TRY(planes_add(jobs, wb, L.rb[r].fin, L.n13, L.in_bps, params + L.ibnw, nullptr,
-                                   c.W.Wb + (size_t)r * L.n13 * L.in_bps, L.in_bps, (long long)nall * L.in_bps, nullptr, 0, 0));
-                DGG_TRY(rowdot_add(rd, wb, L.rb[r].fin, L.n13, L.in_bps, params + L.ibnb, params + L.rb[r].b13,
-                                   c.W.cbias + (size_t)r * L.n13));
-            }
-        }
-        DGG_TRY(planes_run(jobs, st));
-        DGG_TRY(rowdot_run(rd, st));
-        GemmBatch gb;
-        memset(&gb, 0, sizeof(gb));
-        gb.nprob = 1;
-        GemmProb& q = gb.p[0];
-        prob_init(q, reinterpret_cast<const float*>(c.W.Xb), L.in_bps, reinterpret_cast<const float*>(c.W.Wb), L.in_bps,
-                  c.W.xslabs, nall, B, nall, L.in_bps);
-        q.a_plane = (long long)B * L.in_bps;
-        q.b_plane = (long long)nall * L.in_bps;
-        prob_split(q, c.W.xsplits, (long long)B * nall);
-        if (q.splits != c.W.xsplits) return DGG_ERR_INVALID;
-        DGG_TRY(gemm_planes_launch(gb, false, st));
-        c.xs = c.W.xslabs;
-        c.xs_n = q.splits;
-        c.xcbias = c.W.cbias;
-        if (share && share->mode == 1) {
-            share->xslabs = c.W.xslabs;
-            share->xnslab = q.splits;
-            share->xcbias = c.W.cbias;
-            share->xbt = c.W.Xbt;
-            if (share->events && hipEventRecord(share->xready, st) != hipSuccess) return DGG_ERR_LAUNCH;
-        }
-    } else if (c.p3 && consumer) {
-        if (!share->xslabs || !share->xcbias) return DGG_ERR_INVALID;
-        c.xs = share->xslabs;
-        c.xs_n = share->xnslab;
-        c.xcbias = share->xcbias;
-        if (share->events && hipStreamWaitEvent(st, share->xready, 0) != hipSuccess) return DGG_ERR_LAUNCH;
+                                 params + L.ibnw, params + L.ibnb, c.W.aff_scale, c.W.aff_shift, st, &fz));
     }
     const bool drop = (L.net == DGG_NET_EVA) && c.train;
     for (int r = 0; r < L.nrb; ++r) {
@@ -1114,9 +944,6 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     if (c.sw == st) c.sw = nullptr;
     carve(L, B, ws, c.W);
     if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
-    // the forward left x_hat^T planes of the BPS block (this pass', or — fake pass of a shared D gradient — the real pass')
-    c.p3 = c.train && c.W.p3 && gemm_algo() == 2 && !skip;
-    c.xbt = (share && share->mode == 2) ? share->xbt : c.W.Xbt;
     const bool want_in = d_in && d_in_hi > d_in_lo;
     // columns of X0 whose gradient is needed: only those for which the caller wants INPUT gradients —
     // the input BatchNorm's parameter gradients come out of the wgrad epilogue
@@ -1415,8 +1242,7 @@ static int objects_forward(const NetL& L, const float* params, float* bn, void* 
         {
             BnFused fz{c.W.part, 0, bn + R.rm2, bn + R.rv2, A.mean2, A.rstd2};
             DGG_TRY(res_out_launch(A.a13 + L.hid, L.n13, A.a2, L.nn, B, B, L.nn, A.mean2, A.rstd2, params + R.bn2w,
-                                   params + R.bn2b, 0, nullptr, 0, 0, nullptr, A.y, L.nn, st, &fz, nullptr,
-                                   params + R.b2));
+                                   params + R.bn2b, 0, nullptr, 0, 0, nullptr, A.y, L.nn, st, &fz, params + R.b2));
         }
     }
     const int sig = L.net != DGG_NET_GEN;
@@ -1746,7 +1572,7 @@ struct PendingReal {
     float* d_bn;            // its running statistics (advanced by the pass) and their state before it
     const float* bn_snap;
     int nbn;
-    hipEvent_t ev[7];     // fwd_done, bwd_done, 3 x share.ready, D-free, share.xready; created with the slot
+    hipEvent_t ev[7];     // fwd_done, bwd_done, 3 x share.ready, D-free, (one spare); created with the slot
     bool events_ok, dfree_set;
     Share share;
     unsigned long long stamp;
@@ -1827,7 +1653,6 @@ int dgg_cgan_d_real_prefetch(const dgg_cfg* cfg, const dgg_gan_state* s, const d
         P.share.slabs[r] = S.dshare[r];
         P.share.ready[r] = P.ev[2 + r];
     }
-    P.share.xready = P.ev[6];
     P.valid = false;
     // the pass advances D's running statistics one batch early: keep what they were, so that a pass that is not picked
     // up (another batch follows, a serial entry point, a checkpoint: dgg_cgan_drop_prefetch) leaves no trace
@@ -1887,7 +1712,6 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
             share.slabs[r] = S.dshare[r];
             if (fork && !(share.ready[r] = next_event())) return DGG_ERR_LAUNCH;
         }
-        if (fork && !(share.xready = next_event())) return DGG_ERR_LAUNCH;
         // ---- stream B: the real-batch pass
         DGG_TRY(real_pass(cfg, s, hp, S, Ld, B, bps, rot9, transl, joint, losses + DGG_L_BCE_REAL, sb, share, ev[1],
                           ev[2]));
@@ -2469,11 +2293,11 @@ int dgg_eva_phase_graph(const dgg_cfg* cfg, const float* e_params, float* e_grad
 }
 
 int dgg_gemm_occupancy(int mode, int bm, int bn) {
-    return gemm_algo() == 1 && bm == 128 && bn == 128 ? gemm_x3_occupancy(mode) : gemm_occupancy(mode, bm, bn);
+    return gemm_algo() == 1 && bm == 128 && bn == 128 ? 1 : gemm_occupancy(mode, bm, bn);   // (gemm_x5_kernel: 130 KB of LDS, one per CU)
 }
 
 int dgg_set_gemm_algo(int algo) {
-    if (algo != DGG_GEMM_F32 && algo != DGG_GEMM_BF16X3 && algo != DGG_GEMM_PLANES && algo != DGG_GEMM_BF16) return DGG_ERR_INVALID;
+    if (algo != DGG_GEMM_F32 && algo != DGG_GEMM_BF16X3 && algo != DGG_GEMM_BF16) return DGG_ERR_INVALID;
     gemm_set_algo(algo);
     return DGG_OK;
 }
@@ -2531,48 +2355,5 @@ int dgg_set_grad_events(const float* grads, void* const* events, int n, int accu
     return DGG_OK;
 }
 
-size_t dgg_gemm_planes_workspace_bytes(int M, int N, int K) {
-    return (size_t)(3 * (round64(M) + round64(N)) * round64(K) * 2 + 256);
-}
-
-int dgg_gemm_planes(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb,
-                    float* C, int ldc, int splits, float* slabs, int accumulate, void* ws, size_t ws_bytes, void* stream) {
-    // A == NULL && Bm == NULL: the planes a previous call left in `ws` for the same (M, N, K) are multiplied again — the
-    // GEMM kernel alone (bench.py times it that way)
-    const bool reuse = !A && !Bm;
-    if ((!reuse && (!A || !Bm)) || (!C && splits < 1) || M < 1 || N < 1 || K < 1 || !ws) return DGG_ERR_INVALID;
-    if (ws_bytes < dgg_gemm_planes_workspace_bytes(M, N, K) || ((uintptr_t)ws & 15)) return DGG_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    const int ldk = (int)round64(K);
-    __bf16* pa = (__bf16*)ws;
-    __bf16* pb = pa + 3 * round64(M) * ldk;
-    const long long apl = (long long)round64(M) * ldk, bpl = (long long)round64(N) * ldk;
-    // k-major operand ([K][rows] in memory): the transposing branch of the producer
-    if (!reuse) {
-        if (a_kmajor) DGG_TRY(planes_launch(A, lda, K, M, nullptr, nullptr, nullptr, 0, 0, pa, ldk, apl, st));
-        else DGG_TRY(planes_launch(A, lda, M, K, nullptr, nullptr, pa, ldk, apl, nullptr, 0, 0, st));
-        if (b_kmajor) DGG_TRY(planes_launch(Bm, ldb, K, N, nullptr, nullptr, nullptr, 0, 0, pb, ldk, bpl, st));
-        else DGG_TRY(planes_launch(Bm, ldb, N, K, nullptr, nullptr, pb, ldk, bpl, nullptr, 0, 0, st));
-    }
-    GemmBatch g;
-    memset(&g, 0, sizeof(g));
-    g.nprob = 1;
-    const int Kp = (K + 31) / 32 * 32;
-    if (splits >= 1) {
-        if (!slabs || accumulate) return DGG_ERR_INVALID;
-        prob_init(g.p[0], (const float*)pa, ldk, (const float*)pb, ldk, slabs, N, M, N, Kp);
-        prob_split(g.p[0], splits, (long long)M * N);
-    } else {
-        prob_init(g.p[0], (const float*)pa, ldk, (const float*)pb, ldk, C, ldc, M, N, Kp);
-        g.p[0].accumulate = accumulate;
-    }
-    g.p[0].a_plane = apl;
-    g.p[0].b_plane = bpl;
-    DGG_TRY(gemm_planes_launch(g, false, st));
-    if (splits >= 1 && C)
-        return reduce_bias_launch(slabs, g.p[0].splits, (long long)M * N, N, nullptr, C, ldc, M, M, 1, N, 0, 0, 0, 0, nullptr,
-                                  st);
-    return DGG_OK;
-}
 
 }  // extern "C"

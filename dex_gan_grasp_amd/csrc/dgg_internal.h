@@ -65,9 +65,6 @@ struct GemmProb {
     float* a_out;
     const float* c_bias;
     float* c_part;
-    // gemm_p3 only: the operands are bf16 planes (A / B point at plane 0, lda / ldb and these plane distances count
-    // bf16 elements); 0 = fp32 operand
-    long long a_plane, b_plane;
 };
 constexpr int kMaxProb = 6;   // problems of one grouped launch
 struct GemmBatch {
@@ -88,8 +85,7 @@ int gemm_algo();
 void gemm_set_algo(int a);
 int gemm_side_work();            // per thread, see dgg_set_side_work
 void gemm_set_side_work(int on);
-void gemm_x3_dispatch(int mode, const GemmBatch& batch, hipStream_t st);  // gemm_x3.hip, 128 x 128 tiles
-// gemm_x4.hip: the same products with the split done by loader waves (opt-in: DGG_X4=1)
+// gemm_x4.hip: the bf16x3 products with the split done by loader waves (launches of >= 1024 workgroups; DGG_X4=1 / 0 forces)
 void gemm_x4_dispatch(int mode, const GemmBatch& batch, hipStream_t st);
 bool gemm_x4_enabled(long total_blocks);
 // gemm_x5.hip: the same products with ONE wave per 128 x 128 accumulator block (the workgroup's waves split K); default
@@ -98,73 +94,13 @@ void gemm_x5_dispatch(int mode, const GemmBatch& batch, hipStream_t st);
 bool gemm_x5_usable(const GemmBatch& batch);
 bool gemm_x5_enabled();
 bool gemm_x5_prob_ok(const GemmProb& p);
-// gemm_p4.hip / gemm_p3_block.h: C = A B^T on pre-split bf16 planes (forward, and the wgrad over transposed planes).
-// A weight-gradient (TN) launch of gemm_launch may carry ONE such problem beside its fp32 problems (a_plane != 0: "NT
-// over transposed planes", gemm_p3_block.h inside gemm_x3_kernel): the BPS block's weight gradient and its riders —
-// the columns around it, the previous block's segment, fc2, the heads — stay one launch.
-// gemm_p4.hip: the same product (same operands, same bits) with specialised waves — 4 MFMA waves + 4 LDS-DMA loader waves
-int gemm_p4_launch(GemmBatch& batch, bool wgrad, hipStream_t st);
-// the stand-alone planes GEMM (forward): gemm_p4
-int gemm_planes_launch(GemmBatch& batch, bool wgrad, hipStream_t st);
 // dx / da3 of THIS pass plus the same tensor of another pass, written next to the plain output (the discriminator's
 // weight gradient over the BPS columns takes dY_real + dY_fake in one product, see Share::bwd_mode)
 struct SumOut {
     const float* other;   // NULL: none
-    float* sum;           // NULL: the fp32 sum is not stored (only the transposed planes, which then hold the SUM)
+    float* sum;
     int ld;               // pitch of both
 };
-// Plane outputs of the column kernels (ibn_apply, res_out, bn_bwd_apply, res_out_bwd; one batch group only): what the
-// kernel writes as fp32 also goes out split into bf16 planes, so that the large GEMMs run without a split of their own.
-//   row-major  [3][rows][ld]: element (row, col0 + c);  columns up to `ld` are zero-filled where a kernel says so
-//   transposed [3][cols][ldT]: element (col0 + c, row); rows B .. ldT-1 zero-filled (the K padding of the wgrad)
-struct PlaneOut {
-    __bf16* p;      // NULL: none
-    int ld, col0;
-    long long plane;
-    __bf16* pT;     // NULL: none
-    int ldT, colT0;
-    long long planeT;
-    // ibn_apply only: win_n > 0 restricts the planes to the output columns [win_lo, win_lo + win_n) of X0 — the BPS
-    // block —, stored at plane column (c - win_lo) + col0 / transposed row (c - win_lo) + colT0
-    int win_lo, win_n;
-};
-// fp32 [R][C] -> planes [3][R][ldp] (affine per column optional) and / or transposed planes [3][C][ldpT]
-static const int kPlanesJobs = 6;
-struct PlanesJob {
-    const float* src;
-    int ld, R, C;
-    const float *scale, *shift;
-    __bf16* dst;
-    int ldp;
-    long long dplane;
-    __bf16* dstT;
-    int ldpT;
-    long long tplane;
-    int gx, gy;
-};
-struct PlanesJobs {
-    PlanesJob j[kPlanesJobs];
-    int n;
-};
-int planes_add(PlanesJobs& jobs, const float* src, int ld, int R, int C, const float* scale, const float* shift, void* dst,
-               int ldp, long long dplane, void* dstT, int ldpT, long long tplane);
-int planes_run(const PlanesJobs& jobs, hipStream_t st);
-int planes_launch(const float* src, int ld, int R, int C, const float* scale, const float* shift, void* dst, int ldp,
-                  long long dplane, void* dstT, int ldpT, long long tplane, hipStream_t st);
-// out[n] = bias[n] + sum_c W[n][c] * v[c]  for up to 3 matrices in one launch (one wave per row, fixed summation order):
-// the bias the folded BatchNorm shift adds to the BPS products (NetW::cbias)
-struct RowDotJob {
-    const float *w, *v, *bias;
-    float* out;
-    int ld, R, C;
-};
-struct RowDotJobs {
-    RowDotJob j[3];
-    int n;
-};
-int rowdot_add(RowDotJobs& jobs, const float* w, int ld, int R, int C, const float* v, const float* bias, float* out);
-int rowdot_run(const RowDotJobs& jobs, hipStream_t st);
-int gemm_x3_occupancy(int mode);
 
 // ---------------------------------------------------------------- BPS encode (bps_encode.hip)
 int bps_encode_launch(const float* clouds, int B, int N, const float* basis, int P, float* dists, int32_t* ids, void* ws,
@@ -205,9 +141,7 @@ int ibn_refresh_launch(const float* mean, const float* var_u, float* run_mean, f
 int ibn_apply_launch(const ColSrcs& srcs, int B, int rows_per_group, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, const float* prefix, int nprefix, float* X0, int ldx,
                      const float* aff_gamma, const float* aff_beta, float* aff_scale, float* aff_shift,
-                     hipStream_t st, const BnFused* fused = nullptr, const PlaneOut* planes = nullptr);
-// planes (ibn_apply): x_hat, row-major and / or transposed (prefix columns as they are; PlaneOut::win_* restricts them
-// to the BPS block)
+                     hipStream_t st, const BnFused* fused = nullptr);
 
 // out[m][c] = sum_s slabs[s][m][c] (+ sum_s slabs2[s][m][c], same stride / pitch) + bias[c];  columns [stat_lo, stat_hi) get partial statistics,
 // columns [act_lo, act_hi) get LeakyReLU applied before the store.
@@ -233,7 +167,7 @@ int bn_act_launch(const float* a, int lda, int B, int rows_per_group, int N, con
 int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, int rows_per_group, int N,
                    const float* mean, const float* rstd, const float* gamma, const float* beta, int drop_mode,
                    const float* keep_in, uint64_t seed, uint64_t seed_off, uint8_t* keep_out, float* y, int ldy,
-                   hipStream_t st, const BnFused* fused = nullptr, const PlaneOut* planes = nullptr, const float* a2_bias = nullptr);
+                   hipStream_t st, const BnFused* fused = nullptr, const float* a2_bias = nullptr);
 // heads: out[m][j] = sum_k y[m][k] Wh[j][k] + bh[j]; sigmoid optionally.
 int heads_fwd_launch(const float* y, int ldy, int B, int K, const float* wh, const float* bh, int nh, int sigmoid,
                      float* out, int ldo, float* scratch, hipStream_t st);
@@ -252,7 +186,6 @@ int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const
                        int rows_per_group, int N, float* dpre, float* da3, int ldda3, float* part,
                        hipStream_t st, const float* hd_dout = nullptr, const float* hd_w = nullptr, int nq = 3,
                        int nslab = 0, long long slab_stride = 0,  // nslab > 1: dy = split-K slabs, summed in order
-                       const PlaneOut* planes = nullptr,           // transposed da3 only
                        const SumOut* sum = nullptr);
 // Stage 2/4 (BN backward apply): dx = gamma*rstd*(dz - sum_dz/B - xhat*sum_dzx/B) (train) or
 //          gamma*rstd*dz (eval);  partial sums of dx (-> bias gradient of the preceding Linear).
@@ -273,8 +206,7 @@ struct ColFin {
 int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, const float* mean, const float* rstd,
                         const float* gamma, const float* sums /*[groups][2][N]*/, int train, int B,
                         int rows_per_group, int N, float* dx, int lddx, float* part, hipStream_t st,
-                        const ColFin* fin = nullptr, const PlaneOut* planes = nullptr,  // planes: transposed dx only
-                        const SumOut* sum = nullptr);
+                        const ColFin* fin = nullptr, const SumOut* sum = nullptr);
 // Stage 3: dq = dh * lrelu'(h) (in place on dh allowed); partial sums: sum dq, sum dq*xhat1.
 int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const float* a1, int lda1, const float* mean,
                    const float* rstd, int B, int rows_per_group, int N, float* dq, int lddq, float* part,

@@ -20,7 +20,6 @@ namespace dgg {
 constexpr int RB = kRowBlock;
 constexpr int SUB = 4;          // waves per workgroup, each takes RB/SUB rows of the row block
 constexpr int RS = RB / SUB;    // rows per wave
-static_assert(RS == 8, "the transposed plane stores pack exactly 8 rows into 16 bytes");
 
 // These kernels are latency-bound (a workgroup touches 32 rows x 64 columns): every wave loads ALL its RS rows before
 // it uses any — a `for (r < n)` loop with a data-dependent trip count compiles to one load, one s_waitcnt vmcnt(0) per
@@ -47,64 +46,6 @@ __device__ __forceinline__ void row_stats(bool fused, const Res& res, const floa
             const int g = (r0 + row_clamp(r, n > 0 ? n : 1)) / rpg;
             mu[r] = mean[g * stride + c];
             rs[r] = rstd[g * stride + c];
-        }
-    }
-}
-
-// ---- bf16 planes beside the fp32 outputs (PlaneOut): the split of gemm_x3.hip / gemm_p3.hip, one element at a time
-typedef __bf16 ew_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float ew_f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned ew_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned ew_pack(float a, float b) {  // v_cvt_pk_bf16_f32 (RNE): low half = a
-    ew_f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ew_bf16x2));
-}
-// two values -> their (hi, mid, lo) bf16 pairs
-__device__ __forceinline__ void ew_split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
-    hi = ew_pack(x0, x1);
-    const float r0 = x0 - __builtin_bit_cast(float, hi << 16), r1 = x1 - __builtin_bit_cast(float, hi & 0xffff0000u);
-    mid = ew_pack(r0, r1);
-    const float q0 = r0 - __builtin_bit_cast(float, mid << 16), q1 = r1 - __builtin_bit_cast(float, mid & 0xffff0000u);
-    lo = ew_pack(q0, q1);
-}
-// row-major planes: this lane's column `col`, rows row0 .. row0 + n - 1 (n <= RS) hold v[0 .. n-1]; a wave writes 128
-// contiguous bytes per row and plane
-__device__ __forceinline__ void planes_store_rows(const PlaneOut& P, int col, int row0, int n, const float (&v)[RB / 4]) {
-    unsigned short* base = reinterpret_cast<unsigned short*>(P.p) + (size_t)row0 * P.ld + P.col0 + col;
-#pragma unroll
-    for (int r = 0; r < RB / 4; r += 2) {
-        unsigned hi, mid, lo;
-        ew_split2(v[r], v[r + 1], hi, mid, lo);
-        if (r < n) {
-            unsigned short* o = base + (size_t)r * P.ld;
-            o[0] = (unsigned short)hi; o[P.plane] = (unsigned short)mid; o[2 * P.plane] = (unsigned short)lo;
-        }
-        if (r + 1 < n) {
-            unsigned short* o = base + (size_t)(r + 1) * P.ld;
-            o[0] = (unsigned short)(hi >> 16); o[P.plane] = (unsigned short)(mid >> 16); o[2 * P.plane] = (unsigned short)(lo >> 16);
-        }
-    }
-}
-// transposed planes: this lane's column is row `colT0 + col` of the transposed matrix; the wave's RS rows row0 .. are 16
-// contiguous bytes per plane (rows >= n are stored as zeros: K padding).  The last row block of the grid also
-// zero-fills whatever lies between the end of its 32 rows and the pitch.
-__device__ __forceinline__ void planes_store_cols(const PlaneOut& P, int col, int row0, int n, const float (&v)[RB / 4],
-                                                  bool last_block) {
-    if (row0 >= P.ldT) return;
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int r = 0; r < RB / 4; r += 2)
-        ew_split2(r < n ? v[r] : 0.f, r + 1 < n ? v[r + 1] : 0.f, h[r >> 1], m[r >> 1], l[r >> 1]);
-    unsigned short* o = reinterpret_cast<unsigned short*>(P.pT) + (size_t)(P.colT0 + col) * P.ldT + row0;
-    *reinterpret_cast<ew_u32x4*>(o) = (ew_u32x4){h[0], h[1], h[2], h[3]};
-    *reinterpret_cast<ew_u32x4*>(o + P.planeT) = (ew_u32x4){m[0], m[1], m[2], m[3]};
-    *reinterpret_cast<ew_u32x4*>(o + 2 * P.planeT) = (ew_u32x4){l[0], l[1], l[2], l[3]};
-    if (last_block) {
-        for (int rz = row0 + RB; rz < P.ldT; rz += RB) {
-            unsigned short* z = o + (rz - row0);
-            *reinterpret_cast<ew_u32x4*>(z) = (ew_u32x4){0u, 0u, 0u, 0u};
-            *reinterpret_cast<ew_u32x4*>(z + P.planeT) = (ew_u32x4){0u, 0u, 0u, 0u};
-            *reinterpret_cast<ew_u32x4*>(z + 2 * P.planeT) = (ew_u32x4){0u, 0u, 0u, 0u};
         }
     }
 }
@@ -323,7 +264,7 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
                                                         const float* __restrict__ aff_gamma,
                                                         const float* __restrict__ aff_beta,
                                                         float* __restrict__ aff_scale, float* __restrict__ aff_shift,
-                                                        BnFin fin, PlaneOut PL) {
+                                                        BnFin fin) {
     __shared__ float sh[SUB][3][64];
     __shared__ float res[2][2][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
@@ -333,10 +274,6 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
     const int c = bnc ? oc - nprefix : 0;
     const int groups = B / rpg;
     const bool fused = fin.mean_out != nullptr;
-    // planes window (PlaneOut::win_n): only the BPS block of X0 goes out as planes, at column oc - win_lo
-    const bool pwin = PL.win_n > 0;
-    const bool pin = !pwin || (oc >= PL.win_lo && oc < PL.win_lo + PL.win_n);
-    const int pc = pwin ? oc - PL.win_lo : oc;
     if (aff_scale && ook && blockIdx.y == 0 && sub == 0) {
         aff_scale[oc] = oc < nprefix ? 1.f : aff_gamma[oc - nprefix];
         aff_shift[oc] = oc < nprefix ? 0.f : aff_beta[oc - nprefix];
@@ -369,31 +306,11 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
         if (rbk >= nrb_total) break;
         const int r0 = rbk * RB + sub * RS;
         const int n = min(RS, B - r0);
-        const bool last_block = rbk == nrb_total - 1;
-        if (!ook) {  // columns between the operand's width and the planes' pitch: the forward GEMM's K padding
-            if (PL.p && !pwin && oc < PL.ld && n > 0) {
-                float zv[RS];
-#pragma unroll
-                for (int r = 0; r < RS; ++r) zv[r] = 0.f;
-                planes_store_rows(PL, oc, r0, n, zv);
-            }
-            continue;
-        }
-        if (n <= 0) {
-            if (PL.pT && pin) {
-                float zv[RS];
-#pragma unroll
-                for (int r = 0; r < RS; ++r) zv[r] = 0.f;
-                planes_store_cols(PL, pc, r0, 0, zv, last_block);
-            }
-            continue;
-        }
+        if (!ook || n <= 0) continue;
         if (!bnc) {  // prefix columns pass through
 #pragma unroll
             for (int r = 0; r < RS; ++r)
                 if (r < n) X0[(size_t)(r0 + r) * ldx + oc] = xv[k][r];
-            if (PL.p && pin) planes_store_rows(PL, pc, r0, n, xv[k]);
-            if (PL.pT && pin) planes_store_cols(PL, pc, r0, n, xv[k], last_block);
             continue;
         }
         float mu_[RS], rs_[RS];
@@ -407,10 +324,6 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
             xv[k][r] = fmaf(xv[k][r], sc, shf);
             if (r < n) X0[(size_t)row * ldx + oc] = xv[k][r];
         }
-        if (PL.pT && pin) planes_store_cols(PL, pc, r0, n, xv[k], last_block);
-        // (the row-major planes hold x_hat as well: the BatchNorm scale is folded into the weight planes, the shift into
-        // the bias — net_forward —, so that the operand does not depend on the parameters)
-        if (PL.p && pin) planes_store_rows(PL, pc, r0, n, xv[k]);
     }
 }
 
@@ -572,7 +485,7 @@ __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ 
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       int drop_mode, const float* __restrict__ keep_in, uint64_t seed,
                                                       uint64_t seed_off, uint8_t* __restrict__ keep_out,
-                                                      float* __restrict__ y, int ldy, BnFin fin, PlaneOut PL,
+                                                      float* __restrict__ y, int ldy, BnFin fin,
                                                       const float* __restrict__ a2_bias) {
     __shared__ float sh[SUB][3][64];
     __shared__ float res[2][2][64];
@@ -594,17 +507,7 @@ __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ 
         kv[r] = 1.f;
     }
     if (fused) bn_block_stats(fin, rpg, B / rpg, N, c, cok, blockIdx.y == 0, sh, res);
-    if (!cok) return;
-    const bool last_block = blockIdx.y == gridDim.y - 1;
-    float yv[RS];
-    if (n <= 0) {
-        if (PL.pT) {
-#pragma unroll
-            for (int r = 0; r < RS; ++r) yv[r] = 0.f;
-            planes_store_cols(PL, c, r0, 0, yv, last_block);
-        }
-        return;
-    }
+    if (!cok || n <= 0) return;
     const float ga = gamma[c], be = beta[c];
     const float ab = a2_bias ? a2_bias[c] : 0.f;  // a2 arrives without fc2's bias (inference path: plain GEMM output)
     const float inv_keep = 1.0f / (1.0f - kDropP);
@@ -632,13 +535,8 @@ __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ 
                 v = v * k * inv_keep;
             }
             y[(size_t)row * ldy + c] = v;
-            yv[r] = v;
-        } else {
-            yv[r] = 0.f;
         }
     }
-    if (PL.p) planes_store_rows(PL, c, r0, n, yv);
-    if (PL.pT) planes_store_cols(PL, c, r0, n, yv, last_block);
 }
 
 // one wave per row; K <= 512*? handled in chunks of 64 lanes
@@ -691,7 +589,7 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
                                                           int ldda3, float* __restrict__ part,
                                                           const float* __restrict__ hd_dout,
                                                           const float* __restrict__ hd_w, int nq, int nslab,
-                                                          long long slab_stride, PlaneOut PL, SumOut SO) {
+                                                          long long slab_stride, SumOut SO) {
     // nslab > 1: `dy` is a stack of split-K slabs of the next block's dgrad GEMM, summed here in slab (= k) order
     __shared__ float sh[SUB][5][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
@@ -705,9 +603,6 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
     const float inv_keep = 1.0f / (1.0f - kDropP);
     const float wv = hd_dout ? hd_w[c] : 0.f;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
-    float d3v[RS];
-#pragma unroll
-    for (int r = 0; r < RS; ++r) d3v[r] = 0.f;
     if (n > 0) {
         float yv_[RS], dv_[RS], av_[RS], sv_[RS], ov_[RS];
         unsigned kp_[RS];   // (a register each: bytes packed into one register made every row's loads wait for the previous row's)
@@ -763,7 +658,6 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
                 if (cok) dpre[row * N + c] = d;
                 const float xh = (av_[r] - mu) * rs;
                 const float d3 = d * lrelu_grad(sv_[r]);
-                d3v[r] = SO.other ? d3 + ov_[r] : d3;   // the planes carry the SUM where another pass' tensor is given
                 if (cok) da3[row * ldda3 + c] = d3;
                 if (SO.sum && cok) SO.sum[row * SO.ld + c] = d3 + ov_[r];
                 s0 += d;
@@ -772,7 +666,6 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
             }
         }
     }
-    if (PL.pT && cok) planes_store_cols(PL, c, r0, n, d3v, rb == nrb - 1);
     sh[sub][0][lane] = s0;
     sh[sub][1][lane] = s1;
     sh[sub][2][lane] = s2;
@@ -794,7 +687,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ sums, int train, int rpg,
                                                            int nrb, int N, float* __restrict__ dx, int lddx,
-                                                           float* __restrict__ part, ColFin fin, PlaneOut PL, SumOut SO) {
+                                                           float* __restrict__ part, ColFin fin, SumOut SO) {
     constexpr int kFinQ = 5;   // quantities a ColFin finalizes at most (fin.nq)
     __shared__ float sh[SUB][1][64];
     __shared__ float shq[SUB][kFinQ][64];
@@ -883,9 +776,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         m1 = sums[(size_t)(g * 2 + 1) * N + c] * inv_n;
     }
     float sb = 0.f;
-    float xo[RS];
-#pragma unroll
-    for (int r = 0; r < RS; ++r) xo[r] = 0.f;
     if (n > 0) {
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
@@ -895,12 +785,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 const float v = k * (dv_[r] - m0 - xh * m1);
                 if (cok) dx[row * lddx + c] = v;
                 if (SO.sum && cok) SO.sum[row * SO.ld + c] = v + ov_[r];
-                xo[r] = SO.other ? v + ov_[r] : v;   // (planes only: the column sum below stays this pass' own)
                 sb += v;
             }
         }
     }
-    if (PL.pT && cok) planes_store_cols(PL, c, r0, n, xo, rb == nrb - 1);
     sh[sub][0][lane] = sb;
     __syncthreads();
     if (sub == 0 && cok)
@@ -1561,21 +1449,13 @@ int ibn_refresh_launch(const float* mean, const float* var_u, float* run_mean, f
 
 int ibn_apply_launch(const ColSrcs& srcs, int B, int rpg, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, const float* prefix, int nprefix, float* X0, int ldx, const float* aff_gamma,
-                     const float* aff_beta, float* aff_scale, float* aff_shift, hipStream_t st, const BnFused* fz,
-                     const PlaneOut* planes) {
+                     const float* aff_beta, float* aff_scale, float* aff_shift, hipStream_t st, const BnFused* fz) {
     BnFin fin;
     if (int rc = make_fin(fz, rpg, fin)) return rc;
-    PlaneOut pl = {};
-    int width = nprefix + srcs.total;
-    if (planes) {
-        if (B != rpg || gamma || !aff_gamma || !aff_beta) return DGG_ERR_INVALID;  // x_hat stored un-affined, one group
-        pl = *planes;
-        if (pl.p && pl.win_n == 0 && pl.ld > width) width = pl.ld;
-        if (pl.win_n > 0 && (pl.win_lo < 0 || pl.win_lo + pl.win_n > nprefix + srcs.total)) return DGG_ERR_INVALID;
-    }
+    const int width = nprefix + srcs.total;
     dim3 grid(cdiv(width, 64), cdiv(B, RB * kIbnBlocks));
     hipLaunchKernelGGL(ibn_apply_kernel, grid, dim3(256), 0, st, srcs, B, rpg, mean, rstd, gamma, beta, prefix,
-                       nprefix, X0, ldx, aff_gamma, aff_beta, aff_scale, aff_shift, fin, pl);
+                       nprefix, X0, ldx, aff_gamma, aff_beta, aff_scale, aff_shift, fin);
     return check_launch("ibn_apply");
 }
 
@@ -1723,17 +1603,12 @@ int bn_act_launch(const float* a, int lda, int B, int rpg, int N, const float* m
 int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, int rpg, int N, const float* mean,
                    const float* rstd, const float* gamma, const float* beta, int drop_mode, const float* keep_in,
                    uint64_t seed, uint64_t seed_off, uint8_t* keep_out, float* y, int ldy, hipStream_t st,
-                   const BnFused* fz, const PlaneOut* planes, const float* a2_bias) {
+                   const BnFused* fz, const float* a2_bias) {
     BnFin fin;
     if (int rc = make_fin(fz, rpg, fin)) return rc;
-    PlaneOut pl = {};
-    if (planes) {
-        if (B != rpg) return DGG_ERR_INVALID;
-        pl = *planes;
-    }
     dim3 grid(cdiv(N, 64), cdiv(B, RB));
     hipLaunchKernelGGL(res_out_kernel, grid, dim3(256), 0, st, s, lds, a2, lda2, B, rpg, N, mean, rstd, gamma, beta,
-                       drop_mode, keep_in, seed, seed_off, keep_out, y, ldy, fin, pl, a2_bias);
+                       drop_mode, keep_in, seed, seed_off, keep_out, y, ldy, fin, a2_bias);
     return check_launch("res_out");
 }
 
@@ -1842,35 +1717,24 @@ int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B,
 int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const uint8_t* keep, const float* s,
                        int lds, const float* a2, int lda2, const float* mean, const float* rstd, int B, int rpg, int N,
                        float* dpre, float* da3, int ldda3, float* part, hipStream_t st, const float* hd_dout,
-                       const float* hd_w, int nq, int nslab, long long slab_stride, const PlaneOut* planes,
-                       const SumOut* sum) {
+                       const float* hd_w, int nq, int nslab, long long slab_stride, const SumOut* sum) {
     if (!dy && !hd_dout) return DGG_ERR_INVALID;
     SumOut so = {nullptr, nullptr, 0};
     if (sum && sum->other) so = *sum;
     if (hd_dout) nslab = 0;
-    PlaneOut pl = {};
-    if (planes) {
-        if (B != rpg) return DGG_ERR_INVALID;
-        pl = *planes;
-    }
     const int groups = B / rpg;
     dim3 grid(cdiv(N, 64), groups * nrb_of(rpg));
     hipLaunchKernelGGL(res_out_bwd_kernel, grid, dim3(256), 0, st, dy, lddy, y, ldy, keep, s, lds, a2, lda2, mean,
-                       rstd, rpg, nrb_of(rpg), N, dpre, da3, ldda3, part, hd_dout, hd_w, nq, nslab, slab_stride, pl, so);
+                       rstd, rpg, nrb_of(rpg), N, dpre, da3, ldda3, part, hd_dout, hd_w, nq, nslab, slab_stride, so);
     return check_launch("res_out_bwd");
 }
 
 int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, const float* mean, const float* rstd,
                         const float* gamma, const float* sums, int train, int B, int rpg, int N, float* dx, int lddx,
-                        float* part, hipStream_t st, const ColFin* fin, const PlaneOut* planes, const SumOut* sum) {
+                        float* part, hipStream_t st, const ColFin* fin, const SumOut* sum) {
     const int groups = B / rpg;
     SumOut so = {nullptr, nullptr, 0};
     if (sum && sum->other) so = *sum;
-    PlaneOut pl = {};
-    if (planes) {
-        if (groups != 1) return DGG_ERR_INVALID;
-        pl = *planes;
-    }
     dim3 grid(cdiv(N, 64), groups * nrb_of(rpg));
     ColFin f = {};
     if (fin) {
@@ -1880,7 +1744,7 @@ int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, cons
         if (!f.zero1) f.nz1 = 0;
     }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, dz, lddz, a, lda, mean, rstd, gamma, sums, train,
-                       rpg, nrb_of(rpg), N, dx, lddx, part, f, pl, so);
+                       rpg, nrb_of(rpg), N, dx, lddx, part, f, so);
     return check_launch("bn_bwd_apply");
 }
 

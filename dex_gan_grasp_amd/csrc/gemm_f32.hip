@@ -477,22 +477,20 @@ static void launch_shape(int bm, int bn, const GemmBatch& b, hipStream_t st) {
         hipLaunchKernelGGL((gemm_f32_kernel<64, 64, A_KC, B_KC>), grid, block, 0, st, b);
 }
 
-// Which kernel family executes the large GEMMs: 1 (default) = bf16x3 on fp32 operands, split inside the GEMM (gemm_x3.hip;
-// DGG_X4=1: by loader waves, gemm_x4.hip); 2 = the BPS block of a train pass — the K = 4096 part of every fused fc1 || fc3 product and of its weight
-// gradient — on operands pre-split into bf16 planes by their producers (gemm_p4.hip: one batched launch per pass forward;
-// backward one planes problem inside the block's weight-gradient launch), everything else as 1; 0 = native f32 MFMA
-// (this file); 3 = plain bf16 (the hi plane only: one product, fp32 accumulate — BASELINE config 3, never the default).
-// Process-wide; DGG_GEMM_ALGO=f32 / planes / bf16 select 0 / 2 / 3 at start-up.
+// Which arithmetic the large GEMMs (128 x 128 tiles) run: 1 (default) = bf16x3 on fp32 operands, split inside the GEMM
+// (gemm_x5.hip: one wave per 128 x 128 accumulator block; launches of >= 1024 workgroups: gemm_x4.hip, loader / consumer
+// waves); 0 = native f32 MFMA (this file); 3 = plain bf16 (the hi plane only: one product, fp32 accumulate — BASELINE
+// config 3, never the default).  Process-wide; DGG_GEMM_ALGO=f32 / bf16 select 0 / 3 at start-up.  (2 was the pre-split
+// "planes" path of rounds 3-4, removed in round 5.)
 static int g_algo = -1;
 int gemm_algo() {
     if (g_algo < 0) {
         const char* e = getenv("DGG_GEMM_ALGO");
-        g_algo = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : (e && (e[0] == 'p' || e[0] == '2')) ? 2
-                 : (e && (e[0] == 'b' || e[0] == '3')) ? 3 : 1;
+        g_algo = (e && (e[0] == 'f' || e[0] == '0')) ? 0 : (e && (e[0] == 'b' || e[0] == '3')) ? 3 : 1;
     }
     return g_algo;
 }
-void gemm_set_algo(int a) { g_algo = a < 0 ? 0 : a > 3 ? 3 : a; }
+void gemm_set_algo(int a) { g_algo = a == 0 ? 0 : a == 3 ? 3 : 1; }
 
 // "Side work" (dgg_set_side_work, per calling thread): the launches that follow run beside a latency-critical chain on
 // another stream — their large forward products take half the chip for twice as long (the bf16x3 kernel walks two work
@@ -508,24 +506,9 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
     if (batch.nprob < 1 || batch.nprob > kMaxProb) return DGG_ERR_INVALID;
     int bm, bn;
     int big = 0;  // the problem with the most work decides the tile shape
-    bool planes = false;
     for (int i = 1; i < batch.nprob; ++i)
         if ((double)batch.p[i].M * batch.p[i].N * batch.p[i].K > (double)batch.p[big].M * batch.p[big].N * batch.p[big].K) big = i;
-    for (int i = 0; i < batch.nprob; ++i) planes = planes || batch.p[i].a_plane != 0;
     gemm_tile_shape(mode, batch.p[big].M, batch.p[big].N, bm, bn, batch.p[big].K);
-    if (planes) {
-        // a problem on pre-split planes (weight-gradient launches): 128 x 128 tiles on the bf16x3 kernel only, operands as
-        // gemm_p4_launch wants them
-        if (mode != GEMM_TN || gemm_algo() < 1) return DGG_ERR_INVALID;
-        bm = bn = 128;
-        for (int i = 0; i < batch.nprob; ++i) {
-            const GemmProb& p = batch.p[i];
-            if (!p.a_plane) continue;
-            if (!p.b_plane || p.splits > 0 || (p.K & 31) || (p.lda & 7) || (p.ldb & 7) || (p.a_plane & 7) || (p.b_plane & 7) ||
-                p.lda < p.K || p.ldb < p.K || (((uintptr_t)p.A | (uintptr_t)p.B) & 15))
-                return DGG_ERR_INVALID;
-        }
-    }
     int blocks = 0;
     for (int i = 0; i < batch.nprob; ++i) {
         GemmProb& p = batch.p[i];
@@ -545,10 +528,9 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
     batch.total_blocks = blocks;
     if (mode != GEMM_NT && mode != GEMM_NN && mode != GEMM_TN) return DGG_ERR_INVALID;
     if (gemm_algo() >= 1 && bm == 128 && bn == 128) {
-        // (a planes problem rides in gemm_x3_kernel)
         // gemm_x4_kernel fetches a k-strided operand ([K][rows]: B of NN, A and B of TN) in quads of 4 rows: with
         // rows % 4 != 0 the last quad of EVERY k-row reads up to 12 bytes past the row — past the operand itself on its last
-        // k-row when the pitch is the row count.  Such problems stay on gemm_x3_kernel, whose padding rule is
+        // k-row when the pitch is the row count.  Such problems stay on gemm_x5_kernel, whose padding rule is
         // in include/dgg.h (dgg_gemm_f32); inside the library every pitch covers the quad.
         bool quads_ok = true;
         for (int i = 0; i < batch.nprob; ++i) {
@@ -556,37 +538,31 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
             if (mode == GEMM_TN && p.lda < ((p.M + 3) & ~3)) quads_ok = false;
             if (mode != GEMM_NT && p.ldb < ((p.N + 3) & ~3)) quads_ok = false;
         }
-        if (!planes && quads_ok && gemm_algo() != 3 && gemm_x4_enabled(batch.total_blocks)) {
+        if (quads_ok && gemm_algo() != 3 && gemm_x4_enabled(batch.total_blocks)) {
             gemm_x4_dispatch(mode, batch, st);
             return check_launch("gemm_x4");
         }
-        if (!planes && gemm_algo() == 1 && gemm_x5_enabled()) {
+        if (gemm_x5_enabled()) {
             // gemm_x5_kernel takes every problem with at least 64 of K; a grouped launch that also carries short ones (the
             // 24 pose columns beside the shared BPS block of a discriminator pass) is cut in two: the short problems are a
-            // handful of tiles on gemm_x3_kernel
-            static const bool cut = [] { const char* e = getenv("DGG_X5_CUT"); return !e || atoi(e) != 0; }();   // diagnostics
-            if (!cut && !gemm_x5_usable(batch)) goto x3_path;
-            GemmBatch big, small;
-            big.nprob = small.nprob = 0;
-            big.total_blocks = small.total_blocks = 0;
+            // handful of tiles on the f32-MFMA kernel of this file
+            GemmBatch large, small;
+            large.nprob = small.nprob = 0;
+            large.total_blocks = small.total_blocks = 0;
             for (int i = 0; i < batch.nprob; ++i) {
-                GemmBatch& dst = gemm_x5_prob_ok(batch.p[i]) ? big : small;
+                GemmBatch& dst = gemm_x5_prob_ok(batch.p[i]) ? large : small;
                 GemmProb& q = dst.p[dst.nprob++];
                 q = batch.p[i];
                 q.blk_begin = dst.total_blocks;
                 dst.total_blocks += q.tiles_m * q.tiles_n * (q.splits > 0 ? q.splits : 1);
             }
-            if (big.nprob > 0) {
-                gemm_x5_dispatch(mode, big, st);
+            if (large.nprob > 0) {
+                gemm_x5_dispatch(mode, large, st);
                 DGG_TRY_RC(check_launch("gemm_x5"));
                 if (small.nprob == 0) return DGG_OK;
-                gemm_x3_dispatch(mode, small, st);
-                return check_launch("gemm_x3");
+                batch = small;   // (tiled 128 x 128 above)
             }
         }
-    x3_path:
-        gemm_x3_dispatch(mode, batch, st);
-        return check_launch("gemm_x3");
     }
     if (mode == GEMM_NT) launch_shape<true, true>(bm, bn, batch, st);
     else if (mode == GEMM_NN) launch_shape<true, false>(bm, bn, batch, st);

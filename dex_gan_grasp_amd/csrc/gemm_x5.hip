@@ -112,7 +112,9 @@ __host__ __device__ constexpr FD fdec(int c) { return FD{c >> 4, (c >> 3) & 1, c
 template <int C>
 using FC = std::integral_constant<int, C>;
 
-template <bool A_KC, bool B_KC, bool AFF>
+// X1 (DGG_GEMM_BF16, BASELINE config 3 "bf16 MFMA fc stacks"; never the default): plain bf16 — only the hi plane, ONE
+// product per fragment pair, fp32 accumulate, fp32 master operands rounded while they are staged.
+template <bool A_KC, bool B_KC, bool AFF, bool X1>
 __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int bid, char* smem) {
     // ---- work assignment: identical to gemm_x3_kernel (problem select, XCD-contiguous remap, split-K range)
     int pi = 0;
@@ -282,12 +284,14 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
 #endif
     f32x16 acc[4][4];
     auto zero_acc = [&]() {
+        float z = 0.f;
+        asm volatile("" : "+v"(z));   // (a literal zero vector is hoisted to the kernel's entry and spilled across the k loop)
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = z;
     };
     Frag PA[2][4], PB[2][4];   // [parity of the k-step][32-row block]
     float rawb[2][8];          // raw fragments, one window ahead of the split
@@ -312,7 +316,14 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
     // the split in 11 slices of 4 vector instructions, one per MFMA of the window
     auto slice = [&](auto qc, const float (&x)[8], Frag& out) {
         constexpr int q = decltype(qc)::value;
-        if constexpr (q == 0) {
+        if constexpr (X1) {   // plain bf16: one conversion, nothing else
+            if constexpr (q == 0) {
+                unsigned hh[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) hh[p] = pack_bf16(x[2 * p], x[2 * p + 1]);
+                out.p[0] = __builtin_bit_cast(bf16x8, (u32x4){hh[0], hh[1], hh[2], hh[3]});
+            }
+        } else if constexpr (q == 0) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) sh_[p] = pack_bf16(x[2 * p], x[2 * p + 1]);
         } else if constexpr (q == 1 || q == 3) {
@@ -373,7 +384,8 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
                 constexpr int a = TY == 0 ? grp : inner, b = TY == 0 ? inner : grp;
                 constexpr int ia = pr == 0 ? 2 : pr == 2 || pr == 3 ? 1 : 0;
                 constexpr int ib = pr == 1 ? 2 : pr == 2 || pr == 4 ? 1 : 0;
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[cur][a].p[ia], PB[cur][b].p[ib], acc[a][b], 0, 0, 0);
+                if constexpr (!X1 || pr == 5)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[cur][a].p[ia], PB[cur][b].p[ib], acc[a][b], 0, 0, 0);
             }
             constexpr FD f = frag_of(TY, n);
             constexpr bool have = NEXT || f.par == cur;
@@ -412,7 +424,7 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
             __builtin_amdgcn_sched_barrier(0);
             zero_acc();   // while the first stage lands
             __builtin_amdgcn_sched_barrier(0);
-            wait_vm<NDMA>();
+            wait_vm<0>();   // both stages: no counted wait anywhere in this kernel (17 pieces of two widths are in flight)
             read_aff(1);
             static_for<4>([&](auto ac) {
                 constexpr int a = decltype(ac)::value;
@@ -440,7 +452,7 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
             __builtin_amdgcn_sched_barrier(0);
             zero_acc();   // while the first stage lands
             __builtin_amdgcn_sched_barrier(0);
-            wait_vm<NDMA>();
+            wait_vm<0>();   // both stages: no counted wait anywhere in this kernel (17 pieces of two widths are in flight)
             read_aff(0);
             static_for<4>([&](auto bc) {
                 constexpr int b = decltype(bc)::value;
@@ -550,22 +562,22 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
 #endif
 }
 
-template <bool A_KC, bool B_KC, bool AFF>
+template <bool A_KC, bool B_KC, bool AFF, bool X1>
 __global__ __launch_bounds__(256) void gemm_x5_kernel(const GemmBatch batch) {
     __shared__ __attribute__((aligned(16))) char smem[YSMEM];
     for (int bid = (int)blockIdx.x; bid < batch.total_blocks; bid += (int)gridDim.x) {
-        gemm_x5_block<A_KC, B_KC, AFF>(batch, bid, smem);
+        gemm_x5_block<A_KC, B_KC, AFF, X1>(batch, bid, smem);
         if (bid + (int)gridDim.x < batch.total_blocks) __syncthreads();  // the epilogue's LDS scratch is done with
     }
 }
 
-template <bool A_KC, bool B_KC, bool AFF>
+template <bool A_KC, bool B_KC, bool AFF, bool X1 = false>
 static void launch_x5(const GemmBatch& b, hipStream_t st) {
     int grid = b.total_blocks;
     // side work (dgg_set_side_work): as launch_x3 — the forward products walk two work items per workgroup
     static const int kdiv = [] { const char* e = getenv("DGG_SIDE_DIV"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
     if (gemm_side_work() && A_KC && B_KC && grid > 64) grid = ((grid + kdiv - 1) / kdiv + 7) / 8 * 8;
-    hipLaunchKernelGGL((gemm_x5_kernel<A_KC, B_KC, AFF>), dim3(grid), dim3(256), 0, st, b);
+    hipLaunchKernelGGL((gemm_x5_kernel<A_KC, B_KC, AFF, X1>), dim3(grid), dim3(256), 0, st, b);
 }
 
 }  // namespace x5
@@ -576,14 +588,12 @@ extern "C" int dgg_x5_debug_stamps(unsigned long long* host_out, int nblocks) {
 }
 #endif
 
-// A problem needs at least YMINK of K inside each split (a k-step moved back to the split's end must stay inside the
-// split) and fp32 operands.
+// A problem needs at least YMINK of K inside each split (a k-step moved back to the split's end must stay inside the split).
 bool gemm_x5_enabled() {
     static const int on = [] { const char* e = getenv("DGG_X5"); return e ? atoi(e) : 1; }();
     return on != 0;
 }
 bool gemm_x5_prob_ok(const GemmProb& p) {
-    if (p.a_plane || p.b_plane) return false;
     if (p.K < x5::YMINK) return false;
     if (p.splits > 0) {
         if (p.kchunk < x5::YMINK) return false;
@@ -600,15 +610,21 @@ bool gemm_x5_usable(const GemmBatch& batch) {
 }
 
 void gemm_x5_dispatch(int mode, const GemmBatch& batch, hipStream_t st) {
+    const bool x1 = gemm_algo() == 3;   // DGG_GEMM_BF16: the same kernel, hi plane only
     if (mode == GEMM_NT) {
         bool any = false;
         for (int i = 0; i < batch.nprob; ++i) any = any || batch.p[i].a_scale != nullptr;
-        if (any) x5::launch_x5<true, true, true>(batch, st);
+        if (x1) {
+            if (any) x5::launch_x5<true, true, true, true>(batch, st);
+            else x5::launch_x5<true, true, false, true>(batch, st);
+        } else if (any) x5::launch_x5<true, true, true>(batch, st);
         else x5::launch_x5<true, true, false>(batch, st);
     } else if (mode == GEMM_NN) {
-        x5::launch_x5<true, false, false>(batch, st);
+        if (x1) x5::launch_x5<true, false, false, true>(batch, st);
+        else x5::launch_x5<true, false, false>(batch, st);
     } else {
-        x5::launch_x5<false, false, false>(batch, st);
+        if (x1) x5::launch_x5<false, false, false, true>(batch, st);
+        else x5::launch_x5<false, false, false>(batch, st);
     }
 }
 

@@ -395,50 +395,39 @@ int dgg_translate_along_axis(float* transl, const float* rot9, int B, int axis, 
  * mode 0: C[M,N] = A[M,K] * B[N,K]^T;  1: C[M,N] = A[M,K] * B[K,N];  2: C[M,N] = A[K,M]^T * B[K,N].
  * splits >= 1 (split-K through `slabs`, S*M*N floats; reduced into C, or left as slabs when C is
  * NULL); accumulate: C += . */
-/* GEMM arithmetic (process-wide; default DGG_GEMM_BF16X3; DGG_GEMM_ALGO=f32 / planes in the environment select the others):
+/* GEMM arithmetic (process-wide; default DGG_GEMM_BF16X3; DGG_GEMM_ALGO=f32 / bf16 in the environment select the others):
  *   DGG_GEMM_F32    : v_mfma_f32_32x32x2_f32, a k-ordered fp32 fma chain (157 TFLOP/s peak on MI355X);
  *   DGG_GEMM_BF16X3 : each fp32 operand split exactly into three bf16 pieces, the six leading partial products
  *                     accumulated in fp32 on v_mfma_f32_32x32x16_bf16 — error below the fp32 accumulation's own
- *                     rounding, 6/16 of the f32-MFMA cost;
- *   DGG_GEMM_PLANES : the same bf16x3 arithmetic, with the split hoisted out of the GEMM for the BPS block of a TRAIN pass
- *                     (the K = in_bps part of every fused fc1 || fc3 product and of its weight gradient): the input
- *                     BatchNorm emits x_hat's bf16 planes, one pass over W13 per forward the weights' (BatchNorm scale
- *                     folded in, shift as a bias), bn_bwd_apply / res_out_bwd those of dY; ONE batched launch per pass
- *                     forms the BPS products of all ResBlocks (csrc/gemm_p4.hip), the weight gradient is one planes
- *                     problem inside the block's weight-gradient launch (csrc/gemm_p3_block.h).  Everything else runs as
- *                     under DGG_GEMM_BF16X3.  Faster kernels (0.38-0.46 of the bf16x3 bound against 0.27), slower step
- *                     (1.93 vs 1.74 ms: DESIGN.md 3.1): optional.
+ *                     rounding, 6/16 of the f32-MFMA cost.  Kernels: csrc/gemm_x5.hip (one wave per 128 x 128
+ *                     accumulator block, the workgroup's four waves split K; every product of a train step), csrc/
+ *                     gemm_x4.hip (loader / consumer waves; launches of >= 1024 workgroups: the inference sweep);
  *   DGG_GEMM_BF16   : plain bf16 (BASELINE config 3, "bf16 MFMA fc stacks"; never the default, never the headline dtype):
  *                     the large (128 x 128-tile) products take only the hi plane — fp32 master operands rounded to bf16
  *                     while they are staged, ONE product, fp32 accumulate; the K = 256 products, BatchNorm, losses and
  *                     Adam stay fp32.  Measured against the fp32 goldens: tests/test_gpu_steps.py::test_bf16_mode_* state the
- *                     tolerances (scores ~1e-2, losses ~1e-2 relative) — outside the 1e-4 contract by construction. */
-enum { DGG_GEMM_F32 = 0, DGG_GEMM_BF16X3 = 1, DGG_GEMM_PLANES = 2, DGG_GEMM_BF16 = 3 };
+ *                     tolerances (scores ~1e-2, losses ~1e-2 relative) — outside the 1e-4 contract by construction.
+ * (Value 2 was the pre-split "planes" path of rounds 3-4: faster kernels, slower step; removed in round 5 together with
+ *  its producers and the first in-register-split kernel, gemm_x3.) */
+enum { DGG_GEMM_F32 = 0, DGG_GEMM_BF16X3 = 1, DGG_GEMM_BF16 = 3 };
 int dgg_set_gemm_algo(int algo);
 int dgg_get_gemm_algo(void);
 /* Diagnostic: workgroups of the GEMM variant (mode, tile) resident per CU according to the HIP occupancy API. */
 int dgg_gemm_occupancy(int mode, int bm, int bn);
-/* Diagnostic / test entry of the fp32 GEMM family (gemm_f32 / gemm_x3 / gemm_x4 kernels): mode 0 NT (A [M][K], B [N][K]),
+/* Diagnostic / test entry of the fp32 GEMM family (gemm_f32 / gemm_x5 / gemm_x4 kernels): mode 0 NT (A [M][K], B [N][K]),
  * 1 NN (B [K][N]), 2 TN (A [K][M], B [K][N]); splits >= 1: split-K partial products into `slabs` [splits][M][N]
  * (summed into C too when C != NULL).  Operand bases and pitches need 4-byte alignment only.  PADDING: the bf16x3
- * kernel (gemm_x3_kernel, the default for 128 x 128 tiles) stages operands in 16-byte chunks and clamps, it does not
- * mask — on a partial last k-tile of a k-contiguous operand, and on the last 4-column group of a k-strided one, it
- * reads up to 12 bytes past the last element of an operand ROW (never used in a result).  Inside the library every
- * operand lies in a larger buffer (flat parameter buffers, workspaces); a caller-owned A / B whose last row ends exactly
- * at the end of its allocation with K % 4 != 0 (or, k-strided, a row count % 4 != 0) must be padded by 12 bytes — or run
- * with DGG_X4=1 / DGG_GEMM_ALGO=f32, whose k-tails are fetched element by element (launches of >= 1024 workgroups take
- * the DGG_X4 kernel by themselves).  SIZE: the epilogues address C through 32-bit byte offsets — M * ldc * 4 must stay below
- * 2 GiB (DGG_ERR_INVALID otherwise; the library's own products are 50 000 x 768 at most, callers chunk their rows). */
+ * kernel (gemm_x5_kernel, the default for 128 x 128 tiles) stages operands in 16-byte chunks.  Along K it never leaves
+ * the operand (a partial last k-step is moved back to end at K and the overlap masked); a k-STRIDED operand ([K][rows]:
+ * B of mode 1, A and B of mode 2) is fetched in groups of 4 rows, clamped, not masked: on the last group of every k-row
+ * it reads up to 12 bytes past the last element of that k-row (never used in a result).  Inside the library every
+ * operand lies in a larger buffer (flat parameter buffers, workspaces); a caller-owned k-strided A / B whose last k-row
+ * ends exactly at the end of its allocation with a row count % 4 != 0 must be padded by 12 bytes — or run with
+ * DGG_GEMM_ALGO=f32, whose tails are fetched element by element.  Problems with K < 64 (or split-K chunks that short) run
+ * on the f32-MFMA kernel.  SIZE: the epilogues address C through 32-bit byte offsets — M * ldc * 4 must stay below 2 GiB
+ * (DGG_ERR_INVALID otherwise, dgg_last_error() says so; the library's own products are 50 000 x 768 at most). */
 int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C,
                  int ldc, int splits, float* slabs, int accumulate, void* stream);
-/* Diagnostic / test entry of the pre-split GEMM of the optional planes path (csrc/gemm_p4.hip): C[M,N] = sum_k A(m,k) B(n,k) with both fp32 operands first split into their three bf16 planes in `ws`
- * (dgg_gemm_planes_workspace_bytes).  a_kmajor / b_kmajor != 0: the operand lies [K][rows] in memory (the weight
- * gradient's operands) and goes through the producer's transposing branch.  splits / slabs / accumulate as above.
- * A == NULL and Bm == NULL: multiply the planes a previous call left in `ws` for the same (M, N, K) again — the GEMM
- * kernel alone, without the two producer launches (bench.py's roofline of that kernel). */
-size_t dgg_gemm_planes_workspace_bytes(int M, int N, int K);
-int dgg_gemm_planes(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb,
-                    float* C, int ldc, int splits, float* slabs, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -87,7 +87,7 @@ def _strided(t, ld, off):
                                         (0, (16500, 1000, 203)), (1, (16400, 1100, 77)), (2, (4100, 4100, 129))])
 @pytest.mark.parametrize("align", ["vv", "vu", "uv", "uu"])
 def test_gemm_bf16x3_variants(mode, shape, align):
-    """128 x 128-tile shapes (the ones gemm_x3_kernel serves, and — from 1024 workgroups per launch, the inference
+    """128 x 128-tile shapes (the ones gemm_x5_kernel serves, and — from 1024 workgroups per launch, the inference
     sweep's sizes — gemm_x4_kernel) in every operand orientation and every combination of
     16-byte / 4-byte aligned operands, ragged M / N / K tails included; against fp64 and next to the native f32-MFMA
     kernel on the same data: exact on integers, and on real data — N(0,1) and 12-decade log-normal scales — within
@@ -861,55 +861,73 @@ def test_other_hand_configs():
     np.testing.assert_allclose(p.cpu().numpy(), pr.numpy(), rtol=1e-4, atol=1e-4)
 
 
-# ------------------------------------------------------------------ pre-split planes GEMM (DGG_GEMM_PLANES)
-@pytest.mark.parametrize("shape", [(128, 128, 32, 0, 0, 0), (256, 384, 4120, 0, 0, 0), (1024, 768, 4120, 0, 0, 4),
-                                   (300, 200, 77, 0, 0, 0), (768, 4120, 1024, 1, 1, 0), (130, 515, 300, 1, 1, 0),
-                                   (1024, 768, 517, 0, 0, 2)])
-def test_gemm_planes_vs_fp64(shape):
-    """gemm_p4_kernel behind dgg_gemm_planes: both producer branches (row-major and transposing), K tails inside the
-    zero padding, M / N tails, split-K; integers exact, N(0,1) data at fp32-accumulation error."""
-    _, _lib = _ops()
-    lib = _lib.lib()
-    M, N, K, akm, bkm, splits = shape
-    g = torch.Generator().manual_seed(M + N + K)
+# ------------------------------------------------------------------ gemm_x5_kernel: how K falls onto the four waves
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("K", [64, 65, 79, 80, 96, 111, 112, 127, 128, 129, 160, 1000])
+def test_gemm_x5_k_step_distributions(mode, K):
+    """gemm_x5_kernel (csrc/gemm_x5.hip) gives wave w of a workgroup the 16-deep k-steps w, w + 4, ... of the tile: K = 64
+    is one step per wave, 80 leaves wave 0 with two (an odd and an even count side by side: the odd one starts with the
+    B-outer step body), 65 / 79 / 111 / 127 / 129 / 1000 end on a partial step that is moved back and masked, 96 / 112
+    leave waves without a step or with one.  Ragged M and N (clamped rows, partial tiles), every operand orientation,
+    with and without split-K slabs; integers exact, N(0,1) data within 4e-7 of sum |a||b|."""
+    ops, _lib = _ops()
+    if os.environ.get("DGG_GEMM_ALGO") or os.environ.get("DGG_X5") == "0":
+        pytest.skip("the default GEMM arithmetic / kernel is overridden")
+    M, N = 130, 257
+    g = torch.Generator().manual_seed(K * 3 + mode)
     for kind in ("int", "real"):
         if kind == "int":
-            A = torch.randint(-3, 4, (K, M) if akm else (M, K), generator=g).float().to(DEV)
-            B = torch.randint(-3, 4, (K, N) if bkm else (N, K), generator=g).float().to(DEV)
+            A = torch.randint(-3, 4, (M, K), generator=g).float()
+            Bm = torch.randint(-3, 4, (K, N), generator=g).float()
         else:
-            A = torch.randn((K, M) if akm else (M, K), generator=g).to(DEV)
-            B = torch.randn((K, N) if bkm else (N, K), generator=g).to(DEV)
-        Cm = torch.empty((M, N), device=DEV)
-        nws = int(lib.dgg_gemm_planes_workspace_bytes(M, N, K))
-        ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
-        slabs = torch.empty((max(splits, 1) * M * N,), device=DEV)
-        _lib.check(lib.dgg_gemm_planes(akm, bkm, M, N, K, _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(Cm), N,
-                                       splits, _lib.ptr(slabs) if splits else None, 0, _lib.ptr(ws), nws,
-                                       _lib.stream_ptr()), "dgg_gemm_planes")
-        a64 = A.double().t() if akm else A.double()
-        b64 = B.double() if bkm else B.double().t()
-        ref = a64 @ b64
-        if kind == "int":
-            assert torch.equal(Cm.double(), ref)
-        else:
-            scale = a64.abs() @ b64.abs()
-            assert float(((Cm.double() - ref).abs() / scale).max()) <= 4e-7
+            A, Bm = torch.randn((M, K), generator=g), torch.randn((K, N), generator=g)
+        ref = A.double() @ Bm.double()
+        scale = A.abs().double() @ Bm.abs().double()
+        a_dev = (A if mode in (0, 1) else A.t().contiguous()).to(DEV)
+        b_dev = (Bm.t().contiguous() if mode == 0 else Bm).to(DEV)
+        for splits in ((0, 2) if K >= 128 else (0,)):
+            out = ops.gemm(mode, a_dev, b_dev, M, N, K, splits=splits).cpu().double()
+            if kind == "int":
+                assert torch.equal(out, ref), (K, splits)
+            else:
+                assert ((out - ref).abs() <= 4e-7 * scale + 1e-30).all(), (K, splits)
 
 
-def test_train_step_on_planes_matches_in_register_split():
-    """DGG_GEMM_ALGO=planes (the BPS block's products on bf16 planes split by their producers — ibn_apply, bn_bwd_apply,
-    res_out_bwd, one pass over W13 with the BatchNorm scale folded in —, one batched launch per pass) against the
-    default split inside the GEMM on the same joint steps: same arithmetic up to the summation order of the k tiles and
-    the rounding of gamma * W — losses to 2e-5, every parameter after 2 Adam steps within Adam's reach."""
+def test_gemm_x5_side_work_walks_two_items_per_workgroup():
+    """dgg_set_side_work(1): a forward product beside a latency-critical chain is launched with half the workgroups, each
+    walking two work items (gemm_x5_kernel's stride loop: the reduction's LDS is handed back to the next item's rings).
+    Same items, same sums: bit-identical to the plain launch."""
+    ops, _lib = _ops()
+    lib = _lib.lib()
+    M, N, K = 1024, 1280, 600
+    g = torch.Generator().manual_seed(9)
+    A, W = torch.randn((M, K), generator=g).to(DEV), torch.randn((N, K), generator=g).to(DEV)
+    plain = ops.gemm(0, A, W, M, N, K)
+    try:
+        assert lib.dgg_set_side_work(1) == 0
+        side = ops.gemm(0, A, W, M, N, K)
+    finally:
+        lib.dgg_set_side_work(0)
+    assert torch.equal(plain, side)
+    ref = A.double() @ W.double().t()
+    assert float(((plain.double() - ref).abs() / (A.abs().double() @ W.abs().double().t())).max()) <= 4e-7
+
+
+def test_train_step_bf16x3_matches_f32_mfma_arithmetic():
+    """The default large-GEMM arithmetic (bf16x3 on gemm_x5_kernel) against DGG_GEMM_F32 (v_mfma_f32_32x32x2_f32, a
+    k-ordered fp32 fma chain on the kernels of gemm_f32.hip) on the same joint steps: two independent kernels and
+    summation orders — losses to 2e-5, every parameter after 2 Adam steps within Adam's reach."""
     import test_gpu_fullsize as F
     _, _lib = _ops()
     lib = _lib.lib()
+    if os.environ.get("DGG_GEMM_ALGO"):
+        pytest.skip("DGG_GEMM_ALGO overrides the default GEMM arithmetic this test is about")
     b = 256
     gb = F._dev_inputs(synth.make_batch(b, 1))
     eb = F._dev_inputs(synth.make_batch(b, 2, with_label=True), with_label=True)
     out = {}
     try:
-        for algo in (1, 2):
+        for algo in (1, 0):
             assert lib.dgg_set_gemm_algo(algo) == 0
             eng, _, _ = F._engine("wide")
             store = {}
@@ -926,17 +944,17 @@ def test_train_step_on_planes_matches_in_register_split():
             eng.close()
     finally:
         lib.dgg_set_gemm_algo(1)
-    for l1, l2 in zip(out[1][0], out[2][0]):
+    for l1, l2 in zip(out[1][0], out[0][0]):
         np.testing.assert_allclose(l2[:10].numpy(), l1[:10].numpy(), rtol=2e-5, atol=1e-7)
     # the first step starts from identical parameters: its gradients agree to rounding — unless the two arithmetics put a
     # pre-activation on different sides of a LeakyReLU kink (helpers.assert_grad_tensor_close), which the sides read back
     # from the two runs show
-    flips = sum(int((m1 != m2).sum()) for m1, m2 in zip(out[1][3][0], out[2][3][0]))
-    for g1, g2 in zip(out[1][1][0], out[2][1][0]):
+    flips = sum(int((m1 != m2).sum()) for m1, m2 in zip(out[1][3][0], out[0][3][0]))
+    for g1, g2 in zip(out[1][1][0], out[0][1][0]):
         rel = float((g1 - g2).double().norm() / g1.double().norm())
         assert rel < (2e-4 if flips == 0 else 0.3 / np.sqrt(b)), (rel, flips)
-    print("planes vs in-register split: %d LeakyReLU sides differ in step 1" % flips)
-    for p1, p2 in zip(out[1][2], out[2][2]):
+    print("bf16x3 vs f32 MFMA: %d LeakyReLU sides differ in step 1" % flips)
+    for p1, p2 in zip(out[1][2], out[0][2]):
         assert float((p1 - p2).abs().max()) <= 2.5 * 1e-4 * 2   # hard Adam bound: 2 steps of at most ~lr each
 
 

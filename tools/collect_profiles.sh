@@ -4,7 +4,7 @@
 #   launches, the BPS encode and Adam.  Summaries land in gpurun_out/prof_<tag>/; tools/summarize_profiles.py turns
 #   them into the committed files under profiles/.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -13,11 +13,10 @@ R=$GRAFT_REPO_ROOT
 if [ -z "$ONLY" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 $R/bench.py --no-cpu-baseline --no-sub --repeats 3 > $OUT/bench.log 2>&1
 fi
-# name:[X4=1:]microbench arguments   (x4_*: the opt-in loader / consumer kernel, DGG_X4=1 set in the shell — the program
+# name:[X4=1:]microbench arguments   (x4_*: the loader / consumer kernel of the >= 1024-workgroup launches, forced by DGG_X4=1 set in the shell — the program
 # behind `--` stays python3 itself)
 for what in "gemm_nt:gemm --k 4120 --splits 4 --iters 10" "gemm_tn:gemm --mode 2 --m 768 --n 4120 --k 1024 --splits 0 --iters 10" \
             "x4_nt:X4=1:gemm --k 4120 --splits 4 --iters 10" "x4_tn:X4=1:gemm --mode 2 --m 768 --n 4120 --k 1024 --splits 0 --iters 10" \
-            "p4_batched:planes --m 1024 --n 3072 --k 4096 --splits 4 --iters 10" "p4_batched_e:planes --m 1024 --n 2304 --k 4096 --splits 5 --iters 10" \
             "bps:bps --iters 5" "bps_valu:VALU=1:bps --iters 5"; do
   name=${what%%:*}; args=${what#*:}
   if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $name "; then continue; fi

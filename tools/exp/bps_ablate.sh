@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../../dex_gan_grasp_amd/csrc"
 cp ../libdgg.so /tmp/libdgg_keep.so
-O="_obj/gemm_f32.o _obj/gemm_x3.o _obj/gemm_p3.o _obj/gemm_p4.o _obj/gemm_x4.o _obj/elementwise.o _obj/second_order.o _obj/dgg_api.o"
+O="_obj/gemm_f32.o _obj/gemm_x4.o _obj/gemm_x5.o _obj/elementwise.o _obj/second_order.o _obj/dgg_api.o"
 for a in ${ABL:-"-DBPS_ABLATE=1" "-DBPS_ABLATE=4" "-DBPS_ABLATE=7"}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form $a -c bps_encode.hip -o /tmp/bps_abl.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libdgg.so $O /tmp/bps_abl.o

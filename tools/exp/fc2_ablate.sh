@@ -7,7 +7,7 @@ if [ "$1" = "build" ]; then
   cd dex_gan_grasp_amd/csrc
   for v in $VARS; do n=${v%%:*}; f=${v#*:}
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $f -c gemm_f32.hip -o /tmp/gf_$n.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/exp/libdgg_fc2_$n.so /tmp/gf_$n.o _obj/gemm_x3.o _obj/gemm_p3.o _obj/gemm_p4.o _obj/gemm_x4.o _obj/elementwise.o _obj/second_order.o _obj/bps_encode.o _obj/dgg_api.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/exp/libdgg_fc2_$n.so /tmp/gf_$n.o _obj/gemm_x4.o _obj/gemm_x5.o _obj/elementwise.o _obj/second_order.o _obj/bps_encode.o _obj/dgg_api.o
   done; ls tools/exp/libdgg_fc2_* 2>/dev/null; ls ../../tools/exp/libdgg_fc2_*
 else
   cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

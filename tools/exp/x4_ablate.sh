@@ -10,7 +10,7 @@ if [ "$1" = build ]; then
   done
   wait
   for n in 1 2 3 4; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/libdgg_x4ab$n.so $O/gemm_f32.o $O/gemm_x3.o $O/gemm_p3.o $O/gemm_p4.o scratch/x4ab$n.o $O/elementwise.o $O/second_order.o $O/bps_encode.o $O/dgg_api.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/libdgg_x4ab$n.so $O/gemm_f32.o $O/gemm_x5.o scratch/x4ab$n.o $O/elementwise.o $O/second_order.o $O/bps_encode.o $O/dgg_api.o
   done
   ls -la scratch/*.so
   exit 0

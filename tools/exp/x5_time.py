@@ -1,5 +1,6 @@
-"""gemm_x5_kernel against gemm_x3_kernel (DGG_X5=0 in a child process): error against fp64 and HIP-event time of the train
-step's three large shapes (+ ragged ones).  python3 tools/exp/x5_time.py [check|time]"""
+"""gemm_x5_kernel against the f32-MFMA kernel of gemm_f32.hip (DGG_X5=0 in a child process; until round 5 that switch
+selected gemm_x3_kernel, which this script was written to beat): error against fp64 and HIP-event time of the train step's
+three large shapes (+ ragged ones).  python3 tools/exp/x5_time.py [check|time]"""
 import os, sys, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -52,7 +53,7 @@ def main():
     if os.environ.get("X5_CHILD") is None:
         env = dict(os.environ, X5_CHILD="1", DGG_X5="0")
         r = subprocess.run([sys.executable, os.path.abspath(__file__), what], env=env, capture_output=True, text=True)
-        print("---- DGG_X5=0 (gemm_x3_kernel)")
+        print("---- DGG_X5=0 (f32-MFMA kernel, gemm_f32.hip)")
         print(r.stdout, r.stderr[-2000:])
         print("---- default (gemm_x5_kernel)")
     for mode, M, N, K, splits, name in SHAPES:

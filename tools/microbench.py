@@ -32,7 +32,7 @@ def time_it(fn, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gemm", "planes", "bps", "bps1"])
+    ap.add_argument("what", choices=["gemm", "bps", "bps1"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--k", type=int, default=4613)
     ap.add_argument("--m", type=int, default=1024)
@@ -41,23 +41,7 @@ def main():
     ap.add_argument("--splits", type=int, default=10)
     a = ap.parse_args()
     dev = "cuda"
-    if a.what == "planes":
-        # the planes GEMM (gemm_p4_kernel) through dgg_gemm_planes: NT, split-K slabs;
-        # every call also runs the two planes_kernel launches that split the operands (separate kernels in a trace)
-        M, N, K, S = a.m, a.n, a.k, max(1, a.splits)
-        g = torch.Generator().manual_seed(0)
-        A = torch.randn((M, K), generator=g).to(dev)
-        W = torch.randn((N, K), generator=g).to(dev)
-        lib = _lib.lib()
-        nws = int(lib.dgg_gemm_planes_workspace_bytes(M, N, K))
-        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
-        slabs = torch.empty((S * M * N,), device=dev)
-        fn = lambda: _lib.check(lib.dgg_gemm_planes(0, 0, M, N, K, _lib.ptr(A), K, _lib.ptr(W), K, None, N, S, _lib.ptr(slabs), 0,
-                                                    _lib.ptr(ws), nws, _lib.stream_ptr()))
-        ms = time_it(fn, a.iters)
-        print(json.dumps({"kernel": "gemm_p4_kernel<false> + 2 x planes_kernel", "M": M, "N": N, "K": K, "splits": S,
-                          "ms_incl_planes": ms, "tflops_incl_planes": 2.0 * M * N * K / ms / 1e9}))
-    elif a.what == "gemm":
+    if a.what == "gemm":
         M, N, K, S = a.m, a.n, a.k, a.splits
         g = torch.Generator().manual_seed(0)
         # mode 0: A[M][K] B[N][K];  1: A[M][K] B[K][N];  2: A[K][M] B[K][N]
@@ -73,7 +57,7 @@ def main():
                                                  _lib.stream_ptr()))
         ms = time_it(fn, a.iters)
         fl = 2.0 * M * N * K
-        print(json.dumps({"kernel": ("gemm_x3_kernel<NT>" if lib.dgg_get_gemm_algo() >= 1 else "gemm_f32_kernel<128,128,NT>"), "mode": a.mode, "M": M, "N": N, "K": K, "splits": S, "ms": ms,
+        print(json.dumps({"kernel": ("gemm_x5_kernel" if lib.dgg_get_gemm_algo() >= 1 else "gemm_f32_kernel<128,128,NT>"), "mode": a.mode, "M": M, "N": N, "K": K, "splits": S, "ms": ms,
                           "tflops": fl / ms / 1e9, "algorithmic_bytes": 4 * (M * K + N * K + S * M * N)}))
     else:
         B, Np = (1024, 2048) if a.what == "bps" else (1, 73000)

@@ -47,10 +47,10 @@ if bench_stats:
             open(os.path.join(dst, "%s_bench.json" % tag), "w").write(line)
 
 specs = [
-    ("gemm_nt", "gemm_x3_kernel<true, true", "gemm_x3", {"M": 1024, "N": 768, "K": 4120, "splits": 4},
+    ("gemm_nt", "gemm_x5_kernel<true, true", "gemm_x5", {"M": 1024, "N": 768, "K": 4120, "splits": 4},
      "python3 tools/microbench.py gemm --k 4120 --splits 4 --iters 10", 2.0 * 1024 * 768 * 4120,
      4 * (1024 * 4120 + 768 * 4120 + 4 * 1024 * 768)),
-    ("gemm_tn", "gemm_x3_kernel<false, false", "gemm_x3_tn", {"M": 768, "N": 4120, "K": 1024, "splits": 0},
+    ("gemm_tn", "gemm_x5_kernel<false, false", "gemm_x5_tn", {"M": 768, "N": 4120, "K": 1024, "splits": 0},
      "python3 tools/microbench.py gemm --mode 2 --m 768 --n 4120 --k 1024 --splits 0 --iters 10", 2.0 * 768 * 4120 * 1024,
      4 * (1024 * 768 + 1024 * 4120 + 768 * 4120)),
     ("x4_nt", "gemm_x4_kernel<true, true", "gemm_x4", {"M": 1024, "N": 768, "K": 4120, "splits": 4},
@@ -59,12 +59,6 @@ specs = [
     ("x4_tn", "gemm_x4_kernel<false, false", "gemm_x4_tn", {"M": 768, "N": 4120, "K": 1024, "splits": 0},
      "DGG_X4=1 python3 tools/microbench.py gemm --mode 2 --m 768 --n 4120 --k 1024 --splits 0 --iters 10", 2.0 * 768 * 4120 * 1024,
      4 * (1024 * 768 + 1024 * 4120 + 768 * 4120)),
-    ("p4_batched", "gemm_p4_kernel<false>", "gemm_p4_batched_gd", {"M": 1024, "N": 3072, "K": 4096, "splits": 4},
-     "python3 tools/microbench.py planes --m 1024 --n 3072 --k 4096 --splits 4 --iters 10", 2.0 * 1024 * 3072 * 4096,
-     6 * (1024 * 4096 + 3072 * 4096) + 4 * 4 * 1024 * 3072),
-    ("p4_batched_e", "gemm_p4_kernel<false>", "gemm_p4_batched_e", {"M": 1024, "N": 2304, "K": 4096, "splits": 5},
-     "python3 tools/microbench.py planes --m 1024 --n 2304 --k 4096 --splits 5 --iters 10", 2.0 * 1024 * 2304 * 4096,
-     6 * (1024 * 4096 + 2304 * 4096) + 5 * 4 * 1024 * 2304),
     ("bps", "bps_mfma_kernel", "bps_encode", {"B": 1024, "N": 2048, "P": 4096},
      "python3 tools/microbench.py bps --iters 5", 1024 * 2048 * 4096 * 8.0, 1024 * (2048 * 12 + 4096 * 8) + 4096 * 12),
     ("bps_valu", "bps_batched_kernel", "bps_encode_valu", {"B": 1024, "N": 2048, "P": 4096},
