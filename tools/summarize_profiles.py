@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.environ.get("PROFILES_DST") or os.path.join(ROOT, "profiles")   # PROFILES_DST: scratch summaries of an experiment
 os.makedirs(dst, exist_ok=True)
@@ -106,6 +106,19 @@ for name, ksub, outname, shape, cmd, flops, alg_bytes in specs:
             mi = 8.0 * c.get("SQ_INSTS_MFMA", 0.0) / simd_cycles
             out["derived"].update({"valu_issue_active_frac": round(va, 4), "mfma_issue_frac": round(mi, 4),
                                    "vector_issue_port_busy_frac": round(va + mi, 4)})
+        # GRBM_GUI_ACTIVE / 8 / duration reads HIGH on dispatches shorter than ~0.3 ms (MI355X_MICROARCH.md, DVFS give-back): 2.5 GHz
+        # on a 60-us launch, 3.5 GHz on a 44-us one, where in-kernel s_memtime / s_memrealtime stamps say 1.85-2.05.
+        # SQ_BUSY_CYCLES sums the busy cycles of the 32 shader engines of the chip: / 32 / duration reproduces the stamped
+        # clock (round 5: 1.88 GHz on the 43.8-us weight-gradient launch, tools/exp/x5_stamps.py 1.87-1.95) — the
+        # occupancies below are also given against THAT cycle count.
+        if c.get("SQ_BUSY_CYCLES"):
+            cyc = c["SQ_BUSY_CYCLES"] / 32.0
+            d2 = {"shader_clock_ghz_from_SQ_BUSY_CYCLES": round(cyc / (dur * 1e-9) / 1e9, 3),
+                  "mfma_pipe_busy_frac_of_SQ_BUSY_cycles": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 256 * 4), 4)}
+            if "SQ_ACTIVE_INST_VALU" in c:
+                d2["vector_issue_port_busy_frac_of_SQ_BUSY_cycles"] = round(
+                    (4.0 * c["SQ_ACTIVE_INST_VALU"] + 8.0 * c.get("SQ_INSTS_MFMA", 0.0)) / (cyc * 256 * 4), 4)
+            out["derived"].update(d2)
         if "SQ_WAVE_CYCLES" in c and "SQ_WAIT_ANY" in c:
             out["derived"].update({"wave_wait_any_frac": round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4),
                                    "wave_wait_inst_any_frac": round(c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)})
