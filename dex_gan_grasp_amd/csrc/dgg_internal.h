@@ -71,6 +71,7 @@ struct GemmBatch {
     GemmProb p[kMaxProb];
     int nprob;
     int total_blocks;
+    int diag;   // diagnostics (gemm_x5: bit 0 = element-wise epilogue everywhere, DGG_X5_WIDE=0); 0 in every product path
 };
 enum GemmMode { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
 // Fills tiling fields of one problem for the tile shape the launcher will use; returns #blocks.

@@ -549,6 +549,7 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
             GemmBatch large, small;
             large.nprob = small.nprob = 0;
             large.total_blocks = small.total_blocks = 0;
+            large.diag = small.diag = 0;
             for (int i = 0; i < batch.nprob; ++i) {
                 GemmBatch& dst = gemm_x5_prob_ok(batch.p[i]) ? large : small;
                 GemmProb& q = dst.p[dst.nprob++];

@@ -52,6 +52,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4_u __attribute__((aligned(4)));   // a 16-byte global access at any dword address (row pitches are the checkpoint's: 4101, 4613, ...)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) float lds_f32;
@@ -111,6 +112,133 @@ __host__ __device__ constexpr int fcode(FD f) { return f.op * 16 + f.par * 8 + f
 __host__ __device__ constexpr FD fdec(int c) { return FD{c >> 4, (c >> 3) & 1, c & 7}; }
 template <int C>
 using FC = std::integral_constant<int, C>;
+
+// Epilogue of a tile that lies inside the matrix, with 16-byte stores and loads.  The MFMA layout hands a lane ONE column
+// and 4 consecutive rows per register quad — row-major C then takes 64 one-dword store instructions per wave, and four
+// waves storing at once are bound by store ISSUE (3.4-4.3k cycles; MI355X_MICROARCH.md: a store tail of narrow stores).  The
+// wave turns its 64 x 64 quadrant through its own (now idle) 16 KB of LDS: 64 ds_write_b32 in the MFMA layout (lanes = 32
+// consecutive columns: conflict-free), 16 ds_read_b128 row-major (lane = row (lane >> 4) + 4 i, columns 4 (lane & 15) ..:
+// with a 256-byte row pitch the 16 lanes of a read group cover all 64 banks).  Then 16 instructions of 4 rows x 256
+// contiguous bytes each.  Same values as gemm_epilogue() for the plain / slab / accumulate forms; the BatchNorm-aware
+// weight-gradient form (GemmProb::ep_gamma) adds up its per-column partials in another — fixed — order.
+template <bool WGRAD>
+__device__ __forceinline__ void x5_epilogue_rows(const GemmProb& P, const f32x16 (&res)[2][2], unsigned lds_wave, float* red,
+                                                 int split, int tm_i, int m0, int n0, int wave, int lane, int tid) {
+    {
+        const unsigned wb = lds_wave + (unsigned)((4 * (lane >> 5)) * 64 + (lane & 31)) * 4u;
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    *(lds_f32*)(size_t)(wb + (unsigned)(((32 * ta + (r & 3) + 8 * (r >> 2)) * 64 + 32 * tb) * 4)) = res[ta][tb][r];
+    }
+    f32x4 v[16];
+    {
+        const unsigned rb_ = lds_wave + (unsigned)((lane >> 4) * 64 + 4 * (lane & 15)) * 4u;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = *(lds_f32x4*)(size_t)(rb_ + (unsigned)(4 * i * 64 * 4));
+    }
+    const int row0 = m0 + 64 * (wave >> 1) + (lane >> 4);          // this lane's rows: row0 + 4 i
+    const int col0 = n0 + 64 * (wave & 1) + 4 * (lane & 15);        // ... and its 4 columns
+    float* Cb = P.C + (P.splits > 0 ? (size_t)split * (size_t)P.slab_stride : (size_t)0);
+    const bool accum = (P.splits == 0) && P.accumulate;
+    char* const Cbytes = reinterpret_cast<char*>(Cb);
+    auto c_at = [&](int i) { return reinterpret_cast<f32x4_u*>(Cbytes + ((unsigned)(row0 + 4 * i) * (unsigned)P.ldc + (unsigned)col0) * 4u); };
+    if constexpr (WGRAD) {
+        if (P.ep_gamma) {   // dW[n][k] = gamma[k] T + beta[k] cs[n]; per-column partials of sum_n W T and sum_n W cs (GemmProb)
+            const char* const Wbytes = reinterpret_cast<const char*>(P.ep_w);
+            auto w_at = [&](int i) {
+                return reinterpret_cast<const f32x4_u*>(Wbytes + ((unsigned)(row0 + 4 * i) * (unsigned)P.ep_ldw + (unsigned)col0) * 4u);
+            };
+            const f32x4 ga = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const char*>(P.ep_gamma) + (unsigned)col0 * 4u);
+            const f32x4 be = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const char*>(P.ep_beta) + (unsigned)col0 * 4u);
+            // column sums of dY per output row; the wave's 64 rows lie on one side of ep_split (a multiple of 64: the caller checks)
+            float csn[16];
+            const int rbase = m0 + 64 * (wave >> 1);
+            if (rbase + 64 <= P.ep_split) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) csn[i] = 0.f;
+                if (P.ep_cs0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) csn[i] = P.ep_cs0[row0 + 4 * i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) csn[i] = P.ep_cs1[row0 + 4 * i - P.ep_split];
+                if (P.ep_cs1b) {
+                    float t[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) t[i] = P.ep_cs1b[row0 + 4 * i - P.ep_split];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) csn[i] += t[i];
+                }
+            }
+            f32x4 pg = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h8 = 0; h8 < 16; h8 += 8) {   // 8 rows per batch of loads
+                f32x4 w[8], old[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w[i] = *w_at(h8 + i);
+                if (accum) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) old[i] = *c_at(h8 + i);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no load of the epilogue outlives it (see gemm_epilogue.h)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x4 t = v[h8 + i];
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        pg[j] = __builtin_fmaf(w[i][j], t[j], pg[j]);
+                        pb[j] = __builtin_fmaf(w[i][j], csn[h8 + i], pb[j]);
+                        o[j] = __builtin_fmaf(ga[j], t[j], be[j] * csn[h8 + i]);
+                        if (accum) o[j] += old[i][j];
+                    }
+                    *c_at(h8 + i) = o;
+                }
+            }
+            // the wave's 64 rows: lanes l, l + 16, l + 32, l + 48 hold the same columns
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pg[j] += __shfl_xor(pg[j], 16);
+                pg[j] += __shfl_xor(pg[j], 32);
+                pb[j] += __shfl_xor(pb[j], 16);
+                pb[j] += __shfl_xor(pb[j], 32);
+            }
+            if (lane < 16) {
+                const int c = 64 * (wave & 1) + 4 * lane;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    red[((wave >> 1) * 2 + 0) * YT + c + j] = pg[j];
+                    red[((wave >> 1) * 2 + 1) * YT + c + j] = pb[j];
+                }
+            }
+            __syncthreads();
+            {
+                const int q = tid >> 7, cidx = tid & 127;   // 256 threads: 2 quantities x 128 columns; the two row halves in order
+                const float t = red[q * YT + cidx] + red[(2 + q) * YT + cidx];
+                P.ep_part[((size_t)tm_i * 2 + q) * (P.ep_part_ld ? P.ep_part_ld : P.N) + n0 + cidx] = t;
+            }
+            return;
+        }
+    }
+    if (accum) {
+        f32x4 old[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) old[i] = *c_at(i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 16; ++i) old[i] = v[i] + old[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *c_at(i) = old[i];
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) *c_at(i) = v[i];
+}
 
 // X1 (DGG_GEMM_BF16, BASELINE config 3 "bf16 MFMA fc stacks"; never the default): plain bf16 — only the hi plane, ONE
 // product per fragment pair, fp32 accumulate, fp32 master operands rounded while they are staged.
@@ -552,7 +680,13 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
 #if DGG_X5_STAMP
     stamp[5] = __builtin_amdgcn_s_memtime();
 #endif
-    gemm_epilogue<YT, YT, 2, 2, !A_KC && !B_KC>(P, res, reinterpret_cast<float*>(smem + 128 * 1024), split, tm_i, m0, n0, (int)threadIdx.x);
+    // a tile inside the matrix (and, for the BatchNorm-aware form, quadrants on one side of the fc1 | fc3 row split) stores
+    // row-major with 16-byte accesses; the others take the shared element-wise epilogue (workgroup-uniform choice)
+    if (!(batch.diag & 1) && m0 + YT <= M && n0 + YT <= N && (!P.ep_gamma || (P.ep_split & 63) == 0))
+        x5_epilogue_rows<!A_KC && !B_KC>(P, res, lds0 + (unsigned)wave * 32768u, reinterpret_cast<float*>(smem + 128 * 1024), split, tm_i,
+                                         m0, n0, wave, lane, (int)threadIdx.x);
+    else
+        gemm_epilogue<YT, YT, 2, 2, !A_KC && !B_KC>(P, res, reinterpret_cast<float*>(smem + 128 * 1024), split, tm_i, m0, n0, (int)threadIdx.x);
 #if DGG_X5_STAMP
     stamp[6] = __builtin_amdgcn_s_memtime();
     stamp[7] = __builtin_amdgcn_s_memrealtime();
@@ -577,7 +711,10 @@ static void launch_x5(const GemmBatch& b, hipStream_t st) {
     // side work (dgg_set_side_work): as launch_x3 — the forward products walk two work items per workgroup
     static const int kdiv = [] { const char* e = getenv("DGG_SIDE_DIV"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
     if (gemm_side_work() && A_KC && B_KC && grid > 64) grid = ((grid + kdiv - 1) / kdiv + 7) / 8 * 8;
-    hipLaunchKernelGGL((gemm_x5_kernel<A_KC, B_KC, AFF, X1>), dim3(grid), dim3(256), 0, st, b);
+    static const int diag = [] { const char* e = getenv("DGG_X5_WIDE"); return (e && e[0] == '0') ? 1 : 0; }();
+    GemmBatch bb = b;
+    bb.diag = diag;
+    hipLaunchKernelGGL((gemm_x5_kernel<A_KC, B_KC, AFF, X1>), dim3(grid), dim3(256), 0, st, bb);
 }
 
 }  // namespace x5
