@@ -548,11 +548,13 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
         if (odd) {
             const int k0 = k0_of(0), k1 = k0_of(nw > 1 ? 1 : 0);   // (a single step is staged twice: the count in flight is fixed)
             static_for<NDMA>([&](auto tc) { dma_piece(tc, k0, 1, row_a(k0), row_b(k0)); });
-            static_for<NDMA>([&](auto tc) { dma_piece(tc, k1, 0, row_a(k1), row_b(k1)); });
             __builtin_amdgcn_sched_barrier(0);
             zero_acc();   // while the first stage lands
             __builtin_amdgcn_sched_barrier(0);
-            wait_vm<0>();   // both stages: no counted wait anywhere in this kernel (17 pieces of two widths are in flight)
+            wait_vm<0>();   // (no counted wait anywhere in this kernel: its pieces come in two widths)
+            // the second stage is requested only now: it lands behind the splits below and is waited for 24 MFMAs into step 0
+            static_for<NDMA>([&](auto tc) { dma_piece(tc, k1, 0, row_a(k1), row_b(k1)); });
+            __builtin_amdgcn_sched_barrier(0);
             read_aff(1);
             static_for<4>([&](auto ac) {
                 constexpr int a = decltype(ac)::value;
@@ -576,11 +578,12 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
         } else {
             const int k0 = k0_of(0), k1 = k0_of(1);
             static_for<NDMA>([&](auto tc) { dma_piece(tc, k0, 0, row_a(k0), row_b(k0)); });
-            static_for<NDMA>([&](auto tc) { dma_piece(tc, k1, 1, row_a(k1), row_b(k1)); });
             __builtin_amdgcn_sched_barrier(0);
             zero_acc();   // while the first stage lands
             __builtin_amdgcn_sched_barrier(0);
-            wait_vm<0>();   // both stages: no counted wait anywhere in this kernel (17 pieces of two widths are in flight)
+            wait_vm<0>();
+            static_for<NDMA>([&](auto tc) { dma_piece(tc, k1, 1, row_a(k1), row_b(k1)); });
+            __builtin_amdgcn_sched_barrier(0);
             read_aff(0);
             static_for<4>([&](auto bc) {
                 constexpr int b = decltype(bc)::value;
