@@ -1,11 +1,15 @@
-// bf16x3 GEMM on fp32 operands with SPECIALISED waves (round 3): the arithmetic, problem descriptors, split-K slabs, tile
-// (128 x 128 x 32) and epilogues of gemm_x3.hip, but the fp32 -> (hi, mid, lo) split has left the MFMA waves:
+// bf16x3 GEMM on fp32 operands with SPECIALISED waves (round 3; since round 5 the kernel of launches of >= 1024 workgroups
+// only — the inference sweep — beside gemm_x5.hip, which explains the arithmetic): problem descriptors, split-K slabs and
+// epilogues as every GEMM kernel of the library, 128 x 128 x 32 tiles, and the fp32 -> (hi, mid, lo) split outside the
+// MFMA waves.  ("gemm_x3_kernel" below is the first in-register-split kernel, rounds 2-4, 2 x 2 waves of 64 x 64 that
+// each split their own fragments; "gemm_p3 / gemm_p4" were the pre-split planes kernels.  Both are deleted; the
+// measurements against them stay in the comments because they are why this kernel looks the way it does.)
 //   waves 4-7 ("loaders", the second wave of each SIMD): global -> VGPR (coalesced: 16 rows x 128 B of a k-contiguous
 //             operand, 8 k-rows x 256 B of a k-strided one), [input-BatchNorm affine, k-tail mask], split ONCE per workgroup
 //             (gemm_x3_kernel: every element split by the two waves that share it), three ds_write_b128 per lane and
 //             task into the bf16 plane tiles of an LDS stage;
 //   waves 0-3 ("consumers", 2 x 2 of 64 x 64): 24 ds_read_b128 + 48 v_mfma_f32_32x32x16_bf16 per k-tile, nothing else —
-//             the loop of gemm_p4_kernel on the LDS image of gemm_p3.hip (plane tile = [128 rows][64 B], 16-byte chunks
+//             (LDS image: plane tile = [128 rows][64 B], 16-byte chunks
 //             XOR-swizzled by (row >> 2) & 3: fragment reads and loader stores are both bank-conflict-free).
 // Why this works where gemm_x3_kernel is issue-bound (2760 cycles per k-tile against 1536 of MFMA): a SIMD's vector ALU
 // work of ANOTHER wave does fit into the shadow of an MFMA stream — tools/exp/split_probe.hip: with 176 split
@@ -53,7 +57,7 @@ __device__ __forceinline__ unsigned x4_pack(float a, float b) {  // v_cvt_pk_bf1
     yf32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ybf16x2));
 }
-// 8 consecutive-k fp32 values of one operand row -> 16 bytes of each plane (the split of gemm_x3.hip, stage by stage so
+// 8 consecutive-k fp32 values of one operand row -> 16 bytes of each plane (the exact 3-way split, stage by stage so
 // that the four dependent chains overlap)
 __device__ __forceinline__ void x4_split(const float (&x)[8], yu32x4& hi, yu32x4& mid, yu32x4& lo) {
     unsigned h[4], m[4], l[4];
@@ -90,7 +94,7 @@ struct X4Frags {
 //        instruction reads 16 rows x 128 contiguous bytes);
 //   !KC (stored [k][row]): lane -> row quad lane % 16 (rows 64 hf + 4 quad .. + 3), k-chunk lane / 16; load i fetches the
 //        quad at k = 8 chunk + i (a wave instruction reads 4 k-rows x 256 contiguous bytes) — after 8 loads the lane holds
-//        4 rows x 8 k: the transposition costs nothing.  Row indices are clamped into the matrix as in gemm_x3_kernel (a
+//        4 rows x 8 k: the transposition costs nothing.  Row indices are clamped into the matrix (a
 //        quad may extend up to 12 bytes past the last row index: such bytes lie inside the operand's row pitch or the
 //        next row and feed accumulator columns that are never stored).
 // The loads of tile j+1 are issued before tile j is split and stay in flight meanwhile; the compiler places the counted
@@ -283,7 +287,7 @@ __device__ __forceinline__ void x4_loader(const float* __restrict__ G, const int
 // return from the kernel behind it).
 template <bool A_KC, bool B_KC, bool AFF>
 __device__ __forceinline__ void gemm_x4_block(const GemmBatch& batch, const int bid, char* smem, const bool first, const bool last) {
-    // ---- work assignment: identical to gemm_x3_kernel (problem select, XCD-contiguous remap, split-K range)
+    // ---- work assignment: as in gemm_x5_kernel (problem select, XCD-contiguous remap, split-K range)
     GemmProb P = batch.p[0];
 #pragma unroll
     for (int q = 1; q < kMaxProb; ++q)
@@ -400,7 +404,7 @@ __device__ __forceinline__ void gemm_x4_block(const GemmBatch& batch, const int 
 }
 
 // One workgroup per work item — or, launched with fewer workgroups than items ("side work", forward products only: their
-// epilogue neither touches the LDS nor holds a barrier), a stride loop over them (see gemm_x3_kernel).
+// epilogue neither touches the LDS nor holds a barrier), a stride loop over them (see gemm_x5_kernel).
 template <bool A_KC, bool B_KC, bool AFF>
 __global__ __launch_bounds__(512) void gemm_x4_kernel(const GemmBatch batch) {
     __shared__ __attribute__((aligned(16))) char smem[YS * YSTAGE];
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(512) void gemm_x4_kernel(const GemmBatch batch) {
 void gemm_x4_dispatch(int mode, const GemmBatch& batch, hipStream_t st) {
     int nwg = batch.total_blocks;
     // side work (dgg_set_side_work): the forward products walk two work items per workgroup — same items, same sums,
-    // half the CUs for twice as long (gemm_x3.hip: launch_x3)
+    // half the CUs for twice as long (gemm_x5.hip: launch_x5)
     static const int kdiv = [] { const char* e = getenv("DGG_SIDE_DIV"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
     if (gemm_side_work() && mode == GEMM_NT && nwg > 64) nwg = ((nwg + kdiv - 1) / kdiv + 7) / 8 * 8;
     const dim3 grid(nwg), blk(512);
@@ -439,7 +443,8 @@ bool gemm_x4_enabled(long total_blocks) {
     // kernels of the other streams find fewer CUs to co-reside on than beside gemm_x3_kernel's 4 waves.  Where ONE stream
     // runs long launches it does pay: the config-5 inference sweep (1250 objects x 200 grasps, products of 250 000 rows)
     // 15.15 -> 13.95 ms.  Hence: launches of >= 1024 workgroups (four rounds of the chip; the train step's largest has
-    // 240) take it, everything else gemm_x3_kernel.  DGG_X4=1 / 0 forces it on / off for every launch.
+    // 240) take it, everything else gemm_x5_kernel (round 5: sweep 13.1 ms here against 13.9 there).  DGG_X4=1 / 0 forces it
+    // on / off for every launch.
     static const int mode = [] {
         const char* e = getenv("DGG_X4");
         return !e ? -1 : (e[0] == '1' ? 1 : 0);

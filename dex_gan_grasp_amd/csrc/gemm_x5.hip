@@ -1,8 +1,14 @@
 // bf16x3 GEMM, round 5: ONE wave owns the whole 128 x 128 accumulator block.
 //
-// Same arithmetic as gemm_x3.hip (fp32 operands split exactly into three bf16 pieces, six partial products per
-// product on v_mfma_f32_32x32x16_bf16, fp32 accumulate), same problem descriptors, work assignment and epilogues.  What
-// changes is who computes what.  gemm_x3_kernel gives each of its four waves a 64 x 64 quarter of the output tile: per
+// Arithmetic ("bf16x3"): on gfx950 the f32 MFMA (v_mfma_f32_32x32x2_f32) peaks at 157 TFLOP/s while
+// v_mfma_f32_32x32x16_bf16 runs 16x faster, so every fp32 operand element x is split EXACTLY into three bf16 pieces
+//     hi = bf16(x),  mid = bf16(x - hi),  lo = bf16(x - hi - mid)         (round-to-nearest-even each)
+// (|x - hi - mid - lo| <= 2^-27 |x|: the three 8-bit significands cover fp32's 24 bits) and a product a*b is accumulated
+// as the six leading partial products  a_hi b_hi + a_hi b_mid + a_mid b_hi + a_hi b_lo + a_lo b_hi + a_mid b_mid  — each
+// exact in the MFMA's fp32 accumulator.  The dropped terms are below 2^-25 |a b|, under the rounding error of the fp32
+// accumulation itself: an fp32-accurate GEMM at 6/16 of the f32-MFMA cost.  Problem descriptors, work assignment and
+// epilogues are those of gemm_f32.hip.
+// Who computes what.  The kernel of rounds 2-4 (gemm_x3_kernel, deleted) gave each of its four waves a 64 x 64 quarter of the output tile: per
 // 16-deep k-step a wave splits 4 fragments for 24 MFMAs — 7.3 vector instructions per MFMA, where an MFMA's 32 cycles
 // hide about five (MI355X_MICROARCH.md, cycle constants) — and every element is split by two waves; measured 57
 // cycles per MFMA.  Here the four waves of a workgroup split the K range instead: wave w takes the k-steps w, w + 4,
@@ -66,7 +72,7 @@ constexpr int YSTAGE = 2 * YOP + 256;
 constexpr int YWAVE = 2 * YSTAGE;       // a wave's private ring
 constexpr int YSMEM = 4 * YWAVE;        // 133120 B; the reduction at the end reuses it (128 KB + 2 KB of epilogue scratch)
 constexpr int YNP = YOP / 1024;         // DMA pieces per operand and k-step (8)
-constexpr int YMINK = 64;               // shorter problems stay on gemm_x3_kernel
+constexpr int YMINK = 64;               // shorter problems run on gemm_f32_kernel
 
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -244,7 +250,7 @@ __device__ __forceinline__ void x5_epilogue_rows(const GemmProb& P, const f32x16
 // product per fragment pair, fp32 accumulate, fp32 master operands rounded while they are staged.
 template <bool A_KC, bool B_KC, bool AFF, bool X1>
 __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int bid, char* smem) {
-    // ---- work assignment: identical to gemm_x3_kernel (problem select, XCD-contiguous remap, split-K range)
+    // ---- work assignment (problem select, XCD-contiguous remap: each XCD gets a contiguous run of (split, tile) items; split-K range)
     int pi = 0;
 #pragma unroll
     for (int q = 1; q < kMaxProb; ++q)
@@ -272,7 +278,9 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
     const int nks = (kend - kbeg + YK - 1) / YK;   // k-steps of this work item (kend - kbeg >= 16: gemm_x5_usable)
 
     unsigned lds0 = (unsigned)(size_t)(lds_char*)smem;
-    asm volatile("" : "+s"(lds0));   // the compiler does not model the DMA's LDS writes (see gemm_x3.hip)
+    // The compiler does not model the DMA's lane-dependent LDS writes: the LDS offset is laundered so that reads of the staged
+    // bytes cannot be reasoned about (a __shared__ array nobody stores to folds its loads to undef).
+    asm volatile("" : "+s"(lds0));
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
