@@ -121,6 +121,7 @@ SIGNATURES = {
     "dgg_resblock_forward": (_I, [_I, _VP, _VP, _VP, _SZ, _I, _U, _VP, _I, _VP, _VP]),
     "dgg_resblock_backward": (_I, [_I, _VP, _VP, _VP, _SZ, _I, _U, _VP, _I, _VP, _VP, _VP]),
     "dgg_gemm_f32": (_I, [_I, _I, _I, _I, _VP, _I, _VP, _I, _VP, _I, _I, _VP, _I, _VP]),
+    "dgg_gemm_route": (_I, [_I, _I, _I, _I, _I, _I, _I, _I]),
     "dgg_set_grad_events": (_I, [_VP, _VP, _I, _I]),
     "dgg_set_side_work": (_I, [_I]),
 }

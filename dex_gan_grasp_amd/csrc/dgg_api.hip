@@ -2324,6 +2324,11 @@ int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const f
     return gemm_launch(mode, g, st);
 }
 
+int dgg_gemm_route(int mode, int M, int N, int K, int lda, int ldb, int ldc, int splits) {
+    if (M < 1 || N < 1 || K < 1 || mode < 0 || mode > 2 || splits < 0) return DGG_ERR_INVALID;
+    return gemm_route_single(mode, M, N, K, lda, ldb, ldc, splits);
+}
+
 int dgg_set_side_work(int on) {
     gemm_set_side_work(on);
     return DGG_OK;

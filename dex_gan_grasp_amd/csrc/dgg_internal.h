@@ -74,6 +74,8 @@ struct GemmBatch {
     int diag;   // diagnostics (gemm_x5: bit 0 = element-wise epilogue everywhere, DGG_X5_WIDE=0); 0 in every product path
 };
 enum GemmMode { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
+enum GemmRoute { GEMM_ROUTE_F32 = 0, GEMM_ROUTE_X4 = 4, GEMM_ROUTE_X5 = 5 };   // dgg.h: DGG_KERNEL_*
+int gemm_route_single(int mode, int M, int N, int K, int lda, int ldb, int ldc, int splits);
 // Fills tiling fields of one problem for the tile shape the launcher will use; returns #blocks.
 int gemm_plan(GemmProb& p, int mode, int splits);
 int gemm_launch(int mode, GemmBatch& batch, hipStream_t st);

@@ -17,6 +17,7 @@
 // partial products go to slabs that the bias/BN-statistics reduce kernel sums.
 #include <stdlib.h>
 #include <type_traits>
+#include <string.h>
 #include "dgg_internal.h"
 #include "gemm_epilogue.h"
 
@@ -499,12 +500,14 @@ static thread_local int g_side_work = 0;
 int gemm_side_work() { return g_side_work; }
 void gemm_set_side_work(int on) { g_side_work = on ? 1 : 0; }
 
-// All problems of one grouped launch must use the same tile shape: the launcher derives it from
-// problem 0 and re-plans the others with it.
-#define DGG_TRY_RC(expr) do { const int rc__ = (expr); if (rc__ != DGG_OK) return rc__; } while (0)
-int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
+// Plans the tiles of a grouped launch and decides which kernel(s) run it — without launching anything:
+//   returns DGG_OK and fills bm / bn, every problem's tiles_m / tiles_n / blk_begin, batch.total_blocks and `route`:
+//   GEMM_ROUTE_F32 (this file's f32-MFMA kernels, any tile shape), GEMM_ROUTE_X4 (gemm_x4_kernel: bf16x3, launches of >= 1024
+//   workgroups), GEMM_ROUTE_X5 (gemm_x5_kernel: bf16x3 / plain bf16; `large` / `small` then hold the problems it takes and the
+//   short-K ones left to the f32-MFMA kernel at the same 128 x 128 tiling).
+static int gemm_route(int mode, GemmBatch& batch, int& bm, int& bn, int& route, GemmBatch& large, GemmBatch& small) {
     if (batch.nprob < 1 || batch.nprob > kMaxProb) return DGG_ERR_INVALID;
-    int bm, bn;
+    if (mode != GEMM_NT && mode != GEMM_NN && mode != GEMM_TN) return DGG_ERR_INVALID;
     int big = 0;  // the problem with the most work decides the tile shape
     for (int i = 1; i < batch.nprob; ++i)
         if ((double)batch.p[i].M * batch.p[i].N * batch.p[i].K > (double)batch.p[big].M * batch.p[big].N * batch.p[big].K) big = i;
@@ -526,7 +529,8 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
         blocks += p.tiles_m * p.tiles_n * (p.splits > 0 ? p.splits : 1);
     }
     batch.total_blocks = blocks;
-    if (mode != GEMM_NT && mode != GEMM_NN && mode != GEMM_TN) return DGG_ERR_INVALID;
+    route = GEMM_ROUTE_F32;
+    large.nprob = small.nprob = 0;
     if (gemm_algo() >= 1 && bm == 128 && bn == 128) {
         // gemm_x4_kernel fetches a k-strided operand ([K][rows]: B of NN, A and B of TN) in quads of 4 rows: with
         // rows % 4 != 0 the last quad of EVERY k-row reads up to 12 bytes past the row — past the operand itself on its last
@@ -539,15 +543,13 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
             if (mode != GEMM_NT && p.ldb < ((p.N + 3) & ~3)) quads_ok = false;
         }
         if (quads_ok && gemm_algo() != 3 && gemm_x4_enabled(batch.total_blocks)) {
-            gemm_x4_dispatch(mode, batch, st);
-            return check_launch("gemm_x4");
+            route = GEMM_ROUTE_X4;
+            return DGG_OK;
         }
         if (gemm_x5_enabled()) {
             // gemm_x5_kernel takes every problem with at least 64 of K; a grouped launch that also carries short ones (the
             // 24 pose columns beside the shared BPS block of a discriminator pass) is cut in two: the short problems are a
             // handful of tiles on the f32-MFMA kernel of this file
-            GemmBatch large, small;
-            large.nprob = small.nprob = 0;
             large.total_blocks = small.total_blocks = 0;
             large.diag = small.diag = 0;
             for (int i = 0; i < batch.nprob; ++i) {
@@ -557,19 +559,52 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
                 q.blk_begin = dst.total_blocks;
                 dst.total_blocks += q.tiles_m * q.tiles_n * (q.splits > 0 ? q.splits : 1);
             }
-            if (large.nprob > 0) {
-                gemm_x5_dispatch(mode, large, st);
-                DGG_TRY_RC(check_launch("gemm_x5"));
-                if (small.nprob == 0) return DGG_OK;
-                batch = small;   // (tiled 128 x 128 above)
-            }
+            if (large.nprob > 0) route = GEMM_ROUTE_X5;
         }
+    }
+    return DGG_OK;
+}
+
+// All problems of one grouped launch must use the same tile shape: the launcher derives it from the problem with the
+// most work and re-plans the others with it.
+#define DGG_TRY_RC(expr) do { const int rc__ = (expr); if (rc__ != DGG_OK) return rc__; } while (0)
+int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
+    int bm, bn, route;
+    GemmBatch large, small;
+    DGG_TRY_RC(gemm_route(mode, batch, bm, bn, route, large, small));
+    if (route == GEMM_ROUTE_X4) {
+        gemm_x4_dispatch(mode, batch, st);
+        return check_launch("gemm_x4");
+    }
+    if (route == GEMM_ROUTE_X5) {
+        gemm_x5_dispatch(mode, large, st);
+        DGG_TRY_RC(check_launch("gemm_x5"));
+        if (small.nprob == 0) return DGG_OK;
+        batch = small;   // (tiled 128 x 128 by gemm_route)
     }
     if (mode == GEMM_NT) launch_shape<true, true>(bm, bn, batch, st);
     else if (mode == GEMM_NN) launch_shape<true, false>(bm, bn, batch, st);
-    else if (mode == GEMM_TN) launch_shape<false, false>(bm, bn, batch, st);
-    else return DGG_ERR_INVALID;
+    else launch_shape<false, false>(bm, bn, batch, st);
     return check_launch("gemm_f32");
+}
+
+// Which kernel a single product would run on (dgg_gemm_route: diagnostics and CPU tests of the routing rules; nothing is
+// launched, no pointer is dereferenced).  10 * kernel + (short problems left to the f32 kernel ? 1 : 0) is not needed for one
+// problem: returns GEMM_ROUTE_*.
+int gemm_route_single(int mode, int M, int N, int K, int lda, int ldb, int ldc, int splits) {
+    GemmBatch g;
+    memset(&g, 0, sizeof(g));
+    g.nprob = 1;
+    GemmProb& p = g.p[0];
+    static float dummy;
+    p.A = p.B = &dummy;
+    p.C = &dummy;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    gemm_plan(p, mode, splits);
+    int bm, bn, route;
+    GemmBatch large, small;
+    const int rc = gemm_route(mode, g, bm, bn, route, large, small);
+    return rc != DGG_OK ? rc : route;
 }
 
 // Residency query (advisory, see MI355X notes on the occupancy API): workgroups of the given GEMM variant that

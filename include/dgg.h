@@ -428,6 +428,14 @@ int dgg_gemm_occupancy(int mode, int bm, int bn);
  * (DGG_ERR_INVALID otherwise, dgg_last_error() says so; the library's own products are 50 000 x 768 at most). */
 int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C,
                  int ldc, int splits, float* slabs, int accumulate, void* stream);
+/* Which kernel dgg_gemm_f32 — and every internal product of that shape launched alone — runs on under the current
+ * arithmetic; nothing is launched, no pointer is read (host-only: usable without a GPU).  Rules: tiles of 128 x 128 are
+ * chosen where they fill the chip (alone, or with split-K in mode 0); on them DGG_GEMM_BF16X3 takes gemm_x4_kernel from 1024
+ * workgroups up and gemm_x5_kernel otherwise, provided K >= 64 (and every split-K chunk >= 64, the last one >= 16); everything
+ * else, and all of DGG_GEMM_F32, runs on the f32-MFMA kernels; DGG_GEMM_BF16 uses gemm_x5_kernel for the same shapes.
+ * Returns DGG_KERNEL_* or a negative dgg_status (e.g. the 2 GiB limit of C). */
+enum { DGG_KERNEL_F32 = 0, DGG_KERNEL_X4 = 4, DGG_KERNEL_X5 = 5 };
+int dgg_gemm_route(int mode, int M, int N, int K, int lda, int ldb, int ldc, int splits);
 
 #ifdef __cplusplus
 }

@@ -169,3 +169,46 @@ def test_bps_workspace_plan_and_route_switch():
     assert lib.dgg_bps_encode_ws(None, 1, 10, None, P, None, None, None, 0, None) == -1
     assert lib.dgg_set_gemm_algo(3) == 0 and lib.dgg_get_gemm_algo() == 3 and lib.dgg_set_gemm_algo(1) == 0   # DGG_GEMM_BF16
     assert lib.dgg_set_gemm_algo(4) == -1
+
+
+def test_gemm_routing_rules_and_the_2gib_limit():
+    """dgg_gemm_route (host only): which kernel a product runs on.  The train step's large products — forward 1024 x 768 x 4120
+    in 4 split-K slabs, weight gradient 768 x 4120 x 1024, every column count of the checkpoint — take gemm_x5_kernel; the
+    inference sweep's products (>= 1024 workgroups) gemm_x4_kernel; products with K < 64 (the 24 pose columns, the 5 latent
+    columns), split-K chunks that short, and the small ones (fc2, heads: 64-wide tiles) the f32-MFMA kernels; DGG_GEMM_F32
+    everything on those; DGG_GEMM_BF16 the same shapes as bf16x3 but never gemm_x4_kernel; the removed planes value is refused;
+    an output beyond 32-bit byte offsets is refused with a message that says what to do."""
+    from dex_gan_grasp_amd import _lib
+    lib = _lib.lib()
+    F32, X4, X5 = 0, 4, 5
+    if os.environ.get("DGG_GEMM_ALGO") or os.environ.get("DGG_X4") or os.environ.get("DGG_X5"):
+        pytest.skip("the kernel selection is overridden in the environment")
+    route = lib.dgg_gemm_route
+    assert route(0, 1024, 768, 4120, 4120, 4120, 768, 4) == X5          # forward of fc1 || fc3
+    assert route(0, 1024, 768, 4101, 4101, 4101, 768, 4) == X5          # the generator's 4101 columns (K tail of 5)
+    assert route(0, 512, 768, 4120, 4120, 4120, 768, 8) == X5           # config 4's per-rank batch
+    assert route(2, 768, 4120, 1024, 768, 4120, 4120, 0) == X5          # weight gradient
+    assert route(2, 768, 4120, 256, 768, 4120, 4120, 0) == X5           # ... at B = 256
+    assert route(0, 1024, 768, 512, 4632, 4632, 768, 0) == F32          # the previous block's 512 columns ALONE: 48 tiles do not fill
+                                                                        # the chip (in the step they ride in the launch above)
+    assert route(0, 1024, 768, 24, 4120, 4120, 768, 0) == F32           # the pose columns: K < 64
+    assert route(0, 1024, 768, 5, 4101, 4101, 768, 0) == F32            # the latent columns
+    assert route(0, 1024, 768, 4120, 4120, 4120, 768, 100) == X4        # 65 slabs x 48 tiles: >= 1024 workgroups
+    assert route(0, 250000, 768, 512, 512, 512, 768, 0) == X4           # config 5: 1250 objects x 200 grasps
+    assert route(1, 250000, 512, 768, 768, 512, 512, 0) == X4
+    assert route(0, 1024, 512, 256, 256, 256, 512, 0) == F32            # fc2: 64-wide tiles
+    assert route(0, 64, 64, 32, 32, 32, 64, 0) == F32
+    assert route(2, 768, 4101, 300, 768 + 1, 4101 + 3, 4101, 0) == X5   # pitches that cover gemm_x4's quads do not matter here
+    try:
+        assert lib.dgg_set_gemm_algo(0) == 0
+        assert route(0, 1024, 768, 4120, 4120, 4120, 768, 4) == F32 and route(0, 250000, 768, 512, 512, 512, 768, 0) == F32
+        assert lib.dgg_set_gemm_algo(3) == 0
+        assert route(0, 1024, 768, 4120, 4120, 4120, 768, 4) == X5 and route(0, 250000, 768, 512, 512, 512, 768, 0) == X5
+        assert lib.dgg_set_gemm_algo(2) == -1                           # the planes path of rounds 3-4 is gone
+    finally:
+        assert lib.dgg_set_gemm_algo(1) == 0
+    assert route(0, 0, 768, 512, 512, 512, 768, 0) == -1 and route(3, 64, 64, 64, 64, 64, 64, 0) == -1
+    assert route(0, 699050, 768, 512, 512, 512, 768, 0) in (X4, X5)     # the last row count under 2 GiB at pitch 768
+    assert route(0, 699051, 768, 512, 512, 512, 768, 0) == -1
+    msg = lib.dgg_last_error().decode()
+    assert "2 GiB" in msg and "699050" in msg, msg
