@@ -975,7 +975,7 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     if (!fold_head)
         DGG_TRY(heads_bwd_launch(c.W.rb[L.nrb - 1].y, L.nn, d_out, L.nh, B, L.nn, params + L.wh, L.nh, dy, L.nn,
                                  skip ? nullptr : grads + L.wh, skip ? nullptr : grads + L.bh, accum ? 1 : 0,
-                                 skip ? 1 : (heads_ride ? 2 : 0), c.W.part, st));
+                                 skip ? 1 : (heads_ride ? ((flags & kHeadBiasDone) ? 3 : 2) : 0), c.W.part, st));
     for (int r = L.nrb - 1; r >= 0; --r) {
         Seg segs[2];
         int nseg;
@@ -1261,6 +1261,8 @@ struct StepW {
         *d_heads;
     float* dshare[3];  // per ResBlock of D: split-K slabs of the BPS-column product shared by the real and fake pass
     float* bn_snap;    // D's running statistics as they were before a prefetched real pass advanced them (dropped pass: restored)
+    float* gl_part;    // gen_loss_kernel's per-workgroup partial sums (gen_loss_scratch_floats)
+    unsigned* ticket;  // GenLossFin::ticket: cleared by the G phase's loss-gradient launch, drawn by gen_loss_kernel's workgroups
     int d_nrb, d_n13, d_nbn;
     size_t bytes;
 };
@@ -1296,6 +1298,8 @@ static int carve_step(const dgg_cfg* cfg, int B, void* base, StepW& S) {
     S.d_n13 = Ld.n13;
     S.d_nbn = (int)Ld.nbn;
     S.bn_snap = b.take<float>((size_t)Ld.nbn);
+    S.gl_part = b.take<float>((size_t)gen_loss_scratch_floats(cfg, B));
+    S.ticket = b.take<unsigned>(1);
     for (int r = 0; r < 3; ++r) {
         S.dshare[r] = nullptr;
         if (r >= Ld.nrb) continue;
@@ -1754,6 +1758,25 @@ int dgg_cgan_d_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
     return dgg_cgan_d_phase2(cfg, s, hp, ws, ws_bytes, B, bps, rot9, transl, joint, z, losses, stream, nullptr);
 }
 
+// The tail of a G phase (cGAN and WGAN): :272-307 reconstruction losses + total — d_heads combines the MSE gradients with D's
+// input gradient S.d_pose — then :814-815 zero_grad + backward through G.  The loss launch also forms the heads' bias
+// gradient and finishes its own sums (GenLossFin; S.ticket was cleared by the phase's loss-gradient launch).
+static int gen_loss_and_backward(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, StepW& S, int B,
+                                 const float* bps, const float* rot9, const float* transl, const float* joint, const float* z,
+                                 float* losses, int wass, hipStream_t st) {
+    NetL Lg;
+    DGG_TRY(build_layout(DGG_NET_GEN, cfg, Lg));
+    const bool spread = (B + 63) / 64 >= 2;   // gen_loss_launch's condition for the 64-rows-per-workgroup form
+    GenLossFin fin;
+    fin.ticket = S.ticket;
+    fin.gbh = spread ? s->g_grads + Lg.bh : nullptr;
+    DGG_TRY(gen_loss_launch(cfg, hp, B, S.heads, rot9, transl, joint, S.p_gen, S.d_pose, losses, S.d_heads, st, S.gl_part,
+                            wass, &fin));
+    (void)z;
+    return net_backward(Lg, s->g_params, s->g_grads, S.ws_g, S.g_bytes, B, DGG_TRAIN | (spread ? kHeadBiasDone : 0u),
+                        srcs_gen(cfg, bps), S.d_heads, nullptr, 0, 0, nullptr, st);
+}
+
 int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, void* ws, size_t ws_bytes,
                      int B, const float* bps, const float* rot9, const float* transl, const float* joint,
                      const float* z, float* losses, void* stream) {
@@ -1780,18 +1803,12 @@ int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
         return DGG_ERR_LAUNCH;
     }
     // :293-296 BCE(fake_score, 1) and its gradient; backward through D for the pose inputs only
-    DGG_TRY(bce_launch(S.p_gen, nullptr, 1.f, B, (float)hp->bce_weight, 1.0f, losses + DGG_L_GEN_FAKE, S.dl_gen, st));
+    DGG_TRY(bce_launch(S.p_gen, nullptr, 1.f, B, (float)hp->bce_weight, 1.0f, losses + DGG_L_GEN_FAKE, S.dl_gen, st, nullptr,
+                       DGG_L_BCE_REAL, S.ticket));
     DGG_TRY(dgg_disc_backward(cfg, s->d_params, nullptr, S.ws_df, S.d_bytes, B,
                               DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_NEED_INPUT_GRADS, bps, S.rfake, g_transl, g_joint,
                               S.dl_gen, S.d_pose, stream));
-    // :272-307 reconstruction losses + total; d_heads combines the MSE gradients with D's input gradient
-    // S.dl_gen (B floats) is free again: D's backward has consumed it
-    DGG_TRY(gen_loss_launch(cfg, hp, B, S.heads, rot9, transl, joint, S.p_gen, S.d_pose, losses, S.d_heads, st,
-                            B >= 4 * ((B + 63) / 64) ? S.dl_gen : nullptr));
-    // :814-815 zero_grad + backward through G
-    DGG_TRY(dgg_gen_backward(cfg, s->g_params, s->g_grads, S.ws_g, S.g_bytes, B, DGG_TRAIN, z, bps, S.d_heads, nullptr,
-                             nullptr, stream));
-    return DGG_OK;
+    return gen_loss_and_backward(cfg, s, hp, S, B, bps, rot9, transl, joint, z, losses, 0, st);
 }
 
 int dgg_cgan_step(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, void* ws, size_t ws_bytes, int B,
@@ -2252,14 +2269,11 @@ int dgg_wgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
     // :808 D forward with the updated discriminator; :258 gen_loss_fake = -mean(fake_score)
     DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN, bps, S.rfake, S.f_transl, S.f_joint,
                              S.p_gen, stream));
-    DGG_TRY(wass_launch(S.p_gen, B, -1.f, nullptr, S.dl_gen, st));
+    DGG_TRY(wass_launch(S.p_gen, B, -1.f, nullptr, S.dl_gen, st, S.ticket));
     DGG_TRY(dgg_disc_backward(cfg, s->d_params, nullptr, S.ws_df, S.d_bytes, B,
                               DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_NEED_INPUT_GRADS, bps, S.rfake, S.f_transl, S.f_joint,
                               S.dl_gen, S.d_pose, stream));
-    DGG_TRY(gen_loss_launch(cfg, hp, B, S.heads, rot9, transl, joint, S.p_gen, S.d_pose, losses, S.d_heads, st,
-                            B >= 4 * ((B + 63) / 64) ? S.dl_gen : nullptr, 1));
-    return dgg_gen_backward(cfg, s->g_params, s->g_grads, S.ws_g, S.g_bytes, B, DGG_TRAIN, z, bps, S.d_heads, nullptr, nullptr,
-                            stream);
+    return gen_loss_and_backward(cfg, s, hp, S, B, bps, rot9, transl, joint, z, losses, 1, st);
 }
 
 // ---- HIP-graph-friendly forms: everything that changes from step to step lives in device memory ---------------

@@ -238,20 +238,35 @@ int ibn_bwd_apply_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col
 
 // losses -------------------------------------------------------------------------------------
 int bce_launch(const float* p, const float* labels, float target_const, int B, float weight, float loss_scale,
-               float* loss_out, float* d_logit, hipStream_t st, float* combine = nullptr, int real_slot = DGG_L_BCE_REAL);
+               float* loss_out, float* d_logit, hipStream_t st, float* combine = nullptr, int real_slot = DGG_L_BCE_REAL,
+               unsigned* clear_ticket = nullptr /* set to 0 by the launch (GenLossFin::ticket) */);
 int ortho6d_fwd_launch(const float* o6, int ld, int B, float* rot9, hipStream_t st);
 int fake_pose_launch(const float* heads, int ld, int nj, int B, float* rot9, float* transl, float* joint, hipStream_t st);
 int ortho6d_bwd_launch(const float* o6, int ld, int B, const float* d_rot9, float* d_o6, int ldd, hipStream_t st);
+// The spread form of the generator's loss kernel (64 rows per workgroup) finishes inside its own launch: the workgroup that
+// draws the last ticket adds the per-workgroup partials in order.  ticket: one word that reads 0 when the launch starts (an
+// earlier launch on the same stream clears it: bce_launch / wass_launch `clear_ticket`) — left at 0 again.  gbh (optional):
+// the column sums of d_heads = the heads' bias gradient, written (accumulate: added) there; net_backward is then told not
+// to form it again (kHeadBiasDone).
+struct GenLossFin {
+    unsigned* ticket = nullptr;
+    float* gbh = nullptr;
+    int accumulate = 0;
+};
+constexpr unsigned kHeadBiasDone = 0x10000u;   // net_backward flag, internal: heads' bias gradient already in `grads`
+int gen_loss_scratch_floats(const dgg_cfg* cfg, int B);
 int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const float* heads, const float* gt_rot9,
                     const float* gt_transl, const float* gt_joint, const float* fake_score, const float* d_pose,
-                    float* losses, float* d_heads, hipStream_t st, float* scratch = nullptr /* >= 4*ceil(B/64) floats */,
-                    int wass = 0 /* 1: gen_loss_fake = -mean(fake_score) (dexgangrasp.py:258) instead of BCE(., 1) */);
+                    float* losses, float* d_heads, hipStream_t st, float* scratch = nullptr /* >= gen_loss_scratch_floats */,
+                    int wass = 0 /* 1: gen_loss_fake = -mean(fake_score) (dexgangrasp.py:258) instead of BCE(., 1) */,
+                    const GenLossFin* fin = nullptr);
 
 // ---------------------------------------------------------------- WGAN-GP second-order pass (second_order.hip)
 int gp_interp_launch(const float* alphas, const float* r_rot, const float* r_tr, const float* r_jt, const float* f_rot,
                      const float* f_tr, const float* f_jt, int B, int nj, float* o_rot, float* o_tr, float* o_jt,
                      hipStream_t st);
-int wass_launch(const float* p, int B, float sign, float* loss_out, float* d_logit, hipStream_t st);
+int wass_launch(const float* p, int B, float sign, float* loss_out, float* d_logit, hipStream_t st,
+                unsigned* clear_ticket = nullptr);
 int sig_grad_launch(const float* p, int B, float* d_logit, hipStream_t st);
 int gp_value_parts(int B);   // floats of gp_part
 int gp_value_launch(const float* g, int B, int nj, float gain, float* gp_part, float* v, hipStream_t st);

@@ -1044,6 +1044,7 @@ __global__ __launch_bounds__(256) void ibn_bwd_apply_kernel(ColSrcs S, const flo
 }
 
 // ---------------------------------------------------------------- losses
+constexpr int kNhMax = 32;   // heads of a network at most
 __device__ __forceinline__ float block_sum_1024(float v, float* sh) {
     // deterministic: wave shuffle tree, then thread 0 adds the wave sums in order
 #pragma unroll
@@ -1063,9 +1064,11 @@ __device__ __forceinline__ float block_sum_1024(float v, float* sh) {
 __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ p, const float* __restrict__ labels,
                                                    float target_const, int B, float weight, float loss_scale,
                                                    float* __restrict__ loss_out, float* __restrict__ d_logit,
-                                                   float* __restrict__ combine, int real_slot) {
+                                                   float* __restrict__ combine, int real_slot,
+                                                   unsigned* __restrict__ clear_ticket) {
     __shared__ float sh[16];
     float acc = 0.f;
+    if (clear_ticket && threadIdx.x == 0) clear_ticket[0] = 0u;   // see gen_loss_kernel (GenLossFin)
     for (int i = threadIdx.x; i < B; i += blockDim.x) {
         const float x = p[i];
         const float t = labels ? labels[i] : target_const;
@@ -1231,8 +1234,16 @@ __global__ __launch_bounds__(256) void ortho6d_bwd_kernel(const float* __restric
 // heads (B, nj+9) = [joint | rot6 | transl];  d_pose (B, 12+nj) = [d rot9 | d transl | d joint].
 // One row per thread, rows strided by 21 / 24 floats: a single workgroup pushes ~70 uncoalesced wave-loads of 64
 // cache lines each through one CU's address unit (44 us at B = 1024).  With `partial` the grid spreads the rows
-// over CUs (64 rows per workgroup), writes the four partial sums per workgroup, and gen_loss_final_kernel adds them
-// in workgroup order (deterministic); without it: one workgroup, final values written directly.
+// over CUs (64 rows = one wave per workgroup); every workgroup leaves its partial sums — the four loss terms and, with
+// fin.gbh, the column sums of its 64 rows of d_heads (the heads' bias gradient, networks.py:98-100) — and takes a ticket;
+// the workgroup that draws the last one adds the partials in workgroup order (deterministic) and writes the losses and the
+// bias gradient: what gen_loss_final_kernel and narrow_colsum_kernel did as launches of their own until round 5 (two
+// dependent launches less on the G phase's chain).  The ticket must read 0 when the kernel starts: the G phase's first
+// single-workgroup kernel (bce_kernel / wass_kernel, clear_ticket) clears it; the last workgroup leaves it at 0 again.
+// Without `partial`: one workgroup, final values written directly.
+__device__ __forceinline__ float ld_agent(const float* p) {   // a load that other workgroups' (fenced) stores are visible to
+    return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 __global__ __launch_bounds__(1024) void gen_loss_kernel(int nj, float bce_w, float c_tr, float c_rot, float c_cf,
                                                         int B, const float* __restrict__ heads,
                                                         const float* __restrict__ gt_rot9,
@@ -1240,9 +1251,17 @@ __global__ __launch_bounds__(1024) void gen_loss_kernel(int nj, float bce_w, flo
                                                         const float* __restrict__ gt_joint,
                                                         const float* __restrict__ fake_score,
                                                         const float* __restrict__ d_pose, float* __restrict__ losses,
-                                                        float* __restrict__ d_heads, float* __restrict__ partial) {
+                                                        float* __restrict__ d_heads, float* __restrict__ partial,
+                                                        GenLossFin fin) {
     __shared__ float sh[16];
+    __shared__ float dsh[64][kNhMax + 1];   // the workgroup's rows of d_heads (partial form with fin.gbh: 64 threads)
+    __shared__ float tot_sh[4 + kNhMax];
+    __shared__ int last_sh;
     const int nh = nj + 9;
+    const bool colsum = partial && fin.gbh && d_heads;
+    if (colsum) {
+        for (int e = 0; e < nh; ++e) dsh[threadIdx.x][e] = 0.f;   // rows past B add nothing
+    }
     float l_tr = 0.f, l_rot = 0.f, l_cf = 0.f, l_f = 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
         const float* hrow = heads + (size_t)i * nh;
@@ -1264,61 +1283,85 @@ __global__ __launch_bounds__(1024) void gen_loss_kernel(int nj, float bce_w, flo
         for (int e = 0; e < 3; ++e) {
             const float d = hrow[nj + 6 + e] - gt_transl[(size_t)i * 3 + e];
             l_tr = fmaf(d, d, l_tr);
-            if (d_heads)
-                d_heads[(size_t)i * nh + nj + 6 + e] = k_tr * d + (d_pose ? d_pose[(size_t)i * (12 + nj) + 9 + e] : 0.f);
+            if (d_heads) {
+                const float v = k_tr * d + (d_pose ? d_pose[(size_t)i * (12 + nj) + 9 + e] : 0.f);
+                d_heads[(size_t)i * nh + nj + 6 + e] = v;
+                if (colsum) dsh[threadIdx.x][nj + 6 + e] = v;
+            }
         }
         const float k_cf = c_cf * 2.f / ((float)nj * (float)B);
         for (int e = 0; e < nj; ++e) {
             const float d = hrow[e] - gt_joint[(size_t)i * nj + e];
             l_cf = fmaf(d, d, l_cf);
-            if (d_heads) d_heads[(size_t)i * nh + e] = k_cf * d + (d_pose ? d_pose[(size_t)i * (12 + nj) + 12 + e] : 0.f);
+            if (d_heads) {
+                const float v = k_cf * d + (d_pose ? d_pose[(size_t)i * (12 + nj) + 12 + e] : 0.f);
+                d_heads[(size_t)i * nh + e] = v;
+                if (colsum) dsh[threadIdx.x][e] = v;
+            }
         }
         if (d_heads) {
             float go[6];
             ortho6d_bwd(R, gR, go);
 #pragma unroll
-            for (int e = 0; e < 6; ++e) d_heads[(size_t)i * nh + nj + e] = go[e];
+            for (int e = 0; e < 6; ++e) {
+                d_heads[(size_t)i * nh + nj + e] = go[e];
+                if (colsum) dsh[threadIdx.x][nj + e] = go[e];
+            }
         }
         if (fake_score) l_f += bce_w < 0.f ? -fake_score[i] : -fmaxf(logf(fake_score[i]), -100.f);  // bce_w < 0: Wasserstein
     }
     const float t_tr = block_sum_1024(l_tr, sh);
     const float t_rot = block_sum_1024(l_rot, sh);
     const float t_cf = block_sum_1024(l_cf, sh);
-    const float t_f = block_sum_1024(l_f, sh);
+    const float t_f = block_sum_1024(l_f, sh);   // (its barriers also order the dsh stores above before the reads below)
+    float ltot[4] = {t_tr, t_rot, t_cf, t_f};
     if (partial) {
-        if (threadIdx.x == 0) {
-            float* o = partial + 4 * blockIdx.x;
-            o[0] = t_tr; o[1] = t_rot; o[2] = t_cf; o[3] = t_f;
+        const int np = 4 + (colsum ? nh : 0);    // partial sums per workgroup
+        float* o = partial + (size_t)np * blockIdx.x;
+        if (threadIdx.x == 0) { o[0] = t_tr; o[1] = t_rot; o[2] = t_cf; o[3] = t_f; }
+        if (colsum && (int)threadIdx.x < nh) {   // column threadIdx.x of the 64 rows, in row order
+            float a = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 64; ++r) a += dsh[r][threadIdx.x];
+            o[4 + threadIdx.x] = a;
         }
-        return;
+        if (!fin.ticket) return;   // (a caller that adds the partials itself)
+        __threadfence();           // the partials are visible device-wide before this workgroup's ticket is
+        __syncthreads();
+        if (threadIdx.x == 0) last_sh = atomicAdd(fin.ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+        __syncthreads();
+        if (!last_sh) return;
+        __threadfence();
+        if ((int)threadIdx.x < np) {
+            float a = 0.f;
+            for (int b0 = 0; b0 < (int)gridDim.x; b0 += 8) {   // 8 loads in flight, added in workgroup order
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = ld_agent(partial + (size_t)np * min(b0 + u, (int)gridDim.x - 1) + threadIdx.x);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (b0 + u < (int)gridDim.x) a += t[u];
+            }
+            tot_sh[threadIdx.x] = a;
+            if (threadIdx.x >= 4) fin.gbh[threadIdx.x - 4] = fin.accumulate ? fin.gbh[threadIdx.x - 4] + a : a;
+        }
+        __syncthreads();
+        if (threadIdx.x != 0) return;
+        fin.ticket[0] = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ltot[q] = tot_sh[q];
     }
     if (threadIdx.x == 0) {
-        const float lf = (bce_w < 0.f ? 1.f : bce_w) * (t_f / (float)B);
-        const float ltr = c_tr * (t_tr / (3.f * (float)B));
-        const float lrot = c_rot * (t_rot / (9.f * (float)B));
-        const float lcf = c_cf * (t_cf / ((float)nj * (float)B));
+        const float lf = (bce_w < 0.f ? 1.f : bce_w) * (ltot[3] / (float)B);
+        const float ltr = c_tr * (ltot[0] / (3.f * (float)B));
+        const float lrot = c_rot * (ltot[1] / (9.f * (float)B));
+        const float lcf = c_cf * (ltot[2] / ((float)nj * (float)B));
         losses[DGG_L_GEN_FAKE] = lf;
         losses[DGG_L_TRANSL] = ltr;
         losses[DGG_L_ROT] = lrot;
         losses[DGG_L_CONF] = lcf;
         losses[DGG_L_TOTAL_GEN] = lf + (ltr + lrot + lcf);
     }
-}
-
-__global__ void gen_loss_final_kernel(int nj, float bce_w, float c_tr, float c_rot, float c_cf, int B, int nblk,
-                                      const float* __restrict__ partial, float* __restrict__ losses) {
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < nblk; ++b)
-        for (int q = 0; q < 4; ++q) t[q] += partial[4 * b + q];
-    const float lf = (bce_w < 0.f ? 1.f : bce_w) * (t[3] / (float)B);
-    const float ltr = c_tr * (t[0] / (3.f * (float)B));
-    const float lrot = c_rot * (t[1] / (9.f * (float)B));
-    const float lcf = c_cf * (t[2] / ((float)nj * (float)B));
-    losses[DGG_L_GEN_FAKE] = lf;
-    losses[DGG_L_TRANSL] = ltr;
-    losses[DGG_L_ROT] = lrot;
-    losses[DGG_L_CONF] = lcf;
-    losses[DGG_L_TOTAL_GEN] = lf + (ltr + lrot + lcf);
 }
 
 // Graph replay: the optimiser's step number lives in device memory.  step[0] += 1; dyn = {lr / (1 - b1^t), sqrt(1 - b2^t)}
@@ -1612,8 +1655,6 @@ int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, in
     return check_launch("res_out");
 }
 
-constexpr int kNhMax = 32;
-
 // column sums of a narrow (B x n <= 32) matrix; one workgroup of 1024 threads = 32 row lanes x 32 columns, 8 loads in
 // flight per thread (a row loop with one load per trip costs B / 8 serial memory round trips: 15 us at B = 1024), fixed
 // summation order
@@ -1696,6 +1737,7 @@ int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B,
         int rc = gemm_launch(GEMM_NN, g, st);
         if (rc || skip_param == 1) return rc;
         // dbh (+)= column sums of dout
+        if (skip_param == 3) return rc;   // ... and the bias gradient was formed where d_out was (gen_loss_kernel)
         if (skip_param == 2) {  // the weight gradient dWh rides in the last ResBlock's weight-gradient launch (net_backward)
             hipLaunchKernelGGL(narrow_colsum_kernel, dim3(1), dim3(1024), 0, st, dout, ldd, B, nh, gbh, accumulate);
             return check_launch("narrow_colsum");
@@ -1792,9 +1834,9 @@ int ibn_bwd_apply_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col
 }
 
 int bce_launch(const float* p, const float* labels, float target_const, int B, float weight, float loss_scale,
-               float* loss_out, float* d_logit, hipStream_t st, float* combine, int real_slot) {
+               float* loss_out, float* d_logit, hipStream_t st, float* combine, int real_slot, unsigned* clear_ticket) {
     hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, st, p, labels, target_const, B, weight, loss_scale,
-                       loss_out, d_logit, combine, real_slot);
+                       loss_out, d_logit, combine, real_slot, clear_ticket);
     return check_launch("bce");
 }
 
@@ -1815,22 +1857,24 @@ int ortho6d_bwd_launch(const float* o6, int ld, int B, const float* d_rot9, floa
 
 int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const float* heads, const float* gt_rot9,
                     const float* gt_transl, const float* gt_joint, const float* fake_score, const float* d_pose,
-                    float* losses, float* d_heads, hipStream_t st, float* scratch, int wass) {
+                    float* losses, float* d_heads, hipStream_t st, float* scratch, int wass, const GenLossFin* fin) {
     // the kernels read a negative BCE weight as "Wasserstein term -mean(fake_score) with weight 1"
     const float bw = wass ? -1.f : (float)hp->bce_weight, ct = (float)hp->transl_coef, cr = (float)hp->rot_coef,
                 cc = (float)hp->conf_coef;
-    const int nblk = cdiv(B, 64);
-    if (!scratch || nblk < 2) {
+    const int nblk = cdiv(B, 64), nh = cfg->n_hand_joints + 9;
+    if (nh > kNhMax) return DGG_ERR_UNSUPPORTED;
+    // the spread form needs the caller's scratch (gen_loss_scratch_floats) and a ticket that reads 0 (GenLossFin)
+    if (!scratch || !fin || !fin->ticket || nblk < 2) {
+        if (fin && fin->gbh) return DGG_ERR_INVALID;   // the bias gradient is formed by the spread form only
         hipLaunchKernelGGL(gen_loss_kernel, dim3(1), dim3(1024), 0, st, cfg->n_hand_joints, bw, ct, cr, cc, B, heads,
-                           gt_rot9, gt_transl, gt_joint, fake_score, d_pose, losses, d_heads, (float*)nullptr);
+                           gt_rot9, gt_transl, gt_joint, fake_score, d_pose, losses, d_heads, (float*)nullptr, GenLossFin{});
         return check_launch("gen_loss");
     }
     hipLaunchKernelGGL(gen_loss_kernel, dim3(nblk), dim3(64), 0, st, cfg->n_hand_joints, bw, ct, cr, cc, B, heads,
-                       gt_rot9, gt_transl, gt_joint, fake_score, d_pose, losses, d_heads, scratch);
-    hipLaunchKernelGGL(gen_loss_final_kernel, dim3(1), dim3(1), 0, st, cfg->n_hand_joints, bw, ct, cr, cc, B, nblk,
-                       scratch, losses);
+                       gt_rot9, gt_transl, gt_joint, fake_score, d_pose, losses, d_heads, scratch, *fin);
     return check_launch("gen_loss");
 }
+int gen_loss_scratch_floats(const dgg_cfg* cfg, int B) { return cdiv(B, 64) * (4 + cfg->n_hand_joints + 9); }
 
 int adam_launch(float* params, const float* grads, float* m, float* v, int64_t n, int step, double lr, double b1,
                 double b2, double eps, double wd, double grad_scale, hipStream_t st) {

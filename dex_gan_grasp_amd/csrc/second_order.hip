@@ -119,9 +119,10 @@ __global__ void gp_interp_kernel(const float* __restrict__ alphas, const float* 
 
 // Wasserstein terms (dexgangrasp.py:199-211, :258): loss_out = mean(p); d_logit = sign * p (1 - p) / B
 __global__ __launch_bounds__(256) void wass_kernel(const float* __restrict__ p, int B, float sign, float* __restrict__ loss_out,
-                                                   float* __restrict__ d_logit) {
+                                                   float* __restrict__ d_logit, unsigned* __restrict__ clear_ticket) {
     __shared__ float sh[256];
     float s = 0.f;
+    if (clear_ticket && threadIdx.x == 0) clear_ticket[0] = 0u;   // GenLossFin::ticket
     for (int b = threadIdx.x; b < B; b += 256) {
         const float v = p[b];
         s += v;
@@ -632,8 +633,8 @@ int gp_interp_launch(const float* alphas, const float* r_rot, const float* r_tr,
                        f_rot, f_tr, f_jt, B, nj, o_rot, o_tr, o_jt);
     return check_launch("gp_interp");
 }
-int wass_launch(const float* p, int B, float sign, float* loss_out, float* d_logit, hipStream_t st) {
-    hipLaunchKernelGGL(wass_kernel, dim3(1), dim3(256), 0, st, p, B, sign, loss_out, d_logit);
+int wass_launch(const float* p, int B, float sign, float* loss_out, float* d_logit, hipStream_t st, unsigned* clear_ticket) {
+    hipLaunchKernelGGL(wass_kernel, dim3(1), dim3(256), 0, st, p, B, sign, loss_out, d_logit, clear_ticket);
     return check_launch("wass");
 }
 int sig_grad_launch(const float* p, int B, float* d_logit, hipStream_t st) {
