@@ -303,9 +303,19 @@ def test_evaluator_step_at_1024_vs_oracle():
 def test_cgan_step_at_256_vs_oracle():
     """BASELINE config 2: the cGAN update alone at B = 256, two steps, through the API-path entry (cgan_step with the
     D-phase fork and the weight-gradient side streams)."""
+    _cgan_steps_vs_oracle(256, 2)
+
+
+def test_cgan_step_ragged_batch_vs_oracle():
+    """B = 100: two workgroups of the generator's loss kernel, the second with 36 of its 64 rows — the form that adds its
+    partial sums under a ticket and forms the heads' bias gradient (gen_loss_kernel, GenLossFin); two steps, so the ticket
+    is drawn twice."""
+    _cgan_steps_vs_oracle(100, 2)
+
+
+def _cgan_steps_vs_oracle(b, nsteps):
     from oracle import dexgan_oracle as O
     L, ops, engine = _mods()
-    b = 256
     eng, sd, _ = _engine("wide")
     ag = O.AdamState([n for n in O.param_names(sd) if n.startswith("generator.")])
     ad = O.AdamState([n for n in O.param_names(sd) if n.startswith("discriminator.")])
@@ -313,7 +323,7 @@ def test_cgan_step_at_256_vs_oracle():
     g_in = _dev_inputs(gb)
     store = {}
     eng.after_d_phase = _sides_hook(store)
-    for i in range(2):
+    for i in range(nsteps):
         z = synth.make_z(b, 100 + i)
         prev = {k: v.clone() for k, v in sd.items()}
         before = {k: _snap_flat(fl) for k, fl in (("G", eng.G), ("D", eng.D))}
