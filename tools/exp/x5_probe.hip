@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <utility>
 #include <type_traits>
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -58,10 +59,46 @@ __device__ __forceinline__ void slice(Split& s) {
     }
 }
 
+// The same split with v_dot2c_f32_bf16 forming the residuals: r = x - hi is ONE instruction, x + (-1) * hi_half + 0 * other_half
+// (exact: the products are exact and the sum is representable), instead of widening the bf16 half back to f32 (shift / and)
+// and subtracting: 28 vector instructions per fragment instead of 44, 7 slices of 4.
+__device__ __forceinline__ float resid(unsigned pk, int half, float x) {
+    typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+    const bf2v m0 = {(__bf16)-1.0f, (__bf16)0.0f}, m1 = {(__bf16)0.0f, (__bf16)-1.0f};
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2v, pk), half ? m1 : m0, x, false);
+}
+template <int k>
+__device__ __forceinline__ void slice2(Split& s) {
+    switch (k) {
+    case 0: for (int p = 0; p < 4; ++p) s.h[p] = pack(s.x[2 * p], s.x[2 * p + 1]); break;
+    case 1: for (int j = 0; j < 4; ++j) s.r[j] = resid(s.h[j >> 1], j & 1, s.x[j]); break;
+    case 2: for (int j = 4; j < 8; ++j) s.r[j] = resid(s.h[j >> 1], j & 1, s.x[j]); break;
+    case 3: for (int p = 0; p < 4; ++p) s.m[p] = pack(s.r[2 * p], s.r[2 * p + 1]); break;
+    case 4: for (int j = 0; j < 4; ++j) s.r[j] = resid(s.m[j >> 1], j & 1, s.r[j]); break;
+    case 5: for (int j = 4; j < 8; ++j) s.r[j] = resid(s.m[j >> 1], j & 1, s.r[j]); break;
+    case 6: for (int p = 0; p < 4; ++p) s.l[p] = pack(s.r[2 * p], s.r[2 * p + 1]); break;
+    default: break;
+    }
+}
+
+// both splits of n values: bitwise comparison of the three planes (host checks)
+__global__ void split_check(const float* x, unsigned* out, int n) {
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 > n) return;
+    Split a, b;
+    for (int j = 0; j < 8; ++j) { a.x[j] = b.x[j] = x[i + j]; a.r[j] = b.r[j] = 0.f; }
+    for (int j = 0; j < 4; ++j) { a.e[j] = b.e[j] = 0.f; a.h[j] = a.m[j] = a.l[j] = b.h[j] = b.m[j] = b.l[j] = 0u; }
+    slice<0>(a); slice<1>(a); slice<2>(a); slice<3>(a); slice<4>(a); slice<5>(a); slice<6>(a); slice<7>(a); slice<8>(a); slice<9>(a); slice<10>(a);
+    slice2<0>(b); slice2<1>(b); slice2<2>(b); slice2<3>(b); slice2<4>(b); slice2<5>(b); slice2<6>(b);
+    unsigned bad = 0;
+    for (int p = 0; p < 4; ++p) bad += (a.h[p] != b.h[p]) + (a.m[p] != b.m[p]) + (a.l[p] != b.l[p]);
+    out[i / 8] = bad;
+}
+
 constexpr int STAGE = 64 * 1024;
 
 // MF: MFMAs, SP: splits, RD: LDS fragment reads, DM: LDS-DMA staging (+ counted wait and barrier)
-template <int T, bool MF, bool SP, bool RD, bool DM>
+template <int T, bool MF, bool SP, bool RD, bool DM, bool D2 = false>
 __global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* out, long long* cyc, int iters, size_t wg_bytes) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -123,8 +160,13 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* o
                 if (q == 0) {
                     for (int j = 0; j < 4; ++j) { s.x[j] = raw[0][j]; s.x[4 + j] = raw[1][j]; }
                 }
-                slice<SPM * q>(s);
-                if (SPM == 2) slice<SPM * q + 1>(s);
+                if (D2) {
+                    if (SPM == 1) slice2<q>(s);                                   // 7 slices over the first 7 of 12 MFMAs
+                    else { slice2<SPM * q>(s); slice2<SPM * q + 1>(s); }
+                } else {
+                    slice<SPM * q>(s);
+                    if (SPM == 2) slice<SPM * q + 1>(s);
+                }
                 if (q == PF - 1) {
                     pl[f][0] = __builtin_bit_cast(bf8, (u4v){s.h[0], s.h[1], s.h[2], s.h[3]});
                     pl[f][1] = __builtin_bit_cast(bf8, (u4v){s.m[0], s.m[1], s.m[2], s.m[3]});
@@ -256,14 +298,14 @@ void run16(const char* name, const float* src, size_t wg_bytes, int nb = 256) {
     hipFree(out); hipFree(cyc);
 }
 
-template <int T, bool MF, bool SP, bool RD, bool DM>
+template <int T, bool MF, bool SP, bool RD, bool DM, bool D2 = false>
 void run(const char* name, const float* src, size_t wg_bytes, int nb = 256) {
     const int iters = T == 4 ? 800 : 3200;   // the same number of MFMAs either way
     float* out; long long* cyc;
     hipMalloc(&out, nb * 256 * 4); hipMalloc(&cyc, nb * 4 * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<T, MF, SP, RD, DM><<<nb, 256>>>(src, out, cyc, 50, wg_bytes);
-    hipEventRecord(e0); k<T, MF, SP, RD, DM><<<nb, 256>>>(src, out, cyc, iters, wg_bytes); hipEventRecord(e1);
+    k<T, MF, SP, RD, DM, D2><<<nb, 256>>>(src, out, cyc, 50, wg_bytes);
+    hipEventRecord(e0); k<T, MF, SP, RD, DM, D2><<<nb, 256>>>(src, out, cyc, iters, wg_bytes); hipEventRecord(e1);
     if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed\n", name); exit(1); }
     float ms; hipEventElapsedTime(&ms, e0, e1);
     static long long h[256 * 4];
@@ -287,6 +329,32 @@ int main() {
         hipMemcpy(src, h, 256 * wg_bytes, hipMemcpyHostToDevice);
         free(h);
     }
+    {   // the two splits agree bit for bit? (values of many magnitudes, both signs, denormal residuals included)
+        const int n = 1 << 22;
+        float* hx = (float*)malloc(n * 4);
+        unsigned long long st = 88172645463325252ull;
+        for (int i = 0; i < n; ++i) {
+            st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+            const unsigned bits = (unsigned)(st >> 16);
+            float f; unsigned b = bits;
+            if (i % 3 == 0) b = (bits & 0x807fffffu) | ((100u + (bits >> 23) % 56u) << 23);   // exponents 2^-27 .. 2^28
+            memcpy(&f, &b, 4);
+            if (!(f == f) || f - f != 0.f) f = 1.5f;   // no NaN / inf
+            hx[i] = f;
+        }
+        float* dx; unsigned* dout;
+        hipMalloc(&dx, n * 4); hipMalloc(&dout, n / 8 * 4);
+        hipMemcpy(dx, hx, n * 4, hipMemcpyHostToDevice);
+        split_check<<<n / 8 / 256, 256>>>(dx, dout, n);
+        unsigned* ho = (unsigned*)malloc(n / 8 * 4);
+        hipMemcpy(ho, dout, n / 8 * 4, hipMemcpyDeviceToHost);
+        long bad = 0; int first = -1;
+        for (int i = 0; i < n / 8; ++i) { if (ho[i] && first < 0) first = i; bad += ho[i]; }
+        printf("split by v_dot2c_f32_bf16 vs shift/and/sub: %ld differing plane registers of %d fragments", bad, n / 8);
+        if (first >= 0) { printf(" (first: fragment %d, values", first); for (int j = 0; j < 8; ++j) printf(" %a", hx[first * 8 + j]); printf(")"); }
+        printf("\n");
+        hipFree(dx); hipFree(dout); free(hx); free(ho);
+    }
     for (int rep = 0; rep < 2; ++rep) {
         run<4, true, false, false, false>("4x4 tiles/wave: MFMA only", src, wg_bytes);
         run<4, true, true, true, false>("4x4: MFMA + splits + LDS reads", src, wg_bytes);
@@ -305,6 +373,12 @@ int main() {
         // 198 workgroups: the weight gradient's grid (58 CUs idle)
         run<4, true, true, true, true>("4x4: all, 198 workgroups", src, wg_bytes, 198);
         run16<true, true, true, true>("16x16x32: all, 198 workgroups", src, wg_bytes, 198);
+        // residuals by v_dot2c_f32_bf16: 28 instead of 44 vector instructions per fragment
+        run<4, true, true, true, false, true>("4x4: MFMA + dot2 splits + LDS reads", src, wg_bytes);
+        run<4, true, true, true, true, true>("4x4: all, dot2 splits", src, wg_bytes);
+        run<4, true, true, true, true, true>("4x4: all, dot2 splits, 198 workgroups", src, wg_bytes, 198);
+        run<4, true, true, true, true>("4x4: all, 198 workgroups (again)", src, wg_bytes, 198);
+        run<4, true, true, true, true, true>("4x4: all, dot2 splits, 198 workgroups (again)", src, wg_bytes, 198);
     }
     return 0;
 }
