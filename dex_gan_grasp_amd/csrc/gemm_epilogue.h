@@ -7,6 +7,14 @@
 
 namespace dgg {
 
+// v of lane (lane ^ mask): __shfl_xor with the lane index handed in.  __shfl_xor takes it from v_mbcnt, which the compiler hoists
+// to the kernel's entry and — in a kernel whose k loop leaves no register free — spills to scratch across the loop; a
+// kernel with a private segment pays for it at every launch (gemm_x5.hip launders the index it passes after its k loop).
+__device__ __forceinline__ float lane_xor(float v, int lane, int mask) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ mask) << 2, __builtin_bit_cast(int, v)));
+}
+
+
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // The workgroup's WM x WN waves tile the BM x BN block (wave w: m-slot w / WN, n-slot w % WN), each holding
@@ -133,8 +141,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmProb& P, f32x16 (&acc)[B
                             if (ok) *c_at(row, col) = v;
                         }
                 }
-                pg += __shfl_xor(pg, 32);
-                pb += __shfl_xor(pb, 32);
+                pg += lane_xor(pg, tid & 63, 32);
+                pb += lane_xor(pb, tid & 63, 32);
                 if (lh == 0) {
                     red[((wave / WN) * 2 + 0) * BN + wn0 + tb * 32 + li] = pg;
                     red[((wave / WN) * 2 + 1) * BN + wn0 + tb * 32 + li] = pb;

@@ -130,6 +130,46 @@ using FC = std::integral_constant<int, C>;
 template <bool WGRAD>
 __device__ __forceinline__ void x5_epilogue_rows(const GemmProb& P, const f32x16 (&res)[2][2], unsigned lds_wave, float* red,
                                                  int split, int tm_i, int m0, int n0, int wave, int lane, int tid) {
+    const int row0 = m0 + 64 * (wave >> 1) + (lane >> 4);          // this lane's rows: row0 + 4 i
+    const int col0 = n0 + 64 * (wave & 1) + 4 * (lane & 15);        // ... and its 4 columns
+    // BatchNorm-aware weight gradient: the per-column affine and the column sums of dY per output row are requested first and
+    // land while the quadrant turns through LDS; they are waited for all at once (one-dword and 16-byte loads in flight
+    // together: never a counted vmcnt over such a mix, tools/vmcnt_audit.py).  The wave's 64 rows lie on one side of
+    // ep_split (a multiple of 64: the caller checks).
+    bool bn_form = false;
+    f32x4 ga = {0.f, 0.f, 0.f, 0.f}, be = {0.f, 0.f, 0.f, 0.f};
+    float csn[16];
+    if constexpr (WGRAD) {
+        if (P.ep_gamma) {
+            bn_form = true;
+            ga = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const char*>(P.ep_gamma) + (unsigned)col0 * 4u);
+            be = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const char*>(P.ep_beta) + (unsigned)col0 * 4u);
+            float cst[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) csn[i] = cst[i] = 0.f;
+            const int rbase = m0 + 64 * (wave >> 1);
+            bool two = false;
+            if (rbase + 64 <= P.ep_split) {
+                if (P.ep_cs0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) csn[i] = P.ep_cs0[row0 + 4 * i];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) csn[i] = P.ep_cs1[row0 + 4 * i - P.ep_split];
+                if (P.ep_cs1b) {
+                    two = true;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) cst[i] = P.ep_cs1b[row0 + 4 * i - P.ep_split];
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (two) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) csn[i] += cst[i];
+            }
+        }
+    }
     {
         const unsigned wb = lds_wave + (unsigned)((4 * (lane >> 5)) * 64 + (lane & 31)) * 4u;
 #pragma unroll
@@ -146,41 +186,16 @@ __device__ __forceinline__ void x5_epilogue_rows(const GemmProb& P, const f32x16
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = *(lds_f32x4*)(size_t)(rb_ + (unsigned)(4 * i * 64 * 4));
     }
-    const int row0 = m0 + 64 * (wave >> 1) + (lane >> 4);          // this lane's rows: row0 + 4 i
-    const int col0 = n0 + 64 * (wave & 1) + 4 * (lane & 15);        // ... and its 4 columns
     float* Cb = P.C + (P.splits > 0 ? (size_t)split * (size_t)P.slab_stride : (size_t)0);
     const bool accum = (P.splits == 0) && P.accumulate;
     char* const Cbytes = reinterpret_cast<char*>(Cb);
     auto c_at = [&](int i) { return reinterpret_cast<f32x4_u*>(Cbytes + ((unsigned)(row0 + 4 * i) * (unsigned)P.ldc + (unsigned)col0) * 4u); };
     if constexpr (WGRAD) {
-        if (P.ep_gamma) {   // dW[n][k] = gamma[k] T + beta[k] cs[n]; per-column partials of sum_n W T and sum_n W cs (GemmProb)
+        if (bn_form) {   // dW[n][k] = gamma[k] T + beta[k] cs[n]; per-column partials of sum_n W T and sum_n W cs (GemmProb)
             const char* const Wbytes = reinterpret_cast<const char*>(P.ep_w);
             auto w_at = [&](int i) {
                 return reinterpret_cast<const f32x4_u*>(Wbytes + ((unsigned)(row0 + 4 * i) * (unsigned)P.ep_ldw + (unsigned)col0) * 4u);
             };
-            const f32x4 ga = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const char*>(P.ep_gamma) + (unsigned)col0 * 4u);
-            const f32x4 be = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const char*>(P.ep_beta) + (unsigned)col0 * 4u);
-            // column sums of dY per output row; the wave's 64 rows lie on one side of ep_split (a multiple of 64: the caller checks)
-            float csn[16];
-            const int rbase = m0 + 64 * (wave >> 1);
-            if (rbase + 64 <= P.ep_split) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) csn[i] = 0.f;
-                if (P.ep_cs0) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) csn[i] = P.ep_cs0[row0 + 4 * i];
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) csn[i] = P.ep_cs1[row0 + 4 * i - P.ep_split];
-                if (P.ep_cs1b) {
-                    float t[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) t[i] = P.ep_cs1b[row0 + 4 * i - P.ep_split];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) csn[i] += t[i];
-                }
-            }
             f32x4 pg = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int h8 = 0; h8 < 16; h8 += 8) {   // 8 rows per batch of loads
@@ -209,10 +224,10 @@ __device__ __forceinline__ void x5_epilogue_rows(const GemmProb& P, const f32x16
             // the wave's 64 rows: lanes l, l + 16, l + 32, l + 48 hold the same columns
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                pg[j] += __shfl_xor(pg[j], 16);
-                pg[j] += __shfl_xor(pg[j], 32);
-                pb[j] += __shfl_xor(pb[j], 16);
-                pb[j] += __shfl_xor(pb[j], 32);
+                pg[j] += lane_xor(pg[j], lane, 16);
+                pg[j] += lane_xor(pg[j], lane, 32);
+                pb[j] += lane_xor(pb[j], lane, 16);
+                pb[j] += lane_xor(pb[j], lane, 32);
             }
             if (lane < 16) {
                 const int c = 64 * (wave & 1) + 4 * lane;
@@ -693,11 +708,15 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
 #endif
     // a tile inside the matrix (and, for the BatchNorm-aware form, quadrants on one side of the fc1 | fc3 row split) stores
     // row-major with 16-byte accesses; the others take the shared element-wise epilogue (workgroup-uniform choice)
+    // (lane-derived values of the epilogue are computed from here on: formed at the kernel's entry they are spilled across the k
+    //  loop, and a kernel with scratch pays for its private segment at every launch)
+    int lane_e = lane, tid_e = (int)threadIdx.x;
+    asm volatile("" : "+v"(lane_e), "+v"(tid_e));
     if (!(batch.diag & 1) && m0 + YT <= M && n0 + YT <= N && (!P.ep_gamma || (P.ep_split & 63) == 0))
         x5_epilogue_rows<!A_KC && !B_KC>(P, res, lds0 + (unsigned)wave * 32768u, reinterpret_cast<float*>(smem + 128 * 1024), split, tm_i,
-                                         m0, n0, wave, lane, (int)threadIdx.x);
+                                         m0, n0, wave, lane_e, tid_e);
     else
-        gemm_epilogue<YT, YT, 2, 2, !A_KC && !B_KC>(P, res, reinterpret_cast<float*>(smem + 128 * 1024), split, tm_i, m0, n0, (int)threadIdx.x);
+        gemm_epilogue<YT, YT, 2, 2, !A_KC && !B_KC>(P, res, reinterpret_cast<float*>(smem + 128 * 1024), split, tm_i, m0, n0, tid_e);
 #if DGG_X5_STAMP
     stamp[6] = __builtin_amdgcn_s_memtime();
     stamp[7] = __builtin_amdgcn_s_memrealtime();
