@@ -306,10 +306,12 @@ def test_cgan_step_at_256_vs_oracle():
     _cgan_steps_vs_oracle(256, 2)
 
 
-def test_cgan_step_ragged_batch_vs_oracle():
+def test_cgan_step_ragged_batch_vs_oracle(monkeypatch):
     """B = 100: two workgroups of the generator's loss kernel, the second with 36 of its 64 rows — the form that adds its
     partial sums under a ticket and forms the heads' bias gradient (gen_loss_kernel, GenLossFin); two steps, so the ticket
-    is drawn twice."""
+    is drawn twice.  The workspace starts as 0xFF bytes (DGG_POISON_WS): the ticket word is whatever the caller's memory
+    held until the G phase's first launch clears it, and no kernel may read workspace it has not written."""
+    monkeypatch.setenv("DGG_POISON_WS", "1")
     _cgan_steps_vs_oracle(100, 2)
 
 
