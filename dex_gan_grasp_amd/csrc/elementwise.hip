@@ -13,6 +13,7 @@
 // A batch may consist of `groups` independent BatchNorm batches of rows_per_group rows
 // (the discriminator's real/fake pair, dexgangrasp.py:788-789).
 #include <string.h>
+#include <type_traits>
 #include "dgg_internal.h"
 
 namespace dgg {
@@ -351,8 +352,8 @@ __global__ __launch_bounds__(256) void reduce_bias_kernel(const float* __restric
 #pragma unroll
     for (int r = 0; r < RS; ++r) v[r] = 0.f;
     if (cok) {
-        // slab order = k order: fixed summation order.  Four slabs (32 independent loads) are in flight per
-        // iteration: the kernel is latency-bound, not bandwidth-bound, at these sizes.
+        // slab order = k order: fixed summation order.  All slabs of a round are in flight together: the kernel is
+        // latency-bound, not bandwidth-bound, at these sizes.
         // slabs [0, nslab) come from `slabs`, [nslab, nslab + nslab2) from `slabs2` (same stride and pitch): a
         // partial product computed once and shared by two reduces (D real / fake pass) needs no copy
         const int ntot = nslab + nslab2;
@@ -364,21 +365,29 @@ __global__ __launch_bounds__(256) void reduce_bias_kernel(const float* __restric
         };
         // (the last group may hold 1-3 slabs: the same batch of loads, not one slab — one round trip per ROW — at a time;
         //  round 4: five or six slabs are the common case, [x_hat | previous block] pieces of a ResBlock input)
-        for (int s = 0; s < ntot; s += 4) {
-            const int nu = min(4, ntot - s);   // uniform
-            float t[4][RS];
+        // (round 5: up to eight slabs per round — the [x_hat | previous block] inputs arrive as five to seven slabs, and a
+        //  second round of four was a second dependent memory round trip; four or fewer slabs keep the round of four)
+        auto round = [&](auto nc, int s) {
+            constexpr int NB = decltype(nc)::value;
+            const int nu = min(NB, ntot - s);   // uniform
+            float t[NB][RS];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NB; ++u) {
                 int ld;
                 const float* p = slab(s + min(u, nu - 1), ld);
 #pragma unroll
                 for (int r = 0; r < RS; ++r) t[u][r] = (r < ns && u < nu) ? p[(size_t)r * ld] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < NB; ++u)
 #pragma unroll
                 for (int r = 0; r < RS; ++r)
                     if (u < nu) v[r] += t[u][r];
+        };
+        if (ntot <= 4) {
+            round(std::integral_constant<int, 4>{}, 0);
+        } else {
+            for (int s = 0; s < ntot; s += 8) round(std::integral_constant<int, 8>{}, s);
         }
         // (old values — accumulate — all at once, then the sums, then the stores: a load or a store per row behind the
         //  previous row's store makes the compiler wait for that store, 8 times in a row)
@@ -430,12 +439,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ a
     const bool cok = c0 < N;
     const int c = cok ? c0 : N - 1;
     const bool fused = fin.mean_out != nullptr;
+    const float ga = gamma[c], be = beta[c];   // (before the merge: see res_out_kernel)
     if (fused) bn_block_stats(fin, rpg, B / rpg, N, c, cok, blockIdx.y == 0, sh, res);
     if (!cok) return;
     const int r0 = blockIdx.y * RB + sub * RS;
     const int n = min(RS, B - r0);
     if (n <= 0) return;
-    const float ga = gamma[c], be = beta[c];
     float av[RS];
 #pragma unroll
     for (int r = 0; r < RS; ++r) av[r] = a[(size_t)(r0 + row_clamp(r, n)) * lda + c];
@@ -506,19 +515,20 @@ __global__ __launch_bounds__(256) void res_out_kernel(const float* __restrict__ 
         av[r] = a2[row * lda2 + c];
         kv[r] = 1.f;
     }
-    if (fused) bn_block_stats(fin, rpg, B / rpg, N, c, cok, blockIdx.y == 0, sh, res);
-    if (!cok || n <= 0) return;
+    // (... and so is everything else the rows need: behind the merge each of these was a dependent round trip of its own)
     const float ga = gamma[c], be = beta[c];
     const float ab = a2_bias ? a2_bias[c] : 0.f;  // a2 arrives without fc2's bias (inference path: plain GEMM output)
-    const float inv_keep = 1.0f / (1.0f - kDropP);
     // drop_mode 3: `seed` carries a device pointer to the seed (graph replay: the seed lives in device memory)
     const uint64_t sd = drop_mode == 3 ? *reinterpret_cast<const uint64_t*>(seed) : seed;
-#pragma unroll
-    for (int r = 0; r < RS; ++r) av[r] += ab;
     if (drop_mode == 1) {   // (one uniform branch around the loop, not a load-or-constant per row)
 #pragma unroll
-        for (int r = 0; r < RS; ++r) kv[r] = keep_in[(size_t)(r0 + row_clamp(r, n)) * N + c];
+        for (int r = 0; r < RS; ++r) kv[r] = keep_in[(size_t)(n > 0 ? r0 + row_clamp(r, n) : 0) * N + c];
     }
+    if (fused) bn_block_stats(fin, rpg, B / rpg, N, c, cok, blockIdx.y == 0, sh, res);
+    if (!cok || n <= 0) return;
+    const float inv_keep = 1.0f / (1.0f - kDropP);
+#pragma unroll
+    for (int r = 0; r < RS; ++r) av[r] += ab;
     float mu_[RS], rs_[RS];
     row_stats(fused, res, mean, rstd, N, c, lane, r0, n, rpg, mu_, rs_);
 #pragma unroll
@@ -547,9 +557,12 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= B) return;
-    float acc[NHMAX];
+    float acc[NHMAX], bj[NHMAX];
 #pragma unroll
-    for (int j = 0; j < NHMAX; ++j) acc[j] = 0.f;
+    for (int j = 0; j < NHMAX; ++j) {
+        acc[j] = 0.f;
+        bj[j] = j < nh ? bh[j] : 0.f;   // (requested with the operands, not behind the reduction)
+    }
     for (int k = lane; k < K; k += 64) {
         const float v = y[(size_t)row * ldy + k];
 #pragma unroll
@@ -563,7 +576,7 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const float* __restrict_
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
             if (lane == 0) {
-                v += bh[j];
+                v += bj[j];
                 if (sigmoid) v = 1.0f / (1.0f + expf(-v));
                 out[(size_t)row * ldo + j] = v;
             }
@@ -620,6 +633,31 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
             kp_[r] = 1u;
             ov_[r] = 0.f;
         }
+        // every operand is requested before anything is waited for: the other pass' gradient, the further slabs of a split-K
+        // dy (three per round: a slab per round was a dependent memory round trip each) and the keep bytes
+        auto slab_loads = [&](int q0, float (&t)[3][RS]) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int q = min(q0 + u, nslab - 1);
+#pragma unroll
+                for (int r = 0; r < RS; ++r)
+                    t[u][r] = dy[(size_t)q * slab_stride + (size_t)(g * rpg + r0 + row_clamp(r, n)) * lddy + c];
+            }
+        };
+        auto slab_adds = [&](int q0, const float (&t)[3][RS]) {   // slab (= k) order
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (q0 + u < nslab) {   // uniform
+#pragma unroll
+                    for (int r = 0; r < RS; ++r) dv_[r] += t[u][r];
+                }
+        };
+        float t0[3][RS];
+        if (nslab > 1) slab_loads(1, t0);
+        if (SO.other) {
+#pragma unroll
+            for (int r = 0; r < RS; ++r) ov_[r] = SO.other[(size_t)(g * rpg + r0 + row_clamp(r, n)) * SO.ld + c];
+        }
         if (keep) {
 #pragma unroll
             for (int r = 0; r < RS; ++r) kp_[r] = (unsigned)keep[(size_t)(g * rpg + r0 + row_clamp(r, n)) * N + c];
@@ -627,17 +665,11 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
             // two widths (tools/vmcnt_audit.py)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (SO.other) {
-#pragma unroll
-            for (int r = 0; r < RS; ++r) ov_[r] = SO.other[(size_t)(g * rpg + r0 + row_clamp(r, n)) * SO.ld + c];
-        }
-        for (int q = 1; q < nslab; ++q) {
-            float t[RS];
-#pragma unroll
-            for (int r = 0; r < RS; ++r)
-                t[r] = dy[(size_t)q * slab_stride + (size_t)(g * rpg + r0 + row_clamp(r, n)) * lddy + c];
-#pragma unroll
-            for (int r = 0; r < RS; ++r) dv_[r] += t[r];
+        if (nslab > 1) slab_adds(1, t0);
+        for (int q0 = 4; q0 < nslab; q0 += 3) {
+            float t[3][RS];
+            slab_loads(q0, t);
+            slab_adds(q0, t);
         }
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
@@ -823,13 +855,23 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
             hv_[r] = h[row * ldh + c];
             av_[r] = a1[row * lda1 + c];
         }
-        for (int q = 1; q < nslab; ++q) {  // slab (= k) order; RS loads in flight per slab
-            float t[RS];
+        // slab (= k) order; three more slabs per round, requested with the loads above: a slab per round was a dependent
+        // memory round trip per slab (four of them behind the fc2 dgrad's four K splits)
+        for (int q0 = 1; q0 < nslab; q0 += 3) {
+            float t[3][RS];
 #pragma unroll
-            for (int r = 0; r < RS; ++r)
-                t[r] = dh[(size_t)q * slab_stride + (size_t)(g * rpg + r0 + row_clamp(r, n)) * lddh + c];
+            for (int u = 0; u < 3; ++u) {
+                const int q = min(q0 + u, nslab - 1);
 #pragma unroll
-            for (int r = 0; r < RS; ++r) dv_[r] += t[r];
+                for (int r = 0; r < RS; ++r)
+                    t[u][r] = dh[(size_t)q * slab_stride + (size_t)(g * rpg + r0 + row_clamp(r, n)) * lddh + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (q0 + u < nslab) {   // uniform
+#pragma unroll
+                    for (int r = 0; r < RS; ++r) dv_[r] += t[u][r];
+                }
         }
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
@@ -934,13 +976,23 @@ __global__ __launch_bounds__(256) void ibn_bwd_stats_kernel(ColSrcs S, const flo
             dv_[r] = dX0[row * ldx + col_off + c];
             xv_[r] = p[row * ld];
         }
-        for (int q = 1; q < nslab; ++q) {
-            float t[RS];
+        // (the pose columns' gradient arrives as ~12 split-K slabs, two ResBlocks x six K splits: seven more per round — with
+        //  the loads above eight slabs in flight — instead of a dependent memory round trip per slab; slab order as before)
+        for (int q0 = 1; q0 < nslab; q0 += 7) {
+            float t[7][RS];
 #pragma unroll
-            for (int r = 0; r < RS; ++r)
-                t[r] = dX0[(size_t)q * slab_stride + (size_t)(g * rpg + r0 + row_clamp(r, n)) * ldx + col_off + c];
+            for (int u = 0; u < 7; ++u) {
+                const int q = min(q0 + u, nslab - 1);
 #pragma unroll
-            for (int r = 0; r < RS; ++r) dv_[r] += t[r];
+                for (int r = 0; r < RS; ++r)
+                    t[u][r] = dX0[(size_t)q * slab_stride + (size_t)(g * rpg + r0 + row_clamp(r, n)) * ldx + col_off + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+                if (q0 + u < nslab) {   // uniform
+#pragma unroll
+                    for (int r = 0; r < RS; ++r) dv_[r] += t[u][r];
+                }
         }
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
@@ -974,61 +1026,80 @@ __global__ __launch_bounds__(256) void ibn_bwd_apply_kernel(ColSrcs S, const flo
                                                             long long slab_stride) {
     // fin_part (train, one group): the column sums come from ibn_bwd_stats' row-block partials [nrb][2][S.total],
     // summed by every workgroup for its own columns in colsum_finalize's order.  nslab > 1: dX0 = split-K slabs.
-    __shared__ float sh[SUB][64];
+    __shared__ float shq[SUB][2][64];
     __shared__ float tq[2][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int c0 = c_lo + blockIdx.x * 64 + lane;
     const bool cok = c0 < c_hi;
     const int c = cok ? c0 : c_hi - 1;
     const float inv_n = 1.0f / (float)rpg;
-    if (fin_part && train) {
-        const int per = (fin_nrb + SUB - 1) / SUB;
-        const int rb_lo = min(fin_nrb, sub * per), rb_hi = min(fin_nrb, rb_lo + per);
-        for (int q = 0; q < 2; ++q) {
-            float sg = 0.f;
-            for (int b8 = rb_lo; b8 < rb_hi; b8 += 8) {
-                float t[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) t[j] = fin_part[((size_t)min(b8 + j, rb_hi - 1) * 2 + q) * S.total + c];
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (b8 + j < rb_hi) sg += t[j];
-            }
-            __syncthreads();
-            sh[sub][lane] = sg;
-            __syncthreads();
-            if (sub == 0) tq[q][lane] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
-        }
-        __syncthreads();
-    }
-    if (!cok) return;
+    // the rows this thread transforms and their statistics are requested first (clamped indices, every thread), the partials of
+    // both column sums in one round behind them: one memory latency where there were four (partials of q = 0, of q = 1, rows,
+    // statistics)
     const int r0 = blockIdx.y * RB + sub * RS;
     const int n = min(RS, B - r0);
-    if (n <= 0) return;
     int ld;
     const float* p = src_col(S, c, ld);
     const float ga = gamma[c];
-    float dv_[RS], xv_[RS];
+    float dv_[RS], xv_[RS], mu_[RS], rs_[RS];
 #pragma unroll
     for (int r = 0; r < RS; ++r) {
-        const size_t row = (size_t)(r0 + row_clamp(r, n));
+        const size_t row = (size_t)(n > 0 ? r0 + row_clamp(r, n) : 0);
+        const int g = (int)row / rpg;
         dv_[r] = dX0[row * ldx + col_off + c];
         xv_[r] = p[row * ld];
+        mu_[r] = mean[g * S.total + c];
+        rs_[r] = rstd[g * S.total + c];
     }
-    for (int q = 1; q < nslab; ++q) {
-        float t[RS];
+    if (fin_part && train) {
+        const int per = (fin_nrb + SUB - 1) / SUB;
+        const int rb_lo = min(fin_nrb, sub * per), rb_hi = min(fin_nrb, rb_lo + per);
+        float sg[2] = {0.f, 0.f};
+        for (int b8 = rb_lo; b8 < rb_hi; b8 += 8) {
+            float t[2][8];
 #pragma unroll
-        for (int r = 0; r < RS; ++r)
-            t[r] = dX0[(size_t)q * slab_stride + (size_t)(r0 + row_clamp(r, n)) * ldx + col_off + c];
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int r = 0; r < RS; ++r) dv_[r] += t[r];
+                for (int j = 0; j < 8; ++j) t[q][j] = fin_part[((size_t)min(b8 + j, rb_hi - 1) * 2 + q) * S.total + c];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (b8 + j < rb_hi) sg[q] += t[q][j];
+        }
+        shq[sub][0][lane] = sg[0];
+        shq[sub][1][lane] = sg[1];
+        __syncthreads();
+        if (sub == 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                tq[q][lane] = ((shq[0][q][lane] + shq[1][q][lane]) + shq[2][q][lane]) + shq[3][q][lane];
+        }
+        __syncthreads();
+    }
+    if (!cok || n <= 0) return;
+    for (int q0 = 1; q0 < nslab; q0 += 7) {   // (eval mode: no statistics pass has summed the slabs; see ibn_bwd_stats_kernel)
+        float t[7][RS];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int q = min(q0 + u, nslab - 1);
+#pragma unroll
+            for (int r = 0; r < RS; ++r)
+                t[u][r] = dX0[(size_t)q * slab_stride + (size_t)(r0 + row_clamp(r, n)) * ldx + col_off + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u)
+            if (q0 + u < nslab) {   // uniform
+#pragma unroll
+                for (int r = 0; r < RS; ++r) dv_[r] += t[u][r];
+            }
     }
 #pragma unroll
     for (int r = 0; r < RS; ++r) {
         if (r < n) {
             const int row = r0 + r;
             const int g = row / rpg;
-            const float mu = mean[g * S.total + c], rs = rstd[g * S.total + c];
+            const float mu = mu_[r], rs = rs_[r];
             float v;
             if (train) {
                 const float m0 = (fin_part ? tq[0][lane] : sums[(size_t)(g * 2 + 0) * S.total + c]) * inv_n;
@@ -1125,9 +1196,7 @@ __device__ __forceinline__ void gld9(const float* p, float (&v)[9]) {
         : "memory");
 }
 
-__device__ __forceinline__ void ortho6d(const float* op, Rot& R) {
-    float o[6];
-    gld6(op, o);
+__device__ __forceinline__ void ortho6d_of(const float (&o)[6], Rot& R) {   // the 6 values already in registers
     const float a0 = o[0], a1 = o[1], a2 = o[2];
     R.b[0] = o[3]; R.b[1] = o[4]; R.b[2] = o[5];
     R.na = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
@@ -1142,6 +1211,11 @@ __device__ __forceinline__ void ortho6d(const float* op, Rot& R) {
     R.y[0] = R.z[1] * R.x[2] - R.z[2] * R.x[1];
     R.y[1] = R.z[2] * R.x[0] - R.z[0] * R.x[2];
     R.y[2] = R.z[0] * R.x[1] - R.z[1] * R.x[0];
+}
+__device__ __forceinline__ void ortho6d(const float* op, Rot& R) {
+    float o[6];
+    gld6(op, o);
+    ortho6d_of(o, R);
 }
 
 __device__ __forceinline__ void cross3(const float* u, const float* v, float* o) {
@@ -1244,7 +1318,8 @@ __global__ __launch_bounds__(256) void ortho6d_bwd_kernel(const float* __restric
 __device__ __forceinline__ float ld_agent(const float* p) {   // a load that other workgroups' (fenced) stores are visible to
     return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
-__global__ __launch_bounds__(1024) void gen_loss_kernel(int nj, float bce_w, float c_tr, float c_rot, float c_cf,
+template <int NT>   // threads per workgroup: 64 (the spread form) or 256 (one workgroup); a row's ~150 values stay in registers
+__global__ __launch_bounds__(NT) void gen_loss_kernel(int nj, float bce_w, float c_tr, float c_rot, float c_cf,
                                                         int B, const float* __restrict__ heads,
                                                         const float* __restrict__ gt_rot9,
                                                         const float* __restrict__ gt_transl,
@@ -1263,10 +1338,51 @@ __global__ __launch_bounds__(1024) void gen_loss_kernel(int nj, float bce_w, flo
         for (int e = 0; e < nh; ++e) dsh[threadIdx.x][e] = 0.f;   // rows past B add nothing
     }
     float l_tr = 0.f, l_rot = 0.f, l_cf = 0.f, l_f = 0.f;
+    constexpr int kNjMax = kNhMax - 9;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+        // Everything the row needs is requested before anything is used (clamped indices where the joint count is short of
+        // kNjMax) and waited for ONCE: as loops of load - use - store the row took ~30 dependent waits (9.9 us at B = 1024).
+        // Rows of 21 / 24 / 27 floats at 4-byte aligned addresses: the compiler may merge neighbouring loads into 8- and 16-byte
+        // pieces — all of them are waited for by the one vmcnt(0) below, never by a counted wait (tools/vmcnt_audit.py).
         const float* hrow = heads + (size_t)i * nh;
+        // (optional operands: loaded from a valid stand-in address when absent and zeroed after the wait — a load under a branch
+        //  merges registers at the join, where the compiler waits with a counted vmcnt)
+        const float* prow = d_pose ? d_pose + (size_t)i * (12 + nj) : hrow;
+        const int pmax = d_pose ? 11 + nj : nh - 1;
+        const float* fsp = fake_score ? fake_score + i : hrow;
+        float hj[kNjMax], gj[kNjMax], pj[kNjMax], o6[6], ht[3], gr[9], gt3[3], pr[9], pt[3];
+#pragma unroll
+        for (int e = 0; e < kNjMax; ++e) {
+            const int ec = e < nj ? e : nj - 1;
+            hj[e] = hrow[ec];
+            gj[e] = gt_joint[(size_t)i * nj + ec];
+            pj[e] = prow[min(12 + ec, pmax)];
+        }
+#pragma unroll
+        for (int e = 0; e < 6; ++e) o6[e] = hrow[nj + e];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            ht[e] = hrow[nj + 6 + e];
+            gt3[e] = gt_transl[(size_t)i * 3 + e];
+            pt[e] = prow[min(9 + e, pmax)];
+        }
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            gr[e] = gt_rot9[(size_t)i * 9 + e];
+            pr[e] = prow[min(e, pmax)];
+        }
+        float fs = *fsp;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!d_pose) {
+#pragma unroll
+            for (int e = 0; e < kNjMax; ++e) pj[e] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) pt[e] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) pr[e] = 0.f;
+        }
         Rot R;
-        ortho6d(hrow + nj, R);
+        ortho6d_of(o6, R);
         float Rm[9];
 #pragma unroll
         for (int r = 0; r < 3; ++r) { Rm[3 * r] = R.x[r]; Rm[3 * r + 1] = R.y[r]; Rm[3 * r + 2] = R.z[r]; }
@@ -1274,41 +1390,49 @@ __global__ __launch_bounds__(1024) void gen_loss_kernel(int nj, float bce_w, flo
         const float k_rot = c_rot * 2.f / (9.f * (float)B);
 #pragma unroll
         for (int e = 0; e < 9; ++e) {
-            const float d = Rm[e] - gt_rot9[(size_t)i * 9 + e];
+            const float d = Rm[e] - gr[e];
             l_rot = fmaf(d, d, l_rot);
-            gR[e] = k_rot * d + (d_pose ? d_pose[(size_t)i * (12 + nj) + e] : 0.f);
+            gR[e] = k_rot * d + pr[e];
         }
         const float k_tr = c_tr * 2.f / (3.f * (float)B);
+        float dtr[3];
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-            const float d = hrow[nj + 6 + e] - gt_transl[(size_t)i * 3 + e];
+            const float d = ht[e] - gt3[e];
             l_tr = fmaf(d, d, l_tr);
-            if (d_heads) {
-                const float v = k_tr * d + (d_pose ? d_pose[(size_t)i * (12 + nj) + 9 + e] : 0.f);
-                d_heads[(size_t)i * nh + nj + 6 + e] = v;
-                if (colsum) dsh[threadIdx.x][nj + 6 + e] = v;
-            }
+            dtr[e] = k_tr * d + pt[e];
         }
         const float k_cf = c_cf * 2.f / ((float)nj * (float)B);
-        for (int e = 0; e < nj; ++e) {
-            const float d = hrow[e] - gt_joint[(size_t)i * nj + e];
-            l_cf = fmaf(d, d, l_cf);
-            if (d_heads) {
-                const float v = k_cf * d + (d_pose ? d_pose[(size_t)i * (12 + nj) + 12 + e] : 0.f);
-                d_heads[(size_t)i * nh + e] = v;
-                if (colsum) dsh[threadIdx.x][e] = v;
-            }
+        float dj[kNjMax];
+#pragma unroll
+        for (int e = 0; e < kNjMax; ++e) {
+            const float d = hj[e] - gj[e];
+            if (e < nj) l_cf = fmaf(d, d, l_cf);
+            dj[e] = k_cf * d + pj[e];
         }
         if (d_heads) {
             float go[6];
             ortho6d_bwd(R, gR, go);
+            float* drow = d_heads + (size_t)i * nh;
+#pragma unroll
+            for (int e = 0; e < kNjMax; ++e) {
+                if (e < nj) {
+                    drow[e] = dj[e];
+                    if (colsum) dsh[threadIdx.x][e] = dj[e];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 6; ++e) {
-                d_heads[(size_t)i * nh + nj + e] = go[e];
+                drow[nj + e] = go[e];
                 if (colsum) dsh[threadIdx.x][nj + e] = go[e];
             }
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                drow[nj + 6 + e] = dtr[e];
+                if (colsum) dsh[threadIdx.x][nj + 6 + e] = dtr[e];
+            }
         }
-        if (fake_score) l_f += bce_w < 0.f ? -fake_score[i] : -fmaxf(logf(fake_score[i]), -100.f);  // bce_w < 0: Wasserstein
+        if (fake_score) l_f += bce_w < 0.f ? -fs : -fmaxf(logf(fs), -100.f);  // bce_w < 0: Wasserstein
     }
     const float t_tr = block_sum_1024(l_tr, sh);
     const float t_rot = block_sum_1024(l_rot, sh);
@@ -1866,11 +1990,11 @@ int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const floa
     // the spread form needs the caller's scratch (gen_loss_scratch_floats) and a ticket that reads 0 (GenLossFin)
     if (!scratch || !fin || !fin->ticket || nblk < 2) {
         if (fin && fin->gbh) return DGG_ERR_INVALID;   // the bias gradient is formed by the spread form only
-        hipLaunchKernelGGL(gen_loss_kernel, dim3(1), dim3(1024), 0, st, cfg->n_hand_joints, bw, ct, cr, cc, B, heads,
+        hipLaunchKernelGGL(gen_loss_kernel<256>, dim3(1), dim3(256), 0, st, cfg->n_hand_joints, bw, ct, cr, cc, B, heads,
                            gt_rot9, gt_transl, gt_joint, fake_score, d_pose, losses, d_heads, (float*)nullptr, GenLossFin{});
         return check_launch("gen_loss");
     }
-    hipLaunchKernelGGL(gen_loss_kernel, dim3(nblk), dim3(64), 0, st, cfg->n_hand_joints, bw, ct, cr, cc, B, heads,
+    hipLaunchKernelGGL(gen_loss_kernel<64>, dim3(nblk), dim3(64), 0, st, cfg->n_hand_joints, bw, ct, cr, cc, B, heads,
                        gt_rot9, gt_transl, gt_joint, fake_score, d_pose, losses, d_heads, scratch, *fin);
     return check_launch("gen_loss");
 }

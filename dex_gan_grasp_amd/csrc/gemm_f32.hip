@@ -195,6 +195,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // the fused fc2 stage's bias: requested here, used by the epilogue (requested there it is a memory round trip between
+    // the last MFMA and the first store)
+    float bias_col = 0.f;
+    if constexpr (BNA) {
+        const int colb = n0 + wn0 + li;
+        bias_col = P.c_bias[colb < N ? colb : N - 1];
+    }
 
     float ra[BM * BK / 256], rb[BN * BK / 256];
     const bool mn_full = (m0 + BM <= M) && (n0 + BN <= N);  // wave-uniform
@@ -263,6 +270,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
         // BatchNorm statistics of the A operand's K columns: thread = column; Chan merge of the row-block partials in
         // row-block order, 8 loads in flight (every workgroup: same order, same bits); eval: running statistics
         if (tid < P.K) {
+            // (requested before the partials: behind the merge they were a dependent memory round trip of their own)
+            const float gamma_k = P.bn_gamma[tid], beta_k = P.bn_beta[tid];
             float mean = 0.f, rstd;
             if (P.bn_train && DGG_FC2_ABLATE == 1) {
                 mean = 0.1f; rstd = 1.f;
@@ -318,9 +327,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
                     P.bn_rstd_out[tid] = rstd;
                 }
             }
-            const float sc = rstd * P.bn_gamma[tid];
+            const float sc = rstd * gamma_k;
             bna_sc[tid] = sc;
-            bna_sh[tid] = P.bn_beta[tid] - mean * sc;
+            bna_sh[tid] = beta_k - mean * sc;
         }
         __syncthreads();
     };
@@ -340,6 +349,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
         store_tile<BM, A_KC>(smem, ra);
         store_tile<BN, B_KC>(smem + BK * LDA_S, rb);
     }
+    if constexpr (BNA) asm volatile("" : "+v"(bias_col));   // (in a register from here on: not re-requested at its use)
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nfull; ++kt) ktile(kt, PF1{});   // next tile full
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
         const int rb = (m0 + wm0) / kRowBlock;
         const int nvalid = min(kRowBlock, M - (m0 + wm0));  // rows of this block inside the batch (wave-uniform)
         if (nvalid > 0) {
-            const float bias = (col < N) ? P.c_bias[col] : 0.f;
+            const float bias = (col < N) ? bias_col : 0.f;
             float v[16];
             float s = 0.f;
 #pragma unroll
