@@ -757,32 +757,38 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const int per = (nrb + SUB - 1) / SUB;
         const int rb_lo = min(nrb, sub * per), rb_hi = min(nrb, rb_lo + per);
         const int nqq = writer ? fin.nq : (train ? 2 : 0);  // workgroup-uniform
-        // all quantities' partials in ONE round of loads and one pair of barriers (they were a round and a pair each);
-        // per quantity the same sums in the same order
-        float sg[kFinQ];
+        // all quantities' partials in ONE round of loads and one pair of barriers (they were a round and a pair each); per
+        // quantity the same sums in the same order.  The number of quantities is a compile-time constant of the body that runs
+        // (a switch over it): with `if (q < nqq)` around each quantity's loads the compiler waited for one quantity's loads
+        // before it requested the next — the "one round" was two to five dependent ones.
+        auto fin_round = [&](auto nqc) {
+            constexpr int NQ = decltype(nqc)::value;
+            float sg[NQ];
 #pragma unroll
-        for (int q = 0; q < kFinQ; ++q) sg[q] = 0.f;
-        for (int b8 = rb_lo; b8 < rb_hi; b8 += 8) {
-            float t[kFinQ][8];
+            for (int q = 0; q < NQ; ++q) sg[q] = 0.f;
+            for (int b8 = rb_lo; b8 < rb_hi; b8 += 8) {
+                float t[NQ][8];
 #pragma unroll
-            for (int q = 0; q < kFinQ; ++q) {
-                if (q < nqq) {
+                for (int q = 0; q < NQ; ++q)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) t[q][j] = fin.part[((size_t)min(b8 + j, rb_hi - 1) * fin.nq + q) * N + c];
-                }
-            }
 #pragma unroll
-            for (int q = 0; q < kFinQ; ++q) {
-                if (q < nqq) {
+                for (int q = 0; q < NQ; ++q)
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
                         if (b8 + j < rb_hi) sg[q] += t[q][j];
-                }
             }
-        }
 #pragma unroll
-        for (int q = 0; q < kFinQ; ++q)
-            if (q < nqq) shq[sub][q][lane] = sg[q];
+            for (int q = 0; q < NQ; ++q) shq[sub][q][lane] = sg[q];
+        };
+        switch (nqq) {   // workgroup-uniform
+        case 1: fin_round(std::integral_constant<int, 1>{}); break;
+        case 2: fin_round(std::integral_constant<int, 2>{}); break;
+        case 3: fin_round(std::integral_constant<int, 3>{}); break;
+        case 4: fin_round(std::integral_constant<int, 4>{}); break;
+        case 5: fin_round(std::integral_constant<int, 5>{}); break;
+        default: break;
+        }
         __syncthreads();
         if (sub == 0) {
 #pragma unroll
