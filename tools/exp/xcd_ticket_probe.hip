@@ -7,7 +7,11 @@
 //   (relaxed agent-scope atomic add); the one that draws S - 1 loads the other members' slabs with sc0 loads (past the L1),
 //   checks every element and resets the ticket.  Reports: XCC mismatches, wrong elements, time per launch.
 //   Variant 1 puts the members of a group on DIFFERENT XCDs (wgid = item): the stale-read rate there is the control.
-// build: hipcc --offload-arch=gfx950 -O3 -o xcd_ticket_probe xcd_ticket_probe.hip ; run: ./xcd_ticket_probe [rounds] [variant]
+//   Round 5: coherence modes for the ACROSS-XCD placement (argv 4): 0 = as above (plain stores, sc0 loads); 1 = write-through
+//   stores and L2-bypassing loads (sc0 sc1 on both: system scope per access, no cache-wide maintenance); 2 = plain stores, an
+//   agent-scope release fence before the ticket and an acquire fence behind it (__threadfence: buffer_wbl2 / buffer_inv sc1 —
+//   the whole L2 of the XCD), plain loads.
+// build: hipcc --offload-arch=gfx950 -O3 -o xcd_ticket_probe xcd_ticket_probe.hip ; run: ./xcd_ticket_probe [rounds] [variant] [load] [coherence]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -26,8 +30,17 @@ __device__ __forceinline__ float load_sc0(const float* p) {
     return v;
 }
 
+__device__ __forceinline__ float load_sys(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void store_sys(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
 __global__ __launch_bounds__(256) void probe(float* slabs, unsigned* tickets, unsigned long long* stats, int ngroups, int round,
-                                             int variant) {
+                                             int variant, int coh) {
     const int wg = blockIdx.x;
     int g, m;
     if (variant == 0) {   // same XCD: xcd = wg & 7 owns groups xcd, xcd + 8, ...; inside an XCD items run group-major
@@ -44,8 +57,13 @@ __global__ __launch_bounds__(256) void probe(float* slabs, unsigned* tickets, un
     xcc &= 0xf;
     if (threadIdx.x == 0 && (int)xcc != (wg & 7)) atomicAdd(&stats[0], 1ull);
     float* mine = slabs + ((size_t)g * S + m) * SLAB;
-    for (int e = threadIdx.x; e < SLAB; e += 256) mine[e] = pattern(g, m, e, round);
+    if (coh == 1) {
+        for (int e = threadIdx.x; e < SLAB; e += 256) store_sys(mine + e, pattern(g, m, e, round));
+    } else {
+        for (int e = threadIdx.x; e < SLAB; e += 256) mine[e] = pattern(g, m, e, round);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (coh == 2) __threadfence();
     __syncthreads();   // every wave's stores are acknowledged
     __shared__ unsigned last;
     if (threadIdx.x == 0) {
@@ -54,12 +72,15 @@ __global__ __launch_bounds__(256) void probe(float* slabs, unsigned* tickets, un
     }
     __syncthreads();
     if (!last) return;
+    if (coh == 2) __threadfence();
     unsigned long long bad = 0;
     for (int mm = 0; mm < S; ++mm) {
         if (mm == m) continue;
         const float* o = slabs + ((size_t)g * S + mm) * SLAB;
-        for (int e = threadIdx.x; e < SLAB; e += 256)
-            if (load_sc0(o + e) != pattern(g, mm, e, round)) ++bad;
+        for (int e = threadIdx.x; e < SLAB; e += 256) {
+            const float v = coh == 1 ? load_sys(o + e) : coh == 2 ? __builtin_nontemporal_load(o + e) : load_sc0(o + e);
+            if (v != pattern(g, mm, e, round)) ++bad;
+        }
     }
     if (bad) atomicAdd(&stats[1], bad);
     if (threadIdx.x == 0) {
@@ -77,6 +98,7 @@ int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 2000;
     const int variant = argc > 2 ? atoi(argv[2]) : 0;
     const int load = argc > 3 ? atoi(argv[3]) : 1;
+    const int coh = argc > 4 ? atoi(argv[4]) : 0;
     const int ngroups = 48;   // 48 output tiles x 4 splits = 192 workgroups, the forward product's launch
     float* slabs; unsigned* tickets; unsigned long long* stats;
     hipMalloc(&slabs, (size_t)ngroups * S * SLAB * 4);
@@ -96,15 +118,15 @@ int main(int argc, char** argv) {
     hipEventRecord(e0, s1);
     for (int r = 0; r < rounds; ++r) {
         if (load && (r % 4) == 0) hipLaunchKernelGGL(churn, dim3(512), dim3(256), 0, s2, ca, cb, cn);
-        hipLaunchKernelGGL(probe, dim3(nwg), dim3(256), 0, s1, slabs, tickets, stats, ngroups, r, variant);
+        hipLaunchKernelGGL(probe, dim3(nwg), dim3(256), 0, s1, slabs, tickets, stats, ngroups, r, variant, coh);
     }
     hipEventRecord(e1, s1);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[3];
     hipMemcpy(h, stats, 24, hipMemcpyDeviceToHost);
-    printf("variant %d (%s), %d rounds, load %d: XCC_ID != wgid %% 8: %llu | wrong elements: %llu | groups finished: %llu of %d | %.2f us per launch\n",
-           variant, variant == 0 ? "group on one XCD" : "group across XCDs", rounds, load, h[0], h[1], h[2], rounds * ngroups,
+    printf("coherence %d, variant %d (%s), %d rounds, load %d: XCC_ID != wgid %% 8: %llu | wrong elements: %llu | groups finished: %llu of %d | %.2f us per launch\n",
+           coh, variant, variant == 0 ? "group on one XCD" : "group across XCDs", rounds, load, h[0], h[1], h[2], rounds * ngroups,
            ms * 1e3 / rounds);
     return 0;
 }
