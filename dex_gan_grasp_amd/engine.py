@@ -66,7 +66,6 @@ class TrainEngine:
         self._side = None        # evaluator stream
         self._side2 = None       # D real-batch pass (fork inside the D phase, prefetch across steps)
         self._side2_busy = None  # event: last work enqueued on _side2 that the main stream has not joined yet
-        self._main = None        # high-priority stream joint_step runs its cGAN chain on
         self._reducers = None    # data parallel: per-network bucketed all-reduce (parallel.BucketReducer)
 
     # ---- helpers
@@ -395,25 +394,6 @@ class TrainEngine:
 
     def joint_step(self, gan_inputs, z, eva_inputs, is_train_gen=True, drop_keep=None, seed=0, lr_gen=None,
                    lr_dis=None, lr_eva=None, two_streams=True, next_gan_inputs=None, graph_mode=False):
-        """_joint_step, optionally (DGG_MAIN_PRIORITY=1) on a high-priority stream of the engine's own, ordered after /
-        before the caller's current stream at entry / exit.  Off by default: the cGAN chain gains ~2 % from being
-        dispatched first, but the extra stream takes one of the four hardware queues and every other entry point of
-        the same process (cgan_step / eva_step with their weight-gradient streams) then runs 2.4x slower."""
-        kw = dict(is_train_gen=is_train_gen, drop_keep=drop_keep, seed=seed, lr_gen=lr_gen, lr_dis=lr_dis, lr_eva=lr_eva,
-                  two_streams=two_streams, next_gan_inputs=next_gan_inputs, graph_mode=graph_mode)
-        if graph_mode or not two_streams or os.environ.get("DGG_MAIN_PRIORITY", "0") != "1":
-            return self._joint_step(gan_inputs, z, eva_inputs, **kw)
-        caller = torch.cuda.current_stream(self.device)
-        if getattr(self, "_main", None) is None:
-            self._main = torch.cuda.Stream(device=self.device, priority=-1)
-        self._main.wait_stream(caller)
-        with torch.cuda.stream(self._main):
-            out = self._joint_step(gan_inputs, z, eva_inputs, **kw)
-        caller.wait_stream(self._main)
-        return out
-
-    def _joint_step(self, gan_inputs, z, eva_inputs, is_train_gen=True, drop_keep=None, seed=0, lr_gen=None,
-                    lr_dis=None, lr_eva=None, two_streams=True, next_gan_inputs=None, graph_mode=False):
         """One update_dexgangrasp + one update_dexevaluator.  The two updates touch disjoint networks, batches
         and workspaces, so the evaluator update runs on a SECOND HIP stream concurrently with the cGAN update:
         most launches of either (column kernels, split-K reduces, the K=256 GEMMs) occupy a fraction of the 256
