@@ -81,6 +81,8 @@ int gemm_plan(GemmProb& p, int mode, int splits);
 int gemm_launch(int mode, GemmBatch& batch, hipStream_t st);
 // NT, one problem with GemmProb::bn_part set (see there): 64 x 64 tiles, no split-K, K <= 256
 int gemm_fc2_fused_launch(GemmBatch& batch, hipStream_t st);
+// fc2_stage.hip: the same stage with one 32 x 32 output tile per workgroup, its waves splitting K = 256
+int fc2_stage_launch(const GemmProb& p, hipStream_t st);
 int gemm_pick_splits(int mode, int M, int N, int K, int other_blocks);
 void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn, int K = 1 << 30);
 int gemm_occupancy(int mode, int bm, int bn);

@@ -102,25 +102,6 @@ __device__ __forceinline__ void affine_tile(float (&r)[BR * BK / 256], const flo
     for (int e = 0; e < BR * BK / 256; ++e) r[e] = __builtin_fmaf(r[e], sc, sh);
 }
 
-// fc2-forward fusion: BatchNorm affine (vectors staged in LDS) + LeakyReLU on the k-contiguous A tile; optionally the
-// activated values go out to `h` (pitch ldh) — this thread holds (row rl + 8 e, k) of the tile
-template <int BR>
-__device__ __forceinline__ void bn_act_tile(float (&r)[BR * BK / 256], const float* __restrict__ sc, const float* __restrict__ sh,
-                                            int k0, int kend, float* __restrict__ h, int ldh, int row0, int nrows) {
-    const int k = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int gk = k0 + k;
-    const bool kok = gk < kend;
-    const float a = kok ? sc[gk] : 0.f, b = kok ? sh[gk] : 0.f;
-#pragma unroll
-    for (int e = 0; e < BR * BK / 256; ++e) {
-        float v = __builtin_fmaf(r[e], a, b);
-        v = v > 0.f ? v : kLrelu * v;
-        r[e] = v;
-        const int gr = row0 + rl + 8 * e;
-        if (h && kok && gr < nrows) h[(size_t)gr * ldh + gk] = v;
-    }
-}
-
 template <int BR, bool KC>
 __device__ __forceinline__ void store_tile(float* __restrict__ S, const float (&r)[BR * BK / 256]) {
     const int tid = threadIdx.x;
@@ -138,18 +119,12 @@ __device__ __forceinline__ void store_tile(float* __restrict__ S, const float (&
     }
 }
 
-constexpr int kBnaMaxK = 256;  // fc2 forward: K = hidden width
-#ifndef DGG_FC2_ABLATE
-#define DGG_FC2_ABLATE 0   // diagnostics only: 1 no statistics merge in the prologue, 2 no statistics in the epilogue
-#endif
-
-template <int BM, int BN, bool A_KC, bool B_KC, bool BNA = false>
+template <int BM, int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch) {
     constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
     constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave along m / n
     constexpr int BUF = BK * (LDA_S + LDB_S);
     __shared__ float smem[2 * BUF];
-    __shared__ float bna_sc[BNA ? kBnaMaxK : 1], bna_sh[BNA ? kBnaMaxK : 1];
 
     // ---- which problem / tile / k-split does this workgroup own (all wave-uniform)
     // (copy by scalar selects, not by a dynamic index: every field stays in SGPRs)
@@ -195,14 +170,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    // the fused fc2 stage's bias: requested here, used by the epilogue (requested there it is a memory round trip between
-    // the last MFMA and the first store)
-    float bias_col = 0.f;
-    if constexpr (BNA) {
-        const int colb = n0 + wn0 + li;
-        bias_col = P.c_bias[colb < N ? colb : N - 1];
-    }
-
     float ra[BM * BK / 256], rb[BN * BK / 256];
     const bool mn_full = (m0 + BM <= M) && (n0 + BN <= N);  // wave-uniform
     const bool aff = A_KC && P.a_scale != nullptr;          // wave-uniform
@@ -255,8 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
         }
         if constexpr (PF != 0 && DGG_ABLATE < 2) {
             float* Sn = smem + ((kt + 1) & 1) * BUF;
-            if constexpr (BNA) bn_act_tile<BM>(ra, bna_sc, bna_sh, k0n, kend, tn_i == 0 ? P.a_out : nullptr, P.K, m0, M);
-            else if constexpr (A_KC) { if (aff) affine_tile<BM>(ra, P.a_scale, P.a_shift, k0n, kend); }
+            if constexpr (A_KC) { if (aff) affine_tile<BM>(ra, P.a_scale, P.a_shift, k0n, kend); }
             store_tile<BM, A_KC>(Sn, ra);
             store_tile<BN, B_KC>(Sn + BK * LDA_S, rb);
         }
@@ -266,73 +232,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
     using PF1 = std::integral_constant<int, 1>;
     using PF2 = std::integral_constant<int, 2>;
 
-    auto bna_prologue = [&]() {
-        // BatchNorm statistics of the A operand's K columns: thread = column; Chan merge of the row-block partials in
-        // row-block order, 8 loads in flight (every workgroup: same order, same bits); eval: running statistics
-        if (tid < P.K) {
-            // (requested before the partials: behind the merge they were a dependent memory round trip of their own)
-            const float gamma_k = P.bn_gamma[tid], beta_k = P.bn_beta[tid];
-            float mean = 0.f, rstd;
-            if (P.bn_train && DGG_FC2_ABLATE == 1) {
-                mean = 0.1f; rstd = 1.f;
-            } else if (P.bn_train) {
-                // Chan merge of the row-block partials: 32 row blocks per round with all 64 loads in flight (one memory
-                // round trip), merged as four interleaved chains (block j goes to chain j % 4) that are then merged in
-                // order — a quarter of the dependent divisions of one long chain.  Every workgroup: same order, same bits.
-                float cnt = 0.f, m2 = 0.f;
-                for (int b0 = 0; b0 < P.bn_nrb; b0 += 32) {
-                    float mb[32], qb[32];
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) {
-                        const float* q = P.bn_part + (size_t)min(b0 + j, P.bn_nrb - 1) * 2 * P.K;
-                        mb[j] = q[tid];
-                        qb[j] = q[P.K + tid];
-                    }
-                    float cc[4] = {0.f, 0.f, 0.f, 0.f}, cm[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int j = 0; j < 32; ++j) {
-                        if (b0 + j < P.bn_nrb) {
-                            const int ch = j & 3;
-                            const float nb = (float)min(kRowBlock, P.bn_rows - (b0 + j) * kRowBlock);
-                            const float tot = cc[ch] + nb;
-                            const float d = mb[j] - cm[ch];
-                            cm[ch] += d * (nb / tot);
-                            cq[ch] += qb[j] + d * d * (cc[ch] * nb / tot);
-                            cc[ch] = tot;
-                        }
-                    }
-#pragma unroll
-                    for (int ch = 0; ch < 4; ++ch) {
-                        if (cc[ch] > 0.f) {
-                            const float tot = cnt + cc[ch];
-                            const float d = cm[ch] - mean;
-                            mean += d * (cc[ch] / tot);
-                            m2 += cq[ch] + d * d * (cnt * cc[ch] / tot);
-                            cnt = tot;
-                        }
-                    }
-                }
-                rstd = 1.0f / sqrtf(m2 / cnt + kBnEps);
-                if (blockIdx.x == 0) {
-                    P.bn_mean_out[tid] = mean;
-                    P.bn_rstd_out[tid] = rstd;
-                    if (P.bn_run_mean) P.bn_run_mean[tid] = (1.f - kBnMom) * P.bn_run_mean[tid] + kBnMom * mean;
-                    if (P.bn_run_var) P.bn_run_var[tid] = (1.f - kBnMom) * P.bn_run_var[tid] + kBnMom * (m2 / (cnt - 1.f));
-                }
-            } else {
-                mean = P.bn_run_mean[tid];
-                rstd = 1.0f / sqrtf(P.bn_run_var[tid] + kBnEps);
-                if (blockIdx.x == 0) {
-                    P.bn_mean_out[tid] = mean;
-                    P.bn_rstd_out[tid] = rstd;
-                }
-            }
-            const float sc = rstd * gamma_k;
-            bna_sc[tid] = sc;
-            bna_sh[tid] = beta_k - mean * sc;
-        }
-        __syncthreads();
-    };
     if (nkt > 0) {  // prologue: tile 0
         if (nfull > 0) {
             load_tile<BM, A_KC, true>(P.A, P.lda, m0, M, kbeg, kend, ra);
@@ -341,77 +240,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmBatch batch)
             load_tile<BM, A_KC, false>(P.A, P.lda, m0, M, kbeg, kend, ra);
             load_tile<BN, B_KC, false>(P.B, P.ldb, n0, N, kbeg, kend, rb);
         }
-        // (the statistics merge runs while tile 0's global loads are in flight)
-        if constexpr (BNA) {
-            bna_prologue();
-            bn_act_tile<BM>(ra, bna_sc, bna_sh, kbeg, kend, tn_i == 0 ? P.a_out : nullptr, P.K, m0, M);
-        } else if constexpr (A_KC) { if (aff) affine_tile<BM>(ra, P.a_scale, P.a_shift, kbeg, kend); }
+        if constexpr (A_KC) { if (aff) affine_tile<BM>(ra, P.a_scale, P.a_shift, kbeg, kend); }
         store_tile<BM, A_KC>(smem, ra);
         store_tile<BN, B_KC>(smem + BK * LDA_S, rb);
     }
-    if constexpr (BNA) asm volatile("" : "+v"(bias_col));   // (in a register from here on: not re-requested at its use)
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nfull; ++kt) ktile(kt, PF1{});   // next tile full
     for (; kt + 1 < nkt; ++kt) ktile(kt, PF2{});     // next tile is a tail (or the M/N edge)
     if (kt < nkt) ktile(kt, PF0{});                  // last tile: nothing to prefetch
 
-    if constexpr (BNA) {
-        // C = acc + bias, and the exact two-pass (mean, M2) of every 32-row block per column: a wave's 32 x 32 tile IS one
-        // row block x 32 columns; lanes l and l + 32 hold its two 16-row halves of a column
-        static_assert(BM == 64 && BN == 64, "one 32 x 32 MFMA tile per wave");
-        const int col = n0 + wn0 + li;
-        const int rb = (m0 + wm0) / kRowBlock;
-        const int nvalid = min(kRowBlock, M - (m0 + wm0));  // rows of this block inside the batch (wave-uniform)
-        if (nvalid > 0) {
-            const float bias = (col < N) ? bias_col : 0.f;
-            float v[16];
-            float s = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                v[r] = acc[0][0][r] + bias;
-                if (rr < nvalid) {
-                    s += v[r];
-                    if (col < N) P.C[(size_t)(m0 + wm0 + rr) * P.ldc + col] = v[r];
-                }
-            }
-            if (DGG_FC2_ABLATE == 2) return;
-            s += __shfl_xor(s, 32);
-            const float mean = s / (float)nvalid;
-            float q = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float d = v[r] - mean;
-                if (rr < nvalid) q += d * d;
-            }
-            q += __shfl_xor(q, 32);
-            if (lh == 0 && col < N) {
-                float* o = P.c_part + (size_t)rb * 2 * N;
-                o[col] = mean;
-                o[N + col] = q;
-            }
-        }
-    } else {
-        gemm_epilogue<BM, BN, 2, 2, !A_KC && !B_KC, 1>(P, acc, smem, split, tm_i, m0, n0, tid);
-    }
+    gemm_epilogue<BM, BN, 2, 2, !A_KC && !B_KC, 1>(P, acc, smem, split, tm_i, m0, n0, tid);
 }
 
+// The ResBlock's middle stage (GemmProb::bn_part set) has a kernel of its own: fc2_stage.hip.
 int gemm_fc2_fused_launch(GemmBatch& batch, hipStream_t st) {
     if (batch.nprob != 1) return DGG_ERR_INVALID;
-    GemmProb& p = batch.p[0];
-    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.K > kBnaMaxK || !p.A || !p.B || !p.C || !p.bn_part || !p.bn_gamma || !p.bn_beta ||
-        !p.bn_mean_out || !p.bn_rstd_out || !p.c_bias || !p.c_part || p.splits != 0 || p.accumulate || p.lda < p.K ||
-        (!p.bn_train && (!p.bn_run_mean || !p.bn_run_var)))
-        return DGG_ERR_INVALID;
-    p.tiles_m = (p.M + 63) / 64;
-    p.tiles_n = (p.N + 63) / 64;
-    p.blk_begin = 0;
-    p.kchunk = p.K;
-    batch.total_blocks = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL((gemm_f32_kernel<64, 64, true, true, true>), dim3(batch.total_blocks), dim3(256), 0, st, batch);
-    return check_launch("gemm_fc2_fused");
+    return fc2_stage_launch(batch.p[0], st);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -39,6 +39,11 @@ JUSTIFIED = {
         "compiler spill reloads only (scratch_load_dword / dwordx2 of 8 set-up values, private segment), in the prologue, outside "
         "the k loop; the kernel's own waits on its LDS-DMA pieces (two widths: 16-byte operand pieces, 4-byte affine pieces) are "
         "all vmcnt(0) — gemm_x5.hip has no counted wait of its own",
+    "fc2_stage_kernel<":
+        "one counted wait (for bn1's gamma) at the join behind the train / eval branch of the statistics prologue, with the 16-byte "
+        "operand loads in flight only along the compiler's EXEC = 0 skip of the eval side (s_cbranch_execz): no lane ever takes "
+        "it — every lane runs the train or the eval side, and both wait vmcnt(0) (explicit asm) before their first use of a "
+        "loaded value, so at run time that wait finds nothing outstanding",
     "gemm_x4_kernel<false, false, false>":
         "compiler spill reloads (scratch_load_dword, private segment; 9 registers) among the loader waves' dwordx4 loads.  The TN "
         "instantiation of the >= 1024-workgroup kernel is reached by no launch of any BASELINE config (weight-gradient launches "
