@@ -706,19 +706,10 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
         if (!c.train)
             DGG_TRY(colsum_finalize_launch(c.W.part2, 1, nrb, 1, L.nn, nullptr, G + R.b2, nullptr, nullptr, acc, c.st));
     }
-    // 3. fc2: dh = da2 W2 (B x 256 output: split-K over slabs fills the chip)
-    {
-        GemmBatch g;
-        memset(&g, 0, sizeof(g));
-        g.nprob = 1;
-        prob_init(g.p[0], da2, L.nn, c.P + R.w2, L.hid, c.W.slabs, L.hid, B, L.hid, L.nn);
-        const long long slab = (long long)B * L.hid;
-        prob_split(g.p[0], 4, slab);
-        DGG_TRY(gemm_launch(GEMM_NN, g, c.st));
-        // 4. slabs -> dh, through lrelu and bn1 -> da1 into dY13[:, 0:256] (the slab sum happens inside act_bwd)
-        DGG_TRY(act_bwd_launch(c.W.slabs, L.hid, A.h, L.hid, A.a13, L.n13, A.mean1, A.rstd1, B, B, L.hid, c.W.dh, L.hid,
-                               c.W.part, c.st, g.p[0].splits, slab));
-    }
+    // 3 + 4. fc2: dh = da2 W2 (K = 512), through lrelu', and bn1's backward partial sums per row block — one launch
+    //    (fc2_bwd_stage_kernel, fc2_stage.hip; until round 5: a split-K GEMM leaving four slabs + act_bwd_kernel summing them)
+    DGG_TRY(fc2_bwd_stage_launch(da2, L.nn, c.P + R.w2, L.hid, A.h, L.hid, A.a13, L.n13, A.mean1, A.rstd1, B, c.W.dh, L.hid,
+                                 c.W.part, c.st));
     {
         ColFin fin = {c.W.part, 2, {gp(R.bn1b), gp(R.bn1w), nullptr, nullptr, nullptr}, acc, nullptr, nullptr, nullptr, 0, 0};
         DGG_TRY(bn_bwd_apply_launch(c.W.dh, L.hid, A.a13, L.n13, A.mean1, A.rstd1, c.P + R.bn1w, nullptr, c.train, B, B,

@@ -83,6 +83,10 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st);
 int gemm_fc2_fused_launch(GemmBatch& batch, hipStream_t st);
 // fc2_stage.hip: the same stage with one 32 x 32 output tile per workgroup, its waves splitting K = 256
 int fc2_stage_launch(const GemmProb& p, hipStream_t st);
+// ... and its backward mirror: dq = (da2 W2) * lrelu'(h) + bn1's backward partial sums per row block, one launch
+int fc2_bwd_stage_launch(const float* da2, int ldda, const float* w2, int ldw, const float* h, int ldh, const float* a1,
+                         int lda1, const float* mean, const float* rstd, int B, float* dq, int lddq, float* part,
+                         hipStream_t st);
 int gemm_pick_splits(int mode, int M, int N, int K, int other_blocks);
 void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn, int K = 1 << 30);
 int gemm_occupancy(int mode, int bm, int bn);
@@ -212,11 +216,7 @@ int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, cons
                         const float* gamma, const float* sums /*[groups][2][N]*/, int train, int B,
                         int rows_per_group, int N, float* dx, int lddx, float* part, hipStream_t st,
                         const ColFin* fin = nullptr, const SumOut* sum = nullptr);
-// Stage 3: dq = dh * lrelu'(h) (in place on dh allowed); partial sums: sum dq, sum dq*xhat1.
-int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const float* a1, int lda1, const float* mean,
-                   const float* rstd, int B, int rows_per_group, int N, float* dq, int lddq, float* part,
-                   hipStream_t st,
-                   int nslab = 0, long long slab_stride = 0);
+// Stage 3 (dq = dh * lrelu'(h); partial sums: sum dq, sum dq*xhat1) lives in fc2_bwd_stage_launch, behind the fc2 dgrad.
 // Sum partial column sums over row blocks: part [groups][nrb][nq][ncols] ->
 //   sums_out [groups][nq][ncols] (may be NULL) and, summed over groups, into up to 3 gradient
 //   destinations (NULL to skip): dst[q][c] (+)= sum.

@@ -833,74 +833,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         part[(size_t)blockIdx.y * N + c] = ((sh[0][0][lane] + sh[1][0][lane]) + sh[2][0][lane]) + sh[3][0][lane];
 }
 
-// grid: (ceil(N/256), groups*nrb)
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dh, int lddh,
-                                                      const float* __restrict__ h, int ldh,
-                                                      const float* __restrict__ a1, int lda1,
-                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                      int rpg, int nrb, int N, float* __restrict__ dq, int lddq,
-                                                      float* __restrict__ part, int nslab, long long slab_stride) {
-    // nslab > 0: `dh` is a stack of split-K slabs (pitch lddh, slab_stride apart) summed here in slab (= k) order —
-    // the separate reduce launch between the dh GEMM and this kernel is gone
-    __shared__ float sh[SUB][2][64];
-    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const int c0 = blockIdx.x * 64 + lane;
-    const bool cok = c0 < N;
-    const int c = cok ? c0 : N - 1;
-    const int g = blockIdx.y / nrb, rb = blockIdx.y % nrb;
-    const int r0 = rb * RB + sub * RS;
-    const int n = min(RS, max(0, rpg - r0));
-    const float mu = mean[g * N + c], rs = rstd[g * N + c];
-    float s0 = 0.f, s1 = 0.f;
-    if (n > 0) {
-        float dv_[RS], hv_[RS], av_[RS];
-#pragma unroll
-        for (int r = 0; r < RS; ++r) {
-            const size_t row = (size_t)(g * rpg + r0 + row_clamp(r, n));
-            dv_[r] = dh[row * lddh + c];
-            hv_[r] = h[row * ldh + c];
-            av_[r] = a1[row * lda1 + c];
-        }
-        // slab (= k) order; three more slabs per round, requested with the loads above: a slab per round was a dependent
-        // memory round trip per slab (four of them behind the fc2 dgrad's four K splits)
-        for (int q0 = 1; q0 < nslab; q0 += 3) {
-            float t[3][RS];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int q = min(q0 + u, nslab - 1);
-#pragma unroll
-                for (int r = 0; r < RS; ++r)
-                    t[u][r] = dh[(size_t)q * slab_stride + (size_t)(g * rpg + r0 + row_clamp(r, n)) * lddh + c];
-            }
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-                if (q0 + u < nslab) {   // uniform
-#pragma unroll
-                    for (int r = 0; r < RS; ++r) dv_[r] += t[u][r];
-                }
-        }
-#pragma unroll
-        for (int r = 0; r < RS; ++r) {
-            if (r < n) {
-                const size_t row = (size_t)(g * rpg + r0 + r);
-                const float d = dv_[r] * lrelu_grad(hv_[r]);
-                if (cok) dq[row * lddq + c] = d;
-                const float xh = (av_[r] - mu) * rs;
-                s0 += d;
-                s1 = fmaf(d, xh, s1);
-            }
-        }
-    }
-    sh[sub][0][lane] = s0;
-    sh[sub][1][lane] = s1;
-    __syncthreads();
-    if (sub == 0 && cok) {
-        float* o = part + (size_t)blockIdx.y * 2 * N;
-        o[c] = ((sh[0][0][lane] + sh[1][0][lane]) + sh[2][0][lane]) + sh[3][0][lane];
-        o[N + c] = ((sh[0][1][lane] + sh[1][1][lane]) + sh[2][1][lane]) + sh[3][1][lane];
-    }
-}
-
 // grid: ceil(nq*ncols/64): 64 (quantity,column) pairs per workgroup, the 4 waves sum disjoint row-block ranges.
 // part[((g*nrb + rb)*nq + q)*ld + c_lo + c], c in [0, ncols)
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int groups, int nrb,
@@ -1918,16 +1850,6 @@ int bn_bwd_apply_launch(const float* dz, int lddz, const float* a, int lda, cons
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, dz, lddz, a, lda, mean, rstd, gamma, sums, train,
                        rpg, nrb_of(rpg), N, dx, lddx, part, f, so);
     return check_launch("bn_bwd_apply");
-}
-
-int act_bwd_launch(const float* dh, int lddh, const float* h, int ldh, const float* a1, int lda1, const float* mean,
-                   const float* rstd, int B, int rpg, int N, float* dq, int lddq, float* part, hipStream_t st,
-                   int nslab, long long slab_stride) {
-    const int groups = B / rpg;
-    dim3 grid(cdiv(N, 64), groups * nrb_of(rpg));
-    hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, st, dh, lddh, h, ldh, a1, lda1, mean, rstd, rpg,
-                       nrb_of(rpg), N, dq, lddq, part, nslab, slab_stride);
-    return check_launch("act_bwd");
 }
 
 int colsum_finalize_launch(const float* part, int groups, int nrb, int nq, int ncols, float* sums_out, float* dst0,

@@ -194,6 +194,99 @@ __global__ __launch_bounds__(256) void fc2_stage_kernel(const GemmProb P) {
     }
 }
 
+// The backward mirror: dh = da2 W2 (K = 512), dq = dh * lrelu'(h), and the row-block partial sums of bn1's backward
+// (sum dq, sum dq * x_hat1 per 32 rows and column) in ONE launch — until round 5 a split-K GEMM on gemm_f32_kernel (four
+// slabs) plus act_bwd_kernel, which summed the slabs: two dependent launches and 4 MB of slabs per ResBlock backward.
+// One 32 x 32 output tile per workgroup, EIGHT waves split K = 512 (64 k each: a lane holds 32 k of one da2 row and of
+// one W2 column), 32 dependent MFMAs per wave, the partial tiles meet in LDS in wave order; wave 0 — which requested its
+// h and a1 values at the start — finishes the tile.
+struct Fc2Bwd {
+    const float* da2; int ldda;     // (B, 512)
+    const float* w2; int ldw;       // (512, 256): W2[k][n]
+    const float* h; int ldh;        // (B, 256) the forward's activated hidden values
+    const float* a1; int lda1;      // (B, .) bn1's input
+    const float* mean; const float* rstd;   // (256) bn1's batch (train) or running (eval) statistics
+    int B;
+    float* dq; int lddq;            // (B, 256)
+    float* part;                    // [row block][2][256]
+};
+constexpr int kKB = 512, kNB = 256;   // K = n_neurons, N = hidden
+
+__global__ __launch_bounds__(512) void fc2_bwd_stage_kernel(const Fc2Bwd P) {
+    __shared__ float red[8][16][64];   // 32 KB: the waves' partial tiles, lane-linear
+    __shared__ float cs[8][2][64];     // per finishing wave: its rows' share of the two column sums
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int M = P.B;
+    const int tiles_m = (M + 31) / 32;
+    const int tn = (int)blockIdx.x / tiles_m, tm = (int)blockIdx.x - tn * tiles_m;
+    const int m0 = tm * 32, n0 = tn * 32;
+    const int kb = 64 * wave + 32 * lh;   // this lane's first k
+    const int arow = min(m0 + li, M - 1), col = n0 + li;
+    // ---- every load of the kernel is requested here; one wait (two widths in flight: never a counted vmcnt over them)
+    f32x4 a4[8];
+    float b[32];
+    {
+        const f32x4_u* ap = reinterpret_cast<const f32x4_u*>(P.da2 + (size_t)arow * P.ldda + kb);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a4[q] = ap[q];
+        const float* bp = P.w2 + (size_t)kb * P.ldw + col;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) b[s] = bp[(size_t)s * P.ldw];
+    }
+    // Wave w finishes the accumulator registers 2 w and 2 w + 1 of the tile: rows (r & 3) + 8 (r >> 2) + 4 lh, column li — its
+    // h and a1 values are requested with the operands
+    float hv[2], av[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int r = 2 * wave + e;
+        const int row = min(m0 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1);
+        hv[e] = P.h[(size_t)row * P.ldh + col];
+        av[e] = P.a1[(size_t)row * P.lda1 + col];
+    }
+    const float mu = P.mean[col], rs = P.rstd[col];
+    __builtin_amdgcn_sched_barrier(0);   // (nothing that uses a loaded value is scheduled in front of the wait)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 32 MFMAs: the wave's share of K (slot 0 = lanes 0-31: k = 64 w + s, slot 1: k = 64 w + 32 + s)
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s >> 2][s & 3], b[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    const int nvalid = min(kRowBlock, M - m0);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int r = 2 * wave + e;
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float d = red[0][r][lane];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) d += red[w][r][lane];   // wave (= k) order
+        d *= hv[e] > 0.f ? 1.f : kLrelu;
+        if (rr < nvalid) {
+            P.dq[(size_t)(m0 + rr) * P.lddq + col] = d;
+            const float xh = (av[e] - mu) * rs;
+            s0 += d;
+            s1 = __builtin_fmaf(d, xh, s1);
+        }
+    }
+    cs[wave][0][lane] = s0;
+    cs[wave][1][lane] = s1;
+    __syncthreads();
+    if (tid < 64) {   // column (tid & 31), quantity (tid >> 5): the 8 waves' shares, both row halves, in a fixed order
+        const int q = tid >> 5, c = tid & 31;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += cs[w][q][c] + cs[w][q][32 + c];
+        P.part[(size_t)tm * 2 * kNB + (size_t)q * kNB + n0 + c] = t;
+    }
+}
+
 }  // namespace fc2
 
 // One problem with GemmProb::bn_part set (see there): K = 256, no split-K.
@@ -209,4 +302,18 @@ int fc2_stage_launch(const GemmProb& p, hipStream_t st) {
     return check_launch("fc2_stage");
 }
 
+}  // namespace dgg
+
+namespace dgg {
+// dq = (da2 W2) * lrelu'(h) and the partial sums of bn1's backward per 32-row block: part [row block][2][256] (what
+// act_bwd_kernel emitted).  K = 512, N = 256, one group of B rows.
+int fc2_bwd_stage_launch(const float* da2, int ldda, const float* w2, int ldw, const float* h, int ldh, const float* a1,
+                         int lda1, const float* mean, const float* rstd, int B, float* dq, int lddq, float* part,
+                         hipStream_t st) {
+    if (!da2 || !w2 || !h || !a1 || !mean || !rstd || !dq || !part || B < 1 || ldda < fc2::kKB || ldw < fc2::kNB) return DGG_ERR_INVALID;
+    fc2::Fc2Bwd P{da2, ldda, w2, ldw, h, ldh, a1, lda1, mean, rstd, B, dq, lddq, part};
+    const int tiles = ((B + 31) / 32) * (fc2::kNB / 32);
+    hipLaunchKernelGGL(fc2::fc2_bwd_stage_kernel, dim3(tiles), dim3(512), 0, st, P);
+    return check_launch("fc2_bwd_stage");
+}
 }  // namespace dgg
