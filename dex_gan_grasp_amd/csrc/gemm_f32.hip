@@ -274,6 +274,11 @@ void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn, int K) {
     // the bf16x3 kernel (128 x 128 only, one workgroup per CU) is worth a partly filled chip: 198 tiles of the
     // 768 x 4101 weight gradient at 128 x 128 beat 780 tiles of 64 x 64 on the f32 pipe by 1.5x
     const long enough = gemm_algo() >= 1 ? 128 : 200;
+    // A weight gradient with few tiles and a long K (the real pass' pose columns + the fc2 rider at B = 1024: 44 tiles of
+    // 64 x 64, each a chain of 32 k-tiles: 45-79 us) is a latency chain on the f32 kernel; on gemm_x5_kernel the four waves of
+    // a workgroup split K: ~37 us at K = 1024 however few the tiles.  Below K = 768 the f32 kernel's chain is the shorter one.
+    // (profiles/r05_experiments.txt 23)
+    if (mode == GEMM_TN && gemm_algo() >= 1 && K >= 768 && K < (1 << 30)) return;
     if (t128 < enough) {
         bm = (M >= 1024) ? 128 : 64;
         bn = 64;
