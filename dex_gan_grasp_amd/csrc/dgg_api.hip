@@ -1832,8 +1832,8 @@ int dgg_eva_phase(const dgg_cfg* cfg, const float* e_params, float* e_grads, flo
     hipStream_t st = (hipStream_t)stream;
     DGG_TRY(dgg_eva_forward(cfg, e_params, e_bn, ws, W.bytes, B, DGG_TRAIN, bps, rot9, transl, drop_keep, seed, p,
                             stream));
-    DGG_TRY(bce_launch(p, label, 0.f, B, (float)hp->bce_weight, 1.0f, losses + DGG_L_TOTAL_EVA, dl, st));
-    DGG_TRY(copy_cols_launch(losses + DGG_L_TOTAL_EVA, 1, losses + DGG_L_BCE_EVA, 1, 1, 1, st));
+    DGG_TRY(bce_launch(p, label, 0.f, B, (float)hp->bce_weight, 1.0f, losses + DGG_L_TOTAL_EVA, dl, st, nullptr, DGG_L_BCE_REAL,
+                       nullptr, losses + DGG_L_BCE_EVA));
     DGG_TRY(dgg_eva_backward(cfg, e_params, e_grads, ws, W.bytes, B, DGG_TRAIN, bps, rot9, transl, dl, nullptr, stream));
     return DGG_OK;
 }
@@ -2291,8 +2291,8 @@ int dgg_eva_phase_graph(const dgg_cfg* cfg, const float* e_params, float* e_grad
     hipStream_t st = (hipStream_t)stream;
     DGG_TRY(dgg_eva_forward(cfg, e_params, e_bn, ws, W.bytes, B, DGG_TRAIN | DGG_SEED_ON_DEVICE, bps, rot9, transl, nullptr,
                             (uint64_t)(uintptr_t)seed_dev, p, stream));
-    DGG_TRY(bce_launch(p, label, 0.f, B, (float)hp->bce_weight, 1.0f, losses + DGG_L_TOTAL_EVA, dl, st));
-    DGG_TRY(copy_cols_launch(losses + DGG_L_TOTAL_EVA, 1, losses + DGG_L_BCE_EVA, 1, 1, 1, st));
+    DGG_TRY(bce_launch(p, label, 0.f, B, (float)hp->bce_weight, 1.0f, losses + DGG_L_TOTAL_EVA, dl, st, nullptr, DGG_L_BCE_REAL,
+                       nullptr, losses + DGG_L_BCE_EVA));
     DGG_TRY(dgg_eva_backward(cfg, e_params, e_grads, ws, W.bytes, B, DGG_TRAIN, bps, rot9, transl, dl, nullptr, stream));
     return seed_bump_launch(seed_dev, st);  // the next replay draws other masks
 }

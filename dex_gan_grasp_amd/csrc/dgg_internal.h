@@ -241,7 +241,8 @@ int ibn_bwd_apply_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col
 // losses -------------------------------------------------------------------------------------
 int bce_launch(const float* p, const float* labels, float target_const, int B, float weight, float loss_scale,
                float* loss_out, float* d_logit, hipStream_t st, float* combine = nullptr, int real_slot = DGG_L_BCE_REAL,
-               unsigned* clear_ticket = nullptr /* set to 0 by the launch (GenLossFin::ticket) */);
+               unsigned* clear_ticket = nullptr /* set to 0 by the launch (GenLossFin::ticket) */,
+               float* loss_copy = nullptr /* the loss value once more */);
 int ortho6d_fwd_launch(const float* o6, int ld, int B, float* rot9, hipStream_t st);
 int fake_pose_launch(const float* heads, int ld, int nj, int B, float* rot9, float* transl, float* joint, hipStream_t st);
 int ortho6d_bwd_launch(const float* o6, int ld, int B, const float* d_rot9, float* d_o6, int ldd, hipStream_t st);

@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ p, 
                                                    float target_const, int B, float weight, float loss_scale,
                                                    float* __restrict__ loss_out, float* __restrict__ d_logit,
                                                    float* __restrict__ combine, int real_slot,
-                                                   unsigned* __restrict__ clear_ticket) {
+                                                   unsigned* __restrict__ clear_ticket, float* __restrict__ loss_copy) {
     __shared__ float sh[16];
     float acc = 0.f;
     if (clear_ticket && threadIdx.x == 0) clear_ticket[0] = 0u;   // see gen_loss_kernel (GenLossFin)
@@ -1092,6 +1092,7 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ p, 
     if (threadIdx.x == 0) {
         const float l = weight * (tot / (float)B);
         loss_out[0] = l;
+        if (loss_copy) loss_copy[0] = l;   // (the evaluator reports its one loss under two names: a copy launch of its own until round 5)
         // combine (the D phase's fake-pass term; dexgangrasp.py:229-231): total = (real + fake) / 2 with the real pass' term
         // taken from `real_slot` (a prefetched real pass leaves it in a spare slot) — what a one-thread kernel of its own did
         // before round 4
@@ -1886,9 +1887,10 @@ int ibn_bwd_apply_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col
 }
 
 int bce_launch(const float* p, const float* labels, float target_const, int B, float weight, float loss_scale,
-               float* loss_out, float* d_logit, hipStream_t st, float* combine, int real_slot, unsigned* clear_ticket) {
+               float* loss_out, float* d_logit, hipStream_t st, float* combine, int real_slot, unsigned* clear_ticket,
+               float* loss_copy) {
     hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, st, p, labels, target_const, B, weight, loss_scale,
-                       loss_out, d_logit, combine, real_slot, clear_ticket);
+                       loss_out, d_logit, combine, real_slot, clear_ticket, loss_copy);
     return check_launch("bce");
 }
 
