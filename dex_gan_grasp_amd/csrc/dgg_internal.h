@@ -83,6 +83,9 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st);
 int gemm_fc2_fused_launch(GemmBatch& batch, hipStream_t st);
 // fc2_stage.hip: the same stage with one 32 x 32 output tile per workgroup, its waves splitting K = 256
 int fc2_stage_launch(const GemmProb& p, hipStream_t st);
+// the generator's pose heads, out (B, nh <= 32) = y (B, 512) wh (nh, 512)^T + bh, in one launch of the same form
+int heads_stage_launch(const float* y, int ldy, int B, const float* wh, const float* bh, int nh, float* out, int ldo,
+                       hipStream_t st);
 // ... and its backward mirror: dq = (da2 W2) * lrelu'(h) + bn1's backward partial sums per row block, one launch
 int fc2_bwd_stage_launch(const float* da2, int ldda, const float* w2, int ldw, const float* h, int ldh, const float* a1,
                          int lda1, const float* mean, const float* rstd, int B, float* dq, int lddq, float* part,

@@ -1768,7 +1768,8 @@ static void one_problem(GemmBatch& g, const float* A, int lda, const float* Bm, 
 }
 
 // nh == 1 (discriminator / evaluator score): one wave per row.  nh > 1 (the generator's 21 pose outputs,
-// networks.py:98-100): the heads are a (B x K)(K x nh) product — MFMA GEMM with split-K slabs + the bias reduce;
+// networks.py:98-100): the heads are a (B x K)(K x nh) product — a stage kernel of its own at K = 512 (heads_stage_kernel), else an
+// MFMA GEMM with split-K slabs + the bias reduce;
 // the per-row kernel spent its time in nh x 6 cross-lane reduction steps (53 us at B = 1024 against 12).
 // scratch: >= 4 * B * nh floats (nh > 1 only).
 int heads_fwd_launch(const float* y, int ldy, int B, int K, const float* wh, const float* bh, int nh, int sigmoid,
@@ -1780,6 +1781,7 @@ int heads_fwd_launch(const float* y, int ldy, int B, int K, const float* wh, con
         return check_launch("heads_fwd");
     }
     if (sigmoid || !scratch) return DGG_ERR_UNSUPPORTED;
+    if (K == 512) return heads_stage_launch(y, ldy, B, wh, bh, nh, out, ldo, st);   // one launch (fc2_stage.hip)
     GemmBatch g;
     one_problem(g, y, ldy, wh, K, scratch, nh, B, nh, K, 4, (long long)B * nh);
     int rc = gemm_launch(GEMM_NT, g, st);

@@ -287,6 +287,55 @@ __global__ __launch_bounds__(512) void fc2_bwd_stage_kernel(const Fc2Bwd P) {
     }
 }
 
+// The generator's pose heads (networks.py:98-100): out = y Wh^T + bh, (B x 512)(512 x nh <= 32) — one 32-row tile per
+// workgroup, eight waves split K = 512 (a lane: 32 k of one y row and of one head's weight row), partial tiles through LDS in
+// wave order, wave w stores the accumulator registers 2 w, 2 w + 1.  Until round 5: a split-K GEMM on gemm_f32_kernel (64
+// workgroups, four slabs) + reduce_bias_kernel.
+struct HeadsFwd {
+    const float* y; int ldy;    // (B, 512)
+    const float* wh;            // (nh, 512)
+    const float* bh;            // (nh)
+    int nh, B;
+    float* out; int ldo;        // (B, nh)
+};
+__global__ __launch_bounds__(512) void heads_stage_kernel(const HeadsFwd P) {
+    __shared__ float red[8][16][64];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = (int)blockIdx.x * 32;
+    const int kb = 64 * wave + 32 * lh;
+    const int arow = min(m0 + li, P.B - 1), brow = min(li, P.nh - 1);
+    f32x4 a4[8], b4[8];
+    {
+        const f32x4_u* ap = reinterpret_cast<const f32x4_u*>(P.y + (size_t)arow * P.ldy + kb);
+        const f32x4_u* bp = reinterpret_cast<const f32x4_u*>(P.wh + (size_t)brow * kKB + kb);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a4[q] = ap[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) b4[q] = bp[q];
+    }
+    const float bias = P.bh[brow];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s >> 2][s & 3], b4[s >> 2][s & 3], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (li >= P.nh) return;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int r = 2 * wave + e;
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float d = red[0][r][lane];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) d += red[w][r][lane];   // wave (= k) order
+        if (row < P.B) P.out[(size_t)row * P.ldo + li] = d + bias;
+    }
+}
+
 }  // namespace fc2
 
 // One problem with GemmProb::bn_part set (see there): K = 256, no split-K.
@@ -315,5 +364,13 @@ int fc2_bwd_stage_launch(const float* da2, int ldda, const float* w2, int ldw, c
     const int tiles = ((B + 31) / 32) * (fc2::kNB / 32);
     hipLaunchKernelGGL(fc2::fc2_bwd_stage_kernel, dim3(tiles), dim3(512), 0, st, P);
     return check_launch("fc2_bwd_stage");
+}
+// out (B, nh) = y (B, 512) wh (nh, 512)^T + bh, nh <= 32
+int heads_stage_launch(const float* y, int ldy, int B, const float* wh, const float* bh, int nh, float* out, int ldo,
+                       hipStream_t st) {
+    if (!y || !wh || !bh || !out || B < 1 || nh < 1 || nh > 32 || ldy < fc2::kKB) return DGG_ERR_INVALID;
+    fc2::HeadsFwd P{y, ldy, wh, bh, nh, B, out, ldo};
+    hipLaunchKernelGGL(fc2::heads_stage_kernel, dim3((B + 31) / 32), dim3(512), 0, st, P);
+    return check_launch("heads_stage");
 }
 }  // namespace dgg
