@@ -2174,7 +2174,12 @@ static int gradient_penalty(const dgg_cfg* cfg, const dgg_gan_state* s, const St
             prob_init(g.p[1], Q.A13dbar, L.n13, P + R.w13 + L.k0, R.fin, Q.ydbar, L.nn, B, L.nn, L.n13);
             DGG_TRY(gemm_launch(GEMM_NN, g, st));
         }
-        DGG_TRY(gemm1(GEMM_NN, Q.A13dbar, L.n13, P + R.w13 + ib, R.fin, Q.tu0bar, np, B, np, L.n13, last ? 0 : 1, st));
+        // (a narrow product: 16 workgroups walking 24 k-tiles on gemm_f32_kernel, 27.6 us — one 32-row tile per workgroup with
+        //  the waves splitting K instead, fc2_stage.hip)
+        if (np <= 32 && L.n13 % 64 == 0 && L.n13 <= 1024)
+            DGG_TRY(narrow_nn_launch(Q.A13dbar, L.n13, P + R.w13 + ib, R.fin, Q.tu0bar, np, B, np, L.n13, last ? 0 : 1, st));
+        else
+            DGG_TRY(gemm1(GEMM_NN, Q.A13dbar, L.n13, P + R.w13 + ib, R.fin, Q.tu0bar, np, B, np, L.n13, last ? 0 : 1, st));
     }
     // input BatchNorm: d gamma0 / d beta0 from the primal epilogue partials, d gamma0 (pose columns) from the tangent
     for (int r = 0; r < 2; ++r)

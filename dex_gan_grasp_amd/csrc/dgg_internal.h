@@ -83,6 +83,9 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st);
 int gemm_fc2_fused_launch(GemmBatch& batch, hipStream_t st);
 // fc2_stage.hip: the same stage with one 32 x 32 output tile per workgroup, its waves splitting K = 256
 int fc2_stage_launch(const GemmProb& p, hipStream_t st);
+// a narrow NN product in the same form: C (M, N <= 32) (+)= A (M, K) B (K, N), K a multiple of 64 up to 1024
+int narrow_nn_launch(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K, int accumulate,
+                     hipStream_t st);
 // the generator's pose heads, out (B, nh <= 32) = y (B, 512) wh (nh, 512)^T + bh, in one launch of the same form
 int heads_stage_launch(const float* y, int ldy, int B, const float* wh, const float* bh, int nh, float* out, int ldo,
                        hipStream_t st);

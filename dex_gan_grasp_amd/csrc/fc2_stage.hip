@@ -336,6 +336,68 @@ __global__ __launch_bounds__(512) void heads_stage_kernel(const HeadsFwd P) {
     }
 }
 
+// A narrow NN product, C (M x N <= 32) (+)= A (M x K) B (K x N), K a multiple of 64 up to 1024: the WGAN-GP step's pose-column
+// adjoint (1024 x 27 x 768; on gemm_f32_kernel: 16 workgroups walking 24 k-tiles, 27.6 us).  One 32-row tile per workgroup,
+// eight waves split K, wave w stores the accumulator registers 2 w, 2 w + 1.
+struct NarrowNN {
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    int M, N, K, accumulate;
+};
+__global__ __launch_bounds__(512) void narrow_nn_kernel(const NarrowNN P) {
+    __shared__ float red[8][16][64];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = (int)blockIdx.x * 32;
+    const int kl = P.K / 16;                // k per lane: K / 8 waves / 2 halves (a multiple of 4, <= 64)
+    const int kb = 2 * kl * wave + kl * lh;
+    const int arow = min(m0 + li, P.M - 1), col = min(li, P.N - 1);
+    constexpr int KLMAX = 64;
+    f32x4 a4[KLMAX / 4];
+    float b[KLMAX];
+    {
+        const f32x4_u* ap = reinterpret_cast<const f32x4_u*>(P.A + (size_t)arow * P.lda + kb);
+        const float* bp = P.B + (size_t)kb * P.ldb + col;
+#pragma unroll
+        for (int q = 0; q < KLMAX / 4; ++q) a4[q] = 4 * q < kl ? ap[q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KLMAX; ++s) b[s] = s < kl ? bp[(size_t)s * P.ldb] : 0.f;
+    }
+    float old[2] = {0.f, 0.f};
+    if (P.accumulate) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = 2 * wave + e;
+            const int row = min(m0 + (r & 3) + 8 * (r >> 2) + 4 * lh, P.M - 1);
+            old[e] = P.C[(size_t)row * P.ldc + col];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (two widths in flight: waited for at once, tools/vmcnt_audit.py)
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KLMAX; ++s)
+        if (s < kl) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s >> 2][s & 3], b[s], acc, 0, 0, 0);   // (uniform)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (li >= P.N) return;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int r = 2 * wave + e;
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float d = red[0][r][lane];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) d += red[w][r][lane];   // wave (= k) order
+        if (row < P.M) P.C[(size_t)row * P.ldc + li] = d + old[e];
+    }
+}
+
 }  // namespace fc2
 
 // One problem with GemmProb::bn_part set (see there): K = 256, no split-K.
@@ -364,6 +426,14 @@ int fc2_bwd_stage_launch(const float* da2, int ldda, const float* w2, int ldw, c
     const int tiles = ((B + 31) / 32) * (fc2::kNB / 32);
     hipLaunchKernelGGL(fc2::fc2_bwd_stage_kernel, dim3(tiles), dim3(512), 0, st, P);
     return check_launch("fc2_bwd_stage");
+}
+// C (M, N <= 32) (+)= A (M, K) B (K, N): K a multiple of 64, 64 <= K <= 1024
+int narrow_nn_launch(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K, int accumulate,
+                     hipStream_t st) {
+    if (!A || !Bm || !C || M < 1 || N < 1 || N > 32 || K < 64 || K > 1024 || K % 64 || lda < K) return DGG_ERR_INVALID;
+    fc2::NarrowNN P{A, lda, Bm, ldb, C, ldc, M, N, K, accumulate};
+    hipLaunchKernelGGL(fc2::narrow_nn_kernel, dim3((M + 31) / 32), dim3(512), 0, st, P);
+    return check_launch("narrow_nn");
 }
 // out (B, nh) = y (B, 512) wh (nh, 512)^T + bh, nh <= 32
 int heads_stage_launch(const float* y, int ldy, int B, const float* wh, const float* bh, int nh, float* out, int ldo,
