@@ -465,11 +465,7 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
         k1[t] = k2[t] = k3[t] = k4[t] = __builtin_inff();
     }
     __syncthreads();
-#if defined(BPS_ABLATE) && BPS_ABLATE == 7   // staging only (timing build)
-    if (N < 0) {
-#else
     if (!cloud_bad) {
-#endif
         const bu32x4* pl = planes + col * 2 + h;
         bu32x4 a = pl[0];
         for (int i = 0; i < ntile; ++i) {
@@ -491,12 +487,7 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
                 const float m0 = min3(acc[0], acc[1], acc[2]), m1 = min3(acc[3], acc[4], acc[5]);
                 const float m2 = min3(acc[6], acc[7], acc[8]), m3 = min3(acc[9], acc[10], acc[11]);
                 const float m4 = min3(acc[12], acc[13], acc[14]);
-#if defined(BPS_ABLATE) && BPS_ABLATE == 4   // matrix instructions only
-                const float m = acc[0];
-                (void)m0; (void)m1; (void)m2; (void)m3; (void)m4;
-#else
                 const float m = min2(min3(m0, m1, m2), min3(m3, m4, acc[15]));
-#endif
                 float kf;  // (m & ~127) | tile index, one instruction
                 asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(kf) : "v"(m), "v"(keep), "v"(iv));
                 k4[t] = __builtin_amdgcn_fmed3f(k3[t], k4[t], kf);
@@ -592,10 +583,6 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
         // 2^-23 of the value -> 2^-15 g1 (256 ulp just above a power of two, 512 just below the next; 2^-16 was 128: short
         // when v ~ S sits just above a power of two — tests/test_bps_coarse_bound.py::test_tile_index_bits_in_the_keys)
         const float lim = g1 + (S * (scale * scale) * 0x1.41p-18f + g1 * 0x1p-15f);
-#if defined(BPS_ABLATE)   // timing builds (tools/exp/bps_ablate.sh): no exact stage, results are NOT the answer
-        if (k1[t] == g1) slot[bl] = ((unsigned long long)__builtin_bit_cast(unsigned, g1) << 32) | (unsigned)tile_of(g1);
-        (void)full;
-#else
         if (full || !(k4[t] > lim)) {
             float bb = __builtin_inff();
             int bj = 0;
@@ -621,7 +608,6 @@ __global__ __launch_bounds__(NW * 64, 4) void bps_mfma_kernel(const float* __res
                     }
             }
         }
-#endif
     }
     __builtin_amdgcn_wave_barrier();
     {

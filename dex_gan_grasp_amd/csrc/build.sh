@@ -5,6 +5,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 X3FLAGS="-fno-slp-vectorize"  # packed-f32 VALU beside MFMAs costs more than two scalar ops (MI355X_MICROARCH.md)
+rm -rf _obj   # no stale objects of deleted kernels (they would ship to the GPU box with the snapshot)
 mkdir -p _obj
 pids=""
 $HIPCC $COMMON -c gemm_f32.hip -o _obj/gemm_f32.o & pids="$pids $!"

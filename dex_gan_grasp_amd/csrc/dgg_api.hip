@@ -1359,6 +1359,7 @@ int dgg_get_bps_algo(void) { return bps_algo(); }
 int dgg_gen_forward(const dgg_cfg* cfg, const float* params, float* bnstats, void* ws, size_t ws_bytes, int B,
                     unsigned flags, const float* z, const float* bps, float* out_heads, void* stream) {
     NetL L;
+    flags &= kPublicFlags;   // internal bits (kHeadBiasDone) cannot come in through the C-ABI
     DGG_TRY(build_layout(DGG_NET_GEN, cfg, L));
     if (!z || !bps) return DGG_ERR_INVALID;
     return net_forward(L, params, bnstats, ws, ws_bytes, B, flags, srcs_gen(cfg, bps), z, nullptr, 0, out_heads,
@@ -1369,6 +1370,7 @@ int dgg_gen_backward(const dgg_cfg* cfg, const float* params, float* grads, void
                      unsigned flags, const float* z, const float* bps, const float* d_heads, float* d_z, float* d_bps,
                      void* stream) {
     NetL L;
+    flags &= kPublicFlags;   // internal bits (kHeadBiasDone) cannot come in through the C-ABI
     DGG_TRY(build_layout(DGG_NET_GEN, cfg, L));
     if (!bps) return DGG_ERR_INVALID;
     (void)z;
@@ -1380,6 +1382,7 @@ int dgg_disc_forward(const dgg_cfg* cfg, const float* params, float* bnstats, vo
                      unsigned flags, const float* bps, const float* rot9, const float* transl, const float* joint,
                      float* out_p, void* stream) {
     NetL L;
+    flags &= kPublicFlags;   // internal bits (kHeadBiasDone) cannot come in through the C-ABI
     DGG_TRY(build_layout(DGG_NET_DISC, cfg, L));
     if (!bps || !rot9 || !transl || !joint) return DGG_ERR_INVALID;
     return net_forward(L, params, bnstats, ws, ws_bytes, B, flags, srcs_pose(cfg, bps, rot9, transl, joint), nullptr,
@@ -1390,6 +1393,7 @@ int dgg_disc_backward(const dgg_cfg* cfg, const float* params, float* grads, voi
                       unsigned flags, const float* bps, const float* rot9, const float* transl, const float* joint,
                       const float* d_logit, float* d_pose, void* stream) {
     NetL L;
+    flags &= kPublicFlags;   // internal bits (kHeadBiasDone) cannot come in through the C-ABI
     DGG_TRY(build_layout(DGG_NET_DISC, cfg, L));
     if (!bps || !rot9 || !transl || !joint) return DGG_ERR_INVALID;
     const bool want = (flags & DGG_NEED_INPUT_GRADS) != 0;
@@ -1403,6 +1407,7 @@ int dgg_eva_forward(const dgg_cfg* cfg, const float* params, float* bnstats, voi
                     unsigned flags, const float* bps, const float* rot9, const float* transl, const float* drop_keep,
                     uint64_t seed, float* out_p, void* stream) {
     NetL L;
+    flags &= kPublicFlags;   // internal bits (kHeadBiasDone) cannot come in through the C-ABI
     DGG_TRY(build_layout(DGG_NET_EVA, cfg, L));
     if (!bps || !rot9 || !transl) return DGG_ERR_INVALID;
     return net_forward(L, params, bnstats, ws, ws_bytes, B, flags, srcs_pose(cfg, bps, rot9, transl, nullptr), nullptr,
@@ -1413,6 +1418,7 @@ int dgg_eva_backward(const dgg_cfg* cfg, const float* params, float* grads, void
                      unsigned flags, const float* bps, const float* rot9, const float* transl, const float* d_logit,
                      float* d_pose, void* stream) {
     NetL L;
+    flags &= kPublicFlags;   // internal bits (kHeadBiasDone) cannot come in through the C-ABI
     DGG_TRY(build_layout(DGG_NET_EVA, cfg, L));
     if (!bps || !rot9 || !transl) return DGG_ERR_INVALID;
     const bool want = (flags & DGG_NEED_INPUT_GRADS) != 0;
@@ -1757,7 +1763,7 @@ static int gen_loss_and_backward(const dgg_cfg* cfg, const dgg_gan_state* s, con
                                  float* losses, int wass, hipStream_t st) {
     NetL Lg;
     DGG_TRY(build_layout(DGG_NET_GEN, cfg, Lg));
-    const bool spread = (B + 63) / 64 >= 2;   // gen_loss_launch's condition for the 64-rows-per-workgroup form
+    const bool spread = gen_loss_spread(B);   // gen_loss_launch's own condition for the 64-rows-per-workgroup form (scratch and ticket are given)
     GenLossFin fin;
     fin.ticket = S.ticket;
     fin.gbh = spread ? s->g_grads + Lg.bh : nullptr;

@@ -263,7 +263,10 @@ struct GenLossFin {
     int accumulate = 0;
 };
 constexpr unsigned kHeadBiasDone = 0x10000u;   // net_backward flag, internal: heads' bias gradient already in `grads`
+constexpr unsigned kPublicFlags = DGG_TRAIN | DGG_ACCUM_GRADS | DGG_SKIP_PARAM_GRADS | DGG_NEED_INPUT_GRADS | DGG_SEED_ON_DEVICE |
+                                  DGG_REUSE_INPUT_NORM;   // what an extern "C" entry accepts: internal bits are masked off there
 int gen_loss_scratch_floats(const dgg_cfg* cfg, int B);
+bool gen_loss_spread(int B);   // true: gen_loss_launch (given scratch and a ticket) takes the spread form and writes fin->gbh
 int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const float* heads, const float* gt_rot9,
                     const float* gt_transl, const float* gt_joint, const float* fake_score, const float* d_pose,
                     float* losses, float* d_heads, hipStream_t st, float* scratch = nullptr /* >= gen_loss_scratch_floats */,

@@ -1920,7 +1920,7 @@ int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const floa
     const int nblk = cdiv(B, 64), nh = cfg->n_hand_joints + 9;
     if (nh > kNhMax) return DGG_ERR_UNSUPPORTED;
     // the spread form needs the caller's scratch (gen_loss_scratch_floats) and a ticket that reads 0 (GenLossFin)
-    if (!scratch || !fin || !fin->ticket || nblk < 2) {
+    if (!scratch || !fin || !fin->ticket || !gen_loss_spread(B)) {
         if (fin && fin->gbh) return DGG_ERR_INVALID;   // the bias gradient is formed by the spread form only
         hipLaunchKernelGGL(gen_loss_kernel<256>, dim3(1), dim3(256), 0, st, cfg->n_hand_joints, bw, ct, cr, cc, B, heads,
                            gt_rot9, gt_transl, gt_joint, fake_score, d_pose, losses, d_heads, (float*)nullptr, GenLossFin{});
@@ -1930,6 +1930,8 @@ int gen_loss_launch(const dgg_cfg* cfg, const dgg_hparams* hp, int B, const floa
                        gt_rot9, gt_transl, gt_joint, fake_score, d_pose, losses, d_heads, scratch, *fin);
     return check_launch("gen_loss");
 }
+// the one place that decides between the two forms (the caller tells net_backward whether the heads' bias gradient exists)
+bool gen_loss_spread(int B) { return cdiv(B, 64) >= 2; }
 int gen_loss_scratch_floats(const dgg_cfg* cfg, int B) { return cdiv(B, 64) * (4 + cfg->n_hand_joints + 9); }
 
 int adam_launch(float* params, const float* grads, float* m, float* v, int64_t n, int step, double lr, double b1,

@@ -278,7 +278,7 @@ void gemm_tile_shape(int mode, int M, int N, int& bm, int& bn, int K) {
     // 64 x 64, each a chain of 32 k-tiles: 45-79 us) is a latency chain on the f32 kernel; on gemm_x5_kernel the four waves of
     // a workgroup split K: ~37 us at K = 1024 however few the tiles.  Below K = 768 the f32 kernel's chain is the shorter one.
     // (profiles/r05_experiments.txt 23)
-    if (mode == GEMM_TN && gemm_algo() >= 1 && K >= 768 && K < (1 << 30)) return;
+    if (mode == GEMM_TN && gemm_algo() >= 1 && gemm_x5_enabled() && K >= 768 && K < (1 << 30)) return;
     if (t128 < enough) {
         bm = (M >= 1024) ? 128 : 64;
         bn = 64;
@@ -383,6 +383,21 @@ static int gemm_route(int mode, GemmBatch& batch, int& bm, int& bn, int& route, 
                            p.M, p.ldc, ((1ll << 31) - 1) / (4ll * (p.ldc > 0 ? p.ldc : 1)));
             return DGG_ERR_INVALID;
         }
+        // ... and the bf16x3 kernels form a k-contiguous operand's row base as a 32-bit byte offset (gemm_x5.hip `va` / `vb`,
+        // gemm_x4.hip): rows * pitch * 4 of such an operand must stay below 4 GiB (the f32-MFMA kernel of this file indexes in
+        // 64 bits, but a launch is refused whatever route it would take: the limit is a property of the entry, not of the route)
+        {
+            const bool a_kc = mode != GEMM_TN, b_kc = mode == GEMM_NT;
+            const long long abytes = a_kc ? (long long)p.M * p.lda * 4 : 0, bbytes = b_kc ? (long long)p.N * p.ldb * 4 : 0;
+            if (abytes >= (1ll << 32) || bbytes >= (1ll << 32)) {
+                const bool a_bad = abytes >= (1ll << 32);
+                const int pitch = a_bad ? p.lda : p.ldb;
+                set_error_text("GEMM operand %s of %d rows x pitch %d floats: k-contiguous operands are addressed through 32-bit "
+                               "byte offsets, rows * pitch * 4 must stay below 4 GiB (chunk the batch: at most %lld rows at this pitch)",
+                               a_bad ? "A" : "B", a_bad ? p.M : p.N, pitch, ((1ll << 32) - 1) / (4ll * (pitch > 0 ? pitch : 1)));
+                return DGG_ERR_INVALID;
+            }
+        }
         p.tiles_m = (p.M + bm - 1) / bm;
         p.tiles_n = (p.N + bn - 1) / bn;
         p.blk_begin = blocks;
@@ -440,11 +455,13 @@ int gemm_launch(int mode, GemmBatch& batch, hipStream_t st) {
         gemm_x5_dispatch(mode, large, st);
         DGG_TRY_RC(check_launch("gemm_x5"));
         if (small.nprob == 0) return DGG_OK;
-        batch = small;   // (tiled 128 x 128 by gemm_route)
     }
-    if (mode == GEMM_NT) launch_shape<true, true>(bm, bn, batch, st);
-    else if (mode == GEMM_NN) launch_shape<true, false>(bm, bn, batch, st);
-    else launch_shape<false, false>(bm, bn, batch, st);
+    // (the short problems of a cut launch are tiled 128 x 128 by gemm_route; the caller's batch keeps its own plan — callers
+    //  read p[i].splits back after the launch)
+    const GemmBatch& rest = route == GEMM_ROUTE_X5 ? small : batch;
+    if (mode == GEMM_NT) launch_shape<true, true>(bm, bn, rest, st);
+    else if (mode == GEMM_NN) launch_shape<true, false>(bm, bn, rest, st);
+    else launch_shape<false, false>(bm, bn, rest, st);
     return check_launch("gemm_f32");
 }
 

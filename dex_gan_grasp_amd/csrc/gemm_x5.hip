@@ -42,15 +42,8 @@
 #include "dgg_internal.h"
 #include "gemm_epilogue.h"
 
-#ifndef DGG_X5_STAMP
-#define DGG_X5_STAMP 0  // diagnostics only: per-wave s_memtime / s_memrealtime stamps (never in the shipped build)
-#endif
-
 namespace dgg {
 
-#if DGG_X5_STAMP
-__device__ unsigned long long g_x5_stamp[2048][4][8];
-#endif
 
 namespace x5 {
 
@@ -428,11 +421,6 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
         }
     };
 
-#if DGG_X5_STAMP
-    unsigned long long stamp[8];
-    stamp[0] = __builtin_amdgcn_s_memtime();
-    stamp[1] = __builtin_amdgcn_s_memrealtime();
-#endif
     f32x16 acc[4][4];
     auto zero_acc = [&]() {
         float z = 0.f;
@@ -626,9 +614,6 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
                 prep(FC<fcode(f)>{}, rawb[0], 0, No{});
             }
         }
-#if DGG_X5_STAMP
-        stamp[2] = __builtin_amdgcn_s_memtime();
-#endif
         // ---- pairs (AO, BO): all but the last one stage two steps ahead; the last pair masks the last step's A fragments
         int i = odd ? 1 : 0;
         for (; i + 2 < nw; i += 2) {
@@ -651,13 +636,7 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
     // "everybody parks everything", and all four waves add in both rounds.  Order of the sum: ((own + W^1) + W^2) + W^3 —
     // fixed per element: deterministic.
     f32x16 res[2][2];
-#if DGG_X5_STAMP
-    stamp[3] = __builtin_amdgcn_s_memtime();
-#endif
     __syncthreads();   // every wave's ring is idle
-#if DGG_X5_STAMP
-    stamp[4] = __builtin_amdgcn_s_memtime();
-#endif
     auto slot = [&](int owner, int s, int t, int q4) {   // [owner][source slot][tile of the quadrant][register quad], lane-linear
         return lds0 + (unsigned)((((owner * 2 + s) * 4 + t) * 4 + q4) * 1024) + (unsigned)lane * 16u;
     };
@@ -703,9 +682,6 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
             for (int j = 0; j < 4; ++j) res[t >> 1][t & 1][4 * q4 + j] += v[q4][j];
     });
     __syncthreads();   // (the epilogue's scratch lies behind the slots; the next work item's ring does not)
-#if DGG_X5_STAMP
-    stamp[5] = __builtin_amdgcn_s_memtime();
-#endif
     // a tile inside the matrix (and, for the BatchNorm-aware form, quadrants on one side of the fc1 | fc3 row split) stores
     // row-major with 16-byte accesses; the others take the shared element-wise epilogue (workgroup-uniform choice)
     // (lane-derived values of the epilogue are computed from here on: formed at the kernel's entry they are spilled across the k
@@ -717,13 +693,6 @@ __device__ __forceinline__ void gemm_x5_block(const GemmBatch& batch, const int 
                                          m0, n0, wave, lane_e, tid_e);
     else
         gemm_epilogue<YT, YT, 2, 2, !A_KC && !B_KC>(P, res, reinterpret_cast<float*>(smem + 128 * 1024), split, tm_i, m0, n0, tid_e);
-#if DGG_X5_STAMP
-    stamp[6] = __builtin_amdgcn_s_memtime();
-    stamp[7] = __builtin_amdgcn_s_memrealtime();
-    if (nw == 0) stamp[2] = stamp[0];
-    if (lane == 0 && bid < 2048)
-        for (int q = 0; q < 8; ++q) g_x5_stamp[bid][wave][q] = stamp[q];
-#endif
 }
 
 template <bool A_KC, bool B_KC, bool AFF, bool X1>
@@ -749,11 +718,6 @@ static void launch_x5(const GemmBatch& b, hipStream_t st) {
 
 }  // namespace x5
 
-#if DGG_X5_STAMP
-extern "C" int dgg_x5_debug_stamps(unsigned long long* host_out, int nblocks) {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_x5_stamp), (size_t)nblocks * 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
-}
-#endif
 
 // A problem needs at least YMINK of K inside each split (a k-step moved back to the split's end must stay inside the split).
 bool gemm_x5_enabled() {

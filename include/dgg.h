@@ -18,10 +18,12 @@
  *  - return value: DGG_OK (0) or a negative dgg_status; no exceptions cross the boundary;
  *  - re-entrant across streams with distinct workspaces; not thread-safe on one workspace.
  *  - all tensors fp32 row-major contiguous unless a leading dimension is given;
- *  - batch limit of every forward / backward / phase / step entry: the GEMM epilogues address their outputs through 32-bit
- *    byte offsets, so rows * pitch * 4 of every product stays below 2 GiB — B <= 699 050 rows per call at the widest pitch
- *    (768 floats; the per-object inference entries: O * n rows).  A larger batch returns DGG_ERR_INVALID and
- *    dgg_last_error() says which product; callers chunk their rows (the reference's own batches are 32 .. 5012).
+ *  - batch limit of every forward / backward / phase / step entry: **B <= 260 111 rows per call**.  Two 32-bit byte offsets
+ *    set it: the GEMM epilogues address their outputs (rows * pitch * 4 < 2 GiB: B <= 699 050 at the widest output pitch,
+ *    768 floats) and the bf16x3 kernels address a k-contiguous OPERAND's rows (rows * pitch * 4 < 4 GiB: the normalised
+ *    input block X0 has a pitch of 4128 floats -> B <= 260 111; the per-object inference entries stage O rows of it and
+ *    O * n rows of 512 / 768 floats: O * n <= 699 050).  A larger batch returns DGG_ERR_INVALID and dgg_last_error()
+ *    says which product and how many rows fit; callers chunk their rows (the reference's own batches are 32 .. 5012).
  *
  * Hidden state (everything else is stateless).  The library keeps, PER CALLING THREAD:
  *  (a) a pool of 64 timing-disabled HIP events used for its internal fork/join between streams;
@@ -424,8 +426,9 @@ int dgg_gemm_occupancy(int mode, int bm, int bn);
  * operand lies in a larger buffer (flat parameter buffers, workspaces); a caller-owned k-strided A / B whose last k-row
  * ends exactly at the end of its allocation with a row count % 4 != 0 must be padded by 12 bytes — or run with
  * DGG_GEMM_ALGO=f32, whose tails are fetched element by element.  Problems with K < 64 (or split-K chunks that short) run
- * on the f32-MFMA kernel.  SIZE: the epilogues address C through 32-bit byte offsets — M * ldc * 4 must stay below 2 GiB
- * (DGG_ERR_INVALID otherwise, dgg_last_error() says so; the library's own products are 50 000 x 768 at most). */
+ * on the f32-MFMA kernel.  SIZE: the epilogues address C through 32-bit byte offsets — M * ldc * 4 must stay below 2 GiB —
+ * and the bf16x3 kernels a k-contiguous operand's rows — M * lda * 4 (modes 0, 1) and N * ldb * 4 (mode 0) must stay below
+ * 4 GiB (DGG_ERR_INVALID otherwise on every route, dgg_last_error() says so; the library's own products are 50 000 x 768 at most). */
 int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const float* Bm, int ldb, float* C,
                  int ldc, int splits, float* slabs, int accumulate, void* stream);
 /* Which kernel dgg_gemm_f32 — and every internal product of that shape launched alone — runs on under the current
@@ -433,7 +436,7 @@ int dgg_gemm_f32(int mode, int M, int N, int K, const float* A, int lda, const f
  * chosen where they fill the chip (alone, or with split-K in mode 0); on them DGG_GEMM_BF16X3 takes gemm_x4_kernel from 1024
  * workgroups up and gemm_x5_kernel otherwise, provided K >= 64 (and every split-K chunk >= 64, the last one >= 16); everything
  * else, and all of DGG_GEMM_F32, runs on the f32-MFMA kernels; DGG_GEMM_BF16 uses gemm_x5_kernel for the same shapes.
- * Returns DGG_KERNEL_* or a negative dgg_status (e.g. the 2 GiB limit of C). */
+ * Returns DGG_KERNEL_* or a negative dgg_status (e.g. the 2 GiB limit of C, the 4 GiB limit of a k-contiguous operand). */
 enum { DGG_KERNEL_F32 = 0, DGG_KERNEL_X4 = 4, DGG_KERNEL_X5 = 5 };
 int dgg_gemm_route(int mode, int M, int N, int K, int lda, int ldb, int ldc, int splits);
 

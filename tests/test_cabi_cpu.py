@@ -212,3 +212,11 @@ def test_gemm_routing_rules_and_the_2gib_limit():
     assert route(0, 699051, 768, 512, 512, 512, 768, 0) == -1
     msg = lib.dgg_last_error().decode()
     assert "2 GiB" in msg and "699050" in msg, msg
+    # a k-contiguous OPERAND is addressed through 32-bit byte offsets by the bf16x3 kernels — rows * pitch * 4 must
+    # stay below 4 GiB (the X0 block of a forward: pitch 4128 -> 260 111 rows), refused on every route with the row count that fits
+    assert route(0, 260111, 768, 4120, 4128, 4120, 768, 16) in (X4, X5)
+    assert route(0, 260112, 768, 4120, 4128, 4120, 768, 16) == -1
+    msg = lib.dgg_last_error().decode()
+    assert "4 GiB" in msg and "260111" in msg and "operand A" in msg, msg
+    assert route(1, 260112, 512, 768, 4128, 512, 512, 0) == -1          # A of a dgrad is k-contiguous too
+    assert route(2, 768, 4120, 300000, 768, 4128, 4120, 0) == X5        # k-strided operands are addressed by 64-bit row bases
