@@ -63,7 +63,7 @@ def _time_stream(fn, iters, warm=3):
 def _pmc_traffic(name, shape):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 correction +
     WRITE_SIZE; separate passes, see profiles/): PMC counters cannot be read from inside a run."""
-    for rnd in ("r05",):   # (rounds 1-4 profiled other kernels: gemm_x3_kernel, deleted in round 5)
+    for rnd in ("r06", "r05"):   # (rounds 1-4 profiled other kernels: gemm_x3_kernel, deleted in round 5)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "%s_%s_pmc.json" % (rnd, name))))
             if pmc.get("shape") == shape:
@@ -71,6 +71,51 @@ def _pmc_traffic(name, shape):
         except Exception:
             continue
     return None, None
+
+
+def large_product_flops(B, nj=12, in_bps=4096, latent=5):
+    """FLOPs of the products of ONE gen+eval step that run on gemm_x5_kernel (bf16x3: 128 x 128 tiles), 2*M*N*K each — the
+    numerator of roofline.step_mfma_frac.  Per ResBlock r of a network with input width k0: forward [a1|a3] = X W13^T
+    (N = 768, K = k0 + 512 r) and its weight gradient (same M*N*K); the fc2 weight gradient (512 x 256 x B) and the
+    generator heads' (21 x 512 x B) ride in those launches.  Not counted (f32-MFMA kernels): fc2 forward / dgrad stages,
+    the K = 768 dgrads, the pose / latent column segments (K < 64).  D: the BPS columns' forward product is shared by the
+    real and fake pass and its weight gradient formed once on dY_real + dY_fake; the G phase's pass through the updated D
+    is a full forward, no weight gradient."""
+    n13, nn, hid = 768, 512, 256
+    pose_d, pose_e = 12 + nj, 12
+    f = 0.0
+    fc2w = 2.0 * nn * hid * B
+    # generator: forward + weight gradient, blocks 0 and 1 (the 5 latent columns run on the f32 kernel)
+    for r in range(2):
+        k = in_bps + nn * r
+        f += 2 * (2.0 * B * n13 * k) + fc2w
+    f += 2.0 * (nj + 9) * nn * B
+    # discriminator: shared BPS forward (once per D phase) + the previous block's 512 columns in each of the two passes;
+    # the G phase's full forward; weight gradients: BPS block once, previous block's columns per pass
+    for r in range(2):
+        f += 2.0 * B * n13 * in_bps + 2 * (2.0 * B * n13 * nn * r)          # D phase forwards
+        f += 2.0 * B * n13 * (in_bps + pose_d + nn * r)                      # G phase forward (pose columns ride: K >= 64 whole)
+        f += 2.0 * B * n13 * in_bps + 2 * (2.0 * B * n13 * nn * r) + 2 * fc2w  # weight gradients
+    # evaluator: three blocks, forward + weight gradient
+    for r in range(3):
+        k = in_bps + pose_e + (nn if r else 0)
+        f += 2 * (2.0 * B * n13 * k) + fc2w
+    return f
+
+
+def in_step_profile():
+    """What the committed kernel trace of THIS command says about the timed region (tools/collect_profiles.sh runs
+    `rocprofv3 --kernel-trace --stats -- python3 bench.py ...`; tools/summarize_profiles.py keeps the per-kernel statistics as
+    profiles/r06_bench_kernel_stats.csv and, from the trace itself, profiles/r06_bench_in_step.json: per (kernel, grid) mean
+    durations and the launches per step and hardware queue).  A trace cannot be taken from inside the run it traces."""
+    out = {}
+    path = os.path.join(ROOT, "profiles", "r06_bench_in_step.json")
+    try:
+        out = json.load(open(path))
+        out["source"] = "profiles/r06_bench_in_step.json (+ r06_bench_kernel_stats.csv, same trace)"
+    except Exception:
+        return None
+    return out
 
 
 def gemm_roofline(dev, mode, M, N, K, lda, ldb, splits, what, pmc_name, iters=20):
@@ -447,6 +492,13 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch (BASELINE: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub", action="store_true")
+    ap.add_argument("--same-batch", action="store_true",
+                    help="rounds 1-5: ONE resident gan batch and ONE eva batch stepped forever (their BPS blocks and x_hat stay "
+                         "L2 / Infinity-Cache warm across steps); default since round 6: --nbatch distinct resident batches "
+                         "rotate and the look-ahead real pass gets the NEXT batch")
+    ap.add_argument("--nbatch", type=int, default=4, help="distinct resident gan / eva batches that rotate (default 4)")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip the short comparison run in the other data mode "
+                                                                  "(profiling: the trace then holds one mode only)")
     args = ap.parse_args()
 
     # DGG_REHEARSE=1: rehearsal of the multi-rank code path on a 1-GPU box (gloo backend, all ranks on cuda:0);
@@ -464,40 +516,60 @@ def main():
     fe.load_state_dict(synth.make_state_dict("evaluator", 5))
     eng = engine.TrainEngine(cfg, fg, fd, fe, dev)
     # synthetic batches of this rank's shard (seeds offset by rank), resident in HBM before timing
-    gb = synth.make_batch(B, 1 + 100 * rank)
-    eb = synth.make_batch(B, 2 + 100 * rank, with_label=True)
     f = lambda t: t.float().to(dev).contiguous()
-    g_in = (f(gb["bps_object"]), f(gb["rot_matrix"]).reshape(B, 9), f(gb["transl"]), f(gb["joint_conf"]))
-    e_in = (f(eb["bps_object"]), f(eb["rot_matrix"]).reshape(B, 9), f(eb["transl"]), f(eb["label"]))
+    nb = 1 if args.same_batch else max(1, args.nbatch)
+    g_ins, e_ins = [], []
+    for j in range(nb):   # (batch 0 = the batches of rounds 1-5: seeds 1 / 2)
+        gb = synth.make_batch(B, 1 + 100 * rank + 1000 * j)
+        eb = synth.make_batch(B, 2 + 100 * rank + 1000 * j, with_label=True)
+        g_ins.append((f(gb["bps_object"]), f(gb["rot_matrix"]).reshape(B, 9), f(gb["transl"]), f(gb["joint_conf"])))
+        e_ins.append((f(eb["bps_object"]), f(eb["rot_matrix"]).reshape(B, 9), f(eb["transl"]), f(eb["label"])))
     zs = [synth.make_z(B, 3 + 100 * rank + i).to(dev) for i in range(4)]
     it = [0]
 
-    def step():
-        # one update_dexgangrasp + one update_dexevaluator; gradient all-reduces (N > 1) overlap with the
-        # independent phase, see engine.TrainEngine.joint_step
-        i = it[0]
-        it[0] += 1
-        eng.joint_step(g_in, zs[i % 4], e_in, True, None, 1234 + i, next_gan_inputs=g_in if PIPELINE else None)
+    def make_step(n_rot):
+        def step():
+            # one update_dexgangrasp + one update_dexevaluator; gradient all-reduces (N > 1) overlap with the
+            # independent phase, see engine.TrainEngine.joint_step.  The look-ahead real pass gets the NEXT batch.
+            i = it[0]
+            it[0] += 1
+            eng.joint_step(g_ins[i % n_rot], zs[i % 4], e_ins[i % n_rot], True, None, 1234 + i,
+                           next_gan_inputs=g_ins[(i + 1) % n_rot] if PIPELINE else None)
+        return step
 
-    for _ in range(args.warmup):
-        step()
-    blocks = []
-    for _ in range(max(1, args.repeats)):
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+    def timed(step, repeats):
+        for _ in range(args.warmup):
             step()
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        blocks.append(time.perf_counter() - t0)
-    if world > 1:   # MAX over ranks, block by block
-        t = torch.tensor(blocks, device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        blocks = [float(x) for x in t.cpu()]
+        blocks = []
+        for _ in range(max(1, repeats)):
+            if world > 1:
+                torch.distributed.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            blocks.append(time.perf_counter() - t0)
+        if world > 1:   # MAX over ranks, block by block
+            t = torch.tensor(blocks, device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            blocks = [float(x) for x in t.cpu()]
+        return blocks
+
+    step = make_step(nb)
+    blocks = timed(step, args.repeats)
     dt = statistics.median(blocks)
+    # the other data mode beside it (fewer blocks): how much of the step the warm caches of a never-changing batch were worth
+    other_ms = None
+    if nb > 1 and not args.no_other_mode:
+        it[0] = 0
+        ob = timed(make_step(1), min(5, max(1, args.repeats)))
+        other_ms = statistics.median(ob) / args.steps * 1e3
+        it[0] = 0
+        for _ in range(4):   # back to the rotating mode for the trace steps below
+            step()
     losses = eng.losses.cpu().numpy()
     assert all(map(lambda x: x == x, losses[:10])), "NaN in losses"
 
@@ -546,6 +618,10 @@ def main():
             "config": {"workload": "cGAN step (update_dexgangrasp) + evaluator step (update_dexevaluator), "
                                    "batch %d per GPU, BPS-4096, fp32, Adam included" % B,
                        "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "data_rotation": ("one resident gan batch and one eva batch, stepped forever (--same-batch)" if nb == 1 else
+                                         "%d distinct resident gan batches and %d eva batches rotate; the look-ahead real "
+                                         "pass gets the next batch" % (nb, nb)),
+                       "ms_per_step_same_batch": round(other_ms, 4) if other_ms is not None else None,
                        "phase_us_after_step_begin": phase_us,
                        "timed_blocks": len(blocks),
                        "block_ms_per_step_min_median_max": [round(min(blocks) / args.steps * 1e3, 4),
@@ -569,7 +645,21 @@ def main():
         nt = gemm_roofline(dev, 0, B, 768, 4120, 4120, 4632, 4,
                            "gemm_x5_kernel, forward of fc1||fc3 (NT): a13[%d,768] = X0[%d,4120] W13[768,4120]^T, split-K 4" % (B, B),
                            "gemm_x5")
-        res["roofline"] = tn
+        res["roofline"] = dict(tn)
+        # ... and where the step runs: the same instantiation INSIDE the timed region, from the committed
+        # kernel trace of this command; and the whole step against the same bound
+        prof = in_step_profile()
+        if prof and prof.get("dominant_tn"):
+            d = prof["dominant_tn"]
+            res["roofline"]["in_step"] = {
+                "mean_us": d["mean_us"], "min_us": d["min_us"], "max_us": d["max_us"], "launches": d["launches"],
+                "achieved": round(2.0 * 768 * 4120 * B / (d["mean_us"] * 1e-6) / 1e12, 2) if B == 1024 else None,
+                "frac": round(2.0 * 768 * 4120 * B / (d["mean_us"] * 1e-6) / 1e12 / tn["peak"], 4) if B == 1024 else None,
+                "what": d["what"], "source": prof["source"]}
+            res["main_stream_launches_per_step"] = prof.get("launches_per_step_by_queue")
+        lp = large_product_flops(B)
+        res["roofline"]["step_mfma_frac"] = round(lp / (dt / args.steps) / 1e12 / tn["peak"], 4)
+        res["roofline"]["step_large_product_gflop"] = round(lp / 1e9, 2)
         res["roofline_kernels"] = {"gemm_wgrad_tn": tn, "gemm_forward_nt": nt, "bps_encode": bps_roofline(dev),
                                    "bps_encode_one_cloud": bps_one_cloud(dev),
                                    "adam": adam_roofline(dev)}
@@ -601,6 +691,13 @@ def main():
             t_serial = (sr["cgan_step_b1024"]["ms_per_step"] + sr["config3_eva_step_b1024"]["ms_per_step"]) * 1e-3
             res["value_serial"] = round(1024 / t_serial, 1) if B == 1024 else None
             res["value_dropin"] = sr["api_path_b1024"]["grasps_per_s"] if B == 1024 else None
+            res["config"]["value_serial"] = {"grasps_per_s": res["value_serial"],
+                                             "formula": "SURVEY 8(d): B / (t_cGAN_step + t_evaluator_step), the two engine steps "
+                                                        "timed one after the other (sub_results.cgan_step_b1024, config3_eva_step_b1024)",
+                                             "t_cgan_ms": sr["cgan_step_b1024"]["ms_per_step"],
+                                             "t_eval_ms": sr["config3_eva_step_b1024"]["ms_per_step"]}
+            res["config"]["value_dropin"] = {"grasps_per_s": res["value_dropin"],
+                                             "what": "unchanged train.py order through the drop-in wrapper (sub_results.api_path_b1024)"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, B)
         print(json.dumps(res))

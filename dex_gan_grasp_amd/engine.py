@@ -14,6 +14,7 @@ from ._lib import check, lib, ptr, stream_ptr, f32c
 
 
 SEED_STRIDE = 0x9E3779B97F4A7C15   # what dgg_eva_phase_graph adds to the device-resident dropout seed per step
+LOSS_RING = 1024                   # steps a returned loss vector stays valid (TrainEngine.losses)
 
 
 class _side_work:
@@ -42,6 +43,7 @@ class GraphStep:
 
     def __init__(self, eng, graph, keep, is_train_gen):
         self.eng, self.graph, self.keep, self.is_train_gen = eng, graph, keep, is_train_gen
+        self.loss_view = eng.losses   # the ring slot whose address the captured kernels write (TrainEngine.losses)
 
     def replay(self):
         self.graph.replay()
@@ -51,7 +53,7 @@ class GraphStep:
         e.E._step += 1
         if self.is_train_gen:
             e.G._step += 1
-        return e.losses
+        return self.loss_view
 
 
 class TrainEngine:
@@ -60,7 +62,12 @@ class TrainEngine:
         self.G, self.D, self.E = flat_g, flat_d, flat_e
         self.device = torch.device(device)
         self.ccfg = _lib.make_cfg(cfg)
-        self.losses = torch.zeros(16, dtype=torch.float32, device=self.device)
+        # The loss vector of a step (16 floats, slots _lib.L_*) is written by the kernels of that step into ONE slot of a
+        # ring; every step takes the next slot and returns a VIEW of it — no copy kernel on the step's stream (until round 5:
+        # `losses.clone()` per call, a launch + its gap on the chain; the reference only reads the values every print_freq
+        # steps, train.py:254-258).  A returned vector stays valid for LOSS_RING - 1 further steps of this engine.
+        self._loss_ring = torch.zeros((LOSS_RING, 16), dtype=torch.float32, device=self.device)
+        self._loss_slot = 0
         self._ws = {}
         self._ws_e = {}
         self._side = None        # evaluator stream
@@ -69,6 +76,23 @@ class TrainEngine:
         self._reducers = None    # data parallel: per-network bucketed all-reduce (parallel.BucketReducer)
 
     # ---- helpers
+    @property
+    def losses(self):
+        """The loss vector of the step enqueued last (a view of its ring slot)."""
+        return self._loss_ring[self._loss_slot]
+
+    def _next_losses(self, kinds=("gan", "eva")):
+        """The ring slot this update writes.  A slot holds at most one cGAN update and one evaluator update — one gen+eval
+        step: an update whose kind the current slot does not hold yet joins it (cgan_step then eva_step, or the other way
+        round, leave ONE vector with both sets of entries, as the single buffer of rounds 1-5 did); otherwise the ring
+        advances.  joint_step writes both kinds and always advances."""
+        have = getattr(self, "_slot_kinds", None)
+        if have is None or have & set(kinds):
+            self._loss_slot = (self._loss_slot + 1) % LOSS_RING
+            have = set()
+        self._slot_kinds = have | set(kinds)
+        return self._loss_ring[self._loss_slot]
+
     def _hp(self, lr_gen=None, lr_dis=None, lr_eva=None):
         hp = ops.make_hparams(self.cfg, parallel.grad_scale())
         if lr_gen is not None:
@@ -209,7 +233,8 @@ class TrainEngine:
         _, s2 = self._streams(two_streams)
         cfg_p, args = C.byref(self.ccfg), (ptr(bps), ptr(rot9), ptr(transl), ptr(joint), ptr(z))
         self._arm_reducers()
-        check(lib().dgg_cgan_d_phase2(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(self.losses),
+        L = self._next_losses(("gan",))
+        check(lib().dgg_cgan_d_phase2(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(L),
                                       stream_ptr(dev), s2), "dgg_cgan_d_phase2")
         if getattr(self, "after_d_phase", None) is not None:   # tests: the fake pass' LeakyReLU sides (kink_sides)
             self.after_d_phase(self, B)
@@ -217,10 +242,10 @@ class TrainEngine:
         self.D.adam_step(hp.lr_dis, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
         if is_train_gen:
             check(lib().dgg_cgan_g_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args,
-                                         ptr(self.losses), stream_ptr(dev)), "dgg_cgan_g_phase")
+                                         ptr(L), stream_ptr(dev)), "dgg_cgan_g_phase")
             self._reduce("G")
             self.G.adam_step(hp.lr_gen, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
-        return self.losses.clone()
+        return L
 
     # ---- N3: WGAN-GP variant of the cGAN step (cfg["is_wgan"], dexgangrasp.py:149-211, 234-270)
     def _wgan_ws(self, B):
@@ -249,16 +274,17 @@ class TrainEngine:
         st = self._state()
         cfg_p = C.byref(self.ccfg)
         args = (ptr(bps), ptr(rot9), ptr(transl), ptr(joint), ptr(z))
+        L = self._next_losses(("gan",))
         check(lib().dgg_wgan_d_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(alphas),
-                                     float(penalty_gain), ptr(self.losses), stream_ptr(dev)), "dgg_wgan_d_phase")
+                                     float(penalty_gain), ptr(L), stream_ptr(dev)), "dgg_wgan_d_phase")
         parallel.allreduce_sum_(self.D.grads)
         self.D.adam_step(hp.lr_dis, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
         if is_train_gen:
             check(lib().dgg_wgan_g_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args,
-                                         ptr(self.losses), stream_ptr(dev)), "dgg_wgan_g_phase")
+                                         ptr(L), stream_ptr(dev)), "dgg_wgan_g_phase")
             parallel.allreduce_sum_(self.G.grads)
             self.G.adam_step(hp.lr_gen, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
-        return self.losses.clone()
+        return L
 
     # ---- A11
     def eva_step(self, bps, rot9, transl, label, drop_keep=None, seed=0, lr=None, two_streams=False):
@@ -273,12 +299,13 @@ class TrainEngine:
         if two_streams:
             self._map_wgrad_streams(torch.cuda.current_stream(dev))
         self._arm_reducers()
+        L = self._next_losses(("eva",))
         check(lib().dgg_eva_phase(C.byref(self.ccfg), ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(ws),
                                   ws.numel(), B, ptr(bps), ptr(rot9), ptr(transl), ptr(label), ptr(dk), int(seed),
-                                  ptr(self.losses), stream_ptr(dev)), "dgg_eva_phase")
+                                  ptr(L), stream_ptr(dev)), "dgg_eva_phase")
         self._reduce("E")
         E.adam_step(hp.lr_eva, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
-        return self.losses.clone()
+        return L
 
     def eva_keep_masks(self, B):
         """The dropout keep masks (3, B, 512) uint8 that the last train-mode evaluator pass at batch B wrote into
@@ -444,7 +471,11 @@ class TrainEngine:
             side = main
         self._arm_reducers(force=two_streams and not graph_mode)
         self._mark("step_begin")
-        check(lib().dgg_cgan_d_phase2(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(self.losses),
+        # this step's loss vector: the next ring slot (a look-ahead real pass enqueued by the previous step has already
+        # written its BCE term there); a captured step keeps ONE slot, its address is baked into the graph
+        L = self.losses if graph_mode else self._next_losses()
+        L_next = self._loss_ring[(self._loss_slot + 1) % LOSS_RING]
+        check(lib().dgg_cgan_d_phase2(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(L),
                                       stream_ptr(dev), s2), "dgg_cgan_d_phase2")
         self._mark("d_phase_end")
         if getattr(self, "after_d_phase", None) is not None:   # tests: snapshot the fake pass' workspace (kink_sides)
@@ -464,12 +495,12 @@ class TrainEngine:
             if graph_mode:
                 check(lib().dgg_eva_phase_graph(cfg_p, ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(wse),
                                                 wse.numel(), Be, ptr(ebps), ptr(erot9), ptr(etransl), ptr(elabel),
-                                                ptr(self._seed_dev), ptr(self.losses), stream_ptr(dev)),
+                                                ptr(self._seed_dev), ptr(L), stream_ptr(dev)),
                       "dgg_eva_phase_graph")
             else:
                 check(lib().dgg_eva_phase(cfg_p, ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(wse),
                                           wse.numel(), Be, ptr(ebps), ptr(erot9), ptr(etransl), ptr(elabel), ptr(dk),
-                                          int(seed), ptr(self.losses), stream_ptr(dev)), "dgg_eva_phase")
+                                          int(seed), ptr(L), stream_ptr(dev)), "dgg_eva_phase")
             w_e = self._reduce("E", async_op=True, feeder=self._side2 if two_streams else None)
             self._mark("e_phase_end", side)
             # the evaluator's optimiser step follows on its own stream at once (it blocks nothing else there; enqueued
@@ -494,7 +525,7 @@ class TrainEngine:
         w_g = None
         if is_train_gen:
             check(lib().dgg_cgan_g_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args,
-                                         ptr(self.losses), stream_ptr(dev)), "dgg_cgan_g_phase")
+                                         ptr(L), stream_ptr(dev)), "dgg_cgan_g_phase")
             self._mark("g_phase_end")
             # a ragged next batch (last of an epoch) is simply not prefetched: the workspace is carved per batch size
             if two_streams and next_gan_inputs is not None and next_gan_inputs[0].shape[0] == B:
@@ -508,7 +539,7 @@ class TrainEngine:
                 with _side_work(polite):
                     check(lib().dgg_cgan_d_real_prefetch(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(),
                                                          nb.shape[0], ptr(nb), ptr(nr), ptr(nt), ptr(nj_),
-                                                         ptr(self.losses), s2), "dgg_cgan_d_real_prefetch")
+                                                         ptr(L_next), s2), "dgg_cgan_d_real_prefetch")
                 self._side2_busy = self._side2.record_event()
                 self._mark("prefetch_end", self._side2)
             # (G's collectives are issued AFTER the prefetch is enqueued: see below)
@@ -530,5 +561,5 @@ class TrainEngine:
                 E._step += 1
                 if is_train_gen:
                     G._step += 1
-            return self.losses
-        return self.losses.clone()
+            return L
+        return L

@@ -159,9 +159,12 @@ class DexGanGrasp(object):
                 st = torch.tensor([flat.step], dtype=torch.int64, device=self.device)
                 parallel.broadcast_(st)
                 flat.step = int(st.item())
-            for m in mod.modules():
-                if isinstance(m, torch.nn.BatchNorm1d):
-                    parallel.broadcast_(m.num_batches_tracked)
+            # (the counters are host tensors, networks._pin_bn_counters: one device vector carries them all)
+            bns = [m for m in mod.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+            cnt = torch.tensor([int(m.num_batches_tracked) for m in bns], dtype=torch.int64, device=self.device)
+            parallel.broadcast_(cnt)
+            for m, v in zip(bns, cnt.cpu()):
+                m.num_batches_tracked.fill_(int(v))
 
     def _eng(self):
         if self._engine is None:
@@ -572,10 +575,36 @@ class DexGanGrasp(object):
             print('learning rate generator = %.7f' % self.optim_dexgenerator.param_groups[0]['lr'])
 
     # ------------------------------------------------------------------ training steps
+    _Z_BLOCK = 32   # steps whose latents one torch.randn launch draws (same generator, same distribution: :770 per step)
+
     def _draw_z(self, n):
+        """The latent of one update (dexgangrasp.py:770 draws torch.randn per step).  Drawn from the same device generator
+        in blocks of _Z_BLOCK steps: one launch per block instead of one per step on the step's stream (part of the wrapper's
+        overhead over the engine calls; tests inject theirs through _z_override)."""
         if self._z_override is not None:
             return self._z_override.to(self.device, self.dtype)
-        return torch.randn((n, self.DexGANGrasp.latentD), dtype=self.DexGANGrasp.dtype, device=self.DexGANGrasp.device)
+        blk = getattr(self, "_z_block", None)
+        if blk is None or blk[0].shape[1] != n or blk[1] >= self._Z_BLOCK:
+            blk = [torch.randn((self._Z_BLOCK, n, self.DexGANGrasp.latentD), dtype=self.DexGANGrasp.dtype,
+                               device=self.DexGANGrasp.device), 0]
+            self._z_block = blk
+        z = blk[0][blk[1]]
+        blk[1] += 1
+        return z
+
+    def _gen_losses(self, out, is_train_gen):
+        """last_loss_dict_gen (:299-306 caches the generator's loss terms; :817-822 re-reports them while is_train_gen is
+        False).  The entries are views of the step's loss vector, which lives in a ring (engine.TrainEngine.losses): the
+        first call that RE-reports them takes a copy, so that they outlive the ring however long the generator pauses."""
+        if is_train_gen:
+            self.last_loss_dict_gen = {'gen_loss_fake': out[_lib.L_GEN_FAKE], 'transl_loss': out[_lib.L_TRANSL],
+                                       'rot_loss': out[_lib.L_ROT], 'conf_loss': out[_lib.L_CONF],
+                                       'total_loss_gen': out[_lib.L_TOTAL_GEN]}
+            self._gen_losses_are_views = True
+        elif getattr(self, "_gen_losses_are_views", False):
+            self.last_loss_dict_gen = {k: v.clone() for k, v in self.last_loss_dict_gen.items()}
+            self._gen_losses_are_views = False
+        return self.last_loss_dict_gen
 
     def update_dexevaluator(self, data):
         """dexgangrasp.py:739-755 as one fused phase (dgg_eva_phase) + dgg_adam_l2."""
@@ -630,10 +659,7 @@ class DexGanGrasp(object):
                      'bce_loss_fake': out[_lib.L_BCE_FAKE]}
         if is_train_gen:
             real_data["rot_matrix"] = real_data["rot_matrix"].view(n, -1)  # :810 mutates the caller's dict
-            self.last_loss_dict_gen = {'gen_loss_fake': out[_lib.L_GEN_FAKE], 'transl_loss': out[_lib.L_TRANSL],
-                                       'rot_loss': out[_lib.L_ROT], 'conf_loss': out[_lib.L_CONF],
-                                       'total_loss_gen': out[_lib.L_TOTAL_GEN]}
-        loss_dict.update(self.last_loss_dict_gen)
+        loss_dict.update(self._gen_losses(out, is_train_gen))
         return loss_dict, {'total_loss_eva': out[_lib.L_TOTAL_EVA], 'bce_loss': out[_lib.L_BCE_EVA]}
 
     def update_dexgangrasp(self, real_data, is_train_gen=True):
@@ -667,8 +693,5 @@ class DexGanGrasp(object):
                      'bce_loss_fake': out[_lib.L_BCE_FAKE]}
         if is_train_gen:
             real_data["rot_matrix"] = real_data["rot_matrix"].view(n_samples, -1)  # :810 mutates the caller's dict
-            self.last_loss_dict_gen = {'gen_loss_fake': out[_lib.L_GEN_FAKE], 'transl_loss': out[_lib.L_TRANSL],
-                                       'rot_loss': out[_lib.L_ROT], 'conf_loss': out[_lib.L_CONF],
-                                       'total_loss_gen': out[_lib.L_TOTAL_GEN]}
-        loss_dict.update(self.last_loss_dict_gen)
+        loss_dict.update(self._gen_losses(out, is_train_gen))
         return loss_dict

@@ -274,6 +274,67 @@ def test_benched_joint_step_with_prefetch_and_philox_vs_oracle(b, variant, front
     eng.close()
 
 
+def test_joint_step_at_1024_vs_unsteered_oracle():
+    """the benched step (B = 1024, joint_step, "wide" weights) against a FULLY INDEPENDENT oracle — no
+    forced_slopes, no adopted post-Adam discriminator, dropout masks injected into both.  Whether an unsteered comparison
+    can be strict is a property of the data: wherever a pre-activation lies within rounding distance of a LeakyReLU kink
+    the two evaluations may take different sides.  So a handful of data seeds is searched for one on which
+    the oracle's OWN sides (record_slopes) equal the sides the HIP path stored, at every one of the 33 LeakyReLU sites of
+    the step (G 6, D real 6, D fake 6, the G phase's pass through the updated D 6, E 9) — then nothing is steered and
+    everything is compared as in the steered tests: losses 1e-4, every gradient tensor of G, D and E strictly, Adam of the
+    engine's own gradients exactly, the parameters after the step.  Shows that the steering of the other tests is not
+    load-bearing: on data without kink crossings the independent oracle agrees by itself."""
+    from oracle import dexgan_oracle as O
+    L, ops, engine = _mods()
+    b = 1024
+    tried = []
+    for seed in range(40, 48):
+        eng, sd, sde = _engine("wide")
+        ag = O.AdamState([n for n in O.param_names(sd) if n.startswith("generator.")])
+        ad = O.AdamState([n for n in O.param_names(sd) if n.startswith("discriminator.")])
+        ae = O.AdamState(O.param_names(sde))
+        gb, eb = synth.make_batch(b, seed), synth.make_batch(b, seed + 100, with_label=True)
+        z, masks = synth.make_z(b, seed + 200), synth.make_dropout_masks(b, seed + 300)
+        store = {}
+        eng.after_d_phase = _sides_hook(store)
+        before = {k: _snap_flat(fl) for k, fl in (("G", eng.G), ("D", eng.D), ("E", eng.E))}
+        got = eng.joint_step(_dev_inputs(gb), z.to(DEV), _dev_inputs(eb, with_label=True), True, masks.to(DEV), 0)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        sl = _slopes_after(eng, store, b, b)
+        hip_sides = sl["gan"]["d"] + sl["gan"]["g"]
+        prev, preve = {k: v.clone() for k, v in sd.items()}, {k: v.clone() for k, v in sde.items()}
+        with O.record_slopes() as rec_g:     # the oracle on its own: plain F.leaky_relu, its sides only written down
+            ref, g_d, g_g, _ = O.cgan_step(sd, H.clone_batch(gb), z, ag, ad, CFG, True, return_grads=True)
+        with O.record_slopes() as rec_e:
+            refe, g_e, _ = O.eva_step(sde, H.clone_batch(eb), ae, CFG, masks, return_grads=True)
+        assert len(rec_g.masks) == len(hip_sides) == 24 and len(rec_e.masks) == len(sl["eva"]["e"]) == 9
+        diff = sum(int((torch.as_tensor(h).bool() != o).sum()) for h, o in zip(hip_sides, rec_g.masks))
+        for h, o in zip(sl["eva"]["e"], rec_e.masks):   # int8 with -1 = dropped unit: no side on the device
+            h = torch.as_tensor(h)
+            diff += int(((h > 0) != o)[h >= 0].sum()) if h.dtype != torch.bool else int((h != o).sum())
+        tried.append((seed, diff))
+        if diff:
+            eng.close()
+            continue
+        for k, n in enumerate(LOSS_NAMES):
+            np.testing.assert_allclose(got[k], float(ref[n]), rtol=1e-4, atol=1e-6, err_msg=n)
+        np.testing.assert_allclose(got[L.L_TOTAL_EVA], float(refe["total_loss_eva"]), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(got[L.L_BCE_EVA], float(refe["bce_loss"]), rtol=1e-4, atol=1e-6)
+        _check_strict(_grad_items(eng.G, g_g, "generator.", b), "G unsteered")
+        _check_strict(_grad_items(eng.D, g_d, "discriminator.", b), "D unsteered")
+        _check_strict(_grad_items(eng.E, g_e, "", b), "E unsteered")
+        for key, fl in (("G", eng.G), ("D", eng.D), ("E", eng.E)):
+            _cmp_adam_of_own_grads(fl, before[key], what=key + " unsteered")
+        _cmp_update(eng.G, sd, prev, "generator.", skip_running=True, l2_frac=0.1)
+        _cmp_update(eng.D, sd, prev, "discriminator.", skip_running=True, l2_frac=0.1)
+        _cmp_update(eng.E, sde, preve, "", skip_running=True, l2_frac=0.1)
+        eng.close()
+        print("unsteered oracle: data seed %d has no LeakyReLU side in dispute (seeds tried, sides in dispute: %s)" % (seed, tried))
+        return
+    raise AssertionError("no data seed without a kink crossing among %s" % (tried,))
+
+
 def test_evaluator_step_at_1024_vs_oracle():
     """BASELINE config 3: the evaluator update alone at B = 1024 (injected masks), two steps, through the API-path
     entry (eva_step with side streams)."""
@@ -727,6 +788,34 @@ def test_config5_sweep_at_rank_share_size():
                 # when two grasps agree in their first coordinate to within the 1e-6 the two paths differ by)
                 dist = np.abs(a[:, None, :] - c[None, :, :]).max(-1)
                 assert a.shape == c.shape and dist.min(1).max() <= 2e-5 and dist.min(0).max() <= 2e-5, (o, thr)
+    # ... and the ORACLE's per-object sequence on the same four objects: until round 5 the sweep at this
+    # size was compared with the HIP wrapper only — pinned to the reference transitively, through the n = 32 goldens.
+    # oracle.generate_grasps / evaluate_grasps / filter_grasps restate dexgangrasp.py:495-514, :367-391, :393-442 on the
+    # CPU: grasps to 2e-5 (as above), scores to 1e-4 (the north star's tolerance), and the SAME kept index set at every
+    # threshold no score lies within 1e-5 of.
+    from oracle import dexgan_oracle as O
+    sd_g, sd_e = H.gan_sd("wide"), H.eva_sd("wide")
+    for o in (0, 1, 617, n_obj - 1):
+        zo = z[o * n:(o + 1) * n].cpu()
+        og = O.generate_grasps(sd_g, rows[o], zo)
+        np.testing.assert_allclose(out["transl"][o].cpu().numpy(), og["transl"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(out["rot_matrix"][o].cpu().numpy().reshape(n, 3, 3), og["rot_matrix"].reshape(n, 3, 3),
+                                   rtol=0, atol=2e-5)
+        np.testing.assert_allclose(out["joint_conf"][o].cpu().numpy(), og["joint_conf"], rtol=0, atol=2e-5)
+        osc = O.evaluate_grasps(sd_e, rows[o], og)
+        score = out["score"][o].cpu().numpy()
+        np.testing.assert_allclose(score, osc, rtol=0, atol=1e-4)
+        for t, thr in enumerate(thresholds):
+            cnt = int(out["count"][t, o])
+            kept = set(out["order"][o, :cnt].cpu().numpy().tolist())
+            if ((np.abs(osc - thr) < 1e-5) | (np.abs(score - thr) < 1e-5)).any():
+                continue
+            assert kept == set(np.nonzero(osc > thr)[0].tolist()), (o, thr)
+            try:
+                of = O.filter_grasps(sd_e, rows[o], og, thresh=thr)
+                assert of["transl"].shape[0] == cnt, (o, thr, cnt, of["transl"].shape[0])
+            except ValueError:
+                assert cnt == 0, (o, thr, cnt)
     # the factorised passes against the tiled (dense) ones on a slice: same grasps and scores up to the summation order
     dn = m.sweep_objects(rows[:40], n, thresholds=thresholds, z=z[:40 * n], dense=True)
     for k in ("transl", "rot_matrix", "joint_conf", "score"):

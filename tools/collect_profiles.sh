@@ -4,14 +4,14 @@
 #   launches, the BPS encode and Adam.  Summaries land in gpurun_out/prof_<tag>/; tools/summarize_profiles.py turns
 #   them into the committed files under profiles/.
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 # ONLY="bps bps_valu": just those microbench passes, no bench trace
 if [ -z "$ONLY" ]; then
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 $R/bench.py --no-cpu-baseline --no-sub --repeats 3 > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python3 $R/bench.py --no-cpu-baseline --no-sub --no-other-mode --repeats 3 > $OUT/bench.log 2>&1
 fi
 # name:[X4=1:]microbench arguments   (x4_*: the loader / consumer kernel of the >= 1024-workgroup launches, forced by DGG_X4=1 set in the shell — the program
 # behind `--` stays python3 itself)

@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.environ.get("PROFILES_DST") or os.path.join(ROOT, "profiles")   # PROFILES_DST: scratch summaries of an experiment
 os.makedirs(dst, exist_ok=True)
@@ -45,6 +45,42 @@ if bench_stats:
     for line in open(os.path.join(src, "bench.log")):
         if line.startswith("{"):
             open(os.path.join(dst, "%s_bench.json" % tag), "w").write(line)
+
+# The step's dominant instantiation INSIDE the timed region + launches per step and hardware queue, from the bench trace itself
+# (VERDICT r5 item 3): profiles/<tag>_bench_in_step.json, read back by bench.py (roofline.in_step, main_stream_launches_per_step).
+bench_trace = glob.glob(os.path.join(src, "bench", "*kernel_trace.csv"))
+if bench_trace:
+    tr = []
+    for r in rows(bench_trace[0]):
+        tr.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id") or r.get("Stream_Id"),
+                   int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0)))
+    tr.sort()
+    marks = [i for i, r in enumerate(tr) if "fake_pose" in r[2]]
+    # the timed region of the default bench.py run: skip the first 15 steps (warm-up) and whatever follows the last step mark
+    lo, hi = (marks[15], marks[-1]) if len(marks) > 40 else (marks[0], marks[-1])
+    inside = tr[lo:hi]
+    nsteps = sum(1 for i in marks if lo <= i < hi)
+    big = [(e - b) / 1e3 for b, e, k, q, g in inside if "gemm_x5_kernel<false, false" in k and g >= 192 * 256]
+    nt = [(e - b) / 1e3 for b, e, k, q, g in inside if "gemm_x5_kernel<true, true" in k and g >= 96 * 256]
+    byq = {}
+    for b, e, k, q, g in inside:
+        byq[q] = byq.get(q, 0) + 1
+    order = sorted(byq.items(), key=lambda kv: -kv[1])
+    js = {"trace": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-sub --no-other-mode --repeats 3 (tools/collect_profiles.sh)",
+          "steps_in_region": nsteps,
+          "dominant_tn": {"what": "gemm_x5_kernel<false,false> (weight gradients, TN) launches of >= 192 workgroups inside the step "
+                                  "(768 x 4101..4632 x B with their riders)",
+                          "mean_us": round(sum(big) / len(big), 2), "min_us": round(min(big), 2), "max_us": round(max(big), 2),
+                          "launches": len(big)},
+          "forward_nt": {"what": "gemm_x5_kernel<true,true> (forward products, NT) launches of >= 96 workgroups inside the step "
+                                 "(side streams run theirs with half the workgroups for twice as long)",
+                         "mean_us": round(sum(nt) / len(nt), 2), "min_us": round(min(nt), 2), "max_us": round(max(nt), 2),
+                         "launches": len(nt)},
+          "launches_per_step_by_queue": {"main (cGAN chain)": round(order[0][1] / nsteps, 1),
+                                         "side streams": [round(v / nsteps, 1) for _, v in order[1:]],
+                                         "total": round(sum(v for _, v in order) / nsteps, 1)}}
+    json.dump(js, open(os.path.join(dst, "%s_bench_in_step.json" % tag), "w"), indent=1)
+    print("in_step", json.dumps(js["dominant_tn"]), json.dumps(js["launches_per_step_by_queue"]))
 
 specs = [
     ("gemm_nt", "gemm_x5_kernel<true, true", "gemm_x5", {"M": 1024, "N": 768, "K": 4120, "splits": 4},
