@@ -491,6 +491,30 @@ struct Share {
 };
 static const int kShareSlabs = 16;  // plan13 never gives one piece more
 
+// XShare (round 6): the BPS block is the same batch — same column statistics, same x_hat — in the generator's forward
+// (networks.py:88-95), in D's real and fake pass (:148-154; dexgangrasp.py:788-789) and in the G phase's pass through the
+// updated discriminator (:808).  It is normalised ONCE per step, by the real pass (the producer: off the chain, prefetched
+// one step ahead), into shared rows `xs` = [x_hat_bps | pose columns of the fake pass | pad] of D's X0 pitch; the
+// generator's operand [z | x_hat_bps] is the same memory seen `nprefix` floats earlier — its latent sits in the pad at the
+// end of the previous shared row.  A consumer's input stage is one ibn_shared_kernel launch instead of ibn_stats +
+// ibn_apply over 4096-4120 columns (and, for the fake pass, fake_pose_kernel).
+struct XShare {
+    int mode;                 // 1: producer, 2: consumer
+    float* xs;                // the shared rows (D's view: row m at xs + m * ld)
+    int ld;
+    const float *src_mean, *src_rstd, *src_varu;   // consumer: the producer's batch statistics (its NetW.imean / irstd / ivaru)
+    hipEvent_t ready;         // producer records it behind its ibn_apply; a consumer on another stream waits for it (NULL: none)
+    bool record, wait;
+    // the fake pass: pose columns from the generator's output rows
+    const float* heads;
+    int ldh;
+    float *rot9, *transl, *joint;
+};
+static bool xshare_enabled() {   // diagnostics: DGG_XSHARE=0: every pass normalises its own input (rounds 1-5)
+    static const bool v = [] { const char* e = getenv("DGG_XSHARE"); return !(e && e[0] == '0'); }();
+    return v;
+}
+
 struct Ctx {
     Share* share;
     const NetL* L;
@@ -863,7 +887,7 @@ static void make_segs(const NetL& L, NetW& W, int r, Seg* segs, int& nseg) {
 
 static int net_forward(const NetL& L, const float* params, float* bn, void* ws, size_t ws_bytes, int B, unsigned flags,
                        const ColSrcs& srcs, const float* prefix, const float* drop_keep, uint64_t seed, float* out,
-                       hipStream_t st, Share* share = nullptr) {
+                       hipStream_t st, Share* share = nullptr, const XShare* xsh = nullptr) {
     if (!params || !ws || !out || B < 1) return DGG_ERR_INVALID;
     Ctx c;
     c.share = share;
@@ -873,15 +897,41 @@ static int net_forward(const NetL& L, const float* params, float* bn, void* ws, 
     if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
     if (!bn) return DGG_ERR_INVALID;
     const bool reuse_norm = c.train && (flags & DGG_REUSE_INPUT_NORM) != 0;
-    if (c.train && !reuse_norm) DGG_TRY(ibn_stats_launch(srcs, B, 1, c.W.part, st));
+    const bool consume = xsh && xsh->mode == 2;
+    if (xsh && (!c.train || xsh->ld != L.ldx0 || !xsh->xs)) return DGG_ERR_INVALID;
+    if (consume) c.W.X0 = xsh->xs - L.nprefix;   // [prefix | x_hat_bps | pose]: the shared rows, seen nprefix floats earlier
+    if (c.train && !reuse_norm && !consume) DGG_TRY(ibn_stats_launch(srcs, B, 1, c.W.part, st));
     if (reuse_norm) {
         // x_hat, mean and rstd of this workspace are those of the previous train forward over these inputs
         DGG_TRY(ibn_refresh_launch(c.W.imean, c.W.ivaru, bn + L.irm, bn + L.irv, params + L.ibnw, params + L.ibnb,
                                    c.W.aff_scale, c.W.aff_shift, L.nprefix, L.k_in, st));
+    } else if (consume) {
+        if (xsh->wait && xsh->ready && hipStreamWaitEvent(st, xsh->ready, 0) != hipSuccess) return DGG_ERR_LAUNCH;
+        IbnShared q;
+        memset(&q, 0, sizeof(q));
+        q.n_alias = L.in_bps;
+        q.src_mean = xsh->src_mean; q.src_rstd = xsh->src_rstd; q.src_varu = xsh->src_varu;
+        q.mean = c.W.imean; q.rstd = c.W.irstd; q.varu = c.W.ivaru;
+        q.run_mean = bn + L.irm; q.run_var = bn + L.irv;
+        q.gamma = params + L.ibnw; q.beta = params + L.ibnb;
+        q.aff_scale = c.W.aff_scale; q.aff_shift = c.W.aff_shift;
+        q.nprefix = L.nprefix; q.prefix = prefix;
+        q.X0 = c.W.X0; q.ldx = L.ldx0; q.B = B;
+        q.npose = L.k_in - L.in_bps;
+        if (q.npose > 0) {
+            if (!xsh->heads) return DGG_ERR_INVALID;
+            q.nj = q.npose - 12;
+            q.heads = xsh->heads; q.ldh = xsh->ldh;
+            q.rot9 = xsh->rot9; q.transl = xsh->transl; q.joint = xsh->joint;
+        }
+        DGG_TRY(ibn_shared_launch(q, st));
     } else {
         BnFused fz{c.W.part, c.train ? 1 : 0, bn + L.irm, bn + L.irv, c.W.imean, c.W.irstd, c.W.ivaru};
+        const bool produce = xsh && xsh->mode == 1;
         DGG_TRY(ibn_apply_launch(srcs, B, B, c.W.imean, c.W.irstd, nullptr, nullptr, prefix, L.nprefix, c.W.X0, L.ldx0,
-                                 params + L.ibnw, params + L.ibnb, c.W.aff_scale, c.W.aff_shift, st, &fz));
+                                 params + L.ibnw, params + L.ibnb, c.W.aff_scale, c.W.aff_shift, st, &fz,
+                                 produce ? xsh->xs : nullptr, produce ? xsh->ld : 0, produce ? L.in_bps : 0));
+        if (produce && xsh->record && xsh->ready && hipEventRecord(xsh->ready, st) != hipSuccess) return DGG_ERR_LAUNCH;
     }
     const bool drop = (L.net == DGG_NET_EVA) && c.train;
     for (int r = 0; r < L.nrb; ++r) {
@@ -923,7 +973,8 @@ static ColSrcs sub_srcs(const ColSrcs& S, int lo, int hi) {
 // d_prefix (B x nprefix), d_in_lo/hi + d_in (B x (hi-lo)): input-gradient requests on the BN'd concat.
 static int net_backward(const NetL& L, const float* params, float* grads, void* ws, size_t ws_bytes, int B,
                         unsigned flags, const ColSrcs& srcs, const float* d_out, float* d_prefix, int d_in_lo,
-                        int d_in_hi, float* d_in, hipStream_t st, Share* share = nullptr) {
+                        int d_in_hi, float* d_in, hipStream_t st, Share* share = nullptr, float* x0_alias = nullptr) {
+    // x0_alias: the forward ran as an XShare consumer — its operand [prefix | x_hat] lies there (pitch L.ldx0), not in `ws`
     if (!params || !ws || !d_out || B < 1) return DGG_ERR_INVALID;
     const bool skip = (flags & DGG_SKIP_PARAM_GRADS) != 0;
     const bool accum = (flags & DGG_ACCUM_GRADS) != 0;
@@ -935,6 +986,7 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     if (c.sw == st) c.sw = nullptr;
     carve(L, B, ws, c.W);
     if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
+    if (x0_alias) c.W.X0 = x0_alias;
     const bool want_in = d_in && d_in_hi > d_in_lo;
     // columns of X0 whose gradient is needed: only those for which the caller wants INPUT gradients —
     // the input BatchNorm's parameter gradients come out of the wgrad epilogue
@@ -1255,6 +1307,12 @@ struct StepW {
     float* gl_part;    // gen_loss_kernel's per-workgroup partial sums (gen_loss_scratch_floats)
     unsigned* ticket;  // GenLossFin::ticket: cleared by the G phase's loss-gradient launch, drawn by gen_loss_kernel's workgroups
     int d_nrb, d_n13, d_nbn;
+    // XShare: two generations of the shared rows (the real pass of step k + 1 is prefetched into one while step k's
+    // generator backward still reads the other), B x xs_ld floats each behind 64 floats of headroom (the generator's view
+    // of row 0 starts nprefix floats in front of it); xs_ok: this configuration can share (see carve_step)
+    float* xs[2];
+    int xs_ld;
+    bool xs_ok;
     size_t bytes;
 };
 
@@ -1298,6 +1356,17 @@ static int carve_step(const dgg_cfg* cfg, int B, void* base, StepW& S) {
         int widths[3] = {cfg->in_bps, Ld.k0 - cfg->in_bps, Ld.nn}, sp[3];
         plan13(B, Ld.n13, widths, r == 0 ? 2 : 3, sp);
         S.dshare[r] = b.take<float>((size_t)sp[0] * Bz * Ld.n13);
+    }
+    // XShare needs: the generator's and the discriminator's operands on ONE row pitch, room for the latent in the pad
+    // behind a discriminator row, the fake pose in ibn_shared_kernel's one instantiation (12 hand joints: the shipped
+    // configuration), a batch whose fake pose one workgroup holds in LDS, a row per thread (B <= 1024); anything else
+    // normalises per pass as before
+    S.xs_ld = Ld.ldx0;
+    S.xs_ok = xshare_enabled() && Lg.ldx0 == Ld.ldx0 && Lg.in_bps == Ld.in_bps && Ld.ldx0 - Ld.k0 >= Lg.nprefix &&
+              Lg.nprefix <= 64 && cfg->n_hand_joints == 12 && B >= 2 && B <= 1024;
+    for (int i = 0; i < 2; ++i) {
+        float* base_ = b.take<float>(64 + Bz * Ld.ldx0);
+        S.xs[i] = base_ ? base_ + 64 : nullptr;
     }
     S.bytes = (b.off + 255) & ~(size_t)255;
     return DGG_OK;
@@ -1576,9 +1645,12 @@ struct PendingReal {
     hipEvent_t ev[7];     // fwd_done, bwd_done, 3 x share.ready, D-free, (one spare); created with the slot
     bool events_ok, dfree_set;
     Share share;
+    int xpar;             // XShare: the generation of shared rows the prefetched real pass wrote
+    int step_xpar;        // ... and the one the step in flight (D phase -> G phase) uses
+    bool step_set;        // a D phase has run on this workspace since the slot was (re)assigned
     unsigned long long stamp;
 };
-static const int kPendingSlots = 4;   // step workspaces that pipeline concurrently on one thread
+static const int kPendingSlots = 16;  // step workspaces in use on one thread (a G phase finds its D phase's state here)
 static thread_local PendingReal g_pending[kPendingSlots] = {};
 static thread_local unsigned long long g_pending_clock = 0;
 static const int kLossRealNext = 12;  // losses[] slot of a prefetched real pass' BCE term
@@ -1601,6 +1673,8 @@ static PendingReal* pending_slot(const void* ws, bool create) {
     lru->valid = false;
     lru->dfree_set = false;
     lru->step_B = 0;
+    lru->xpar = lru->step_xpar = 0;
+    lru->step_set = false;
     lru->stamp = ++g_pending_clock;
     return lru;
 }
@@ -1609,10 +1683,17 @@ static PendingReal* pending_slot(const void* ws, bool create) {
 // (dexgangrasp.py:788, :215-218, :793)
 static int real_pass(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, const StepW& S, const NetL& Ld,
                      int B, const float* bps, const float* rot9, const float* transl, const float* joint,
-                     float* loss_slot, hipStream_t sb, Share& share, hipEvent_t fwd_done, hipEvent_t bwd_done) {
+                     float* loss_slot, hipStream_t sb, Share& share, hipEvent_t fwd_done, hipEvent_t bwd_done,
+                     int xpar = -1, hipEvent_t x_ready = nullptr) {
     share.mode = 1;
+    XShare xp;
+    memset(&xp, 0, sizeof(xp));
+    if (xpar >= 0) {   // the BPS block's x_hat also goes to generation `xpar` of the shared rows (XShare producer)
+        xp.mode = 1; xp.xs = S.xs[xpar]; xp.ld = S.xs_ld; xp.ready = x_ready; xp.record = x_ready != nullptr;
+    }
     DGG_TRY(net_forward(Ld, s->d_params, s->d_bn, S.ws_dr, S.d_bytes, B, DGG_TRAIN,
-                        srcs_pose(cfg, bps, rot9, transl, joint), nullptr, nullptr, 0, S.p_real, sb, &share));
+                        srcs_pose(cfg, bps, rot9, transl, joint), nullptr, nullptr, 0, S.p_real, sb, &share,
+                        xpar >= 0 ? &xp : nullptr));
     if (fwd_done && hipEventRecord(fwd_done, sb) != hipSuccess) return DGG_ERR_LAUNCH;
     DGG_TRY(bce_launch(S.p_real, nullptr, 1.f, B, (float)hp->bce_weight, 0.5f, loss_slot, S.dl_real, sb));
     // (bwd_mode 1: the weight gradient of the BPS columns is left to the fake pass, which takes dY_real + dY_fake)
@@ -1658,8 +1739,11 @@ int dgg_cgan_d_real_prefetch(const dgg_cfg* cfg, const dgg_gan_state* s, const d
     // the pass advances D's running statistics one batch early: keep what they were, so that a pass that is not picked
     // up (another batch follows, a serial entry point, a checkpoint: dgg_cgan_drop_prefetch) leaves no trace
     DGG_TRY(copy_cols_launch(s->d_bn, S.d_nbn, S.bn_snap, S.d_nbn, 1, S.d_nbn, sb));
+    // XShare: the step in flight reads generation step_xpar of the shared rows until its generator backward ends — this
+    // pass writes the other one
+    P.xpar = P.step_xpar ^ 1;
     DGG_TRY(real_pass(cfg, s, hp, S, Ld, B, bps, rot9, transl, joint, losses + kLossRealNext, sb, P.share, P.ev[0],
-                      P.ev[1]));
+                      P.ev[1], S.xs_ok ? P.xpar : -1, S.xs_ok ? P.ev[6] : nullptr));
     P.B = B; P.bps = bps; P.rot9 = rot9; P.transl = transl; P.joint = joint;
     P.d_params = s->d_params;
     P.d_bn = s->d_bn; P.bn_snap = S.bn_snap; P.nbn = S.d_nbn;
@@ -1682,7 +1766,8 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
     NetL Ld;
     DGG_TRY(build_layout(DGG_NET_DISC, cfg, Ld));
     // a real pass prefetched for exactly these buffers? (anything else: it is dropped and redone)
-    PendingReal* Pp = pending_slot(ws, false);
+    PendingReal* Pp = pending_slot(ws, S.xs_ok);   // (XShare: the slot also carries the step's generation of shared rows)
+    if (S.xs_ok && !Pp) return DGG_ERR_LAUNCH;
     const bool pre = fork && Pp && Pp->valid && Pp->B == B && Pp->bps == bps && Pp->rot9 == rot9 &&
                      Pp->transl == transl && Pp->joint == joint && Pp->d_params == s->d_params;
     if (Pp && Pp->valid && !pre) {   // dropped: undo its running-statistics update once it has run (its gradients are overwritten)
@@ -1693,6 +1778,17 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     Share share;
     int real_slot = DGG_L_BCE_REAL;
+    // XShare: which generation of the shared rows this step uses — the one a picked-up prefetch wrote, else the one the
+    // previous step did not use — and the event behind the producer's ibn_apply
+    int xpar = -1;
+    hipEvent_t x_ready = nullptr;
+    if (S.xs_ok) {
+        xpar = pre ? Pp->xpar : (Pp->step_xpar ^ 1);
+        Pp->step_xpar = xpar;
+        Pp->step_set = true;
+        x_ready = pre ? Pp->ev[6] : (fork ? next_event() : nullptr);
+        if (!pre && fork && !x_ready) return DGG_ERR_LAUNCH;
+    }
     if (pre) {
         share = Pp->share;
         ev[1] = Pp->ev[0];
@@ -1715,17 +1811,35 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
         }
         // ---- stream B: the real-batch pass
         DGG_TRY(real_pass(cfg, s, hp, S, Ld, B, bps, rot9, transl, joint, losses + DGG_L_BCE_REAL, sb, share, ev[1],
-                          ev[2]));
+                          ev[2], xpar, x_ready));
     }
     // ---- stream A: :772-776 generator forward (train mode, activations kept for the G phase), R = ortho6d(rot_6D)
-    DGG_TRY(dgg_gen_forward(cfg, s->g_params, s->g_bn, S.ws_g, S.g_bytes, B, DGG_TRAIN, z, bps, S.heads, stream));
-    // R = ortho6d(rot_6D); fake transl / joint live inside the heads buffer with pitch nh: contiguous copies for D
-    DGG_TRY(fake_pose_launch(S.heads, nh, nj, B, S.rfake, S.f_transl, S.f_joint, st));
+    XShare xc;   // consumer side of the shared rows: the generator, then the fake pass
+    memset(&xc, 0, sizeof(xc));
+    if (xpar >= 0) {
+        NetW Wr;
+        carve(Ld, B, S.ws_dr, Wr);
+        xc.mode = 2; xc.xs = S.xs[xpar]; xc.ld = S.xs_ld;
+        xc.src_mean = Wr.imean; xc.src_rstd = Wr.irstd; xc.src_varu = Wr.ivaru;
+        xc.ready = x_ready; xc.wait = x_ready != nullptr;
+        NetL Lg;
+        DGG_TRY(build_layout(DGG_NET_GEN, cfg, Lg));
+        DGG_TRY(net_forward(Lg, s->g_params, s->g_bn, S.ws_g, S.g_bytes, B, DGG_TRAIN, srcs_gen(cfg, bps), z, nullptr, 0,
+                            S.heads, st, nullptr, &xc));
+        // (the fake pose — R = ortho6d(rot_6D), contiguous transl / joint — is written by the fake pass' ibn_shared launch)
+        xc.wait = false;
+        xc.heads = S.heads; xc.ldh = nh; xc.rot9 = S.rfake; xc.transl = S.f_transl; xc.joint = S.f_joint;
+    } else {
+        DGG_TRY(dgg_gen_forward(cfg, s->g_params, s->g_bn, S.ws_g, S.g_bytes, B, DGG_TRAIN, z, bps, S.heads, stream));
+        // R = ortho6d(rot_6D); fake transl / joint live inside the heads buffer with pitch nh: contiguous copies for D
+        DGG_TRY(fake_pose_launch(S.heads, nh, nj, B, S.rfake, S.f_transl, S.f_joint, st));
+    }
     // :789 D(fake.detach()): its BatchNorm running-statistic updates must follow those of the real pass
     if (fork && hipStreamWaitEvent(st, ev[1], 0) != hipSuccess) return DGG_ERR_LAUNCH;
     share.mode = 2;
     DGG_TRY(net_forward(Ld, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B, DGG_TRAIN,
-                        srcs_pose(cfg, bps, S.rfake, S.f_transl, S.f_joint), nullptr, nullptr, 0, S.p_fake, st, &share));
+                        srcs_pose(cfg, bps, S.rfake, S.f_transl, S.f_joint), nullptr, nullptr, 0, S.p_fake, st, &share,
+                        xpar >= 0 ? &xc : nullptr));
     // :792-793 the fake pass accumulates onto the real pass' gradients (and the loss terms meet: the BCE kernel of the fake
     // pass also forms the total — one launch less on the chain than a combine kernel of its own)
     if (fork && hipStreamWaitEvent(st, ev[2], 0) != hipSuccess) return DGG_ERR_LAUNCH;
@@ -1745,7 +1859,8 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
         share.bwd_mode = 0;
     }
     DGG_TRY(net_backward(Ld, s->d_params, s->d_grads, S.ws_df, S.d_bytes, B, DGG_TRAIN | DGG_ACCUM_GRADS,
-                         srcs_pose(cfg, bps, S.rfake, S.f_transl, S.f_joint), S.dl_fake, nullptr, 0, 0, nullptr, st, &share));
+                         srcs_pose(cfg, bps, S.rfake, S.f_transl, S.f_joint), S.dl_fake, nullptr, 0, 0, nullptr, st, &share,
+                         xpar >= 0 ? S.xs[xpar] : nullptr));
     return DGG_OK;
 }
 
@@ -1760,7 +1875,7 @@ int dgg_cgan_d_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
 // gradient and finishes its own sums (GenLossFin; S.ticket was cleared by the phase's loss-gradient launch).
 static int gen_loss_and_backward(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, StepW& S, int B,
                                  const float* bps, const float* rot9, const float* transl, const float* joint, const float* z,
-                                 float* losses, int wass, hipStream_t st) {
+                                 float* losses, int wass, hipStream_t st, int xpar = -1) {
     NetL Lg;
     DGG_TRY(build_layout(DGG_NET_GEN, cfg, Lg));
     const bool spread = gen_loss_spread(B);   // gen_loss_launch's own condition for the 64-rows-per-workgroup form (scratch and ticket are given)
@@ -1771,7 +1886,8 @@ static int gen_loss_and_backward(const dgg_cfg* cfg, const dgg_gan_state* s, con
                             wass, &fin));
     (void)z;
     return net_backward(Lg, s->g_params, s->g_grads, S.ws_g, S.g_bytes, B, DGG_TRAIN | (spread ? kHeadBiasDone : 0u),
-                        srcs_gen(cfg, bps), S.d_heads, nullptr, 0, 0, nullptr, st);
+                        srcs_gen(cfg, bps), S.d_heads, nullptr, 0, 0, nullptr, st, nullptr,
+                        xpar >= 0 ? S.xs[xpar] - Lg.nprefix : nullptr);
 }
 
 int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, void* ws, size_t ws_bytes,
@@ -1788,9 +1904,28 @@ int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
     float* g_joint = S.f_joint;
     // (no weight gradient follows this pass: DGG_SKIP_PARAM_GRADS spares the forward the operands only a wgrad reads)
     // Same inputs as the D phase's fake-batch pass, same workspace: the input normalisation is reused.
-    DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B,
-                             DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_REUSE_INPUT_NORM, bps, S.rfake, g_transl, g_joint,
-                             S.p_gen, stream));
+    int xpar = -1;
+    NetL Ld;
+    DGG_TRY(build_layout(DGG_NET_DISC, cfg, Ld));
+    if (S.xs_ok) {   // XShare: the D phase of this step left its generation of shared rows in the workspace's slot
+        PendingReal* Ps = pending_slot(ws, false);
+        if (!Ps || !Ps->step_set) {
+            set_error_text("dgg_cgan_g_phase: no D phase has run on this workspace (or its state was evicted: more than %d "
+                           "step workspaces in use on this thread)", kPendingSlots);
+            return DGG_ERR_INVALID;
+        }
+        xpar = Ps->step_xpar;
+        XShare xc;
+        memset(&xc, 0, sizeof(xc));
+        xc.mode = 2; xc.xs = S.xs[xpar]; xc.ld = S.xs_ld;
+        DGG_TRY(net_forward(Ld, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B,
+                            DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_REUSE_INPUT_NORM,
+                            srcs_pose(cfg, bps, S.rfake, g_transl, g_joint), nullptr, nullptr, 0, S.p_gen, st, nullptr, &xc));
+    } else {
+        DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B,
+                                 DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_REUSE_INPUT_NORM, bps, S.rfake, g_transl, g_joint,
+                                 S.p_gen, stream));
+    }
     // D-free mark: from here on nothing in this step writes D's parameters or running statistics
     if (PendingReal* Pp = pending_slot(ws, true)) {
         if (hipEventRecord(Pp->ev[5], st) != hipSuccess) return DGG_ERR_LAUNCH;
@@ -1802,10 +1937,10 @@ int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
     // :293-296 BCE(fake_score, 1) and its gradient; backward through D for the pose inputs only
     DGG_TRY(bce_launch(S.p_gen, nullptr, 1.f, B, (float)hp->bce_weight, 1.0f, losses + DGG_L_GEN_FAKE, S.dl_gen, st, nullptr,
                        DGG_L_BCE_REAL, S.ticket));
-    DGG_TRY(dgg_disc_backward(cfg, s->d_params, nullptr, S.ws_df, S.d_bytes, B,
-                              DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_NEED_INPUT_GRADS, bps, S.rfake, g_transl, g_joint,
-                              S.dl_gen, S.d_pose, stream));
-    return gen_loss_and_backward(cfg, s, hp, S, B, bps, rot9, transl, joint, z, losses, 0, st);
+    DGG_TRY(net_backward(Ld, s->d_params, nullptr, S.ws_df, S.d_bytes, B,
+                         DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_NEED_INPUT_GRADS, srcs_pose(cfg, bps, S.rfake, g_transl, g_joint),
+                         S.dl_gen, nullptr, cfg->in_bps, Ld.k_in, S.d_pose, st, nullptr, xpar >= 0 ? S.xs[xpar] : nullptr));
+    return gen_loss_and_backward(cfg, s, hp, S, B, bps, rot9, transl, joint, z, losses, 0, st, xpar);
 }
 
 int dgg_cgan_step(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hparams* hp, void* ws, size_t ws_bytes, int B,

@@ -156,7 +156,28 @@ int ibn_refresh_launch(const float* mean, const float* var_u, float* run_mean, f
 int ibn_apply_launch(const ColSrcs& srcs, int B, int rows_per_group, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, const float* prefix, int nprefix, float* X0, int ldx,
                      const float* aff_gamma, const float* aff_beta, float* aff_scale, float* aff_shift,
-                     hipStream_t st, const BnFused* fused = nullptr);
+                     hipStream_t st, const BnFused* fused = nullptr,
+                     float* X0b = nullptr, int ldb = 0, int nb = 0);   // the first nb BN columns stored once more (XShare)
+// What is left of a consumer's input BatchNorm when the BPS block was normalised by another pass (elementwise.hip,
+// ibn_shared_kernel): statistics / running statistics / affine vectors of the n_alias shared columns, the generator's
+// latent prefix, and (npose > 0: the discriminator's fake pass) the fake pose from `heads` with its own BatchNorm.
+struct IbnShared {
+    int n_alias;
+    const float *src_mean, *src_rstd, *src_varu;   // the producer's batch statistics of the shared columns
+    float *mean, *rstd, *varu;                     // the consumer's own arrays [k_in]
+    float *run_mean, *run_var;                     // ... its running statistics [k_in]
+    const float *gamma, *beta;                     // ... its input BatchNorm's parameters [k_in]
+    float *aff_scale, *aff_shift;                  // [nprefix + k_in]
+    int nprefix;
+    const float* prefix;                           // (B, nprefix) or NULL
+    float* X0;                                     // the consumer's operand: row m = [prefix | shared x_hat | pose], pitch ldx
+    int ldx, B;
+    int npose, nj;
+    const float* heads;                            // (B, ldh): [joint (nj) | rot6 | transl]
+    int ldh;
+    float *rot9, *transl, *joint;                  // contiguous copies (B,9) (B,3) (B,nj)
+};
+int ibn_shared_launch(const IbnShared& P, hipStream_t st);
 
 // out[m][c] = sum_s slabs[s][m][c] (+ sum_s slabs2[s][m][c], same stride / pitch) + bias[c];  columns [stat_lo, stat_hi) get partial statistics,
 // columns [act_lo, act_hi) get LeakyReLU applied before the store.

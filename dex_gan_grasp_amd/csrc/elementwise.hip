@@ -265,7 +265,9 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
                                                         const float* __restrict__ aff_gamma,
                                                         const float* __restrict__ aff_beta,
                                                         float* __restrict__ aff_scale, float* __restrict__ aff_shift,
-                                                        BnFin fin) {
+                                                        BnFin fin, float* __restrict__ X0b, int ldb, int nb) {
+    // X0b (optional): the first nb BatchNorm columns are stored once more at X0b[row * ldb + c] (XShare: the real pass of a D
+    // phase normalises the BPS block for the generator and the fake pass as well)
     __shared__ float sh[SUB][3][64];
     __shared__ float res[2][2][64];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
@@ -324,6 +326,11 @@ __global__ __launch_bounds__(256) void ibn_apply_kernel(ColSrcs S, int B, int rp
             const float shf = be - mu * sc;
             xv[k][r] = fmaf(xv[k][r], sc, shf);
             if (r < n) X0[(size_t)row * ldx + oc] = xv[k][r];
+        }
+        if (X0b && c < nb) {
+#pragma unroll
+            for (int r = 0; r < RS; ++r)
+                if (r < n) X0b[(size_t)(r0 + r) * ldb + c] = xv[k][r];
         }
     }
 }
@@ -1555,14 +1562,186 @@ int ibn_refresh_launch(const float* mean, const float* var_u, float* run_mean, f
 
 int ibn_apply_launch(const ColSrcs& srcs, int B, int rpg, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, const float* prefix, int nprefix, float* X0, int ldx, const float* aff_gamma,
-                     const float* aff_beta, float* aff_scale, float* aff_shift, hipStream_t st, const BnFused* fz) {
+                     const float* aff_beta, float* aff_scale, float* aff_shift, hipStream_t st, const BnFused* fz,
+                     float* X0b, int ldb, int nb) {
     BnFin fin;
     if (int rc = make_fin(fz, rpg, fin)) return rc;
     const int width = nprefix + srcs.total;
     dim3 grid(cdiv(width, 64), cdiv(B, RB * kIbnBlocks));
     hipLaunchKernelGGL(ibn_apply_kernel, grid, dim3(256), 0, st, srcs, B, rpg, mean, rstd, gamma, beta, prefix,
-                       nprefix, X0, ldx, aff_gamma, aff_beta, aff_scale, aff_shift, fin);
+                       nprefix, X0, ldx, aff_gamma, aff_beta, aff_scale, aff_shift, fin, X0b, ldb, nb);
     return check_launch("ibn_apply");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// XShare (round 6): the BPS block of a cGAN step — the same batch, hence the same column statistics and the same x_hat —
+// is normalised ONCE, by the discriminator's real-batch pass (ibn_apply_kernel's second destination), for the generator
+// (networks.py:88-95), the fake-batch pass and the G phase's pass through the updated discriminator (:148-154;
+// dexgangrasp.py:772-789,808).  What is left of a consumer's input BatchNorm is this one launch:
+//   workgroups 1..: for the shared columns, copy the producer's batch statistics into the consumer's own arrays (its
+//     backward and a later DGG_REUSE_INPUT_NORM forward read them there), advance the consumer's running statistics with
+//     them, write its affine vectors [1.. | gamma], [0.. | beta], and copy the generator's latent prefix into the slot in
+//     front of every shared row;
+//   workgroup 0 (the fake pass only): the generator's output row [joint | rot6 | transl] -> R = ortho6d(rot6), contiguous
+//     copies of R / transl / joint (what fake_pose_kernel writes), and the train-mode BatchNorm of these npose columns over
+//     the whole batch — two passes over rows the workgroup keeps re-deriving from `heads` (fixed order: deterministic) —
+//     into the shared rows' pose columns, with statistics, running statistics and affine vectors.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kPoseMax = 24;   // 12 + n_hand_joints of the shipped configuration (more: the caller keeps the separate launches)
+template <int NJ>   // hand joints of the fake pose (compile-time: the flat copies below divide by it and by 12 + NJ —
+                    // with run-time divisors those divisions, ~100 per thread, WERE the kernel: 28 us on one CU)
+__global__ __launch_bounds__(1024) void ibn_shared_kernel(IbnShared P) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x > 0 || P.npose == 0) {
+        const int wg = P.npose > 0 ? (int)blockIdx.x - 1 : (int)blockIdx.x;
+        const int nwg = P.npose > 0 ? (int)gridDim.x - 1 : (int)gridDim.x;
+        for (int c = wg * 1024 + tid; c < P.n_alias; c += nwg * 1024) {
+            const float m = P.src_mean[c], vu = P.src_varu[c];
+            P.mean[c] = m;
+            P.rstd[c] = P.src_rstd[c];
+            P.varu[c] = vu;
+            P.run_mean[c] = (1.f - kBnMom) * P.run_mean[c] + kBnMom * m;
+            P.run_var[c] = (1.f - kBnMom) * P.run_var[c] + kBnMom * vu;
+            P.aff_scale[P.nprefix + c] = P.gamma[c];
+            P.aff_shift[P.nprefix + c] = P.beta[c];
+        }
+        for (int i = wg * 1024 + tid; i < P.nprefix; i += nwg * 1024) {
+            P.aff_scale[i] = 1.f;
+            P.aff_shift[i] = 0.f;
+        }
+        if (P.nprefix > 0)
+            for (int i = wg * 1024 + tid; i < P.B * P.nprefix; i += nwg * 1024) {
+                const int m = i / P.nprefix, j = i - m * P.nprefix;
+                P.X0[(size_t)m * P.ldx + j] = P.prefix[i];
+            }
+        return;
+    }
+    // ---- workgroup 0: the fake pose and its BatchNorm (npose = 12 + nj <= kPoseMax columns), B <= 1024: one row per thread.
+    // A row is 21 floats at a pitch of 84 bytes: fetched row by row, every wave-load touches 64 cache lines and 16 waves
+    // queue at one CU's address unit (the first version of this kernel: 44 us; gen_loss_kernel's history says the same).  So
+    // the generator's rows come in as ONE flat, coalesced stream into LDS, every thread takes its row from there, and the
+    // outputs leave the same way: through LDS, as flat coalesced stores.
+    extern __shared__ float lds_dyn[];                 // B * max(ldh, kPoseMax) floats
+    __shared__ float red[32][kPoseMax];
+    __shared__ float tot[2][kPoseMax];
+    constexpr int np = 12 + NJ, nj = NJ, ldh = NJ + 9;   // (the launcher checks P.npose / P.nj / P.ldh against these)
+    const int B = P.B;
+    {   // all loads of a thread in flight at once (a load-then-store loop is one memory round trip per iteration: 21 of them)
+        const int nflt = B * ldh, nvec = nflt >> 2;          // <= 6144 float4 for B <= 1024, ldh <= 24
+        const float4* h4 = reinterpret_cast<const float4*>(P.heads);
+        float4 buf[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) buf[k] = h4[min(tid + k * 1024, nvec > 0 ? nvec - 1 : 0)];
+        float tail = 0.f;
+        const int ti = (nvec << 2) + tid;
+        if (tid < 4) tail = P.heads[min(ti, nflt - 1)];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (tid + k * 1024 < nvec) reinterpret_cast<float4*>(lds_dyn)[tid + k * 1024] = buf[k];
+        if (tid < 4 && ti < nflt) lds_dyn[ti] = tail;
+    }
+    __syncthreads();
+    float v[kPoseMax];
+#pragma unroll
+    for (int c = 0; c < kPoseMax; ++c) v[c] = 0.f;
+    const bool live = tid < B;
+    if (live) {   // [rot9 | transl | joint], as the discriminator's concat has it
+        const float* h = lds_dyn + tid * ldh;
+        float o6[6];   // (ortho6d() itself fetches from GLOBAL memory: the values are taken from LDS here)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o6[k] = h[nj + k];
+        Rot R;
+        ortho6d_of(o6, R);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { v[3 * r] = R.x[r]; v[3 * r + 1] = R.y[r]; v[3 * r + 2] = R.z[r]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[9 + k] = h[nj + 6 + k];
+#pragma unroll
+        for (int k = 0; k < kPoseMax - 12; ++k) v[12 + k] = k < nj ? h[k] : 0.f;
+    }
+    __syncthreads();   // every row has been read: the LDS image turns into [row][np] pose values at a pitch of np + 1
+    // floats (odd: a thread writing its row element by element, 24 floats apart from its neighbour's, would put 64 lanes on
+    // 4 banks — a 16-way conflict on each of 48 writes and 16 waves was most of this kernel's first 23-44 us)
+    constexpr int pp = np + 1;
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < np; ++c) lds_dyn[tid * pp + c] = v[c];
+    }
+    // column totals over all rows, from the LDS image: 32 threads per column take every 32nd row, one thread per column adds
+    // their 32 partial sums in order — a fixed order, and no cross-lane traffic
+    auto col_total = [&](int slot, bool centred) {
+        __syncthreads();   // the image is complete
+        if (tid < 32 * np) {
+            const int c = tid % np, j = tid / np;
+            const float mu = centred ? tot[0][c] : 0.f;
+            float t = 0.f;
+            for (int m = j; m < B; m += 32) {
+                const float d = lds_dyn[m * pp + c] - mu;
+                t += centred ? d * d : d;
+            }
+            red[j][c] = t;
+        }
+        __syncthreads();
+        if (tid < np) {
+            float t = 0.f;
+            for (int j = 0; j < 32; ++j) t += red[j][tid];
+            tot[slot][tid] = slot == 0 ? t / (float)B : t;   // slot 0: the column MEAN, slot 1: M2
+        }
+        __syncthreads();
+    };
+    col_total(0, false);
+    // contiguous copies for the backward / the G phase: R (B,9), transl (B,3), joint (B,nj) — flat, coalesced
+    for (int i = tid; i < B * 9; i += 1024) P.rot9[i] = lds_dyn[(i / 9) * pp + i % 9];
+    for (int i = tid; i < B * 3; i += 1024) P.transl[i] = lds_dyn[(i / 3) * pp + 9 + i % 3];
+    for (int i = tid; i < B * nj; i += 1024) P.joint[i] = lds_dyn[(i / nj) * pp + 12 + i % nj];
+    const float fB = (float)B;
+    col_total(1, true);   // (its barriers also order the copies above before the image is overwritten)
+    if (tid < np) red[0][tid] = 1.0f / sqrtf(tot[1][tid] / fB + kBnEps);   // rstd per column, once
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < np; ++c) {
+            const float rstd = red[0][c];
+            lds_dyn[tid * pp + c] = fmaf(v[c], rstd, 0.f - tot[0][c] * rstd);
+        }
+    }
+    __syncthreads();
+    {   // the pose columns of the shared rows: np contiguous floats per row
+        float* const base = P.X0 + P.nprefix + P.n_alias;
+        for (int i = tid; i < B * np; i += 1024) {
+            const int m = i / np, c = i - m * np;
+            base[(size_t)m * P.ldx + c] = lds_dyn[m * pp + c];
+        }
+    }
+    if (tid < np) {
+        const int c = P.n_alias + tid;
+        const float m2 = tot[1][tid], mu = tot[0][tid];
+        const float var_u = m2 / (fB - 1.f);
+        P.mean[c] = mu;
+        P.rstd[c] = red[0][tid];
+        P.varu[c] = var_u;
+        P.run_mean[c] = (1.f - kBnMom) * P.run_mean[c] + kBnMom * mu;
+        P.run_var[c] = (1.f - kBnMom) * P.run_var[c] + kBnMom * var_u;
+        P.aff_scale[P.nprefix + c] = P.gamma[c];
+        P.aff_shift[P.nprefix + c] = P.beta[c];
+    }
+}
+
+int ibn_shared_launch(const IbnShared& P, hipStream_t st) {
+    if (P.npose > kPoseMax || P.npose < 0) return DGG_ERR_INVALID;
+    // (one instantiation: 12 hand joints, the shipped configuration — carve_step's xs_ok asks for it)
+    if (P.npose > 0 && (P.nj != 12 || P.npose != 24 || P.ldh != 21 || P.B < 2 || P.B > 1024)) return DGG_ERR_INVALID;
+    const int work = P.n_alias > P.B * P.nprefix ? P.n_alias : P.B * P.nprefix;
+    int nwg = cdiv(work, 1024);
+    if (nwg < 1) nwg = 1;
+    if (nwg > 16) nwg = 16;
+    const size_t lds = P.npose > 0 ? (size_t)P.B * (P.npose + 1) * sizeof(float) : 0;   // <= 100 KB (pitch np + 1 >= ldh)
+    static const bool big_lds = [] {   // (more than the 64 KB a launch gets without asking)
+        return hipFuncSetAttribute((const void*)ibn_shared_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+    }();
+    (void)big_lds;
+    hipLaunchKernelGGL(ibn_shared_kernel<12>, dim3(nwg + (P.npose > 0 ? 1 : 0)), dim3(1024), lds, st, P);
+    return check_launch("ibn_shared");
 }
 
 int reduce_bias_launch(const float* slabs, int nslab, long long slab_stride, int ld_slab, const float* bias,

@@ -55,7 +55,7 @@ if bench_trace:
         tr.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id") or r.get("Stream_Id"),
                    int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0)))
     tr.sort()
-    marks = [i for i, r in enumerate(tr) if "fake_pose" in r[2]]
+    marks = [i for i, r in enumerate(tr) if "gen_loss_kernel" in r[2]]
     # the timed region of the default bench.py run: skip the first 15 steps (warm-up) and whatever follows the last step mark
     lo, hi = (marks[15], marks[-1]) if len(marks) > 40 else (marks[0], marks[-1])
     inside = tr[lo:hi]

@@ -14,9 +14,9 @@ rows.sort()
 def short(n):
     n = n.replace("dgg::", "").replace("void ", "")
     return n.split("(")[0][:46]
-# one step period = the window between two consecutive fake_pose launches (once per step, right after the D phase's
+# one step period = the window between two consecutive gen_loss_kernel launches (once per step, in the G phase:
 # generator forward): phase-shifted by that forward, but a full period of every stream
-marks = [i for i, r in enumerate(rows) if "fake_pose" in r[2] or "ortho6d_fwd" in r[2]]
+marks = [i for i, r in enumerate(rows) if "gen_loss_kernel" in r[2]]
 lo, hi = marks[-back - 1], marks[-back]
 step = rows[lo:hi]
 t0 = step[0][0]
