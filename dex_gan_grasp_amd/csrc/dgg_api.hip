@@ -488,6 +488,16 @@ struct Share {
     int bwd_mode;
     const float* dY13_other[3];
     const float* cs13_other[3];
+    // Two-stream form of the backward (round 6; the D phase WITHOUT a look-ahead real pass — the drop-in order): the fake
+    // pass' backward does not wait for the whole real backward, it trails it.  The real pass records bwd_ev[r] behind block
+    // r's element-wise backward stages (its dY13 / column sums of block r are complete, its BatchNorm / bias gradients of
+    // block r written, and — same stream, in order — the weight-gradient launch of block r + 1 enqueued before them done);
+    // the fake pass waits for bwd_ev[nrb - 1] before its first backward kernel (its loss kernel reads the real pass' term)
+    // and for bwd_ev[r - 1] before the weight-gradient launch of block r (r = 0: the real pass' end), which accumulates
+    // onto what the real pass' launch wrote.  NULL events: the fake pass waited for the whole real pass (or shares a stream).
+    hipEvent_t bwd_ev[3];
+    hipEvent_t bwd_end;   // the real pass' end (its last weight-gradient launch and its input-BatchNorm finalize)
+    bool bwd_fine;
 };
 static const int kShareSlabs = 16;  // plan13 never gives one piece more
 
@@ -510,6 +520,10 @@ struct XShare {
     int ldh;
     float *rot9, *transl, *joint;
 };
+static bool fine_bwd() {   // diagnostics: DGG_FINE_BWD=0: the fake pass' backward waits for the whole real pass (rounds 1-5)
+    static const bool v = [] { const char* e = getenv("DGG_FINE_BWD"); return !(e && e[0] == '0'); }();
+    return v;
+}
 static bool xshare_enabled() {   // diagnostics: DGG_XSHARE=0: every pass normalises its own input (rounds 1-5)
     static const bool v = [] { const char* e = getenv("DGG_XSHARE"); return !(e && e[0] == '0'); }();
     return v;
@@ -749,6 +763,15 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     //    input BatchNorm, so dX0 is never needed for parameter gradients.
     //    The weight-gradient GEMMs have no consumer before the optimiser step: with a side stream configured
     //    (dgg_set_wgrad_stream) they run there, concurrently with the dgrad chain of the following blocks.
+    if (share_ok && sh->bwd_fine) {
+        // (see Share::bwd_ev) real pass: block r's element-wise stages are enqueued; fake pass: what its weight-gradient
+        // launch of block r accumulates onto must have been written
+        if (share_r && sh->bwd_ev[r] && hipEventRecord(sh->bwd_ev[r], c.st) != hipSuccess) return DGG_ERR_LAUNCH;
+        if (share_f) {
+            hipEvent_t e = r > 0 ? sh->bwd_ev[r - 1] : sh->bwd_end;
+            if (e && hipStreamWaitEvent(c.st, e, 0) != hipSuccess) return DGG_ERR_LAUNCH;
+        }
+    }
     hipStream_t sw = c.st;
     if (!skip_param && c.sw) {
         hipEvent_t e = next_event();
@@ -1809,6 +1832,15 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
             share.slabs[r] = S.dshare[r];
             if (fork && !(share.ready[r] = next_event())) return DGG_ERR_LAUNCH;
         }
+        // two streams, no look-ahead pass (the drop-in order): the real pass is the LONGER of the two chains that run side by
+        // side (its forward and backward against the generator's and the fake pass' forward), so the fake pass' backward
+        // trails it block by block instead of waiting for its end (Share::bwd_ev)
+        if (fork && share_wgrad() && fine_bwd()) {
+            share.bwd_fine = true;
+            share.bwd_end = ev[2];
+            for (int r = 0; r < S.d_nrb; ++r)
+                if (!(share.bwd_ev[r] = next_event())) return DGG_ERR_LAUNCH;
+        }
         // ---- stream B: the real-batch pass
         DGG_TRY(real_pass(cfg, s, hp, S, Ld, B, bps, rot9, transl, joint, losses + DGG_L_BCE_REAL, sb, share, ev[1],
                           ev[2], xpar, x_ready));
@@ -1842,7 +1874,9 @@ int dgg_cgan_d_phase2(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpar
                         xpar >= 0 ? &xc : nullptr));
     // :792-793 the fake pass accumulates onto the real pass' gradients (and the loss terms meet: the BCE kernel of the fake
     // pass also forms the total — one launch less on the chain than a combine kernel of its own)
-    if (fork && hipStreamWaitEvent(st, ev[2], 0) != hipSuccess) return DGG_ERR_LAUNCH;
+    // (fine-grained form: behind the real pass' first block-backward stages — its loss term is written by then — and its
+    //  weight-gradient launches are waited for one by one in rb_backward)
+    if (fork && hipStreamWaitEvent(st, share.bwd_fine ? share.bwd_ev[S.d_nrb - 1] : ev[2], 0) != hipSuccess) return DGG_ERR_LAUNCH;
     DGG_TRY(bce_launch(S.p_fake, nullptr, 0.f, B, (float)hp->bce_weight, 0.5f, losses + DGG_L_BCE_FAKE, S.dl_fake, st, losses,
                        real_slot));
     // the real pass (bwd_mode 1) kept dY13 / cs13 of every block in its workspace: the BPS columns' weight gradient is

@@ -234,17 +234,22 @@ class TrainEngine:
         cfg_p, args = C.byref(self.ccfg), (ptr(bps), ptr(rot9), ptr(transl), ptr(joint), ptr(z))
         self._arm_reducers()
         L = self._next_losses(("gan",))
+        self._mark("step_begin")
         check(lib().dgg_cgan_d_phase2(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args, ptr(L),
                                       stream_ptr(dev), s2), "dgg_cgan_d_phase2")
+        self._mark("d_phase_end")
         if getattr(self, "after_d_phase", None) is not None:   # tests: the fake pass' LeakyReLU sides (kink_sides)
             self.after_d_phase(self, B)
         self._reduce("D")
         self.D.adam_step(hp.lr_dis, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
+        self._mark("adam_d_end")
         if is_train_gen:
             check(lib().dgg_cgan_g_phase(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(), B, *args,
                                          ptr(L), stream_ptr(dev)), "dgg_cgan_g_phase")
+            self._mark("g_phase_end")
             self._reduce("G")
             self.G.adam_step(hp.lr_gen, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.grad_scale)
+            self._mark("adam_g_end")
         return L
 
     # ---- N3: WGAN-GP variant of the cGAN step (cfg["is_wgan"], dexgangrasp.py:149-211, 234-270)
