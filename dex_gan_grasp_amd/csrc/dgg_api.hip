@@ -682,9 +682,10 @@ static int rb_tail(Ctx& c, int r, int drop_mode, const float* keep_in, uint64_t 
 // Single-score head (D / E) folded into the last ResBlock's backward: d_score (B), the head's weights and the
 // destinations of its parameter gradients.
 struct HeadBwd {
-    const float* d_score;
-    const float* w;
-    float *gw, *gb;
+    const float* d_score;   // (B) — or, n > 1 (the generator's pose heads, round 6): d_out (B, n)
+    const float* w;         // (n, nn)
+    float *gw, *gb;         // n == 1 only: the head's parameter gradients come out of the block's partial sums
+    int n = 1;
 };
 // Multi-column heads (the generator's 21-24 pose heads): dWh = d_out^T y_last rides in the last ResBlock's
 // weight-gradient launch as one more problem (4 tiles beside ~230) instead of a split-K GEMM + reduce of its own.
@@ -708,7 +709,7 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
     float* da2 = c.W.da2[r];
     float* cs13 = c.W.cs13[r];
     // 1. through the output LeakyReLU / dropout; split into the bn2 branch (dpre) and the fc3 branch (da3)
-    const int nq1 = (hb && !skip_param) ? 5 : 3;
+    const int nq1 = (hb && hb->n == 1 && !skip_param) ? 5 : 3;
     // shared BPS weight gradient of the discriminator's two passes (Share::bwd_mode)
     const Share* sh = c.share;
     const bool share_ok = sh && sh->bwd_mode && !skip_param && L.nprefix == 0 && sh->ncols > 0 && sh->ncols < L.k0;
@@ -722,7 +723,7 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
                                had_dropout ? A.keep : nullptr, A.a13 + L.hid, L.n13, A.a2, L.nn, A.mean2, A.rstd2, B, B,
                                L.nn, c.W.dpre, dY13 + L.hid, L.n13, c.W.part, c.st, hb ? hb->d_score : nullptr,
                                hb ? hb->w : nullptr, nq1, dy_slabs ? c.dy_nslab : 0, c.dy_stride,
-                               share_f ? &so3 : nullptr));
+                               share_f ? &so3 : nullptr, hb ? hb->n : 1));
     c.dy_nslab = 0;
     // fc1.bias / fc2.bias feed a train-mode BatchNorm: their gradient is EXACTLY zero (the batch-mean subtraction
     // removes any per-column constant; the reference stores fp32 rounding noise there) — cleared by this launch
@@ -894,6 +895,16 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
 // ------------------------------------------------------------------------------------------------
 // Whole-network forward / backward
 // ------------------------------------------------------------------------------------------------
+// The affine vectors the GEMMs fold into the [prefix | x_hat] operand are [1.. | gamma], [0.. | beta].  A network without
+// prefix columns (D, E) needs no copies: its GEMMs read the input BatchNorm's gamma / beta in the parameter buffer itself (so
+// a second forward with updated parameters — the G phase's pass through D — has nothing to rewrite).
+static void aff_direct(const NetL& L, const float* params, NetW& W) {
+    if (L.nprefix == 0 && L.k_in > 0) {
+        W.aff_scale = const_cast<float*>(params + L.ibnw);
+        W.aff_shift = const_cast<float*>(params + L.ibnb);
+    }
+}
+
 static void make_segs(const NetL& L, NetW& W, int r, Seg* segs, int& nseg) {
     memset(segs, 0, 2 * sizeof(Seg));
     if (r == 0) {
@@ -921,13 +932,16 @@ static int net_forward(const NetL& L, const float* params, float* bn, void* ws, 
     if (!bn) return DGG_ERR_INVALID;
     const bool reuse_norm = c.train && (flags & DGG_REUSE_INPUT_NORM) != 0;
     const bool consume = xsh && xsh->mode == 2;
+    aff_direct(L, params, c.W);
     if (xsh && (!c.train || xsh->ld != L.ldx0 || !xsh->xs)) return DGG_ERR_INVALID;
     if (consume) c.W.X0 = xsh->xs - L.nprefix;   // [prefix | x_hat_bps | pose]: the shared rows, seen nprefix floats earlier
     if (c.train && !reuse_norm && !consume) DGG_TRY(ibn_stats_launch(srcs, B, 1, c.W.part, st));
     if (reuse_norm) {
         // x_hat, mean and rstd of this workspace are those of the previous train forward over these inputs
-        DGG_TRY(ibn_refresh_launch(c.W.imean, c.W.ivaru, bn + L.irm, bn + L.irv, params + L.ibnw, params + L.ibnb,
-                                   c.W.aff_scale, c.W.aff_shift, L.nprefix, L.k_in, st));
+        if (!((flags & kRefreshElsewhere) && L.nprefix == 0))
+            DGG_TRY(ibn_refresh_launch(c.W.imean, c.W.ivaru, bn + L.irm, bn + L.irv, params + L.ibnw, params + L.ibnb,
+                                       L.nprefix ? c.W.aff_scale : nullptr, L.nprefix ? c.W.aff_shift : nullptr, L.nprefix,
+                                       L.k_in, st));
     } else if (consume) {
         if (xsh->wait && xsh->ready && hipStreamWaitEvent(st, xsh->ready, 0) != hipSuccess) return DGG_ERR_LAUNCH;
         IbnShared q;
@@ -937,7 +951,7 @@ static int net_forward(const NetL& L, const float* params, float* bn, void* ws, 
         q.mean = c.W.imean; q.rstd = c.W.irstd; q.varu = c.W.ivaru;
         q.run_mean = bn + L.irm; q.run_var = bn + L.irv;
         q.gamma = params + L.ibnw; q.beta = params + L.ibnb;
-        q.aff_scale = c.W.aff_scale; q.aff_shift = c.W.aff_shift;
+        q.aff_scale = L.nprefix ? c.W.aff_scale : nullptr; q.aff_shift = L.nprefix ? c.W.aff_shift : nullptr;
         q.nprefix = L.nprefix; q.prefix = prefix;
         q.X0 = c.W.X0; q.ldx = L.ldx0; q.B = B;
         q.npose = L.k_in - L.in_bps;
@@ -952,7 +966,8 @@ static int net_forward(const NetL& L, const float* params, float* bn, void* ws, 
         BnFused fz{c.W.part, c.train ? 1 : 0, bn + L.irm, bn + L.irv, c.W.imean, c.W.irstd, c.W.ivaru};
         const bool produce = xsh && xsh->mode == 1;
         DGG_TRY(ibn_apply_launch(srcs, B, B, c.W.imean, c.W.irstd, nullptr, nullptr, prefix, L.nprefix, c.W.X0, L.ldx0,
-                                 params + L.ibnw, params + L.ibnb, c.W.aff_scale, c.W.aff_shift, st, &fz,
+                                 params + L.ibnw, params + L.ibnb, L.nprefix ? c.W.aff_scale : nullptr,
+                                 L.nprefix ? c.W.aff_shift : nullptr, st, &fz,
                                  produce ? xsh->xs : nullptr, produce ? xsh->ld : 0, produce ? L.in_bps : 0));
         if (produce && xsh->record && xsh->ready && hipEventRecord(xsh->ready, st) != hipSuccess) return DGG_ERR_LAUNCH;
     }
@@ -1010,6 +1025,7 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     carve(L, B, ws, c.W);
     if (c.W.bytes > ws_bytes) return DGG_ERR_WORKSPACE;
     if (x0_alias) c.W.X0 = x0_alias;
+    aff_direct(L, params, c.W);
     const bool want_in = d_in && d_in_hi > d_in_lo;
     // columns of X0 whose gradient is needed: only those for which the caller wants INPUT gradients —
     // the input BatchNorm's parameter gradients come out of the wgrad epilogue
@@ -1038,10 +1054,12 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     // most 3 of 4; Share splits the X0 segment only for the discriminator, whose head folds)
     const bool heads_ride = !fold_head && !skip;
     HeadsRide hride{d_out, L.nh, skip ? nullptr : grads + L.wh};
-    if (!fold_head)
-        DGG_TRY(heads_bwd_launch(c.W.rb[L.nrb - 1].y, L.nn, d_out, L.nh, B, L.nn, params + L.wh, L.nh, dy, L.nn,
-                                 skip ? nullptr : grads + L.wh, skip ? nullptr : grads + L.bh, accum ? 1 : 0,
-                                 skip ? 1 : (heads_ride ? ((flags & kHeadBiasDone) ? 3 : 2) : 0), c.W.part, st));
+    // several heads (the generator): dy = d_out Wh is formed inside the last block's first backward stage as well (round 6:
+    // a K = 21 GEMM launch of its own until then); the weight gradient rides in that block's weight-gradient launch, the bias
+    // gradient was formed with d_out (gen_loss_kernel) or takes one small launch
+    HeadBwd hbm{d_out, params + L.wh, nullptr, nullptr, L.nh};
+    if (!fold_head && !skip && !(flags & kHeadBiasDone))
+        DGG_TRY(heads_bias_grad_launch(d_out, L.nh, B, L.nh, grads + L.bh, accum ? 1 : 0, st));
     for (int r = L.nrb - 1; r >= 0; --r) {
         Seg segs[2];
         int nseg;
@@ -1062,7 +1080,7 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
             }
         }
         DGG_TRY(rb_backward(c, r, segs, nseg, dy, drop, accum, skip, ibn_tiles,
-                            (fold_head && r == L.nrb - 1) ? &hb : nullptr,
+                            r == L.nrb - 1 ? (fold_head ? &hb : &hbm) : nullptr,
                             (heads_ride && r == L.nrb - 1) ? &hride : nullptr));
         // block r's parameter gradients (and, for the last block, the heads') are complete on the stream that ran its
         // weight-gradient GEMMs: a data-parallel caller starts that bucket's all-reduce behind this event
@@ -1953,13 +1971,23 @@ int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
         memset(&xc, 0, sizeof(xc));
         xc.mode = 2; xc.xs = S.xs[xpar]; xc.ld = S.xs_ld;
         DGG_TRY(net_forward(Ld, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B,
-                            DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_REUSE_INPUT_NORM,
+                            DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_REUSE_INPUT_NORM | kRefreshElsewhere,
                             srcs_pose(cfg, bps, S.rfake, g_transl, g_joint), nullptr, nullptr, 0, S.p_gen, st, nullptr, &xc));
     } else {
         DGG_TRY(dgg_disc_forward(cfg, s->d_params, s->d_bn, S.ws_df, S.d_bytes, B,
                                  DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_REUSE_INPUT_NORM, bps, S.rfake, g_transl, g_joint,
                                  S.p_gen, stream));
     }
+    // :293-296 BCE(fake_score, 1) and its gradient; backward through D for the pose inputs only.  (XShare: the third advance
+    // of D's running statistics — same batch statistics as the fake pass — rides in this launch: RunUpd.)
+    RunUpd ru = {nullptr, nullptr, nullptr, nullptr, 0};
+    if (xpar >= 0) {
+        NetW Wf;
+        carve(Ld, B, S.ws_df, Wf);
+        ru.mean = Wf.imean; ru.var_u = Wf.ivaru; ru.run_mean = s->d_bn + Ld.irm; ru.run_var = s->d_bn + Ld.irv; ru.n = Ld.k_in;
+    }
+    DGG_TRY(bce_launch(S.p_gen, nullptr, 1.f, B, (float)hp->bce_weight, 1.0f, losses + DGG_L_GEN_FAKE, S.dl_gen, st, nullptr,
+                       DGG_L_BCE_REAL, S.ticket, nullptr, xpar >= 0 ? &ru : nullptr));
     // D-free mark: from here on nothing in this step writes D's parameters or running statistics
     if (PendingReal* Pp = pending_slot(ws, true)) {
         if (hipEventRecord(Pp->ev[5], st) != hipSuccess) return DGG_ERR_LAUNCH;
@@ -1968,9 +1996,6 @@ int dgg_cgan_g_phase(const dgg_cfg* cfg, const dgg_gan_state* s, const dgg_hpara
     } else {
         return DGG_ERR_LAUNCH;
     }
-    // :293-296 BCE(fake_score, 1) and its gradient; backward through D for the pose inputs only
-    DGG_TRY(bce_launch(S.p_gen, nullptr, 1.f, B, (float)hp->bce_weight, 1.0f, losses + DGG_L_GEN_FAKE, S.dl_gen, st, nullptr,
-                       DGG_L_BCE_REAL, S.ticket));
     DGG_TRY(net_backward(Ld, s->d_params, nullptr, S.ws_df, S.d_bytes, B,
                          DGG_TRAIN | DGG_SKIP_PARAM_GRADS | DGG_NEED_INPUT_GRADS, srcs_pose(cfg, bps, S.rfake, g_transl, g_joint),
                          S.dl_gen, nullptr, cfg->in_bps, Ld.k_in, S.d_pose, st, nullptr, xpar >= 0 ? S.xs[xpar] : nullptr));
@@ -2249,6 +2274,7 @@ static int gradient_penalty(const dgg_cfg* cfg, const dgg_gan_state* s, const St
     // (2) tangent forward of v next to the stored activations of that forward
     NetW W;
     carve(L, B, Q.ws_di, W);
+    aff_direct(L, P, W);
     DGG_TRY(bn_jvp_launch(W.X0 + ib, L.ldx0, Q.v, np, nullptr, W.irstd + ib, P + L.ibnw + ib, nullptr, 0, nullptr, 0, B, np,
                           Q.tu0, np, Q.xhd0, np, 1, st));
     for (int r = 0; r < 2; ++r) {

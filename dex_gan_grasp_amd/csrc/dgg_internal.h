@@ -207,12 +207,6 @@ int res_out_launch(const float* s, int lds, const float* a2, int lda2, int B, in
 // heads: out[m][j] = sum_k y[m][k] Wh[j][k] + bh[j]; sigmoid optionally.
 int heads_fwd_launch(const float* y, int ldy, int B, int K, const float* wh, const float* bh, int nh, int sigmoid,
                      float* out, int ldo, float* scratch, hipStream_t st);
-// heads backward: dy = dout * Wh (written), partial dWh/dbh -> finalize into grads.
-// skip_param: 0 all gradients, 1 input gradient only, 2 input gradient + bias gradient (the caller forms dWh itself)
-int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B, int K, const float* wh, int nh,
-                     float* dy, int lddy, float* gwh, float* gbh, int accumulate, int skip_param, float* scratch,
-                     hipStream_t st);
-
 // ResBlock backward element-wise stages ----------------------------------------------------
 // Stage 1 (head mode: dy = hd_dout (x) hd_w formed on the fly, nq == 5 adds the head's parameter-gradient sums):
 //          dpre = dy * [keep/(1-p)] * lrelu'(y);  da3 = dpre * lrelu'(s) -> dY13[:, c3off + c];
@@ -222,7 +216,9 @@ int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const
                        int rows_per_group, int N, float* dpre, float* da3, int ldda3, float* part,
                        hipStream_t st, const float* hd_dout = nullptr, const float* hd_w = nullptr, int nq = 3,
                        int nslab = 0, long long slab_stride = 0,  // nslab > 1: dy = split-K slabs, summed in order
-                       const SumOut* sum = nullptr);
+                       const SumOut* sum = nullptr,
+                       int hd_n = 1);   // heads of the head mode: 1 = d_score (x) w; > 1: dy = d_out (B, hd_n) w (hd_n, N), nq == 3
+int heads_bias_grad_launch(const float* dout, int ldd, int B, int nh, float* gbh, int accumulate, hipStream_t st);
 // Stage 2/4 (BN backward apply): dx = gamma*rstd*(dz - sum_dz/B - xhat*sum_dzx/B) (train) or
 //          gamma*rstd*dz (eval);  partial sums of dx (-> bias gradient of the preceding Linear).
 // `fin` (one group only): the column sums come straight from the producer's row-block partials fin->part
@@ -266,10 +262,16 @@ int ibn_bwd_apply_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col
                          const float* fin_part = nullptr, int nslab = 0, long long slab_stride = 0);
 
 // losses -------------------------------------------------------------------------------------
+// a rider of bce_launch: run_mean / run_var (n columns) advance once more with the stored batch statistics mean / var_u
+struct RunUpd {
+    const float *mean, *var_u;
+    float *run_mean, *run_var;
+    int n;
+};
 int bce_launch(const float* p, const float* labels, float target_const, int B, float weight, float loss_scale,
                float* loss_out, float* d_logit, hipStream_t st, float* combine = nullptr, int real_slot = DGG_L_BCE_REAL,
                unsigned* clear_ticket = nullptr /* set to 0 by the launch (GenLossFin::ticket) */,
-               float* loss_copy = nullptr /* the loss value once more */);
+               float* loss_copy = nullptr /* the loss value once more */, const RunUpd* ru = nullptr);
 int ortho6d_fwd_launch(const float* o6, int ld, int B, float* rot9, hipStream_t st);
 int fake_pose_launch(const float* heads, int ld, int nj, int B, float* rot9, float* transl, float* joint, hipStream_t st);
 int ortho6d_bwd_launch(const float* o6, int ld, int B, const float* d_rot9, float* d_o6, int ldd, hipStream_t st);
@@ -284,6 +286,8 @@ struct GenLossFin {
     int accumulate = 0;
 };
 constexpr unsigned kHeadBiasDone = 0x10000u;   // net_backward flag, internal: heads' bias gradient already in `grads`
+constexpr unsigned kRefreshElsewhere = 0x20000u;   // net_forward flag, internal (with DGG_REUSE_INPUT_NORM): the caller advances
+                                                   // the running statistics itself (a rider of its loss launch: RunUpd)
 constexpr unsigned kPublicFlags = DGG_TRAIN | DGG_ACCUM_GRADS | DGG_SKIP_PARAM_GRADS | DGG_NEED_INPUT_GRADS | DGG_SEED_ON_DEVICE |
                                   DGG_REUSE_INPUT_NORM;   // what an extern "C" entry accepts: internal bits are masked off there
 int gen_loss_scratch_floats(const dgg_cfg* cfg, int B);

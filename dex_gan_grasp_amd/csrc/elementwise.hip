@@ -21,6 +21,7 @@ namespace dgg {
 constexpr int RB = kRowBlock;
 constexpr int SUB = 4;          // waves per workgroup, each takes RB/SUB rows of the row block
 constexpr int RS = RB / SUB;    // rows per wave
+constexpr int kNhMax = 32;      // heads of a network at most
 
 // These kernels are latency-bound (a workgroup touches 32 rows x 64 columns): every wave loads ALL its RS rows before
 // it uses any — a `for (r < n)` loop with a data-dependent trip count compiles to one load, one s_waitcnt vmcnt(0) per
@@ -609,9 +610,13 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
                                                           int ldda3, float* __restrict__ part,
                                                           const float* __restrict__ hd_dout,
                                                           const float* __restrict__ hd_w, int nq, int nslab,
-                                                          long long slab_stride, SumOut SO) {
+                                                          long long slab_stride, SumOut SO, int hd_n) {
     // nslab > 1: `dy` is a stack of split-K slabs of the next block's dgrad GEMM, summed here in slab (= k) order
+    // hd_n > 1 (round 6: the generator's pose heads, networks.py:98-100): dy[row][c] = sum_j d_out[row][j] * w[j][c] is formed
+    // here — hd_n fused multiply-adds per element, the workgroup's 32 rows of d_out staged through LDS — instead of by a
+    // K = 21 GEMM launch of its own in front of this one (rounds 1-5)
     __shared__ float sh[SUB][5][64];
+    __shared__ float sh_d[RB][kNhMax];
     const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 64 + lane;
     const bool cok = c0 < N;
@@ -621,15 +626,27 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
     const int n = min(RS, max(0, rpg - r0));
     const float mu = mean[g * N + c], rs = rstd[g * N + c];
     const float inv_keep = 1.0f / (1.0f - kDropP);
-    const float wv = hd_dout ? hd_w[c] : 0.f;
+    const bool multi = hd_dout && hd_n > 1;
+    const float wv = (hd_dout && !multi) ? hd_w[c] : 0.f;
+    float wm[kNhMax];
+    if (multi) {   // (workgroup-uniform: every thread reaches the barrier)
+#pragma unroll
+        for (int j = 0; j < kNhMax; ++j) wm[j] = j < hd_n ? hd_w[(size_t)j * N + c] : 0.f;
+        const int rows = min(RB, max(0, rpg - rb * RB));
+        for (int i = threadIdx.x; i < rows * hd_n; i += 256) {
+            const int rr = i / hd_n, j = i - rr * hd_n;
+            sh_d[rr][j] = hd_dout[(size_t)(g * rpg + rb * RB + rr) * hd_n + j];
+        }
+        __syncthreads();
+    }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
     if (n > 0) {
         float yv_[RS], dv_[RS], av_[RS], sv_[RS], ov_[RS];
         unsigned kp_[RS];   // (a register each: bytes packed into one register made every row's loads wait for the previous row's)
         // (one load per value, optional operands under ONE uniform branch around their loop: `p ? load_a : load_b` per
         //  element merges two registers at a join, and the compiler waits for both loads there — once per row)
-        const float* dbase = hd_dout ? hd_dout : dy + c;
-        const size_t dstr = hd_dout ? (size_t)1 : (size_t)lddy;
+        const float* dbase = multi ? y + c : hd_dout ? hd_dout : dy + c;   // (multi: a valid address; the value is replaced below)
+        const size_t dstr = multi ? (size_t)ldy : hd_dout ? (size_t)1 : (size_t)lddy;
 #pragma unroll
         for (int r = 0; r < RS; ++r) {
             const size_t row = (size_t)(g * rpg + r0 + row_clamp(r, n));
@@ -684,7 +701,12 @@ __global__ __launch_bounds__(256) void res_out_bwd_kernel(const float* __restric
                 const size_t row = (size_t)(g * rpg + r0 + r);
                 const float yv = yv_[r];
                 float d;
-                if (hd_dout) {
+                if (multi) {
+                    d = 0.f;
+#pragma unroll
+                    for (int j = 0; j < kNhMax; ++j)
+                        if (j < hd_n) d = fmaf(sh_d[sub * RS + r][j], wm[j], d);
+                } else if (hd_dout) {
                     const float ds = dv_[r];
                     d = ds * wv;
                     s3 = fmaf(ds, yv, s3);
@@ -1060,7 +1082,6 @@ __global__ __launch_bounds__(256) void ibn_bwd_apply_kernel(ColSrcs S, const flo
 }
 
 // ---------------------------------------------------------------- losses
-constexpr int kNhMax = 32;   // heads of a network at most
 __device__ __forceinline__ float block_sum_1024(float v, float* sh) {
     // deterministic: wave shuffle tree, then thread 0 adds the wave sums in order
 #pragma unroll
@@ -1081,10 +1102,17 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ p, 
                                                    float target_const, int B, float weight, float loss_scale,
                                                    float* __restrict__ loss_out, float* __restrict__ d_logit,
                                                    float* __restrict__ combine, int real_slot,
-                                                   unsigned* __restrict__ clear_ticket, float* __restrict__ loss_copy) {
+                                                   unsigned* __restrict__ clear_ticket, float* __restrict__ loss_copy,
+                                                   RunUpd ru) {
     __shared__ float sh[16];
     float acc = 0.f;
     if (clear_ticket && threadIdx.x == 0) clear_ticket[0] = 0u;   // see gen_loss_kernel (GenLossFin)
+    // rider (round 6): the running statistics of an input BatchNorm advance once more with stored batch statistics — what
+    // ibn_refresh_kernel did as a launch of its own at the head of the G phase's pass through the updated discriminator
+    for (int c = threadIdx.x; c < ru.n; c += blockDim.x) {
+        ru.run_mean[c] = (1.f - kBnMom) * ru.run_mean[c] + kBnMom * ru.mean[c];
+        ru.run_var[c] = (1.f - kBnMom) * ru.run_var[c] + kBnMom * ru.var_u[c];
+    }
     for (int i = threadIdx.x; i < B; i += blockDim.x) {
         const float x = p[i];
         const float t = labels ? labels[i] : target_const;
@@ -1542,15 +1570,19 @@ __global__ __launch_bounds__(256) void ibn_refresh_kernel(const float* __restric
     const int oc = blockIdx.x * 256 + threadIdx.x;
     if (oc >= nprefix + total) return;
     if (oc < nprefix) {
-        aff_scale[oc] = 1.f;
-        aff_shift[oc] = 0.f;
+        if (aff_scale) {
+            aff_scale[oc] = 1.f;
+            aff_shift[oc] = 0.f;
+        }
         return;
     }
     const int c = oc - nprefix;
     run_mean[c] = (1.f - kBnMom) * run_mean[c] + kBnMom * mean[c];
     run_var[c] = (1.f - kBnMom) * run_var[c] + kBnMom * var_u[c];
-    aff_scale[oc] = gamma[c];
-    aff_shift[oc] = beta[c];
+    if (aff_scale) {   // (NULL: the GEMMs read gamma / beta themselves — a network without prefix columns)
+        aff_scale[oc] = gamma[c];
+        aff_shift[oc] = beta[c];
+    }
 }
 
 int ibn_refresh_launch(const float* mean, const float* var_u, float* run_mean, float* run_var, const float* gamma,
@@ -1602,10 +1634,12 @@ __global__ __launch_bounds__(1024) void ibn_shared_kernel(IbnShared P) {
             P.varu[c] = vu;
             P.run_mean[c] = (1.f - kBnMom) * P.run_mean[c] + kBnMom * m;
             P.run_var[c] = (1.f - kBnMom) * P.run_var[c] + kBnMom * vu;
-            P.aff_scale[P.nprefix + c] = P.gamma[c];
-            P.aff_shift[P.nprefix + c] = P.beta[c];
+            if (P.aff_scale) {
+                P.aff_scale[P.nprefix + c] = P.gamma[c];
+                P.aff_shift[P.nprefix + c] = P.beta[c];
+            }
         }
-        for (int i = wg * 1024 + tid; i < P.nprefix; i += nwg * 1024) {
+        for (int i = wg * 1024 + tid; i < (P.aff_scale ? P.nprefix : 0); i += nwg * 1024) {
             P.aff_scale[i] = 1.f;
             P.aff_shift[i] = 0.f;
         }
@@ -1722,8 +1756,10 @@ __global__ __launch_bounds__(1024) void ibn_shared_kernel(IbnShared P) {
         P.varu[c] = var_u;
         P.run_mean[c] = (1.f - kBnMom) * P.run_mean[c] + kBnMom * mu;
         P.run_var[c] = (1.f - kBnMom) * P.run_var[c] + kBnMom * var_u;
-        P.aff_scale[P.nprefix + c] = P.gamma[c];
-        P.aff_shift[P.nprefix + c] = P.beta[c];
+        if (P.aff_scale) {
+            P.aff_scale[P.nprefix + c] = P.gamma[c];
+            P.aff_shift[P.nprefix + c] = P.beta[c];
+        }
     }
 }
 
@@ -1969,49 +2005,26 @@ int heads_fwd_launch(const float* y, int ldy, int B, int K, const float* wh, con
                               nullptr, st);
 }
 
-// Multi-output heads only (generator).  scratch: >= 8 * nh * K floats of split-K slabs
-int heads_bwd_launch(const float* y, int ldy, const float* dout, int ldd, int B, int K, const float* wh, int nh,
-                     float* dy, int lddy, float* gwh, float* gbh, int accumulate, int skip_param, float* scratch,
-                     hipStream_t st) {
+// the heads' bias gradient alone: column sums of d_out (B, nh) (+)= gbh
+int heads_bias_grad_launch(const float* dout, int ldd, int B, int nh, float* gbh, int accumulate, hipStream_t st) {
     if (nh > kNhMax) return DGG_ERR_UNSUPPORTED;
-    if (nh > 1) {
-        GemmBatch g;
-        // dy = dout Wh  (B x K, reduction over the nh heads)
-        one_problem(g, dout, ldd, wh, K, dy, lddy, B, K, nh, 0, 0);
-        int rc = gemm_launch(GEMM_NN, g, st);
-        if (rc || skip_param == 1) return rc;
-        // dbh (+)= column sums of dout
-        if (skip_param == 3) return rc;   // ... and the bias gradient was formed where d_out was (gen_loss_kernel)
-        if (skip_param == 2) {  // the weight gradient dWh rides in the last ResBlock's weight-gradient launch (net_backward)
-            hipLaunchKernelGGL(narrow_colsum_kernel, dim3(1), dim3(1024), 0, st, dout, ldd, B, nh, gbh, accumulate);
-            return check_launch("narrow_colsum");
-        }
-        // dWh (+)= dout^T y  (nh x K, reduction over the batch: split-K slabs + reduce)
-        one_problem(g, dout, ldd, y, ldy, scratch, K, nh, K, B, 8, (long long)nh * K);
-        rc = gemm_launch(GEMM_TN, g, st);
-        if (rc) return rc;
-        rc = reduce_bias_launch(scratch, g.p[0].splits, (long long)nh * K, K, nullptr, gwh, K, nh, nh, 1, K, 0, 0, 0, 0,
-                                nullptr, st, accumulate);
-        if (rc) return rc;
-        hipLaunchKernelGGL(narrow_colsum_kernel, dim3(1), dim3(1024), 0, st, dout, ldd, B, nh, gbh, accumulate);
-        return check_launch("narrow_colsum");
-    }
-    // nh == 1: folded into the last ResBlock's backward (res_out_bwd head mode), see net_backward
-    return DGG_ERR_INVALID;
+    hipLaunchKernelGGL(narrow_colsum_kernel, dim3(1), dim3(1024), 0, st, dout, ldd, B, nh, gbh, accumulate);
+    return check_launch("narrow_colsum");
 }
 
 int res_out_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const uint8_t* keep, const float* s,
                        int lds, const float* a2, int lda2, const float* mean, const float* rstd, int B, int rpg, int N,
                        float* dpre, float* da3, int ldda3, float* part, hipStream_t st, const float* hd_dout,
-                       const float* hd_w, int nq, int nslab, long long slab_stride, const SumOut* sum) {
+                       const float* hd_w, int nq, int nslab, long long slab_stride, const SumOut* sum, int hd_n) {
     if (!dy && !hd_dout) return DGG_ERR_INVALID;
+    if (hd_dout && (hd_n < 1 || hd_n > kNhMax || (hd_n > 1 && nq != 3))) return DGG_ERR_INVALID;
     SumOut so = {nullptr, nullptr, 0};
     if (sum && sum->other) so = *sum;
     if (hd_dout) nslab = 0;
     const int groups = B / rpg;
     dim3 grid(cdiv(N, 64), groups * nrb_of(rpg));
     hipLaunchKernelGGL(res_out_bwd_kernel, grid, dim3(256), 0, st, dy, lddy, y, ldy, keep, s, lds, a2, lda2, mean,
-                       rstd, rpg, nrb_of(rpg), N, dpre, da3, ldda3, part, hd_dout, hd_w, nq, nslab, slab_stride, so);
+                       rstd, rpg, nrb_of(rpg), N, dpre, da3, ldda3, part, hd_dout, hd_w, nq, nslab, slab_stride, so, hd_n);
     return check_launch("res_out_bwd");
 }
 
@@ -2069,9 +2082,11 @@ int ibn_bwd_apply_launch(const ColSrcs& srcs, const float* dX0, int ldx, int col
 
 int bce_launch(const float* p, const float* labels, float target_const, int B, float weight, float loss_scale,
                float* loss_out, float* d_logit, hipStream_t st, float* combine, int real_slot, unsigned* clear_ticket,
-               float* loss_copy) {
+               float* loss_copy, const RunUpd* ru) {
+    RunUpd r = {nullptr, nullptr, nullptr, nullptr, 0};
+    if (ru) r = *ru;
     hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, st, p, labels, target_const, B, weight, loss_scale,
-                       loss_out, d_logit, combine, real_slot, clear_ticket, loss_copy);
+                       loss_out, d_logit, combine, real_slot, clear_ticket, loss_copy, r);
     return check_launch("bce");
 }
 
