@@ -524,6 +524,10 @@ static bool fine_bwd() {   // diagnostics: DGG_FINE_BWD=0: the fake pass' backwa
     static const bool v = [] { const char* e = getenv("DGG_FINE_BWD"); return !(e && e[0] == '0'); }();
     return v;
 }
+static bool defer_wgrad_enabled() {   // diagnostics: DGG_DEFER_WGRAD=0: one weight-gradient launch per ResBlock (rounds 1-5)
+    static const bool v = [] { const char* e = getenv("DGG_DEFER_WGRAD"); return !(e && e[0] == '0'); }();
+    return v;
+}
 static bool xshare_enabled() {   // diagnostics: DGG_XSHARE=0: every pass normalises its own input (rounds 1-5)
     static const bool v = [] { const char* e = getenv("DGG_XSHARE"); return !(e && e[0] == '0'); }();
     return v;
@@ -544,6 +548,14 @@ struct Ctx {
     // the next rb_backward's first stage instead of the `dy` it is given)
     int dy_nslab = 0;
     long long dy_stride = 0;
+    // Deferred weight gradients (round 6): nothing reads a block's weight gradient before the optimiser step, and every
+    // operand of its launch lives in per-block buffers — so the blocks' launches are collected here and go out as ONE
+    // grouped launch when the pass' last block is through (net_backward): one prologue / ramp / tail for 440-670
+    // workgroups instead of two or three launches of 200-230.  Not with gradient-ready events (data parallel: the
+    // buckets' all-reduces start per block), a weight-gradient side stream, or the fine-grained real / fake order
+    // (Share::bwd_fine: per-block waits assume per-block launches).
+    bool defer_wgrad = false;
+    GemmBatch dw;
 };
 
 static int rb_tail(Ctx& c, int r, int drop_mode, const float* keep_in, uint64_t seed, uint64_t seed_off);
@@ -768,7 +780,7 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
         // (see Share::bwd_ev) real pass: block r's element-wise stages are enqueued; fake pass: what its weight-gradient
         // launch of block r accumulates onto must have been written
         if (share_r && sh->bwd_ev[r] && hipEventRecord(sh->bwd_ev[r], c.st) != hipSuccess) return DGG_ERR_LAUNCH;
-        if (share_f) {
+        if (share_f && !c.defer_wgrad) {   // (deferred: one wait for the real pass' end in front of the grouped launch)
             hipEvent_t e = r > 0 ? sh->bwd_ev[r - 1] : sh->bwd_end;
             if (e && hipStreamWaitEvent(c.st, e, 0) != hipSuccess) return DGG_ERR_LAUNCH;
         }
@@ -853,7 +865,13 @@ static int rb_backward(Ctx& c, int r, const Seg* segs, int nseg, const float* dy
             gemm_tile_shape(GEMM_TN, g.p[big].M, g.p[big].N, bm, bn, g.p[big].K);
             ibn_tiles[r] = (L.n13 + bm - 1) / bm;
             if (ibn_tiles[r] > 12 || (!has_x0 && L.net != kNetResBlock)) return DGG_ERR_INVALID;
-            DGG_TRY(gemm_launch(GEMM_TN, g, sw));
+            if (c.defer_wgrad && c.dw.nprob + np <= kMaxProb) {
+                for (int i = 0; i < np; ++i) c.dw.p[c.dw.nprob++] = g.p[i];
+            } else {
+                if (c.defer_wgrad && share_f && sh->bwd_fine && sh->bwd_end && hipStreamWaitEvent(c.st, sh->bwd_end, 0) != hipSuccess)
+                    return DGG_ERR_LAUNCH;   // (no room in the deferred launch: this one goes out now, behind the real pass' end)
+                DGG_TRY(gemm_launch(GEMM_TN, g, sw));
+            }
         }
     }
     // 6. dgrad: dX_seg[:, lo:hi] (+)= dY13 W13[:, wcol+lo : wcol+hi]
@@ -1057,6 +1075,10 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     // several heads (the generator): dy = d_out Wh is formed inside the last block's first backward stage as well (round 6:
     // a K = 21 GEMM launch of its own until then); the weight gradient rides in that block's weight-gradient launch, the bias
     // gradient was formed with d_out (gen_loss_kernel) or takes one small launch
+    memset(&c.dw, 0, sizeof(c.dw));
+    // (fine-grained real / fake order: the REAL pass keeps its per-block launches — the fake pass' element-wise stages of
+    //  block r accumulate onto what they wrote —, the fake pass defers and waits for the real pass' end once)
+    c.defer_wgrad = !skip && !ge && !c.sw && !(share && share->bwd_fine && share->bwd_mode == 1) && defer_wgrad_enabled();
     HeadBwd hbm{d_out, params + L.wh, nullptr, nullptr, L.nh};
     if (!fold_head && !skip && !(flags & kHeadBiasDone))
         DGG_TRY(heads_bias_grad_launch(d_out, L.nh, B, L.nh, grads + L.bh, accum ? 1 : 0, st));
@@ -1086,6 +1108,12 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
         // weight-gradient GEMMs: a data-parallel caller starts that bucket's all-reduce behind this event
         if (ge && r >= 1 && hipEventRecord(ge->ev[r], c.sw ? c.sw : st) != hipSuccess) return DGG_ERR_LAUNCH;
         float* t = dy; dy = other; other = t;
+    }
+    if (c.dw.nprob > 0) {   // the pass' weight gradients, one grouped launch
+        if (share && share->bwd_fine && share->bwd_mode == 2 && share->bwd_end &&
+            hipStreamWaitEvent(st, share->bwd_end, 0) != hipSuccess)
+            return DGG_ERR_LAUNCH;
+        DGG_TRY(gemm_launch(GEMM_TN, c.dw, st));
     }
     // input BatchNorm backward: parameter gradients = sum over ResBlocks and row tiles of the epilogue partials
     if (c.sw) {  // join: everything queued after this call on `st` sees the complete gradient buffer

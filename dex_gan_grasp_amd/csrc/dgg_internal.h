@@ -66,7 +66,7 @@ struct GemmProb {
     const float* c_bias;
     float* c_part;
 };
-constexpr int kMaxProb = 6;   // problems of one grouped launch
+constexpr int kMaxProb = 8;   // problems of one grouped launch (the weight gradients of all ResBlocks of a pass: <= 8)
 struct GemmBatch {
     GemmProb p[kMaxProb];
     int nprob;

@@ -474,7 +474,12 @@ class TrainEngine:
                 self._map_wgrad_streams(side)
         else:
             side = main
-        self._arm_reducers(force=two_streams and not graph_mode)
+        # the two-launch optimiser step (opt-in since round 6, DGG_SPLIT_ADAM=1): the early bucket beside the rest of the
+        # backward.  It paid while the chain was longer (rounds 2-5: -10..-20 us per step); with the chain of round 6 its two
+        # cross-stream waits cost more than the overlap gives (1.350 / 1.344 against 1.339 / 1.335 ms, one box, alternating)
+        split = (two_streams and not graph_mode and os.environ.get("DGG_SPLIT_ADAM", "0") == "1"
+                 and not parallel.is_distributed())
+        self._arm_reducers(force=split)
         self._mark("step_begin")
         # this step's loss vector: the next ring slot (a look-ahead real pass enqueued by the previous step has already
         # written its BCE term there); a captured step keeps ONE slot, its address is baked into the graph
@@ -517,8 +522,6 @@ class TrainEngine:
             self._mark("adam_e_end", side)
         # (data parallel: one optimiser launch per network — the stream that would run the early half is the one feeding
         # the collectives, and every extra cross-stream wait costs ~12 us there: 2.05 vs 1.88 ms with a one-rank group)
-        split = (two_streams and not graph_mode and os.environ.get("DGG_SPLIT_ADAM", "1") != "0"
-                 and not parallel.is_distributed())
         if split:    # (_side2 is idle here: the real pass it prefetched for this step ended long ago)
             self._adam_split("D", hp.lr_dis, hp, w_d, self._side2)
         else:
