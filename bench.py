@@ -651,10 +651,13 @@ def main():
         prof = in_step_profile()
         if prof and prof.get("dominant_tn"):
             d = prof["dominant_tn"]
+            pb = d.get("per_block_mean_us", d["mean_us"])   # a grouped launch holds 2-3 ResBlocks' products (round 6)
             res["roofline"]["in_step"] = {
                 "mean_us": d["mean_us"], "min_us": d["min_us"], "max_us": d["max_us"], "launches": d["launches"],
-                "achieved": round(2.0 * 768 * 4120 * B / (d["mean_us"] * 1e-6) / 1e12, 2) if B == 1024 else None,
-                "frac": round(2.0 * 768 * 4120 * B / (d["mean_us"] * 1e-6) / 1e12 / tn["peak"], 4) if B == 1024 else None,
+                "launches_per_step": d.get("launches_per_step"), "mean_workgroups": d.get("mean_workgroups"),
+                "per_block_mean_us": pb,
+                "achieved": round(2.0 * 768 * 4120 * B / (pb * 1e-6) / 1e12, 2) if B == 1024 else None,
+                "frac": round(2.0 * 768 * 4120 * B / (pb * 1e-6) / 1e12 / tn["peak"], 4) if B == 1024 else None,
                 "what": d["what"], "source": prof["source"]}
             res["main_stream_launches_per_step"] = prof.get("launches_per_step_by_queue")
         lp = large_product_flops(B)

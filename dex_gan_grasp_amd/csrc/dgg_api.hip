@@ -552,8 +552,8 @@ struct Ctx {
     // operand of its launch lives in per-block buffers — so the blocks' launches are collected here and go out as ONE
     // grouped launch when the pass' last block is through (net_backward): one prologue / ramp / tail for 440-670
     // workgroups instead of two or three launches of 200-230.  Not with gradient-ready events (data parallel: the
-    // buckets' all-reduces start per block), a weight-gradient side stream, or the fine-grained real / fake order
-    // (Share::bwd_fine: per-block waits assume per-block launches).
+    // buckets' all-reduces start per block) or a weight-gradient side stream.  (Share::bwd_fine: the fake pass' grouped
+    // launch waits for the real pass' end, once, instead of per block.)
     bool defer_wgrad = false;
     GemmBatch dw;
 };
@@ -1076,9 +1076,10 @@ static int net_backward(const NetL& L, const float* params, float* grads, void* 
     // a K = 21 GEMM launch of its own until then); the weight gradient rides in that block's weight-gradient launch, the bias
     // gradient was formed with d_out (gen_loss_kernel) or takes one small launch
     memset(&c.dw, 0, sizeof(c.dw));
-    // (fine-grained real / fake order: the REAL pass keeps its per-block launches — the fake pass' element-wise stages of
-    //  block r accumulate onto what they wrote —, the fake pass defers and waits for the real pass' end once)
-    c.defer_wgrad = !skip && !ge && !c.sw && !(share && share->bwd_fine && share->bwd_mode == 1) && defer_wgrad_enabled();
+    // (fine-grained real / fake order, Share::bwd_fine: both passes defer — the per-block events cover the real pass'
+    //  element-wise stages, which is what the fake pass' element-wise stages accumulate onto; the fake pass' grouped launch
+    //  accumulates onto the real pass' grouped launch and waits for the real pass' END, once, in front of it)
+    c.defer_wgrad = !skip && !ge && !c.sw && defer_wgrad_enabled();
     HeadBwd hbm{d_out, params + L.wh, nullptr, nullptr, L.nh};
     if (!fold_head && !skip && !(flags & kHeadBiasDone))
         DGG_TRY(heads_bias_grad_launch(d_out, L.nh, B, L.nh, grads + L.bh, accum ? 1 : 0, st));

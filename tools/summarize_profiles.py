@@ -60,7 +60,12 @@ if bench_trace:
     lo, hi = (marks[15], marks[-1]) if len(marks) > 40 else (marks[0], marks[-1])
     inside = tr[lo:hi]
     nsteps = sum(1 for i in marks if lo <= i < hi)
-    big = [(e - b) / 1e3 for b, e, k, q, g in inside if "gemm_x5_kernel<false, false" in k and g >= 192 * 256]
+    # (round 6: a backward pass' weight gradients go out as ONE grouped launch of 440-670 workgroups — two or three ResBlocks'
+    #  768 x 41xx..46xx x B products with their riders; per_block_us = duration / ResBlocks in the launch, the figure
+    #  comparable with the single-block launches of rounds 1-5 and with roofline.ms_per_launch)
+    tn = [((e - b) / 1e3, g // 256) for b, e, k, q, g in inside if "gemm_x5_kernel<false, false" in k and g >= 192 * 256]
+    big = [d for d, w in tn]
+    per_block = [d / max(1, round(w / 215.0)) for d, w in tn]
     nt = [(e - b) / 1e3 for b, e, k, q, g in inside if "gemm_x5_kernel<true, true" in k and g >= 96 * 256]
     byq = {}
     for b, e, k, q, g in inside:
@@ -68,10 +73,12 @@ if bench_trace:
     order = sorted(byq.items(), key=lambda kv: -kv[1])
     js = {"trace": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-sub --no-other-mode --repeats 3 (tools/collect_profiles.sh)",
           "steps_in_region": nsteps,
-          "dominant_tn": {"what": "gemm_x5_kernel<false,false> (weight gradients, TN) launches of >= 192 workgroups inside the step "
-                                  "(768 x 4101..4632 x B with their riders)",
+          "dominant_tn": {"what": "gemm_x5_kernel<false,false> (weight gradients, TN) launches of >= 192 workgroups inside the step: one "
+                                  "grouped launch per backward pass (2-3 ResBlocks: 768 x 4101..4632 x B each, with their riders)",
                           "mean_us": round(sum(big) / len(big), 2), "min_us": round(min(big), 2), "max_us": round(max(big), 2),
-                          "launches": len(big)},
+                          "launches": len(big), "launches_per_step": round(len(big) / nsteps, 2),
+                          "mean_workgroups": round(sum(w for d, w in tn) / len(tn), 1),
+                          "per_block_mean_us": round(sum(per_block) / len(per_block), 2)},
           "forward_nt": {"what": "gemm_x5_kernel<true,true> (forward products, NT) launches of >= 96 workgroups inside the step "
                                  "(side streams run theirs with half the workgroups for twice as long)",
                          "mean_us": round(sum(nt) / len(nt), 2), "min_us": round(min(nt), 2), "max_us": round(max(nt), 2),
