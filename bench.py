@@ -378,6 +378,19 @@ def sub_results(cfg, dev, eng):
     z = synth.make_z(b, 3).to(dev)
     dt = wall(lambda: eng.cgan_step(*g_in, z, True, two_streams=True), 30)
     out["cgan_step_b1024"] = {"ms_per_step": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1)}
+    # the two engine steps ALTERNATING (cGAN, evaluator, cGAN, ...): what the wrapper's gen+eval pair below does minus the
+    # wrapper — value_serial sums the two homogeneous loops above, which is S8(d)'s formula but flatters a caller that
+    # alternates (different weights and workspaces every other step); api_path / this = the wrapper's own overhead
+    e1024 = (f(eb["bps_object"]), f(eb["rot_matrix"]).reshape(b, 9), f(eb["transl"]), f(eb["label"]))
+    kk = [0]
+
+    def pair():
+        kk[0] += 1
+        eng.cgan_step(*g_in, z, True, two_streams=True)
+        eng.eva_step(*e1024, None, 7000 + kk[0], two_streams=True)
+    dt = wall(pair, 30)
+    out["engine_pair_b1024"] = {"ms_per_step": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1),
+                                "workload": "engine.cgan_step + engine.eva_step alternating, batch 1024 (no wrapper)"}
     # N3: the WGAN-GP variant of the same update (is_wgan: Wasserstein losses + gradient penalty through D's double backward)
     al = torch.rand((b, 3), generator=torch.Generator().manual_seed(5)).to(dev)
     dt = wall(lambda: eng.wgan_step(*g_in, z, al, True), 20)
@@ -395,12 +408,24 @@ def sub_results(cfg, dev, eng):
     gd = {"bps_object": g_in[0], "rot_matrix": g_in[1].view(b, 3, 3), "transl": g_in[2], "joint_conf": g_in[3]}
     ed = {"bps_object": e_in[0], "rot_matrix": e_in[1].view(b, 3, 3), "transl": e_in[2], "label": e_in[3]}
 
+    # (a) the reference's own order (train.py:231-285): within an epoch ALL generator batches (update_dexgangrasp), then ALL
+    #     evaluator batches (update_dexevaluator) — two homogeneous loops; ms per gen+eval pair = t_gen + t_eva
+    dt_g = wall(lambda: m.update_dexgangrasp(dict(gd)), 30)
+    dt_e = wall(lambda: m.update_dexevaluator(dict(ed)), 30)
+    dt = dt_g + dt_e
+    out["api_path_b1024"] = {"ms_per_step": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1),
+                             "ms_update_dexgangrasp": round(dt_g * 1e3, 4), "ms_update_dexevaluator": round(dt_e * 1e3, 4),
+                             "workload": "DexGanGrasp.update_dexgangrasp over a loop of batches, then update_dexevaluator over a "
+                                         "loop of batches (the wrapper in train.py's order, :231-285), batch 1024"}
+
+    # (b) a caller that alternates the two updates batch by batch (rounds 1-5 timed this as the drop-in path): the two
+    #     networks' weights, Adam state and workspaces (~0.5 GB) evict each other from the Infinity Cache every other step
     def api():
         m.update_dexgangrasp(dict(gd))
         m.update_dexevaluator(dict(ed))
     dt = wall(api, 30)
-    out["api_path_b1024"] = {"ms_per_step": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1),
-                             "workload": "DexGanGrasp.update_dexgangrasp + update_dexevaluator (wrapper), batch 1024"}
+    out["api_path_alternating_b1024"] = {"ms_per_step": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1),
+                                         "workload": "update_dexgangrasp + update_dexevaluator alternating per batch (wrapper), batch 1024"}
     # config 4 front end (one rank's share of the global batch 4096 = 512 / GPU): synthetic clouds -> BPS encode ->
     # batch dict -> gen+eval step; the encode is reported as its own stage (it is not part of the reference's step)
     from dex_gan_grasp_amd.data.synthetic_data_set import SyntheticGraspBatches
@@ -700,7 +725,14 @@ def main():
                                              "t_cgan_ms": sr["cgan_step_b1024"]["ms_per_step"],
                                              "t_eval_ms": sr["config3_eva_step_b1024"]["ms_per_step"]}
             res["config"]["value_dropin"] = {"grasps_per_s": res["value_dropin"],
-                                             "what": "unchanged train.py order through the drop-in wrapper (sub_results.api_path_b1024)"}
+                                             "what": "unchanged train.py order through the drop-in wrapper: a loop of generator "
+                                                     "batches, then a loop of evaluator batches (sub_results.api_path_b1024)",
+                                             "over_value_serial": round(res["value_dropin"] / res["value_serial"], 4) if B == 1024 else None,
+                                             "alternating_per_batch": {
+                                                 "wrapper_ms": sr["api_path_alternating_b1024"]["ms_per_step"],
+                                                 "engine_ms": sr["engine_pair_b1024"]["ms_per_step"],
+                                                 "note": "a caller that alternates the two updates batch by batch: the networks evict "
+                                                         "each other from the Infinity Cache; wrapper / engine = the wrapper's own overhead"}}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, B)
         print(json.dumps(res))
