@@ -358,7 +358,7 @@ void gemm_set_algo(int a) { g_algo = a == 0 ? 0 : a == 3 ? 3 : 1; }
 // items per workgroup) so that the chain's kernels always find free CUs.
 static thread_local int g_side_work = 0;
 int gemm_side_work() { return g_side_work; }
-void gemm_set_side_work(int on) { g_side_work = on ? 1 : 0; }
+void gemm_set_side_work(int on) { g_side_work = on < 0 ? 0 : on; }   // 0: off; n >= 1: n + 1 work items per workgroup where the default divides by 2
 
 // Plans the tiles of a grouped launch and decides which kernel(s) run it — without launching anything:
 //   returns DGG_OK and fills bm / bn, every problem's tiles_m / tiles_n / blk_begin, batch.total_blocks and `route`:

@@ -422,7 +422,7 @@ void gemm_x4_dispatch(int mode, const GemmBatch& batch, hipStream_t st) {
     // side work (dgg_set_side_work): the forward products walk two work items per workgroup — same items, same sums,
     // half the CUs for twice as long (gemm_x5.hip: launch_x5)
     static const int kdiv = [] { const char* e = getenv("DGG_SIDE_DIV"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
-    if (gemm_side_work() && mode == GEMM_NT && nwg > 64) nwg = ((nwg + kdiv - 1) / kdiv + 7) / 8 * 8;
+    if (gemm_side_work() && mode == GEMM_NT && nwg > 64) { const int dv = kdiv + gemm_side_work() - 1; nwg = ((nwg + dv - 1) / dv + 7) / 8 * 8; }
     const dim3 grid(nwg), blk(512);
     if (mode == GEMM_NT) {
         bool any = false;

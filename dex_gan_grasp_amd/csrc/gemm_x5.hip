@@ -711,7 +711,10 @@ static void launch_x5(const GemmBatch& b, hipStream_t st) {
     static const int kdiv = [] { const char* e = getenv("DGG_SIDE_DIV"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
     // (forward products only: halving the weight-gradient grids of side work as well costs 8-10 us per step — re-measured in
     //  round 6 on the deferred, grouped launches: 1.349 -> 1.356 ms)
-    if (gemm_side_work() && A_KC && B_KC && grid > 64) grid = ((grid + kdiv - 1) / kdiv + 7) / 8 * 8;
+    if (gemm_side_work() && A_KC && B_KC && grid > 64) {
+        const int dv = kdiv + gemm_side_work() - 1;   // dgg_set_side_work(n): n = 1 the default division, n = 2 one more, ...
+        grid = ((grid + dv - 1) / dv + 7) / 8 * 8;
+    }
     static const int diag = [] { const char* e = getenv("DGG_X5_WIDE"); return (e && e[0] == '0') ? 1 : 0; }();
     GemmBatch bb = b;
     bb.diag = diag;

@@ -21,11 +21,11 @@ class _side_work:
     """Context: the library calls inside enqueue side work (dgg_set_side_work), switched off again on exit."""
 
     def __init__(self, on):
-        self.on = bool(on)
+        self.on = int(on)   # 0: off, 1: the default division of the grids, 2: one more, ...
 
     def __enter__(self):
         if self.on:
-            check(lib().dgg_set_side_work(1), "dgg_set_side_work")
+            check(lib().dgg_set_side_work(int(self.on)), "dgg_set_side_work")
 
     def __exit__(self, *exc):
         if self.on:
@@ -501,7 +501,7 @@ class TrainEngine:
         # the evaluator update and the prefetched real pass run BESIDE the cGAN chain: their large GEMMs take half the
         # chip for twice as long (dgg_set_side_work) so that the chain's short kernels keep finding free CUs
         polite = two_streams and os.environ.get("DGG_SIDE_WORK", "1") != "0"
-        with torch.cuda.stream(side), _side_work(polite):
+        with torch.cuda.stream(side), _side_work(int(polite) * int(os.environ.get("DGG_SIDE_EVA_LEVEL", "1"))):
             if graph_mode:
                 check(lib().dgg_eva_phase_graph(cfg_p, ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(wse),
                                                 wse.numel(), Be, ptr(ebps), ptr(erot9), ptr(etransl), ptr(elabel),
@@ -544,7 +544,10 @@ class TrainEngine:
                         raise _lib.DggError("next_gan_inputs must be resident contiguous float32 tensors")
                 self._keep_next = (nb, nr, nt, nj_)   # the C side remembers raw pointers
                 self._mark("prefetch_begin", self._side2)
-                with _side_work(polite):
+                # (the look-ahead pass runs beside the G phase, which has the chain's densest stretch of large launches: its
+                #  forward products take a THIRD of the workgroups, three work items each — 1.300 / 1.292 -> 1.287 / 1.283 ms
+                #  against the evaluator's half; a quarter gives it back, and the evaluator itself is best at a half)
+                with _side_work(int(polite) * int(os.environ.get("DGG_SIDE_PRE_LEVEL", "2"))):
                     check(lib().dgg_cgan_d_real_prefetch(cfg_p, C.byref(st), C.byref(hp), ptr(ws), ws.numel(),
                                                          nb.shape[0], ptr(nb), ptr(nr), ptr(nt), ptr(nj_),
                                                          ptr(L_next), s2), "dgg_cgan_d_real_prefetch")

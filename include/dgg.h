@@ -285,7 +285,9 @@ int dgg_enable_wgrad_stream(void* stream, int enable);
  * latency-critical chain on another stream — the evaluator update and the prefetched real-batch pass beside the cGAN
  * chain in engine.TrainEngine.joint_step.  Their large forward products are then launched with half as many workgroups,
  * each walking two work items: half the chip for twice as long instead of every CU, so that the chain's ~100 short
- * dependent kernels always find free CUs (-3 % per step).  Same work items, same sums: results are bit-identical. */
+ * dependent kernels always find free CUs (-3 % per step).  Same work items, same sums: results are bit-identical.
+ * on: 0 = off; 1 = half the workgroups; n > 1 = 1 / (n + 1) of them (round 6: the look-ahead real pass, which runs beside
+ * the G phase's large launches, takes a third; the evaluator update a half). */
 int dgg_set_side_work(int on);
 
 /* Gradient-ready events for data-parallel callers (per calling thread).  While `events` are registered for a gradient
