@@ -1472,10 +1472,6 @@ __global__ void adam_prep_kernel(int64_t* __restrict__ step, float* __restrict__
 }
 __global__ void seed_bump_kernel(uint64_t* __restrict__ seed) { seed[0] += 0x9E3779B97F4A7C15ull; }
 
-#ifndef DGG_ADAM_NT
-#define DGG_ADAM_NT 0
-#endif
-constexpr bool kAdamNT = DGG_ADAM_NT != 0;
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    float step_size, float bc2_sqrt, float omb1, float b2, float omb2,
@@ -1486,23 +1482,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    typedef float nt4 __attribute__((ext_vector_type(4)));
-    static_assert(sizeof(nt4) == sizeof(float4), "");
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
-        float4 gg, mm, vv;
-        if (kAdamNT) {   // gradients and moments are touched once per step: streamed past the caches the weights live in
-            const nt4 g_ = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(g) + i);
-            const nt4 m_ = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(m) + i);
-            const nt4 v_ = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(v) + i);
-            gg = make_float4(g_[0], g_[1], g_[2], g_[3]);
-            mm = make_float4(m_[0], m_[1], m_[2], m_[3]);
-            vv = make_float4(v_[0], v_[1], v_[2], v_[3]);
-        } else {
-            gg = reinterpret_cast<const float4*>(g)[i];
-            mm = reinterpret_cast<float4*>(m)[i];
-            vv = reinterpret_cast<float4*>(v)[i];
-        }
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
         float* pa = &pp.x; const float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1513,13 +1497,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             pa[e] = pa[e] - step_size * (ma[e] / den);
         }
         reinterpret_cast<float4*>(p)[i] = pp;
-        if (kAdamNT) {
-            __builtin_nontemporal_store((nt4){mm.x, mm.y, mm.z, mm.w}, reinterpret_cast<nt4*>(m) + i);
-            __builtin_nontemporal_store((nt4){vv.x, vv.y, vv.z, vv.w}, reinterpret_cast<nt4*>(v) + i);
-        } else {
-            reinterpret_cast<float4*>(m)[i] = mm;
-            reinterpret_cast<float4*>(v)[i] = vv;
-        }
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
     }
     // tail (n not a multiple of 4)
     const int64_t t = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
