@@ -376,6 +376,13 @@ def test_cgan_step_ragged_batch_vs_oracle(monkeypatch):
     _cgan_steps_vs_oracle(100, 2)
 
 
+def test_cgan_step_above_the_xshare_limit_vs_oracle():
+    """B = 1056: one batch size above what the shared BPS rows of round 6 serve (XShare: B <= 1024, 12 hand joints) — every
+    pass normalises its own input again (ibn_stats / ibn_apply / fake_pose, the path of rounds 1-5), the weight gradients
+    still go out as one grouped launch per pass.  One step through the API-path entry against the oracle."""
+    _cgan_steps_vs_oracle(1056, 1)
+
+
 def _cgan_steps_vs_oracle(b, nsteps):
     from oracle import dexgan_oracle as O
     L, ops, engine = _mods()
