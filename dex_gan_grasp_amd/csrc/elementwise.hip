@@ -2138,6 +2138,13 @@ int adam_launch(float* params, const float* grads, float* m, float* v, int64_t n
     const float bc2_sqrt = (float)sqrt(bc2);
     int64_t blocks = ((n >> 2) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
+    {   // side work (dgg_set_side_work: the evaluator's optimiser step beside the cGAN chain): one workgroup per CU instead of
+        // eight — the launch is HBM-bound either way, and 2048 workgroups arriving at once keep the chain's short kernels
+        // out of the CUs for its whole duration.  1.302 / 1.309 -> 1.294 / 1.294 ms per interleaved step; 128: 1.33, 512: as 256
+        // (DGG_ADAM_SIDE_WGS: diagnostics, 0 = no limit)
+        static const int side = [] { const char* e = getenv("DGG_ADAM_SIDE_WGS"); return e ? atoi(e) : 256; }();
+        if (side > 0 && gemm_side_work() && blocks > side) blocks = side;
+    }
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, m, v, n, step_size,
                        bc2_sqrt, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, (float)wd,
