@@ -267,6 +267,8 @@ struct NetW {
     float* dYs[3];               // dY13 of this pass + dY13 of the discriminator's other pass (Share::bwd_mode 2)
     float *slabs_w;              // split-K slabs of the fc2 weight gradient
     int64_t slab_floats;
+    float* pre[3];               // forward pre-products (net_forward): block r's slabs of X0 W13_r[:, x0 columns]^T; NULL: none
+    int pre_splits;              // K splits of each of them
     size_t bytes;
 };
 static bool share_wgrad() {  // diagnostics: DGG_SHARE_WGRAD=0: both passes of D form their own BPS weight gradient
@@ -342,6 +344,30 @@ static void plan13(int B, int n13, const int* widths, int nseg, int* splits) {
     }
 }
 
+// Forward pre-products (round 6).  The [prefix | x_hat] segment of EVERY ResBlock's fc1 || fc3 product depends on nothing but
+// the normalised input: the blocks' X0 products go out as ONE grouped launch at the head of the pass (nrb problems, the K
+// splits chosen for ~192 work items in total), and a block's own launch is left with the previous block's 512 columns (and
+// the few pose columns of a discriminator pass).  A launch of gemm_x5_kernel costs ~33 us whatever its size: one
+// prologue / ramp / tail instead of nrb, and at small batches twice the k-steps per work item.
+static bool pre_fwd_enabled() {   // diagnostics: DGG_PRE_FWD=0: every block multiplies its whole input itself (rounds 1-5)
+    static const bool v = [] { const char* e = getenv("DGG_PRE_FWD"); return !(e && e[0] == '0'); }();
+    return v;
+}
+static const int kPreSlabs = 8;
+static int pre_splits_of(const NetL& L, int B) {
+    // Small batches only (B <= 512): there a block's own launch has so few k-steps per work item (4-8 per wave) that it is
+    // all prologue and tail, and one launch with twice the k-steps wins (config 2, B = 256: 0.762 -> 0.742 ms; config 4's
+    // B = 512 step with encode 1.263 -> 1.232).  At B = 1024 the blocks' launches are long enough and the grouped one delays
+    // the first block's tail: interleaved step 1.267 -> 1.300 ms, evaluator alone 0.502 -> 0.519 (profiles/r06_experiments.txt).
+    if (!pre_fwd_enabled() || L.nrb < 2 || L.net == kNetResBlock || B > 512) return 0;
+    const int tiles = ((B + 127) / 128) * ((L.n13 + 127) / 128);
+    int s = 192 / (tiles * L.nrb);
+    const int by_k = (L.in_bps / 32) / 4;   // >= 4 k-tiles of 32 per split
+    if (s > by_k) s = by_k;
+    if (s > kPreSlabs) s = kPreSlabs;
+    return s < 1 ? 1 : s;
+}
+
 static void carve(const NetL& L, int B, void* base, NetW& W) {
     Bump b{reinterpret_cast<char*>(base), 0};
     const size_t Bz = (size_t)B;
@@ -397,6 +423,9 @@ static void carve(const NetL& L, int B, void* base, NetW& W) {
     W.dX0 = b.take<float>(Bz * L.ldx0);
     W.dXa = b.take<float>(Bz * L.nn);
     W.dXb = b.take<float>(Bz * L.nn);
+    W.pre_splits = pre_splits_of(L, B);
+    for (int r = 0; r < 3; ++r)
+        W.pre[r] = (W.pre_splits > 0 && r < L.nrb) ? b.take<float>((size_t)(W.pre_splits + 1) * Bz * L.n13) : nullptr;
     W.bytes = (b.off + 255) & ~(size_t)255;
 }
 
@@ -556,6 +585,10 @@ struct Ctx {
     // launch waits for the real pass' end, once, instead of per block.)
     bool defer_wgrad = false;
     GemmBatch dw;
+    // forward pre-products (net_forward): block r's X0 product lies in pre_slabs[r] (pre_nslab[r] slabs) already
+    bool pre = false;
+    float* pre_slabs[3] = {nullptr, nullptr, nullptr};
+    int pre_nslab[3] = {0, 0, 0};
 };
 
 static int rb_tail(Ctx& c, int r, int drop_mode, const float* keep_in, uint64_t seed, uint64_t seed_off);
@@ -569,17 +602,20 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
     // 1. [a1 | a3] partial products: X_piece (B x width) * W13[:, wcol:wcol+width]^T -> split-K slabs.
     //    A piece is a column segment of the concatenated input; with a Share the [prefix | x_hat] segment is cut at
     //    share->ncols into the shared BPS piece and the pass' own pose piece.
-    struct Piece { const float* p; int ld, width, wcol, x0_off; bool x0, shared; };
+    struct Piece { const float* p; int ld, width, wcol, x0_off; bool x0, shared, pre; };
     Piece pc[4];
     int np = 0;
     Share* sh = c.share;
+    bool own_pre = false;   // this pass' own pre-product of the whole X0 segment is summed in below
     for (int i = 0; i < nseg; ++i) {
         if (sh && segs[i].is_x0 && L.nprefix == 0 && sh->ncols > 0 && sh->ncols < segs[i].width) {
-            pc[np++] = Piece{segs[i].p, segs[i].ld, sh->ncols, segs[i].wcol, 0, true, true};
+            pc[np++] = Piece{segs[i].p, segs[i].ld, sh->ncols, segs[i].wcol, 0, true, true, c.pre};
             pc[np++] = Piece{segs[i].p + sh->ncols, segs[i].ld, segs[i].width - sh->ncols, segs[i].wcol + sh->ncols,
-                             sh->ncols, true, false};
+                             sh->ncols, true, false, false};
         } else {
-            pc[np++] = Piece{segs[i].p, segs[i].ld, segs[i].width, segs[i].wcol, 0, segs[i].is_x0, false};
+            const bool pre = c.pre && segs[i].is_x0;
+            own_pre = own_pre || pre;
+            pc[np++] = Piece{segs[i].p, segs[i].ld, segs[i].width, segs[i].wcol, 0, segs[i].is_x0, false, pre};
         }
     }
     int widths[4], sp[4];
@@ -591,6 +627,7 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
     int nslab = 0, nq = 0;
     for (int i = 0; i < np; ++i) {
         float* dst = c.W.slabs + (size_t)nslab * slab;
+        if (pc[i].pre) continue;          // multiplied at the head of the pass (net_forward's pre-products): summed in below
         if (pc[i].shared) {
             if (sh->mode == 2) continue;  // consumer: the producer's slabs are summed in below
             dst = sh->slabs[r];
@@ -614,12 +651,15 @@ static int rb_forward(Ctx& c, int r, const Seg* segs, int nseg, int drop_mode, c
     if (nq > 0) DGG_TRY(gemm_launch(GEMM_NT, gb, c.st));
     const bool shared_here = sh && np > nseg;
     if (shared_here && sh->events) {
-        if (sh->mode == 1 && hipEventRecord(sh->ready[r], c.st) != hipSuccess) return DGG_ERR_LAUNCH;
+        if (sh->mode == 1 && !c.pre && hipEventRecord(sh->ready[r], c.st) != hipSuccess) return DGG_ERR_LAUNCH;
         if (sh->mode == 2 && hipStreamWaitEvent(c.st, sh->ready[r], 0) != hipSuccess) return DGG_ERR_LAUNCH;
     }
-    // 2. sum slabs (k order: shared BPS chunks first) + bias; a1 -> statistics, a3 -> s = lrelu(a3)
+    // 2. sum slabs (k order: shared BPS chunks / the pass' pre-product first) + bias; a1 -> statistics, a3 -> s = lrelu(a3)
     if (shared_here)
         DGG_TRY(reduce_bias_launch(sh->slabs[r], sh->nslab[r], slab, L.n13, c.P + R.b13, A.a13, L.n13, B, B, 1, L.n13,
+                                   0, L.hid, L.hid, L.n13, c.W.part, c.st, 0, c.W.slabs, nslab));
+    else if (own_pre)
+        DGG_TRY(reduce_bias_launch(c.pre_slabs[r], c.pre_nslab[r], slab, L.n13, c.P + R.b13, A.a13, L.n13, B, B, 1, L.n13,
                                    0, L.hid, L.hid, L.n13, c.W.part, c.st, 0, c.W.slabs, nslab));
     else
         DGG_TRY(reduce_bias_launch(c.W.slabs, nslab, slab, L.n13, c.P + R.b13, A.a13, L.n13, B, B, 1, L.n13, 0, L.hid,
@@ -988,6 +1028,35 @@ static int net_forward(const NetL& L, const float* params, float* bn, void* ws, 
                                  L.nprefix ? c.W.aff_shift : nullptr, st, &fz,
                                  produce ? xsh->xs : nullptr, produce ? xsh->ld : 0, produce ? L.in_bps : 0));
         if (produce && xsh->record && xsh->ready && hipEventRecord(xsh->ready, st) != hipSuccess) return DGG_ERR_LAUNCH;
+    }
+    // forward pre-products (see pre_splits_of): every block's X0 product in one grouped launch — the whole [prefix | x_hat]
+    // segment, or, for the producer of a Share (D's real pass), its shared BPS columns, into the shared slabs
+    if (c.W.pre_splits > 0 && !(share && share->mode == 2)) {
+        const bool cut = share && share->mode == 1 && L.nprefix == 0 && share->ncols > 0 && share->ncols < L.k0;
+        if (!share || cut) {
+            GemmBatch g;
+            memset(&g, 0, sizeof(g));
+            const long long slab = (long long)B * L.n13;
+            for (int r = 0; r < L.nrb; ++r) {
+                const RbL& R = L.rb[r];
+                const int wcol = r == 0 ? 0 : (L.x1_first ? L.nn : 0);
+                float* dst = cut ? share->slabs[r] : c.W.pre[r];
+                GemmProb& q = g.p[g.nprob++];
+                prob_init(q, c.W.X0, L.ldx0, params + R.w13 + wcol, R.fin, dst, L.n13, B, L.n13, cut ? share->ncols : L.k0);
+                prob_split(q, c.W.pre_splits, slab);
+                q.a_scale = c.W.aff_scale;
+                q.a_shift = c.W.aff_shift;
+                if (q.splits > (cut ? kShareSlabs : c.W.pre_splits + 1)) return DGG_ERR_WORKSPACE;
+                c.pre_slabs[r] = dst;
+                c.pre_nslab[r] = q.splits;
+                if (cut) share->nslab[r] = q.splits;
+            }
+            DGG_TRY(gemm_launch(GEMM_NT, g, st));
+            if (cut && share->events)
+                for (int r = 0; r < L.nrb; ++r)
+                    if (hipEventRecord(share->ready[r], st) != hipSuccess) return DGG_ERR_LAUNCH;
+            c.pre = true;
+        }
     }
     const bool drop = (L.net == DGG_NET_EVA) && c.train;
     for (int r = 0; r < L.nrb; ++r) {
@@ -1425,7 +1494,8 @@ static int carve_step(const dgg_cfg* cfg, int B, void* base, StepW& S) {
         // as rb_forward cuts the pieces: [BPS | pose] (+ the previous block's output)
         int widths[3] = {cfg->in_bps, Ld.k0 - cfg->in_bps, Ld.nn}, sp[3];
         plan13(B, Ld.n13, widths, r == 0 ? 2 : 3, sp);
-        S.dshare[r] = b.take<float>((size_t)sp[0] * Bz * Ld.n13);
+        const int pre_s = pre_splits_of(Ld, B) + 1;   // (the real pass' pre-product launch may cut the BPS piece otherwise)
+        S.dshare[r] = b.take<float>((size_t)(sp[0] > pre_s ? sp[0] : pre_s) * Bz * Ld.n13);
     }
     // XShare needs: the generator's and the discriminator's operands on ONE row pitch, room for the latent in the pad
     // behind a discriminator row, the fake pose in ibn_shared_kernel's one instantiation (12 hand joints: the shipped
