@@ -446,6 +446,12 @@ def sub_results(cfg, dev, eng):
         bps = ds.encode(clouds)
         eng.joint_step((bps,) + g_in[1:], z, (bps,) + e_in[1:], True, None, 500 + k2[0])
     dt = wall(both, 30)
+    bps0 = ds.encode(clouds)
+
+    def step_only():   # the same step on an already encoded batch
+        k2[0] += 1
+        eng.joint_step((bps0,) + g_in[1:], z, (bps0,) + e_in[1:], True, None, 500 + k2[0])
+    dt_step = wall(step_only, 30)
     # the same with the loader one batch ahead: batch k+1's encode on a side stream, enqueued before step k
     side = torch.cuda.Stream(device=dev)
     pend = [None]
@@ -472,6 +478,7 @@ def sub_results(cfg, dev, eng):
                                      "ms_per_step_encode_one_batch_ahead": round(dt_ahead * 1e3, 4),
                                      "grasps_per_s_encode_one_batch_ahead": round(b / dt_ahead, 1),
                                      "ms_per_step_with_encode": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1),
+                                     "ms_per_step_without_encode": round(dt_step * 1e3, 4),
                                      "workload": "512 clouds x 2048 points -> dgg_bps_encode -> gen+eval step, batch 512 "
                                                  "(one rank's share of global batch 4096)"}
     # config 5 (one rank's share): 1250 objects x 200 grasps, encode (N = 2048) + generate + evaluate + 3 thresholds
