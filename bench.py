@@ -452,6 +452,18 @@ def sub_results(cfg, dev, eng):
         k2[0] += 1
         eng.joint_step((bps0,) + g_in[1:], z, (bps0,) + e_in[1:], True, None, 500 + k2[0])
     dt_step = wall(step_only, 30)
+    # ... and with the next batch's real pass enqueued one step ahead, as in the headline (two resident batches alternate)
+    bt1 = ds.batch(1)
+    pair = [(bps0,) + g_in[1:],
+            (bt1["bps_object"], bt1["rot_matrix"].reshape(b, 9).contiguous(), bt1["transl"], bt1["joint_conf"])]
+
+    def step_ahead():
+        k2[0] += 1
+        cur, nxt = pair[k2[0] & 1], pair[(k2[0] + 1) & 1]
+        eng.joint_step(cur, z, (cur[0],) + e_in[1:], True, None, 500 + k2[0], next_gan_inputs=nxt)
+    eng.flush()
+    dt_step_ahead = wall(step_ahead, 30)
+    eng.flush()
     # the same with the loader one batch ahead: batch k+1's encode on a side stream, enqueued before step k
     side = torch.cuda.Stream(device=dev)
     pend = [None]
@@ -479,6 +491,7 @@ def sub_results(cfg, dev, eng):
                                      "grasps_per_s_encode_one_batch_ahead": round(b / dt_ahead, 1),
                                      "ms_per_step_with_encode": round(dt * 1e3, 4), "grasps_per_s": round(b / dt, 1),
                                      "ms_per_step_without_encode": round(dt_step * 1e3, 4),
+                                     "ms_per_step_without_encode_look_ahead": round(dt_step_ahead * 1e3, 4),
                                      "workload": "512 clouds x 2048 points -> dgg_bps_encode -> gen+eval step, batch 512 "
                                                  "(one rank's share of global batch 4096)"}
     # config 5 (one rank's share): 1250 objects x 200 grasps, encode (N = 2048) + generate + evaluate + 3 thresholds

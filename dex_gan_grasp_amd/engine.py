@@ -501,7 +501,12 @@ class TrainEngine:
         # the evaluator update and the prefetched real pass run BESIDE the cGAN chain: their large GEMMs take half the
         # chip for twice as long (dgg_set_side_work) so that the chain's short kernels keep finding free CUs
         polite = two_streams and os.environ.get("DGG_SIDE_WORK", "1") != "0"
-        with torch.cuda.stream(side), _side_work(int(polite) * int(os.environ.get("DGG_SIDE_EVA_LEVEL", "1"))):
+        # (level of the evaluator update: a half of the workgroups beside a B = 1024 step with a look-ahead pass — 1.293 ms
+        #  against 1.347 at a third —, a third everywhere else: B = 1024 without look-ahead 1.398 -> 1.371, B = 512 0.981 ->
+        #  0.965 / without look-ahead 1.077 -> 1.035, B = 256 0.880 -> 0.811; profiles/r06_experiments.txt 20)
+        ahead = is_train_gen and two_streams and next_gan_inputs is not None and next_gan_inputs[0].shape[0] == B
+        eva_level = os.environ.get("DGG_SIDE_EVA_LEVEL") or ("1" if (ahead and B > 512) else "2")
+        with torch.cuda.stream(side), _side_work(int(polite) * int(eva_level)):
             if graph_mode:
                 check(lib().dgg_eva_phase_graph(cfg_p, ptr(E.params), ptr(E.grads), ptr(E.bn), C.byref(hp), ptr(wse),
                                                 wse.numel(), Be, ptr(ebps), ptr(erot9), ptr(etransl), ptr(elabel),
