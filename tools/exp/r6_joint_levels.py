@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT)
 import torch
 from dex_gan_grasp_amd import _lib, engine, synth
 dev = torch.device("cuda", 0)
+EVA_LEVELS = tuple(int(x) for x in os.environ.get("LEVELS", "0,1,2").split(","))
 cfg = dict(synth.DEFAULT_CFG)
 fg, fd, fe = (_lib.FlatNet(k, cfg, dev) for k in (_lib.NET_GEN, _lib.NET_DISC, _lib.NET_EVA))
 sd = synth.make_state_dict("dexgangrasp", 0)
@@ -36,7 +37,7 @@ for B in (1024, 512, 256):
     for ahead in (True, False):
         res = {}
         for rep in range(3):
-            for eva in (0, 1, 2):
+            for eva in EVA_LEVELS:
                 for pre in ((1, 2) if ahead else (2,)):
                     os.environ["DGG_SIDE_EVA_LEVEL"], os.environ["DGG_SIDE_PRE_LEVEL"] = str(eva), str(pre)
                     eng.flush()
